@@ -1,0 +1,159 @@
+/* k5.h — C ABI of libk5.so, the MI355X (gfx950) denoising engine for Kandinsky-5 T2V Lite.
+ *
+ * The reference (ai-forever/Kandinsky-5) is pure Python/PyTorch and has NO FFI/plugin layer
+ * (SURVEY.md §8b); its seams are Python call signatures.  Each entry point below therefore
+ * cites the reference *Python interface* it stands behind (paths relative to the reference
+ * repo).  The Python host mirror (kandinsky-5_amd/kandinsky/) binds these with ctypes and keeps
+ * the reference's names/arguments/errors; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  `stream` is a hipStream_t passed as void*
+ *     (NULL = the null stream).  All device work is enqueued asynchronously on that stream.
+ *   - device pointers are BORROWED from the caller (torch owns activations); the engine OWNS its
+ *     packed weights and workspaces (hipMalloc).
+ *   - every function returns a k5_status; k5_last_error() gives a thread-local message.
+ *   - a handle is not thread-safe; one handle per GPU per process (one process per GPU).
+ *   - bf16 tensors are row-major with explicit leading dimensions in ELEMENTS.
+ */
+#ifndef K5_H
+#define K5_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  K5_OK = 0, K5_ERR_ARG = 1, K5_ERR_ALIGN = 2, K5_ERR_HIP = 3, K5_ERR_STATE = 4, K5_ERR_KEY = 5,
+  K5_ERR_UNSUPPORTED = 6
+} k5_status;
+typedef enum { K5_F32 = 0, K5_BF16 = 1, K5_F16 = 2 } k5_dtype;
+typedef enum { K5_EPI_BIAS = 0, K5_EPI_BIAS_M = 1, K5_EPI_GELU = 2, K5_EPI_GATE = 3 } k5_epilogue;
+
+int k5_abi_version(void);
+const char* k5_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel-level entry points (used by the parity tests and by torch-side glue).
+ * ---------------------------------------------------------------------------------------- */
+
+/* C[M][N] = A[M][K] . W[N][K]^T (+bias) with fused epilogue; bf16 in/out, fp32 accumulate.
+ * Replaces autocast nn.Linear: kandinsky/models/nn.py:180-191 (get_qkv), :204-206 (out_l),
+ * :352-361 (FeedForward incl. nn.GELU), :71 (TextEmbeddings), :96 (VisualEmbeddings), :382 (OutLayer);
+ * K5_EPI_GATE additionally fuses apply_gate_sum nn.py:30-33: C = bf16(resid + gate[n]*bf16(acc+bias)).
+ * K5_EPI_BIAS_M adds bias[m] (used to emit V^T = W_v . X^T directly). bias/gate are fp32. */
+int k5_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda,
+                 int ldw, int ldc, int epilogue, const void* resid, int ldr, const float* gate, void* stream);
+
+/* O[q][h*64+d] = softmax(Q K^T / 8) V per head (head_dim 64, non-causal, fp32 softmax).
+ * Replaces FA(q,k,v): nn.py:201 (text self-attn), :254 (visual self-attn), :336 (cross-attn).
+ * Q [q_len][ldq], K [kv_len][ldk] with head h at columns h*64..; Vt [H*64][ldvt] is V transposed
+ * (row h*64+d, column key).  kv_nb/kv_idx (optional) select 64-key blocks per (head, 64-query block)
+ * = flex_attention(block_mask) nn.py:257-280:  counts kv_nb[h*nqb+qb], ids kv_idx[(h*nqb+qb)*nkb_stride+i]. */
+int k5_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len,
+                      int ldq, int ldk, int ldvt, int ldo, const int32_t* kv_nb, const int32_t* kv_idx,
+                      int nkb_stride, void* stream);
+
+/* apply_scale_shift_norm nn.py:25-28: out = bf16(LayerNorm(x, eps 1e-5, no affine)*(scale+1)+shift). */
+int k5_ln_modulate_bf16(const void* x, const float* scale, const float* shift, void* out, int rows, int D,
+                        int ldx, int ldo, void* stream);
+/* norm_qk nn.py:193-197 + apply_rotary nn.py:35-40, in place on [rows][ld] holding H heads of 64:
+ * RMSNorm(eps=2^-23, weight[(h/heads_per_weight)*64..]) -> bf16 -> adjacent-pair rotation by
+ * cos/sin[rows][32] (heads < rope_heads; cos==NULL: no rotation) -> bf16. */
+int k5_rmsnorm_rope_bf16(void* x, const float* weight, const float* cos_tab, const float* sin_tab, int rows,
+                         int H, int ld, int heads_per_weight, int rope_heads, void* stream);
+/* apply_gate_sum nn.py:30-33 (standalone form). */
+int k5_gate_sum_bf16(const void* x, const void* y, const float* gate, void* out, int rows, int D, void* stream);
+/* fp32-island GEMV (Modulation nn.py:161-164, TimeEmbeddings nn.py:56-61): y = W.act(x) + b (+add). */
+int k5_gemv_f32(const float* x, const float* W, const float* b, float* y, int N, int K, int silu_in,
+                const float* add, void* stream);
+/* TimeEmbeddings sinusoid nn.py:57-58; t = 1000*sigma by value. */
+int k5_time_features_f32(float t, float* out, int D, void* stream);
+/* TextEmbeddings.norm nn.py:67,72 (LayerNorm affine on bf16 rows, bf16 and/or bf16-rounded fp32 out). */
+int k5_ln_affine_bf16(const void* x, const float* w, const float* b, void* out_bf16, float* out_f32, int rows,
+                      int D, void* stream);
+/* RoPE3D/RoPE1D nn.py:99-150 cos/sin tables [T*H*W][n0+n1+n2]; positions are device int32. */
+int k5_rope_table_f32(float* cos_tab, float* sin_tab, const int32_t* pos_t, const int32_t* pos_h,
+                      const int32_t* pos_w, int T, int H, int W, int n0, int n1, int n2, float s0, float s1,
+                      float s2, const int32_t* tok_perm, void* stream);
+/* VisualEmbeddings patchify nn.py:81-95 (patch (1,2,2)), fp32 (T,H,W,x_channels) -> bf16 [Ntok][Kpad];
+ * channels in [x_channels, Cin_total) read as zero (generation_utils.py:107-112); tok_perm = fractal order. */
+int k5_patchify_bf16(const float* x, void* out, int T, int H, int W, int x_channels, int Cin_total, int Kpad,
+                     const int32_t* tok_perm, void* stream);
+/* OutLayer un-patchify nn.py:384-399: [Ntok][4C] (c,ph,pw) -> (T,2Hp,2Wp,C) bf16. */
+int k5_unpatchify_bf16(const void* x, void* out, int T, int Hp, int Wp, int C, int ldx,
+                       const int32_t* tok_perm, void* stream);
+/* CFG combine + Euler, generation_utils.py:74-76,128.  v_uncond NULL => no guidance. */
+int k5_cfg_euler(float* img, const void* v_cond, const void* v_uncond, float w, float dt, int64_t n,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Engine: DiffusionTransformer3D (kandinsky/models/dit.py:82-181) + sampler loop
+ * (kandinsky/generation_utils.py:39-129).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct k5_dit k5_dit;
+
+/* ctor kwargs of DiffusionTransformer3D, dit.py:83-97 */
+typedef struct k5_dit_config {
+  int in_visual_dim, in_text_dim, in_text_dim2, time_dim, out_visual_dim;
+  int patch_size[3];
+  int model_dim, ff_dim, num_text_blocks, num_visual_blocks;
+  int axes_dims[3];
+  int visual_cond;
+} k5_dit_config;
+
+/* arguments of DiffusionTransformer3D.forward, dit.py:155-165 (+ sparse_params of
+ * generation_utils.py:10-36) */
+typedef struct k5_text_cond {
+  const void* text_embed;   /* device, [text_len][in_text_dim], dtype text_dtype */
+  const void* pooled_embed; /* device, [1][in_text_dim2], dtype text_dtype */
+  int text_dtype;           /* k5_dtype */
+  int text_len;
+  const int32_t* text_rope_pos; /* HOST, [text_len] */
+} k5_text_cond;
+
+typedef struct k5_forward_args {
+  const float* x;           /* device fp32 (T,H,W,x_channels) */
+  int T, H, W, x_channels;  /* x_channels = visual_embed_dim, or in_visual_dim (cond channels implied zero) */
+  k5_text_cond cond;
+  float time;               /* 1000*sigma (generation_utils.py:57) */
+  const int32_t* pos_t;     /* HOST visual_rope_pos[0..2] (generation_utils.py:173-177) */
+  const int32_t* pos_h;
+  const int32_t* pos_w;
+  float scale_factor[3];    /* conf.metrics.scale_factor */
+  int attention_type;       /* 0 = flash (dense), 1 = nabla */
+  float nabla_P; int nabla_wT, nabla_wH, nabla_wW;
+} k5_forward_args;
+
+typedef struct k5_sample_args {
+  k5_forward_args fwd;      /* fwd.x ignored; fwd.time ignored */
+  k5_text_cond null_cond;   /* used when |guidance_weight-1| > 1e-6 */
+  float* latent;            /* device fp32 (T,H,W,in_visual_dim), in: noise, out: final latent */
+  int num_steps;
+  const float* sigmas;      /* HOST [num_steps+1] (generation_utils.py:102-103) */
+  float guidance_weight;
+} k5_sample_args;
+
+int k5_dit_create(const k5_dit_config* cfg, k5_dit** out);
+void k5_dit_destroy(k5_dit* dit);
+/* state_dict entry (checkpoint layout SURVEY.md App. D): host pointer, any of f32/bf16/f16. */
+int k5_dit_load_tensor(k5_dit* dit, const char* key, const void* host_ptr, int dtype, const int64_t* shape,
+                       int rank);
+/* all tensors loaded -> pack (concat Wq|Wk, pad, cast) ; must precede forward */
+int k5_dit_finalize(k5_dit* dit);
+/* number of state_dict keys still missing (0 after a complete load); names via k5_last_error() */
+int k5_dit_missing_keys(k5_dit* dit);
+/* velocity (T,H,W,out_visual_dim) bf16, device */
+int k5_dit_forward(k5_dit* dit, const k5_forward_args* args, void* out_velocity, void* stream);
+/* whole Euler loop on device (generate, generation_utils.py:80-129) */
+int k5_sample(k5_dit* dit, const k5_sample_args* args, void* stream);
+
+/* per-kernel-family accumulated GPU time of the last forward(s), measured with hipEvents on the
+ * engine's stream when profiling is enabled.  names: "attn_self","attn_cross","gemm","elementwise",...  */
+int k5_dit_set_profiling(k5_dit* dit, int enabled);
+int k5_dit_get_profile(k5_dit* dit, const char* family, double* total_ms, int64_t* launches);
+int k5_dit_reset_profile(k5_dit* dit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* K5_H */

@@ -1,0 +1,203 @@
+// attn_fwd.hip — flash-style attention forward for gfx950: O = softmax(Q K^T / sqrt(64)) V,
+// bf16 operands, fp32 softmax/accumulate, head_dim 64, non-causal, ragged q_len / kv_len.
+//
+// Replaces the three FA(q,k,v) call sites of the reference (kandinsky/models/nn.py:201 text
+// self-attention, :254 visual self-attention, :336 cross-attention; flash-attn itself is a
+// third-party wheel, not part of the reference tree).
+//
+// Structure: one workgroup = 8 waves = 256 query rows of one head; each wave owns 32 query rows.
+// K tile [64 keys][64 d] and V^T tile [64 d][64 keys] are double-buffered in LDS (swizzled 16-B
+// chunks, conflict-free ds_read_b128), register-staged: loads of tile t+1 are issued before the
+// MFMAs of tile t and written to LDS after them (one barrier per tile).
+//   S^T = K · Q^T   (MFMA A = K rows, B = Q^T)  -> lane (q = l&31) holds 32 scores of ITS query:
+//                   row max / row sum are in-lane + one exchange with lane^32.
+//   K rows are fed with bits 2,3 of the row index swapped so that the accumulator registers
+//   [8s, 8s+8) of a lane are 8 CONSECUTIVE keys 16s + 8*(l>>5) + j: they are directly the
+//   B-operand fragment of P^T for the second MFMA — no permlane / LDS round trip for P.
+//   O^T = V^T · P^T (MFMA A = V^T rows (d), B = P^T) -> lane again owns one query: the online
+//                   softmax rescale is lane-local.
+// V is consumed TRANSPOSED ([H*64][keys]); the engine produces it for free by running the V
+// projection GEMM with operands swapped (W_v · X^T), so no transposing LDS reads are needed.
+#include "k5_common.h"
+#include "k5_kernels.h"
+
+namespace {
+
+constexpr int QB = 256;   // query rows per workgroup
+constexpr int KB = 64;    // keys per tile
+constexpr int TILE = 64 * 128;  // bytes of one [64][64] bf16 tile
+
+struct AttnP {
+  const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
+  int H, q_len, kv_len, ldq, ldk, ldvt, ldo, nqb;
+  float c;  // softmax scale * log2(e)
+};
+
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
+  char* sK = smem;             // 2 buffers
+  char* sV = smem + 2 * TILE;  // 2 buffers
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int h = lid / p.nqb, qb = lid % p.nqb;
+  const int q0 = qb * QB + wave * 32;
+
+  // Q^T fragments (B operand): lane holds Q[q0 + l31][16kk + 8hi .. +8]
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = p.Q + (size_t)min(q0 + l31, p.q_len - 1) * p.ldq + h * 64 + 8 * hi;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + 16 * kk);
+  }
+
+  // loader mapping: 512 threads, one 16-B chunk of K and one of V^T each
+  const int lrow = tid >> 3, lc = tid & 7;
+  const bf16_t* kbase = p.K + h * 64 + 8 * lc;
+  const bf16_t* vbase = p.Vt + (size_t)(h * 64 + lrow) * p.ldvt + 8 * lc;
+  const int lds_off = lds_swz(lrow, lc);
+  u32x4 rk, rv;
+  auto load_tile = [&](int kv0) {
+    rk = *reinterpret_cast<const u32x4*>(kbase + (size_t)min(kv0 + lrow, p.kv_len - 1) * p.ldk);
+    const int key = kv0 + 8 * lc;
+    if (key + 8 <= p.kv_len) {
+      rv = *reinterpret_cast<const u32x4*>(vbase + kv0);
+    } else {  // ragged tail: never read past kv_len, zero-fill (P is exactly 0 there)
+      uint16_t e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        e[j] = (key + j < p.kv_len) ? reinterpret_cast<const uint16_t*>(vbase + kv0)[j] : (uint16_t)0;
+      rv = u32x4{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                 (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
+    }
+  };
+  auto store_tile = [&](int buf) {
+    *reinterpret_cast<u32x4*>(sK + buf * TILE + lds_off) = rk;
+    *reinterpret_cast<u32x4*>(sV + buf * TILE + lds_off) = rv;
+  };
+
+  // K row permutation: MFMA row i reads key row pi(i) = i with bits 2 and 3 swapped
+  const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+
+  f32x16 ot[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float c = p.c;
+
+  const int ntiles = (p.kv_len + KB - 1) / KB;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    const int kv0 = t * KB;
+    if (t + 1 < ntiles) load_tile(kv0 + KB);
+    const char* cK = sK + buf * TILE;
+    const char* cV = sV + buf * TILE;
+
+    // ---- S^T = K Q^T : two 32-key tiles ----
+    f32x16 st[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[tt][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cK + lds_swz(32 * tt + krow, 2 * kk + hi));
+        st[tt] = mfma32(kf, qf[kk], st[tt]);
+      }
+    }
+    // lane (q=l31, hi) register st[tt][r] is key  kv0 + 32tt + 16(r>>3) + 8hi + (r&7)
+    if (kv0 + KB > p.kv_len) {  // ragged tail tile (wave-uniform branch)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + 32 * tt + 16 * (r >> 3) + 8 * hi + (r & 7);
+          if (key >= p.kv_len) st[tt][r] = -1e30f;
+        }
+    }
+    // ---- online softmax (raw-score max, exp2 with folded scale) ----
+    float mt = st[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, st[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[1][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    if (__any(m_new > m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = m_run * c;
+    bf16x8 pf[4];
+    float ls = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        e[j] = __builtin_amdgcn_exp2f(fmaf(st[s >> 1][8 * (s & 1) + j], c, -mc));
+        ls += e[j];
+      }
+      u32x4 pk = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]),
+                  pack_bf16x2(e[6], e[7])};
+      pf[s] = __builtin_bit_cast(bf16x8, pk);
+    }
+    l_run += ls;
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cV + lds_swz(32 * d + l31, 2 * s + hi));
+        ot[d] = mfma32(vf, pf[s], ot[d]);
+      }
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: normalise, store O[q][h*64 + d] ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < p.q_len) {
+    bf16_t* op = p.O + (size_t)q * p.ldo + h * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        u32x2 o = {pack_bf16x2(ot[d][4 * rg] * inv, ot[d][4 * rg + 1] * inv),
+                   pack_bf16x2(ot[d][4 * rg + 2] * inv, ot[d][4 * rg + 3] * inv)};
+        *reinterpret_cast<u32x2*>(op + 32 * d + 8 * rg + 4 * hi) = o;
+      }
+  }
+}
+
+}  // namespace
+
+int k5_launch_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+                             int kv_len, int ldq, int ldk, int ldvt, int ldo, const int32_t* kv_nb,
+                             const int32_t* kv_idx, int nkb_stride, hipStream_t stream) {
+  if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
+  if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
+  if (kv_nb || kv_idx) return K5_ERR_UNSUPPORTED;
+  (void)nkb_stride;
+  AttnP p;
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+  p.H = H; p.q_len = q_len; p.kv_len = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
+  p.nqb = (q_len + QB - 1) / QB;
+  p.c = 0.125f * 1.44269504088896340736f;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(H * p.nqb), dim3(512), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}

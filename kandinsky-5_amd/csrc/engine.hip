@@ -1,0 +1,669 @@
+// engine.hip — the denoising engine behind the C ABI: DiffusionTransformer3D forward
+// (kandinsky/models/dit.py:155-181) and the flow-matching Euler / CFG loop
+// (kandinsky/generation_utils.py:39-129), scheduled as a fixed sequence of gfx950 kernels on one
+// HIP stream.  Weights are packed once (Wq|Wk concatenated, padded K, bf16 / fp32-island copies),
+// workspaces are persistent, RoPE tables and the batched AdaLN modulation are computed once per
+// forward.  No host synchronisation inside forward()/sample().
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "k5_common.h"
+#include "k5_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void k5_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* k5_last_error(void) { return g_err; }
+extern "C" int k5_abi_version(void) { return 1; }
+
+#define HIPCHK(x)                                                                          \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) {                                                                \
+      k5_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return K5_ERR_HIP;                                                                   \
+    }                                                                                      \
+  } while (0)
+#define K5CHK(x)                                                             \
+  do {                                                                       \
+    int s_ = (x);                                                            \
+    if (s_ != K5_OK) {                                                       \
+      if (!g_err[0]) k5_set_error("%s -> status %d (%s:%d)", #x, s_, __FILE__, __LINE__); \
+      return s_;                                                             \
+    }                                                                        \
+  } while (0)
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t n) {
+    if (n <= bytes) return K5_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; bytes = 0;
+    HIPCHK(hipMalloc(&p, n));
+    bytes = n;
+    return K5_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct HostTensor {  // staged state_dict entry (fp32 on host)
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+float half_to_float(uint16_t h) {
+  const uint32_t s = (h >> 15) & 1, e = (h >> 10) & 31, m = h & 1023;
+  uint32_t bits;
+  if (e == 0) {
+    if (m == 0) bits = s << 31;
+    else {
+      int ee = -1; uint32_t mm = m;
+      do { ++ee; mm <<= 1; } while (!(mm & 1024));
+      bits = (s << 31) | ((uint32_t)(112 - ee) << 23) | ((mm & 1023) << 13);
+    }
+  } else if (e == 31) bits = (s << 31) | 0x7f800000u | (m << 13);
+  else bits = (s << 31) | ((e + 112) << 23) | (m << 13);
+  float f; memcpy(&f, &bits, 4); return f;
+}
+uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1);
+  return (uint16_t)(u >> 16);
+}
+float bf16_round_host(float f) { uint32_t u = (uint32_t)f32_to_bf16_rne(f) << 16; float r; memcpy(&r, &u, 4); return r; }
+
+struct AttnW {  // one attention module, packed
+  DevBuf wqk, wq, wk, wv, wo;       // bf16
+  DevBuf bqk, bq, bk, bv, bo, norm; // fp32 (bias values bf16-rounded); norm = [q_norm | k_norm]
+};
+struct BlockW {
+  AttnW self_attn, cross_attn;
+  DevBuf w1, w2;  // feed_forward in/out, bf16
+  size_t mod_off = 0;  // offset (floats) of this block's modulation vector in mod_all
+};
+
+struct Prof { double ms = 0; int64_t n = 0; };
+
+}  // namespace
+
+struct k5_dit {
+  k5_dit_config cfg{};
+  int D = 0, FF = 0, TD = 0, Hh = 0, Kvis = 0, KvisPad = 0, Fout = 0;
+  bool finalized = false;
+  std::map<std::string, HostTensor> staged;
+  std::vector<std::string> expected;
+
+  // packed weights
+  DevBuf time_w1, time_b1, time_w2, time_b2;                   // fp32
+  DevBuf text_w, text_b, text_lnw, text_lnb;                   // bf16 W, fp32 rest
+  DevBuf pool_w, pool_b, pool_lnw, pool_lnb;
+  DevBuf vis_w, vis_b, out_w, out_b;
+  DevBuf mod_w, mod_b;                                         // all Modulation layers stacked, fp32
+  size_t mod_rows = 0, out_mod_off = 0;
+  std::vector<BlockW> tblocks, vblocks;
+
+  // workspaces
+  DevBuf ws_text_in, ws_text, ws_th, ws_tqk, ws_tvt, ws_to, ws_tff;
+  DevBuf ws_pool_in, ws_pool_lin, ws_pool_f32, ws_time, ws_tfeat, ws_th1, ws_temb, ws_mod;
+  DevBuf ws_xp, ws_vis, ws_h, ws_qk, ws_vt, ws_o, ws_ff, ws_ck, ws_cvt, ws_y;
+  DevBuf ws_vcos, ws_vsin, ws_pos;
+  DevBuf ws_vel_c, ws_vel_u;
+  // rope cache keys
+  std::vector<int32_t> key_vpos; float key_scale[3] = {0, 0, 0}; int key_shape[3] = {0, 0, 0};
+  struct TextRope { std::vector<int32_t> key; DevBuf cosT, sinT, pos; };
+  std::vector<TextRope> text_rope;  // small cache: cond / null-cond position vectors
+
+  // profiling
+  bool profiling = false;
+  std::map<std::string, Prof> prof;
+  struct Pending { std::string fam; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> ev_pool;
+
+  ~k5_dit() {
+    for (auto& e : ev_pool) (void)hipEventDestroy(e);
+    for (auto& pnd : pending) { (void)hipEventDestroy(pnd.a); (void)hipEventDestroy(pnd.b); }
+  }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// profiling helpers: bracket a kernel family with events on the engine stream
+// ---------------------------------------------------------------------------------------------
+hipEvent_t get_event(k5_dit* d) {
+  if (!d->ev_pool.empty()) { hipEvent_t e = d->ev_pool.back(); d->ev_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct Scope {
+  k5_dit* d; hipStream_t s; const char* fam; hipEvent_t a{}, b{}; bool on;
+  Scope(k5_dit* d_, hipStream_t s_, const char* f) : d(d_), s(s_), fam(f), on(d_->profiling) {
+    if (on) { a = get_event(d); b = get_event(d); (void)hipEventRecord(a, s); }
+  }
+  ~Scope() { if (on) { (void)hipEventRecord(b, s); d->pending.push_back({fam, a, b}); } }
+};
+void drain_profile(k5_dit* d) {
+  for (auto& p : d->pending) {
+    (void)hipEventSynchronize(p.b);
+    float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b);
+    auto& e = d->prof[p.fam]; e.ms += ms; e.n += 1;
+    d->ev_pool.push_back(p.a); d->ev_pool.push_back(p.b);
+  }
+  d->pending.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+// expected state_dict keys (dit.py:100-127)
+// ---------------------------------------------------------------------------------------------
+void expected_keys(const k5_dit_config& c, std::vector<std::string>& out) {
+  auto lin = [&](const std::string& n, bool bias = true) {
+    out.push_back(n + ".weight");
+    if (bias) out.push_back(n + ".bias");
+  };
+  lin("time_embeddings.in_layer"); lin("time_embeddings.out_layer");
+  lin("text_embeddings.in_layer"); out.push_back("text_embeddings.norm.weight"); out.push_back("text_embeddings.norm.bias");
+  lin("pooled_text_embeddings.in_layer"); out.push_back("pooled_text_embeddings.norm.weight"); out.push_back("pooled_text_embeddings.norm.bias");
+  lin("visual_embeddings.in_layer");
+  auto attn = [&](const std::string& p) {
+    lin(p + ".to_query"); lin(p + ".to_key"); lin(p + ".to_value");
+    out.push_back(p + ".query_norm.weight"); out.push_back(p + ".key_norm.weight");
+    lin(p + ".out_layer");
+  };
+  for (int i = 0; i < c.num_text_blocks; ++i) {
+    const std::string p = "text_transformer_blocks." + std::to_string(i);
+    lin(p + ".text_modulation.out_layer"); attn(p + ".self_attention");
+    lin(p + ".feed_forward.in_layer", false); lin(p + ".feed_forward.out_layer", false);
+  }
+  for (int i = 0; i < c.num_visual_blocks; ++i) {
+    const std::string p = "visual_transformer_blocks." + std::to_string(i);
+    lin(p + ".visual_modulation.out_layer"); attn(p + ".self_attention"); attn(p + ".cross_attention");
+    lin(p + ".feed_forward.in_layer", false); lin(p + ".feed_forward.out_layer", false);
+  }
+  lin("out_layer.modulation.out_layer"); lin("out_layer.out_layer");
+}
+
+// upload helpers ---------------------------------------------------------------------------
+int upload_f32(DevBuf& b, const float* src, size_t n) {
+  K5CHK(b.ensure(n * 4));
+  HIPCHK(hipMemcpy(b.p, src, n * 4, hipMemcpyHostToDevice));
+  return K5_OK;
+}
+int upload_bf16(DevBuf& b, const float* src, size_t rows, size_t cols, size_t cols_pad) {
+  std::vector<uint16_t> tmp(rows * cols_pad, 0);
+  for (size_t r = 0; r < rows; ++r)
+    for (size_t c = 0; c < cols; ++c) tmp[r * cols_pad + c] = f32_to_bf16_rne(src[r * cols + c]);
+  K5CHK(b.ensure(tmp.size() * 2));
+  HIPCHK(hipMemcpy(b.p, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+  return K5_OK;
+}
+int upload_bias_bf16r(DevBuf& b, const float* src, size_t n) {  // fp32 array of bf16-rounded values
+  std::vector<float> tmp(n);
+  for (size_t i = 0; i < n; ++i) tmp[i] = bf16_round_host(src[i]);
+  return upload_f32(b, tmp.data(), n);
+}
+
+const HostTensor* find(k5_dit* d, const std::string& k) {
+  auto it = d->staged.find(k);
+  return it == d->staged.end() ? nullptr : &it->second;
+}
+
+int pack_attn(k5_dit* d, const std::string& p, AttnW& a, bool fuse_qk) {
+  const size_t D = d->D;
+  const HostTensor *wq = find(d, p + ".to_query.weight"), *wk = find(d, p + ".to_key.weight"),
+                   *wv = find(d, p + ".to_value.weight"), *wo = find(d, p + ".out_layer.weight"),
+                   *bq = find(d, p + ".to_query.bias"), *bk = find(d, p + ".to_key.bias"),
+                   *bv = find(d, p + ".to_value.bias"), *bo = find(d, p + ".out_layer.bias"),
+                   *nq = find(d, p + ".query_norm.weight"), *nk = find(d, p + ".key_norm.weight");
+  if (fuse_qk) {
+    std::vector<float> w(2 * D * D), b(2 * D);
+    memcpy(w.data(), wq->data.data(), D * D * 4); memcpy(w.data() + D * D, wk->data.data(), D * D * 4);
+    memcpy(b.data(), bq->data.data(), D * 4); memcpy(b.data() + D, bk->data.data(), D * 4);
+    K5CHK(upload_bf16(a.wqk, w.data(), 2 * D, D, D));
+    K5CHK(upload_bias_bf16r(a.bqk, b.data(), 2 * D));
+  } else {
+    K5CHK(upload_bf16(a.wq, wq->data.data(), D, D, D)); K5CHK(upload_bias_bf16r(a.bq, bq->data.data(), D));
+    K5CHK(upload_bf16(a.wk, wk->data.data(), D, D, D)); K5CHK(upload_bias_bf16r(a.bk, bk->data.data(), D));
+  }
+  K5CHK(upload_bf16(a.wv, wv->data.data(), D, D, D)); K5CHK(upload_bias_bf16r(a.bv, bv->data.data(), D));
+  K5CHK(upload_bf16(a.wo, wo->data.data(), D, D, D)); K5CHK(upload_bias_bf16r(a.bo, bo->data.data(), D));
+  std::vector<float> n(128);
+  memcpy(n.data(), nq->data.data(), 64 * 4); memcpy(n.data() + 64, nk->data.data(), 64 * 4);
+  K5CHK(upload_f32(a.norm, n.data(), 128));
+  return K5_OK;
+}
+
+inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// one attention module on `rows` tokens:  x_resid += gate * out_l(attn(...)) fused in the out GEMM
+// ---------------------------------------------------------------------------------------------
+int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, void* qk, void* vt,
+                       void* o, const float* cosT, const float* sinT, void* resid, const float* gate,
+                       const char* fam_attn) {
+  const int D = d->D, H = d->Hh;
+  const int ldvt = (int)rup(rows, 8);
+  {
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_bf16(h, a.wqk.p, a.bqk.as<float>(), qk, rows, 2 * D, D, D, D, 2 * D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_gemm_bf16(a.wv.p, h, a.bv.as<float>(), vt, D, rows, D, D, D, ldvt, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+  }
+  {
+    Scope sc(d, s, "elementwise");
+    const int32_t hc[2] = {H, 2 * H};
+    K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s));
+  }
+  {
+    Scope sc(d, s, fam_attn);
+    K5CHK(k5_launch_attention_bf16(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, nullptr, nullptr, 0, s));
+  }
+  {
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_bf16(o, a.wo.p, a.bo.as<float>(), resid, rows, D, D, D, D, D, K5_EPI_GATE, resid, D, gate, s));
+  }
+  return K5_OK;
+}
+
+int run_cross_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, const void* text,
+                        int L, void* q, void* ck, void* cvt, void* o, void* resid, const float* gate) {
+  const int D = d->D, H = d->Hh;
+  const int ldvt = (int)rup(L, 8);
+  {
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_bf16(h, a.wq.p, a.bq.as<float>(), q, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_gemm_bf16(text, a.wk.p, a.bk.as<float>(), ck, L, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_gemm_bf16(a.wv.p, text, a.bv.as<float>(), cvt, D, L, D, D, D, ldvt, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+  }
+  {
+    Scope sc(d, s, "elementwise");
+    K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), nullptr, nullptr, rows, H, D, nullptr, s));
+    K5CHK(k5_launch_rmsnorm_rope(ck, a.norm.as<float>() + 64, nullptr, nullptr, L, H, D, nullptr, s));
+  }
+  {
+    Scope sc(d, s, "attn_cross");
+    K5CHK(k5_launch_attention_bf16(q, ck, cvt, o, H, rows, L, D, D, ldvt, D, nullptr, nullptr, 0, s));
+  }
+  {
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_bf16(o, a.wo.p, a.bo.as<float>(), resid, rows, D, D, D, D, D, K5_EPI_GATE, resid, D, gate, s));
+  }
+  return K5_OK;
+}
+
+int run_ff(k5_dit* d, hipStream_t s, const BlockW& b, const void* h, int rows, void* ff, void* resid, const float* gate) {
+  const int D = d->D, FF = d->FF;
+  Scope sc(d, s, "gemm");
+  K5CHK(k5_launch_gemm_bf16(h, b.w1.p, nullptr, ff, rows, FF, D, D, D, FF, K5_EPI_GELU, nullptr, 0, nullptr, s));
+  K5CHK(k5_launch_gemm_bf16(ff, b.w2.p, nullptr, resid, rows, D, FF, FF, FF, D, K5_EPI_GATE, resid, D, gate, s));
+  return K5_OK;
+}
+
+int ln_mod(k5_dit* d, hipStream_t s, const void* x, const float* mod3, void* out, int rows) {
+  // mod3 = [shift | scale | gate] (dit.py:36,40,64,69,74)
+  Scope sc(d, s, "elementwise");
+  return k5_launch_ln_modulate(x, mod3 + d->D, mod3, out, rows, d->D, d->D, d->D, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+int ensure_workspaces(k5_dit* d, int N, int L) {
+  const size_t D = d->D, FF = d->FF;
+  const size_t Lr = rup(L, 8), Nr = rup(N, 8);
+  K5CHK(d->ws_text_in.ensure((size_t)L * d->cfg.in_text_dim * 2));
+  K5CHK(d->ws_text.ensure(L * D * 2)); K5CHK(d->ws_th.ensure(L * D * 2)); K5CHK(d->ws_tqk.ensure(L * 2 * D * 2));
+  K5CHK(d->ws_tvt.ensure(D * Lr * 2)); K5CHK(d->ws_to.ensure(L * D * 2)); K5CHK(d->ws_tff.ensure(L * FF * 2));
+  K5CHK(d->ws_pool_in.ensure((size_t)rup(d->cfg.in_text_dim2, 8) * 2)); K5CHK(d->ws_pool_lin.ensure(d->TD * 2));
+  K5CHK(d->ws_pool_f32.ensure(d->TD * 4)); K5CHK(d->ws_time.ensure(16)); K5CHK(d->ws_tfeat.ensure(D * 4));
+  K5CHK(d->ws_th1.ensure(d->TD * 4)); K5CHK(d->ws_temb.ensure(d->TD * 4)); K5CHK(d->ws_mod.ensure(d->mod_rows * 4));
+  K5CHK(d->ws_xp.ensure((size_t)N * d->KvisPad * 2)); K5CHK(d->ws_vis.ensure(N * D * 2)); K5CHK(d->ws_h.ensure(N * D * 2));
+  K5CHK(d->ws_qk.ensure((size_t)N * 2 * D * 2)); K5CHK(d->ws_vt.ensure(D * Nr * 2)); K5CHK(d->ws_o.ensure(N * D * 2));
+  K5CHK(d->ws_ff.ensure((size_t)N * FF * 2)); K5CHK(d->ws_ck.ensure(L * D * 2)); K5CHK(d->ws_cvt.ensure(D * Lr * 2));
+  K5CHK(d->ws_y.ensure((size_t)N * d->Fout * 2));
+  K5CHK(d->ws_vcos.ensure((size_t)N * 32 * 4)); K5CHK(d->ws_vsin.ensure((size_t)N * 32 * 4));
+  return K5_OK;
+}
+
+int prepare_rope(k5_dit* d, hipStream_t s, const k5_forward_args* a, int Tp, int Hp, int Wp) {
+  // visual tables: recompute only when the (shape, positions, scale) key changes — step-invariant (K15)
+  std::vector<int32_t> key;
+  key.insert(key.end(), a->pos_t, a->pos_t + Tp); key.insert(key.end(), a->pos_h, a->pos_h + Hp);
+  key.insert(key.end(), a->pos_w, a->pos_w + Wp);
+  const bool same = key == d->key_vpos && d->key_shape[0] == Tp && d->key_shape[1] == Hp && d->key_shape[2] == Wp &&
+                    !memcmp(d->key_scale, a->scale_factor, 12);
+  if (!same) {
+    K5CHK(d->ws_pos.ensure(key.size() * 4));
+    HIPCHK(hipMemcpyAsync(d->ws_pos.p, key.data(), key.size() * 4, hipMemcpyHostToDevice, s));
+    const int32_t* p = d->ws_pos.as<int32_t>();
+    const int n0 = d->cfg.axes_dims[0] / 2, n1 = d->cfg.axes_dims[1] / 2, n2 = d->cfg.axes_dims[2] / 2;
+    K5CHK(k5_launch_rope_table(d->ws_vcos.as<float>(), d->ws_vsin.as<float>(), p, p + Tp, p + Tp + Hp, Tp, Hp, Wp, n0, n1,
+                               n2, a->scale_factor[0], a->scale_factor[1], a->scale_factor[2], nullptr, s));
+    HIPCHK(hipStreamSynchronize(s));  // key vector is host memory reused below; once per shape only
+    d->key_vpos = key; d->key_shape[0] = Tp; d->key_shape[1] = Hp; d->key_shape[2] = Wp;
+    memcpy(d->key_scale, a->scale_factor, 12);
+  }
+  return K5_OK;
+}
+
+int prepare_text_rope(k5_dit* d, hipStream_t s, const k5_text_cond& c, const float** cosT, const float** sinT) {
+  // RoPE1D tables (nn.py:99-116) are step-invariant: cache per position vector (cond / null cond)
+  std::vector<int32_t> key(c.text_rope_pos, c.text_rope_pos + c.text_len);
+  for (auto& e : d->text_rope)
+    if (e.key == key) { *cosT = e.cosT.as<float>(); *sinT = e.sinT.as<float>(); return K5_OK; }
+  if (d->text_rope.size() >= 8) {
+    HIPCHK(hipStreamSynchronize(s));
+    for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
+    d->text_rope.clear();
+  }
+  d->text_rope.emplace_back();
+  auto& e = d->text_rope.back();
+  e.key = key;
+  K5CHK(e.pos.ensure(key.size() * 4)); K5CHK(e.cosT.ensure(key.size() * 32 * 4)); K5CHK(e.sinT.ensure(key.size() * 32 * 4));
+  HIPCHK(hipMemcpyAsync(e.pos.p, e.key.data(), key.size() * 4, hipMemcpyHostToDevice, s));
+  K5CHK(k5_launch_rope_table(e.cosT.as<float>(), e.sinT.as<float>(), e.pos.as<int32_t>(), nullptr, nullptr, c.text_len, 1,
+                             1, 32, 0, 0, 1.f, 1.f, 1.f, nullptr, s));
+  HIPCHK(hipStreamSynchronize(s));  // once per distinct prompt length
+  *cosT = e.cosT.as<float>(); *sinT = e.sinT.as<float>();
+  return K5_OK;
+}
+
+int to_bf16(k5_dit* d, hipStream_t s, const void* src, int dtype, size_t n, DevBuf& dst, const void** out) {
+  (void)d;
+  if (dtype == K5_BF16) { *out = src; return K5_OK; }
+  if (dtype != K5_F32) { k5_set_error("text embeddings must be f32 or bf16"); return K5_ERR_UNSUPPORTED; }
+  K5CHK(dst.ensure(n * 2));
+  K5CHK(k5_launch_cast_f32_bf16((const float*)src, dst.p, (int64_t)n, s));
+  *out = dst.p;
+  return K5_OK;
+}
+
+int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, float time, const float* x,
+                 int x_channels, void* out_velocity, hipStream_t s) {
+  const k5_dit_config& c = d->cfg;
+  if (!d->finalized) { k5_set_error("k5_dit_forward before k5_dit_finalize"); return K5_ERR_STATE; }
+  if (a->attention_type != 0) { k5_set_error("nabla attention not built yet"); return K5_ERR_UNSUPPORTED; }
+  if (c.patch_size[0] != 1 || c.patch_size[1] != 2 || c.patch_size[2] != 2) return K5_ERR_UNSUPPORTED;
+  const int Tp = a->T, Hp = a->H / 2, Wp = a->W / 2;
+  const int N = Tp * Hp * Wp, L = cond.text_len, D = d->D;
+  const int Cin = c.visual_cond ? 2 * c.in_visual_dim + 1 : c.in_visual_dim;
+  if (N <= 0 || L <= 0 || (a->H & 1) || (a->W & 1)) { k5_set_error("bad shapes"); return K5_ERR_ARG; }
+  if (x_channels != Cin && x_channels != c.in_visual_dim) { k5_set_error("x_channels must be %d or %d", Cin, c.in_visual_dim); return K5_ERR_ARG; }
+  K5CHK(ensure_workspaces(d, N, L));
+  K5CHK(prepare_rope(d, s, a, Tp, Hp, Wp));
+  const float *tcos = nullptr, *tsin = nullptr;
+  K5CHK(prepare_text_rope(d, s, cond, &tcos, &tsin));
+
+  const float* mod = d->ws_mod.as<float>();
+  // ---- before_text_transformer_blocks (dit.py:129-137) ----
+  {
+    Scope sc(d, s, "prologue");
+    const void* text_bf; const void* pool_bf;
+    K5CHK(to_bf16(d, s, cond.text_embed, cond.text_dtype, (size_t)L * c.in_text_dim, d->ws_text_in, &text_bf));
+    K5CHK(to_bf16(d, s, cond.pooled_embed, cond.text_dtype, (size_t)c.in_text_dim2, d->ws_pool_in, &pool_bf));
+    K5CHK(k5_launch_gemm_bf16(text_bf, d->text_w.p, d->text_b.as<float>(), d->ws_th.p, L, D, c.in_text_dim, c.in_text_dim,
+                              c.in_text_dim, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_ln_affine(d->ws_th.p, d->text_lnw.as<float>(), d->text_lnb.as<float>(), d->ws_text.p, nullptr, L, D, s));
+    K5CHK(k5_launch_gemm_bf16(pool_bf, d->pool_w.p, d->pool_b.as<float>(), d->ws_pool_lin.p, 1, d->TD, c.in_text_dim2,
+                              c.in_text_dim2, c.in_text_dim2, d->TD, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_ln_affine(d->ws_pool_lin.p, d->pool_lnw.as<float>(), d->pool_lnb.as<float>(), nullptr,
+                              d->ws_pool_f32.as<float>(), 1, d->TD, s));
+    K5CHK(k5_launch_time_features(time, d->ws_tfeat.as<float>(), D, s));
+    K5CHK(k5_launch_gemv_f32(d->ws_tfeat.as<float>(), d->time_w1.as<float>(), d->time_b1.as<float>(), d->ws_th1.as<float>(),
+                             d->TD, D, 0, nullptr, s));
+    K5CHK(k5_launch_gemv_f32(d->ws_th1.as<float>(), d->time_w2.as<float>(), d->time_b2.as<float>(), d->ws_temb.as<float>(),
+                             d->TD, d->TD, 1, d->ws_pool_f32.as<float>(), s));
+    // every Modulation layer of the network in one GEMV (they all consume the same time_embed)
+    K5CHK(k5_launch_gemv_f32(d->ws_temb.as<float>(), d->mod_w.as<float>(), d->mod_b.as<float>(), d->ws_mod.as<float>(),
+                             (int)d->mod_rows, d->TD, 1, nullptr, s));
+    K5CHK(k5_launch_patchify(x, d->ws_xp.p, a->T, a->H, a->W, x_channels, Cin, d->KvisPad, nullptr, s));
+    K5CHK(k5_launch_gemm_bf16(d->ws_xp.p, d->vis_w.p, d->vis_b.as<float>(), d->ws_vis.p, N, D, d->KvisPad, d->KvisPad,
+                              d->KvisPad, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+  }
+  // ---- text blocks (dit.py:170-171, 33-44) ----
+  for (int i = 0; i < c.num_text_blocks; ++i) {
+    const BlockW& b = d->tblocks[i];
+    const float* m = mod + b.mod_off;
+    K5CHK(ln_mod(d, s, d->ws_text.p, m, d->ws_th.p, L));
+    K5CHK(run_self_attention(d, s, b.self_attn, d->ws_th.p, L, d->ws_tqk.p, d->ws_tvt.p, d->ws_to.p, tcos, tsin, d->ws_text.p, m + 2 * D, "attn_text"));
+    K5CHK(ln_mod(d, s, d->ws_text.p, m + 3 * D, d->ws_th.p, L));
+    K5CHK(run_ff(d, s, b, d->ws_th.p, L, d->ws_tff.p, d->ws_text.p, m + 5 * D));
+  }
+  // ---- visual blocks (dit.py:176-178, 61-79) ----
+  for (int i = 0; i < c.num_visual_blocks; ++i) {
+    const BlockW& b = d->vblocks[i];
+    const float* m = mod + b.mod_off;
+    K5CHK(ln_mod(d, s, d->ws_vis.p, m, d->ws_h.p, N));
+    K5CHK(run_self_attention(d, s, b.self_attn, d->ws_h.p, N, d->ws_qk.p, d->ws_vt.p, d->ws_o.p, d->ws_vcos.as<float>(),
+                             d->ws_vsin.as<float>(), d->ws_vis.p, m + 2 * D, "attn_self"));
+    K5CHK(ln_mod(d, s, d->ws_vis.p, m + 3 * D, d->ws_h.p, N));
+    K5CHK(run_cross_attention(d, s, b.cross_attn, d->ws_h.p, N, d->ws_text.p, L, d->ws_qk.p, d->ws_ck.p, d->ws_cvt.p,
+                              d->ws_o.p, d->ws_vis.p, m + 5 * D));
+    K5CHK(ln_mod(d, s, d->ws_vis.p, m + 6 * D, d->ws_h.p, N));
+    K5CHK(run_ff(d, s, b, d->ws_h.p, N, d->ws_ff.p, d->ws_vis.p, m + 8 * D));
+  }
+  // ---- after_blocks / OutLayer (dit.py:149-153, nn.py:374-400) ----
+  {
+    Scope sc(d, s, "epilogue");
+    const float* m = mod + d->out_mod_off;  // [shift | scale]
+    K5CHK(k5_launch_ln_modulate(d->ws_vis.p, m + D, m, d->ws_h.p, N, D, D, D, s));
+    K5CHK(k5_launch_gemm_bf16(d->ws_h.p, d->out_w.p, d->out_b.as<float>(), d->ws_y.p, N, d->Fout, D, D, D, d->Fout,
+                              K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_unpatchify(d->ws_y.p, out_velocity, Tp, Hp, Wp, c.out_visual_dim, d->Fout, nullptr, s));
+  }
+  return K5_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: engine
+// ---------------------------------------------------------------------------------------------
+extern "C" int k5_dit_create(const k5_dit_config* cfg, k5_dit** out) {
+  g_err[0] = 0;
+  if (!cfg || !out) return K5_ERR_ARG;
+  const int hd = cfg->axes_dims[0] + cfg->axes_dims[1] + cfg->axes_dims[2];
+  if (hd != 64) { k5_set_error("head_dim = sum(axes_dims) must be 64 (got %d)", hd); return K5_ERR_UNSUPPORTED; }
+  if (cfg->model_dim % 64 || cfg->model_dim % 8 || cfg->ff_dim % 8 || cfg->time_dim % 8 || cfg->in_text_dim % 8 ||
+      cfg->in_text_dim2 % 8) {
+    k5_set_error("model_dim %% 64, ff_dim/time_dim/in_text_dim(2) %% 8 must be 0"); return K5_ERR_UNSUPPORTED;
+  }
+  k5_dit* d = new k5_dit();
+  d->cfg = *cfg;
+  d->D = cfg->model_dim; d->FF = cfg->ff_dim; d->TD = cfg->time_dim; d->Hh = cfg->model_dim / 64;
+  const int Cin = cfg->visual_cond ? 2 * cfg->in_visual_dim + 1 : cfg->in_visual_dim;
+  d->Kvis = cfg->patch_size[0] * cfg->patch_size[1] * cfg->patch_size[2] * Cin;
+  d->KvisPad = (int)rup(d->Kvis, 8);
+  d->Fout = cfg->patch_size[0] * cfg->patch_size[1] * cfg->patch_size[2] * cfg->out_visual_dim;
+  expected_keys(*cfg, d->expected);
+  *out = d;
+  return K5_OK;
+}
+
+extern "C" void k5_dit_destroy(k5_dit* d) {
+  if (!d) return;
+  // DevBufs are released with the process; explicit frees for long-lived hosts:
+  DevBuf* all[] = {&d->time_w1, &d->time_b1, &d->time_w2, &d->time_b2, &d->text_w, &d->text_b, &d->text_lnw, &d->text_lnb,
+                   &d->pool_w, &d->pool_b, &d->pool_lnw, &d->pool_lnb, &d->vis_w, &d->vis_b, &d->out_w, &d->out_b, &d->mod_w,
+                   &d->mod_b, &d->ws_text_in, &d->ws_text, &d->ws_th, &d->ws_tqk, &d->ws_tvt, &d->ws_to, &d->ws_tff,
+                   &d->ws_pool_in, &d->ws_pool_lin, &d->ws_pool_f32, &d->ws_time, &d->ws_tfeat, &d->ws_th1, &d->ws_temb,
+                   &d->ws_mod, &d->ws_xp, &d->ws_vis, &d->ws_h, &d->ws_qk, &d->ws_vt, &d->ws_o, &d->ws_ff, &d->ws_ck,
+                   &d->ws_cvt, &d->ws_y, &d->ws_vcos, &d->ws_vsin, &d->ws_pos, &d->ws_vel_c,
+                   &d->ws_vel_u};
+  for (DevBuf* b : all) b->release();
+  for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
+  auto rel_attn = [](AttnW& a) {
+    DevBuf* bs[] = {&a.wqk, &a.wq, &a.wk, &a.wv, &a.wo, &a.bqk, &a.bq, &a.bk, &a.bv, &a.bo, &a.norm};
+    for (DevBuf* b : bs) b->release();
+  };
+  for (auto* v : {&d->tblocks, &d->vblocks})
+    for (auto& b : *v) { rel_attn(b.self_attn); rel_attn(b.cross_attn); b.w1.release(); b.w2.release(); }
+  delete d;
+}
+
+extern "C" int k5_dit_load_tensor(k5_dit* d, const char* key, const void* host_ptr, int dtype, const int64_t* shape, int rank) {
+  g_err[0] = 0;
+  if (!d || !key || !host_ptr || rank < 1 || rank > 2) return K5_ERR_ARG;
+  if (d->finalized) { k5_set_error("load_tensor after finalize"); return K5_ERR_STATE; }
+  bool known = false;
+  for (auto& e : d->expected) if (e == key) { known = true; break; }
+  if (!known) { k5_set_error("unexpected key in state_dict: %s", key); return K5_ERR_KEY; }
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < rank; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  t.data.resize(n);
+  // hipMemcpyDefault: the source may be host memory (safetensors on CPU) or device memory
+  if (dtype == K5_F32) HIPCHK(hipMemcpy(t.data.data(), host_ptr, n * 4, hipMemcpyDefault));
+  else if (dtype == K5_BF16 || dtype == K5_F16) {
+    std::vector<uint16_t> raw(n);
+    HIPCHK(hipMemcpy(raw.data(), host_ptr, n * 2, hipMemcpyDefault));
+    if (dtype == K5_BF16)
+      for (size_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)raw[i] << 16; memcpy(&t.data[i], &u, 4); }
+    else
+      for (size_t i = 0; i < n; ++i) t.data[i] = half_to_float(raw[i]);
+  } else return K5_ERR_ARG;
+  d->staged[key] = std::move(t);
+  return K5_OK;
+}
+
+extern "C" int k5_dit_missing_keys(k5_dit* d) {
+  if (!d) return -1;
+  int miss = 0; std::string names;
+  for (auto& e : d->expected)
+    if (!d->staged.count(e)) { if (miss < 8) names += e + " "; ++miss; }
+  if (miss) k5_set_error("missing %d key(s): %s", miss, names.c_str());
+  return d->finalized ? 0 : miss;
+}
+
+extern "C" int k5_dit_finalize(k5_dit* d) {
+  g_err[0] = 0;
+  if (!d) return K5_ERR_ARG;
+  if (d->finalized) return K5_OK;
+  if (k5_dit_missing_keys(d)) return K5_ERR_KEY;
+  const k5_dit_config& c = d->cfg;
+  const size_t D = d->D, FF = d->FF, TD = d->TD;
+  auto shape_is = [&](const char* k, size_t r, size_t cc) -> bool {
+    const HostTensor* t = find(d, k);
+    const bool ok = t && ((cc == 0 && t->shape.size() == 1 && (size_t)t->shape[0] == r) ||
+                          (cc && t->shape.size() == 2 && (size_t)t->shape[0] == r && (size_t)t->shape[1] == cc));
+    if (!ok) k5_set_error("shape mismatch for %s", k);
+    return ok;
+  };
+  if (!shape_is("time_embeddings.in_layer.weight", TD, D) || !shape_is("time_embeddings.out_layer.weight", TD, TD) ||
+      !shape_is("text_embeddings.in_layer.weight", D, c.in_text_dim) ||
+      !shape_is("pooled_text_embeddings.in_layer.weight", TD, c.in_text_dim2) ||
+      !shape_is("visual_embeddings.in_layer.weight", D, d->Kvis) || !shape_is("out_layer.out_layer.weight", d->Fout, D) ||
+      !shape_is("out_layer.modulation.out_layer.weight", 2 * D, TD))
+    return K5_ERR_ARG;
+  K5CHK(upload_f32(d->time_w1, find(d, "time_embeddings.in_layer.weight")->data.data(), TD * D));
+  K5CHK(upload_f32(d->time_b1, find(d, "time_embeddings.in_layer.bias")->data.data(), TD));
+  K5CHK(upload_f32(d->time_w2, find(d, "time_embeddings.out_layer.weight")->data.data(), TD * TD));
+  K5CHK(upload_f32(d->time_b2, find(d, "time_embeddings.out_layer.bias")->data.data(), TD));
+  K5CHK(upload_bf16(d->text_w, find(d, "text_embeddings.in_layer.weight")->data.data(), D, c.in_text_dim, c.in_text_dim));
+  K5CHK(upload_bias_bf16r(d->text_b, find(d, "text_embeddings.in_layer.bias")->data.data(), D));
+  K5CHK(upload_f32(d->text_lnw, find(d, "text_embeddings.norm.weight")->data.data(), D));
+  K5CHK(upload_f32(d->text_lnb, find(d, "text_embeddings.norm.bias")->data.data(), D));
+  K5CHK(upload_bf16(d->pool_w, find(d, "pooled_text_embeddings.in_layer.weight")->data.data(), TD, c.in_text_dim2, c.in_text_dim2));
+  K5CHK(upload_bias_bf16r(d->pool_b, find(d, "pooled_text_embeddings.in_layer.bias")->data.data(), TD));
+  K5CHK(upload_f32(d->pool_lnw, find(d, "pooled_text_embeddings.norm.weight")->data.data(), TD));
+  K5CHK(upload_f32(d->pool_lnb, find(d, "pooled_text_embeddings.norm.bias")->data.data(), TD));
+  K5CHK(upload_bf16(d->vis_w, find(d, "visual_embeddings.in_layer.weight")->data.data(), D, d->Kvis, d->KvisPad));
+  K5CHK(upload_bias_bf16r(d->vis_b, find(d, "visual_embeddings.in_layer.bias")->data.data(), D));
+  K5CHK(upload_bf16(d->out_w, find(d, "out_layer.out_layer.weight")->data.data(), d->Fout, D, D));
+  K5CHK(upload_bias_bf16r(d->out_b, find(d, "out_layer.out_layer.bias")->data.data(), d->Fout));
+
+  // stacked modulation
+  d->mod_rows = (size_t)c.num_text_blocks * 6 * D + (size_t)c.num_visual_blocks * 9 * D + 2 * D;
+  std::vector<float> mw(d->mod_rows * TD), mb(d->mod_rows);
+  size_t off = 0;
+  auto put_mod = [&](const std::string& p, size_t rows) -> bool {
+    const HostTensor *w = find(d, p + ".weight"), *b = find(d, p + ".bias");
+    if (!w || w->data.size() != rows * TD || b->data.size() != rows) { k5_set_error("shape mismatch for %s", p.c_str()); return false; }
+    memcpy(mw.data() + off * TD, w->data.data(), rows * TD * 4);
+    memcpy(mb.data() + off, b->data.data(), rows * 4);
+    off += rows;
+    return true;
+  };
+  d->tblocks.resize(c.num_text_blocks); d->vblocks.resize(c.num_visual_blocks);
+  for (int i = 0; i < c.num_text_blocks; ++i) {
+    const std::string p = "text_transformer_blocks." + std::to_string(i);
+    d->tblocks[i].mod_off = off;
+    if (!put_mod(p + ".text_modulation.out_layer", 6 * D)) return K5_ERR_ARG;
+    K5CHK(pack_attn(d, p + ".self_attention", d->tblocks[i].self_attn, true));
+    K5CHK(upload_bf16(d->tblocks[i].w1, find(d, p + ".feed_forward.in_layer.weight")->data.data(), FF, D, D));
+    K5CHK(upload_bf16(d->tblocks[i].w2, find(d, p + ".feed_forward.out_layer.weight")->data.data(), D, FF, FF));
+  }
+  for (int i = 0; i < c.num_visual_blocks; ++i) {
+    const std::string p = "visual_transformer_blocks." + std::to_string(i);
+    d->vblocks[i].mod_off = off;
+    if (!put_mod(p + ".visual_modulation.out_layer", 9 * D)) return K5_ERR_ARG;
+    K5CHK(pack_attn(d, p + ".self_attention", d->vblocks[i].self_attn, true));
+    K5CHK(pack_attn(d, p + ".cross_attention", d->vblocks[i].cross_attn, false));
+    K5CHK(upload_bf16(d->vblocks[i].w1, find(d, p + ".feed_forward.in_layer.weight")->data.data(), FF, D, D));
+    K5CHK(upload_bf16(d->vblocks[i].w2, find(d, p + ".feed_forward.out_layer.weight")->data.data(), D, FF, FF));
+  }
+  d->out_mod_off = off;
+  if (!put_mod("out_layer.modulation.out_layer", 2 * D)) return K5_ERR_ARG;
+  K5CHK(upload_f32(d->mod_w, mw.data(), mw.size()));
+  K5CHK(upload_f32(d->mod_b, mb.data(), mb.size()));
+  d->staged.clear();
+  d->finalized = true;
+  return K5_OK;
+}
+
+extern "C" int k5_dit_forward(k5_dit* d, const k5_forward_args* a, void* out_velocity, void* stream) {
+  g_err[0] = 0;
+  if (!d || !a || !out_velocity || !a->x) return K5_ERR_ARG;
+  const int st = forward_impl(d, a, a->cond, a->time, a->x, a->x_channels, out_velocity, (hipStream_t)stream);
+  return st;
+}
+
+extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
+  g_err[0] = 0;
+  if (!d || !a || !a->latent || !a->sigmas || a->num_steps <= 0) return K5_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const k5_dit_config& c = d->cfg;
+  const int64_t n = (int64_t)a->fwd.T * a->fwd.H * a->fwd.W * c.out_visual_dim;
+  if (c.in_visual_dim != c.out_visual_dim) return K5_ERR_UNSUPPORTED;
+  K5CHK(d->ws_vel_c.ensure(n * 2));
+  const bool cfg_on = fabsf(a->guidance_weight - 1.0f) > 1e-6f;  // generation_utils.py:63
+  if (cfg_on) K5CHK(d->ws_vel_u.ensure(n * 2));
+  for (int i = 0; i < a->num_steps; ++i) {
+    const float t1000 = a->sigmas[i] * 1000.0f;          // t * 1000, fp32 (:57)
+    const float dt = a->sigmas[i + 1] - a->sigmas[i];    // torch.diff(timesteps) (:105)
+    K5CHK(forward_impl(d, &a->fwd, a->fwd.cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_c.p, s));
+    if (cfg_on) K5CHK(forward_impl(d, &a->fwd, a->null_cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_u.p, s));
+    {
+      Scope sc(d, s, "elementwise");
+      K5CHK(k5_launch_cfg_euler(a->latent, d->ws_vel_c.p, cfg_on ? d->ws_vel_u.p : nullptr, a->guidance_weight, dt, n, s));
+    }
+  }
+  return K5_OK;
+}
+
+extern "C" int k5_dit_set_profiling(k5_dit* d, int enabled) { if (!d) return K5_ERR_ARG; d->profiling = enabled != 0; return K5_OK; }
+extern "C" int k5_dit_reset_profile(k5_dit* d) { if (!d) return K5_ERR_ARG; drain_profile(d); d->prof.clear(); return K5_OK; }
+extern "C" int k5_dit_get_profile(k5_dit* d, const char* family, double* total_ms, int64_t* launches) {
+  if (!d || !family) return K5_ERR_ARG;
+  drain_profile(d);
+  auto it = d->prof.find(family);
+  if (total_ms) *total_ms = it == d->prof.end() ? 0.0 : it->second.ms;
+  if (launches) *launches = it == d->prof.end() ? 0 : it->second.n;
+  return K5_OK;
+}

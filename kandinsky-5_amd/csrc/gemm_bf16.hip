@@ -1,0 +1,196 @@
+// gemm_bf16.hip — C[M][N] = A[M][K] · W[N][K]^T (+bias) with fused epilogues, bf16 in, fp32
+// accumulate on MFMA 32x32x16, bf16 out.  Both operands are K-contiguous ("NT").
+//
+// Replaces the autocast nn.Linear call sites of the reference DiT (kandinsky/models/nn.py:
+// get_qkv :180-191/:233-244/:317-326, out_l :204-206/:282-284/:339-341, FeedForward :352-361,
+// TextEmbeddings.in_layer :71, VisualEmbeddings.in_layer :96, OutLayer.out_layer :382) and fuses
+// apply_gate_sum (nn.py:30-33) and nn.GELU (nn.py:356) into the epilogue.
+//
+// Structure (gfx950): 128x128x64 block tile, 256 threads = 4 waves (2 along M x 2 along N), each
+// wave a 64x64 sub-tile as 2x2 MFMA 32x32 tiles.  The MFMA "A" operand is the W tile (rows = n)
+// and the "B" operand is the A tile (rows = m), so an accumulator lane owns ONE token row m and
+// 4-element runs of consecutive n: row reductions over n (RMSNorm) and adjacent-pair ops (RoPE)
+// stay in-lane, and the C store is 8 B per lane.  LDS tiles are [128][64] bf16 with the 16-B
+// chunk swizzle of k5_common.h (conflict-free ds_read_b128), double buffered, register staged:
+// the global loads of tile k+1 are issued before the MFMAs of tile k and written to LDS after.
+#include "k5_common.h"
+#include "k5_kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 128;  // [128 rows][64 bf16]
+
+struct GemmP {
+  const bf16_t* A; const bf16_t* W; bf16_t* C;
+  const float* bias;      // per n (or per m when BIAS_M), fp32 holding bf16-rounded values; may be null
+  const bf16_t* resid;    // EPI_GATE: residual stream [M][ldr]
+  const float* gate;      // EPI_GATE: per-n gate (fp32)
+  int M, N, K, lda, ldw, ldc, ldr;
+  int tiles_m, tiles_n;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  char* sA = smem;                   // 2 buffers
+  char* sW = smem + 2 * TILE_BYTES;  // 2 buffers
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
+
+  // block -> tile: XCD-contiguous ranges, then 8-row groups so that the ~64 tiles resident on
+  // one XCD form an 8x8 patch sharing 8 A panels and 8 W panels in that XCD's L2.
+  const int nblk = p.tiles_m * p.tiles_n;
+  int lid = xcd_remap(blockIdx.x, nblk);
+  constexpr int GM = 8;
+  const int per_group = GM * p.tiles_n;
+  const int g = lid / per_group, first_m = g * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int tm = first_m + (lid % per_group) % gsz;
+  const int tn = (lid % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // loader mapping: 1024 16-B chunks per operand tile, 4 per thread
+  int ld_row[4], ld_c[4];
+  const bf16_t* pa[4]; const bf16_t* pw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + 256 * i;
+    ld_row[i] = q >> 3; ld_c[i] = q & 7;
+    pa[i] = p.A + (size_t)min(m0 + ld_row[i], p.M - 1) * p.lda + 8 * ld_c[i];
+    pw[i] = p.W + (size_t)min(n0 + ld_row[i], p.N - 1) * p.ldw + 8 * ld_c[i];
+  }
+  u32x4 ra[4], rw[4];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = (k0 + 8 * ld_c[i]) < p.K;
+      const u32x4 z = {0, 0, 0, 0};
+      ra[i] = ok ? *reinterpret_cast<const u32x4*>(pa[i] + k0) : z;
+      rw[i] = ok ? *reinterpret_cast<const u32x4*>(pw[i] + k0) : z;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = lds_swz(ld_row[i], ld_c[i]);
+      *reinterpret_cast<u32x4*>(sA + buf * TILE_BYTES + off) = ra[i];
+      *reinterpret_cast<u32x4*>(sW + buf * TILE_BYTES + off) = rw[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    const char* cA = sA + buf * TILE_BYTES;
+    const char* cW = sW + buf * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = 2 * ks + hi;
+      bf16x8 fw[2], fx[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        fw[i] = *reinterpret_cast<const bf16x8*>(cW + lds_swz(wn * 64 + i * 32 + l31, c));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fx[j] = *reinterpret_cast<const bf16x8*>(cA + lds_swz(wm * 64 + j * 32 + l31, c));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fw[i], fx[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns token row m, 4 consecutive n per register group ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wm * 64 + j * 32 + l31;
+    if (m >= p.M) continue;
+    float bias_m = 0.f;
+    if (EPI == K5_EPI_BIAS_M && p.bias) bias_m = p.bias[m];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int n = n0 + wn * 64 + i * 32 + 8 * rg + 4 * hi;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e];
+        const bool full = (n + 3 < p.N);
+        if (EPI == K5_EPI_BIAS_M) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bias_m;
+        } else if (p.bias) {
+          if (full) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
+          }
+        }
+        if (EPI == K5_EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(bf_round(v[e]));
+        }
+        if (EPI == K5_EPI_GATE) {
+          const bf16_t* rp = p.resid + (size_t)m * p.ldr + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) v[e] = bf2f(rp[e]) + p.gate[n + e] * bf_round(v[e]);
+        }
+        bf16_t* cp = p.C + (size_t)m * p.ldc + n;
+        if (full && ((p.ldc & 3) == 0)) {
+          u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(cp) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = f2bf(v[e]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Host launcher (C++ linkage, used by the C-ABI layer in k5_api.hip and by the engine).
+int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K,
+                        int lda, int ldw, int ldc, int epi, const void* resid, int ldr,
+                        const float* gate, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return K5_ERR_ARG;
+  if ((K & 7) || (lda & 7) || (ldw & 7)) return K5_ERR_ALIGN;  // 16-B aligned rows
+  if (epi == K5_EPI_GATE && (!resid || !gate)) return K5_ERR_ARG;
+  GemmP p;
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = (bf16_t*)C; p.bias = bias;
+  p.resid = (const bf16_t*)resid; p.gate = gate;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  switch (epi) {
+    case K5_EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_kernel<K5_EPI_BIAS>, grid, block, 0, stream, p); break;
+    case K5_EPI_BIAS_M: hipLaunchKernelGGL(gemm_bf16_kernel<K5_EPI_BIAS_M>, grid, block, 0, stream, p); break;
+    case K5_EPI_GELU: hipLaunchKernelGGL(gemm_bf16_kernel<K5_EPI_GELU>, grid, block, 0, stream, p); break;
+    case K5_EPI_GATE: hipLaunchKernelGGL(gemm_bf16_kernel<K5_EPI_GATE>, grid, block, 0, stream, p); break;
+    default: return K5_ERR_ARG;
+  }
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}

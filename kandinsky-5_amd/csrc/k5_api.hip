@@ -1,0 +1,82 @@
+// k5_api.hip — kernel-level entry points of the C ABI (include/k5.h): thin extern "C" shims over the
+// C++ launchers so that parity tests and host glue can call every kernel with raw device pointers.
+#include "k5_kernels.h"
+
+void k5_set_error(const char* fmt, ...);
+
+static int ret(int st, const char* what) {
+  if (st != K5_OK) {
+    const hipError_t e = hipGetLastError();
+    k5_set_error("%s: status %d (%s)", what, st, e == hipSuccess ? "argument/alignment" : hipGetErrorString(e));
+  }
+  return st;
+}
+
+extern "C" {
+
+int k5_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
+                 int ldc, int epilogue, const void* resid, int ldr, const float* gate, void* stream) {
+  return ret(k5_launch_gemm_bf16(A, W, bias, C, M, N, K, lda, ldw, ldc, epilogue, resid, ldr, gate, (hipStream_t)stream),
+             "k5_gemm_bf16");
+}
+
+int k5_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                      int ldk, int ldvt, int ldo, const int32_t* kv_nb, const int32_t* kv_idx, int nkb_stride,
+                      void* stream) {
+  return ret(k5_launch_attention_bf16(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, kv_nb, kv_idx, nkb_stride,
+                                      (hipStream_t)stream), "k5_attention_bf16");
+}
+
+int k5_ln_modulate_bf16(const void* x, const float* scale, const float* shift, void* out, int rows, int D, int ldx,
+                        int ldo, void* stream) {
+  return ret(k5_launch_ln_modulate(x, scale, shift, out, rows, D, ldx, ldo, (hipStream_t)stream), "k5_ln_modulate_bf16");
+}
+
+int k5_rmsnorm_rope_bf16(void* x, const float* weight, const float* cos_tab, const float* sin_tab, int rows, int H,
+                         int ld, int heads_per_weight, int rope_heads, void* stream) {
+  const int32_t hc[2] = {heads_per_weight, rope_heads};
+  return ret(k5_launch_rmsnorm_rope(x, weight, cos_tab, sin_tab, rows, H, ld, hc, (hipStream_t)stream),
+             "k5_rmsnorm_rope_bf16");
+}
+
+int k5_gate_sum_bf16(const void* x, const void* y, const float* gate, void* out, int rows, int D, void* stream) {
+  return ret(k5_launch_gate_sum(x, y, gate, out, rows, D, (hipStream_t)stream), "k5_gate_sum_bf16");
+}
+
+int k5_gemv_f32(const float* x, const float* W, const float* b, float* y, int N, int K, int silu_in, const float* add,
+                void* stream) {
+  return ret(k5_launch_gemv_f32(x, W, b, y, N, K, silu_in, add, (hipStream_t)stream), "k5_gemv_f32");
+}
+
+int k5_time_features_f32(float t, float* out, int D, void* stream) {
+  return ret(k5_launch_time_features(t, out, D, (hipStream_t)stream), "k5_time_features_f32");
+}
+
+int k5_ln_affine_bf16(const void* x, const float* w, const float* b, void* out_bf16, float* out_f32, int rows, int D,
+                      void* stream) {
+  return ret(k5_launch_ln_affine(x, w, b, out_bf16, out_f32, rows, D, (hipStream_t)stream), "k5_ln_affine_bf16");
+}
+
+int k5_rope_table_f32(float* cos_tab, float* sin_tab, const int32_t* pos_t, const int32_t* pos_h, const int32_t* pos_w,
+                      int T, int H, int W, int n0, int n1, int n2, float s0, float s1, float s2,
+                      const int32_t* tok_perm, void* stream) {
+  return ret(k5_launch_rope_table(cos_tab, sin_tab, pos_t, pos_h, pos_w, T, H, W, n0, n1, n2, s0, s1, s2, tok_perm,
+                                  (hipStream_t)stream), "k5_rope_table_f32");
+}
+
+int k5_patchify_bf16(const float* x, void* out, int T, int H, int W, int x_channels, int Cin_total, int Kpad,
+                     const int32_t* tok_perm, void* stream) {
+  return ret(k5_launch_patchify(x, out, T, H, W, x_channels, Cin_total, Kpad, tok_perm, (hipStream_t)stream),
+             "k5_patchify_bf16");
+}
+
+int k5_unpatchify_bf16(const void* x, void* out, int T, int Hp, int Wp, int C, int ldx, const int32_t* tok_perm,
+                       void* stream) {
+  return ret(k5_launch_unpatchify(x, out, T, Hp, Wp, C, ldx, tok_perm, (hipStream_t)stream), "k5_unpatchify_bf16");
+}
+
+int k5_cfg_euler(float* img, const void* v_cond, const void* v_uncond, float w, float dt, int64_t n, void* stream) {
+  return ret(k5_launch_cfg_euler(img, v_cond, v_uncond, w, dt, n, (hipStream_t)stream), "k5_cfg_euler");
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// k5_common.h — shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libk5.
+// wave = 64 lanes, MFMA 32x32x16 bf16, LDS 160 KiB/CU.  No portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define K5_DEV __device__ __forceinline__
+
+// ---- bf16 <-> f32 (round-to-nearest-even, hardware v_cvt_pk_bf16_f32 on gfx950) ----
+K5_DEV float bf2f(bf16_t v) { return (float)v; }
+K5_DEV bf16_t f2bf(float v) { return (bf16_t)v; }
+K5_DEV float bfbits2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+K5_DEV uint32_t pack_bf16x2(float lo, float hi) {
+  f32x2 t = {lo, hi};
+  bf16x2 r = __builtin_convertvector(t, bf16x2);
+  return __builtin_bit_cast(uint32_t, r);
+}
+K5_DEV float bf_round(float v) { return (float)(bf16_t)v; }
+
+// MFMA 32x32x16 bf16: D[i][j] += sum_k A[i][k] B[k][j]
+//   A operand: lane l holds A[i = l&31][k = 8*(l>>5) + 0..7]
+//   B operand: lane l holds B[k = 8*(l>>5) + 0..7][j = l&31]
+//   C/D:       lane l, reg r holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31]
+K5_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+K5_DEV int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// LDS tile of [rows][64] bf16 (128 B rows, eight 16-B chunks per row).  Chunk swizzle
+// c' = c ^ ((row >> 1) & 7): two rows share one 256-B bank row, so (row&1, c') covers all
+// sixteen 16-B slots for any 16 rows distinct mod 16 -> ds_read_b128 fragment reads of one
+// k-chunk from 16 different rows are conflict free (guide §2 / T2).
+K5_DEV int lds_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+K5_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+K5_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU (nn.GELU default, approximate='none'), fp32 math
+K5_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+K5_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// bijective XCD-aware block remap (guide T1): physical block b runs on XCD b%8; give each XCD a
+// contiguous range of logical tiles so that neighbours share operand panels in that XCD's L2.
+K5_DEV int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}

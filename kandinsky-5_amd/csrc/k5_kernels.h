@@ -1,0 +1,57 @@
+// k5_kernels.h — internal C++ launchers shared by the C-ABI layer (k5_api.hip) and the engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "k5.h"  // status codes, epilogue ids (public C ABI)
+
+int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K,
+                        int lda, int ldw, int ldc, int epi, const void* resid, int ldr,
+                        const float* gate, hipStream_t stream);
+
+// Attention: O[q][h*64+d] = softmax(Q K^T / 8) V, bf16, head_dim 64, non-causal.
+//   Q  [q_len][ldq]  (head h at columns h*64..), K [kv_len][ldk], Vt [H*64][ldvt] = V transposed
+//   (row h*64+d, column = key), O [q_len][ldo].
+//   kv_blocks (optional, NABLA): for head h, query block qb (64 rows): count at
+//   kv_nb[h*nqb + qb], indices at kv_idx[(h*nqb + qb)*nkb + i] (64-key block ids).
+int k5_launch_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+                             int kv_len, int ldq, int ldk, int ldvt, int ldo, const int32_t* kv_nb,
+                             const int32_t* kv_idx, int nkb_stride, hipStream_t stream);
+
+// K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
+int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,
+                          int D, int ldx, int ldo, hipStream_t stream);
+// K5 + K3: in place over [rows][ld] (H heads of 64): RMSNorm(eps, weight) -> bf16 -> RoPE (optional)
+//   x holds H heads per row; head h uses weight[(h / heads_per_weight)*64 ..]; RoPE (cos/sin [rows][32]) on heads
+//   < rope_heads.  heads_cfg = host pointer to {heads_per_weight, rope_heads} or null (= {H, H}).
+int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cos, const float* sin, int rows,
+                           int H, int ld, const int32_t* heads_cfg, hipStream_t stream);
+// K15: cos/sin tables [T*H*W][n0+n1+n2] for RoPE3D (RoPE1D: H=W=1, n1=n2=0), optional token permutation
+int k5_launch_rope_table(float* cosT, float* sinT, const int32_t* p0, const int32_t* p1, const int32_t* p2, int T,
+                         int H, int W, int n0, int n1, int n2, float s0, float s1, float s2, const int32_t* tok_perm,
+                         hipStream_t stream);
+// K2 (standalone form): out = bf16(x + gate * y)
+int k5_launch_gate_sum(const void* x, const void* y, const float* gate, void* out, int rows, int D,
+                       hipStream_t stream);
+// fp32 GEMV with optional SiLU on the input: y[n] = sum_k act(x[k]) * W[n][k] + b[n]   (K11, K12)
+int k5_launch_gemv_f32(const float* x, const float* W, const float* b, float* y, int N, int K, int silu_in,
+                       const float* add, hipStream_t stream);
+// sinusoidal time features (K12): out[0..D/2) = cos(t f_i), out[D/2..D) = sin(t f_i)
+int k5_launch_time_features(float t, float* out, int D, hipStream_t stream);
+// LayerNorm with affine over bf16 rows (K13): out = bf16(LN(x) * w + b); also fp32 output option
+int k5_launch_ln_affine(const void* x, const float* w, const float* b, void* out_bf16, float* out_f32, int rows,
+                        int D, hipStream_t stream);
+// patchify (K14) fp32 latent (T,H,W,C) [+ zero visual_cond channels] -> bf16 [Ntok][Kpad], optional
+// token permutation (fractal order, K16)
+int k5_launch_patchify(const float* x, void* out, int T, int H, int W, int C, int Cin_total, int Kpad,
+                       const int32_t* tok_perm, hipStream_t stream);
+// un-patchify (K17 tail): [Ntok][C*4] bf16 (feature order c,ph,pw) -> (T,H,W,C) bf16, token perm optional
+int k5_launch_unpatchify(const void* x, void* out, int T, int Hp, int Wp, int C, int ldx,
+                         const int32_t* tok_perm, hipStream_t stream);
+// K18: CFG combine + Euler.  v = cond (bf16) or bf16(u + bf16(w * bf16(c-u))); img += float(bf16(dt*v))
+int k5_launch_cfg_euler(float* img, const void* v_cond, const void* v_uncond, float w, float dt, int64_t n,
+                        hipStream_t stream);
+// fp32 -> bf16 cast, bf16 -> fp32
+int k5_launch_cast_f32_bf16(const float* x, void* out, int64_t n, hipStream_t stream);
+
+const char* k5_hip_error_string();

@@ -1,0 +1,363 @@
+// small_ops.hip — HBM-bound elementwise / normalisation kernels and the fp32 "island" ops of the
+// Kandinsky-5 DiT for gfx950.  All bf16 traffic is 16 B per lane (8 x bf16), coalesced over the
+// feature axis; row statistics are wave-level (64-lane) shuffles.  Reference call sites:
+//   apply_scale_shift_norm  kandinsky/models/nn.py:25-28      -> ln_modulate_kernel     (K1)
+//   apply_gate_sum          nn.py:30-33                        -> gate_sum_kernel        (K2)
+//   norm_qk + apply_rotary  nn.py:193-197, 35-40               -> rmsnorm_rope_kernel    (K5+K3)
+//   Modulation / TimeEmbeddings linears (fp32 islands) nn.py:56-61,161-164 -> gemv_f32_kernel
+//   TimeEmbeddings sinusoid nn.py:57-58                        -> time_features_kernel
+//   TextEmbeddings.norm     nn.py:67,72                        -> ln_affine_kernel       (K13)
+//   VisualEmbeddings patchify nn.py:81-95 (+ fractal_flatten models/utils.py:31-41) -> patchify_kernel
+//   OutLayer un-patchify    nn.py:384-399 (+ fractal_unflatten :44-51)             -> unpatchify_kernel
+//   CFG combine + Euler     generation_utils.py:74-76,128      -> cfg_euler_kernel       (K18)
+//   RoPE1D/RoPE3D tables    nn.py:99-150                        -> rope_table_kernel      (K15)
+#include "k5_common.h"
+#include "k5_kernels.h"
+
+namespace {
+
+constexpr int MAXC = 4;  // 16-B chunks per lane per row: D <= 64*8*4 = 2048
+
+// ---------------------------------------------------------------------------------------------
+// K1: one wave per row
+template <bool AFFINE>
+__global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, const float* __restrict__ a,
+                                                 const float* __restrict__ b, bf16_t* __restrict__ out,
+                                                 float* __restrict__ out_f32, int rows, int D, int ldx, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = D >> 3;
+  float v[MAXC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)row * ldx + 8 * ch);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[i][2 * j] = __uint_as_float(raw[j] << 16);
+        v[i][2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u);
+        sum += v[i][2 * j] + v[i][2 * j + 1];
+      }
+    }
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    if (lane + 64 * i < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      float o[8];
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(a + 8 * ch), a1 = *reinterpret_cast<const f32x4*>(a + 8 * ch + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + 8 * ch), b1 = *reinterpret_cast<const f32x4*>(b + 8 * ch + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float n = (v[i][j] - mean) * rstd;
+        const float aj = j < 4 ? a0[j] : a1[j - 4], bj = j < 4 ? b0[j] : b1[j - 4];
+        // K1: n * (scale + 1) + shift ; K13: n * weight + bias
+        o[j] = AFFINE ? __fadd_rn(__fmul_rn(n, aj), bj) : __fadd_rn(__fmul_rn(n, aj + 1.0f), bj);
+      }
+      if (out) {
+        u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + 8 * ch) = pk;
+      }
+      if (out_f32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out_f32[(size_t)row * D + 8 * ch + j] = bf_round(o[j]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 + K3: one thread per 16-B chunk (8 of the 64 head elements); 8-lane groups own one head.
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ x, const float* __restrict__ weight,
+                                                           const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                           int rows, int H, int heads_per_weight, int ld, int rope_heads) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)rows * H * 8;
+  const bool valid = gid < total;
+  const int64_t g = valid ? gid : total - 1;
+  const int c = (int)(g & 7);
+  const int head = (int)((g >> 3) % H);
+  const int row = (int)((g >> 3) / H);
+  bf16_t* px = x + (size_t)row * ld + head * 64 + 8 * c;
+  const u32x4 raw = *reinterpret_cast<const u32x4*>(px);
+  float v[8];
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[2 * j] = __uint_as_float(raw[j] << 16);
+    v[2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u);
+    sq += v[2 * j] * v[2 * j] + v[2 * j + 1] * v[2 * j + 1];
+  }
+  sq += __shfl_xor(sq, 1, 64);
+  sq += __shfl_xor(sq, 2, 64);
+  sq += __shfl_xor(sq, 4, 64);
+  const float rs = rsqrtf(sq * (1.0f / 64.0f) + 1.1920928955078125e-07f);  // eps = finfo(fp32).eps
+  const float* w = weight + (head / heads_per_weight) * 64 + 8 * c;
+  float y[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) y[j] = bf_round(__fmul_rn(__fmul_rn(v[j], rs), w[j]));  // .type_as(q)
+  if (cosT && head < rope_heads) {
+    const f32x4 cs = *reinterpret_cast<const f32x4*>(cosT + (size_t)row * 32 + 4 * c);
+    const f32x4 sn = *reinterpret_cast<const f32x4*>(sinT + (size_t)row * 32 + 4 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x0 = y[2 * j], x1 = y[2 * j + 1];
+      y[2 * j] = __fadd_rn(__fmul_rn(cs[j], x0), __fmul_rn(-sn[j], x1));
+      y[2 * j + 1] = __fadd_rn(__fmul_rn(sn[j], x0), __fmul_rn(cs[j], x1));
+    }
+  }
+  if (valid) {
+    u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+    *reinterpret_cast<u32x4*>(px) = pk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_sum_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
+                                                       const float* __restrict__ gate, bf16_t* __restrict__ out,
+                                                       int64_t nchunks, int chunks_per_row) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < nchunks; g += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(g % chunks_per_row);
+    const u32x4 rx = *reinterpret_cast<const u32x4*>(x + g * 8);
+    const u32x4 ry = *reinterpret_cast<const u32x4*>(y + g * 8);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate + 8 * ch), g1 = *reinterpret_cast<const f32x4*>(gate + 8 * ch + 4);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gl = j < 2 ? g0[2 * j] : g1[2 * j - 4], gh = j < 2 ? g0[2 * j + 1] : g1[2 * j - 3];
+      o[2 * j] = __fadd_rn(__uint_as_float(rx[j] << 16), __fmul_rn(gl, __uint_as_float(ry[j] << 16)));
+      o[2 * j + 1] = __fadd_rn(__uint_as_float(rx[j] & 0xffff0000u), __fmul_rn(gh, __uint_as_float(ry[j] & 0xffff0000u)));
+    }
+    u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(out + g * 8) = pk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 GEMV, one wave per output row (weights streamed once, 16 B per lane)
+__global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                       const float* __restrict__ b, float* __restrict__ y, int N, int K,
+                                                       int silu_in, const float* __restrict__ add) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* w = W + (size_t)n * K;
+  float acc = 0.f;
+  for (int k = 4 * lane; k < K; k += 256) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+    f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
+    if (silu_in) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[j] = xv[j] / (1.0f + expf(-xv[j]));
+    }
+    acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float r = acc + (b ? b[n] : 0.f);
+    if (add) r += add[n];
+    y[n] = r;
+  }
+}
+
+__global__ void time_features_kernel(float t, float* __restrict__ out, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = D / 2;
+  if (i >= half) return;
+  // get_freqs(models/utils.py:21-28): exp(-ln(1e4) * i / half) in fp32
+  const float f = expf(__fdiv_rn(__fmul_rn(-9.210340371976184f, (float)i), (float)half));
+  const float a = __fmul_rn(t, f);
+  out[i] = cosf(a);
+  out[half + i] = sinf(a);
+}
+
+// cos/sin tables [ntok][32]: column j in [0,n0) uses axis 0 ... ; angle = pos * freq / scale
+__global__ void rope_table_kernel(float* __restrict__ cosT, float* __restrict__ sinT, const int32_t* __restrict__ p0,
+                                  const int32_t* __restrict__ p1, const int32_t* __restrict__ p2, int T, int H, int W,
+                                  int n0, int n1, int n2, float s0, float s1, float s2, const int32_t* __restrict__ tok_perm) {
+  const int np = n0 + n1 + n2;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)T * H * W * np;
+  if (gid >= total) return;
+  const int j = (int)(gid % np);
+  const int64_t row = gid / np;
+  const int64_t tok = tok_perm ? tok_perm[row] : row;
+  const int w = (int)(tok % W), h = (int)((tok / W) % H), t = (int)(tok / ((int64_t)W * H));
+  int pos, i, n;
+  float sc;
+  if (j < n0) { pos = p0[t]; i = j; n = n0; sc = s0; }
+  else if (j < n0 + n1) { pos = p1[h]; i = j - n0; n = n1; sc = s1; }
+  else { pos = p2[w]; i = j - n0 - n1; n = n2; sc = s2; }
+  const float f = expf(__fdiv_rn(__fmul_rn(-9.210340371976184f, (float)i), (float)n));
+  const float a = __fdiv_rn(__fmul_rn((float)pos, f), sc);
+  cosT[gid] = cosf(a);
+  sinT[gid] = sinf(a);
+}
+
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int T, int H,
+                                                       int W, int Cx, int Cin, int Kpad, const int32_t* __restrict__ tok_perm) {
+  // one thread per output element of [Ntok][Kpad]; feature = (ph*2+pw)*Cin + c  (pt = 1)
+  const int Hp = H / 2, Wp = W / 2;
+  const int64_t total = (int64_t)T * Hp * Wp * Kpad;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const int f = (int)(g % Kpad);
+    const int64_t row = g / Kpad;
+    float v = 0.f;
+    if (f < 4 * Cin) {
+      const int64_t tok = tok_perm ? tok_perm[row] : row;
+      const int wp = (int)(tok % Wp), hp = (int)((tok / Wp) % Hp), t = (int)(tok / ((int64_t)Wp * Hp));
+      const int c = f % Cin, pp = f / Cin, ph = pp >> 1, pw = pp & 1;
+      if (c < Cx) v = x[(((int64_t)t * H + 2 * hp + ph) * W + 2 * wp + pw) * Cx + c];
+    }
+    out[g] = f2bf(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void unpatchify_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int T,
+                                                         int Hp, int Wp, int C, int ldx, const int32_t* __restrict__ tok_perm) {
+  // x [Ntok][C*4] feature (c, ph, pw) -> out (T, 2Hp, 2Wp, C)
+  const int F = 4 * C;
+  const int64_t total = (int64_t)T * Hp * Wp * F;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const int f = (int)(g % F);
+    const int64_t row = g / F;
+    const int64_t tok = tok_perm ? tok_perm[row] : row;
+    const int wp = (int)(tok % Wp), hp = (int)((tok / Wp) % Hp), t = (int)(tok / ((int64_t)Wp * Hp));
+    const int c = f >> 2, ph = (f >> 1) & 1, pw = f & 1;
+    out[(((int64_t)t * 2 * Hp + 2 * hp + ph) * (2 * Wp) + 2 * wp + pw) * C + c] = x[row * ldx + f];
+  }
+}
+
+__global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ img, const bf16_t* __restrict__ vc,
+                                                        const bf16_t* __restrict__ vu, float w, float dt, int64_t n) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) {
+    float v = bf2f(vc[g]);
+    if (vu) {  // uncond + w * (cond - uncond), each eager bf16 op rounds (generation_utils.py:74-76)
+      const float u = bf2f(vu[g]);
+      v = bf_round(__fadd_rn(u, bf_round(__fmul_rn(w, bf_round(__fsub_rn(v, u))))));
+    }
+    img[g] = __fadd_rn(img[g], bf_round(__fmul_rn(dt, v)));  // :128, (0-dim fp32)*(bf16) -> bf16
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int64_t n) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) out[g] = f2bf(x[g]);
+}
+
+inline int grid_for(int64_t n, int per_block = 256, int cap = 8192) {
+  int64_t b = (n + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+inline int done() { return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP; }
+
+}  // namespace
+
+int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows, int D,
+                          int ldx, int ldo, hipStream_t s) {
+  if (rows <= 0 || D <= 0) return K5_ERR_ARG;
+  if ((D & 7) || (ldx & 7) || (ldo & 7)) return K5_ERR_ALIGN;
+  if (D > 64 * 8 * MAXC) return K5_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ln_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, scale, shift,
+                     (bf16_t*)out, (float*)nullptr, rows, D, ldx, ldo);
+  return done();
+}
+
+int k5_launch_ln_affine(const void* x, const float* w, const float* b, void* out_bf16, float* out_f32, int rows,
+                        int D, hipStream_t s) {
+  if (rows <= 0 || D <= 0) return K5_ERR_ARG;
+  if (D & 7) return K5_ERR_ALIGN;
+  if (D > 64 * 8 * MAXC) return K5_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ln_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, w, b,
+                     (bf16_t*)out_bf16, out_f32, rows, D, D, D);
+  return done();
+}
+
+int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, const float* sinT, int rows, int H,
+                           int ld, const int32_t* heads_cfg, hipStream_t s) {
+  // heads_cfg (host pointer, optional): {heads_per_weight, rope_heads}; default: one weight, rope on all heads
+  if (rows <= 0 || H <= 0) return K5_ERR_ARG;
+  if (ld & 7) return K5_ERR_ALIGN;
+  const int hpw = heads_cfg ? heads_cfg[0] : H;
+  const int rope_heads = heads_cfg ? heads_cfg[1] : H;
+  const int64_t total = (int64_t)rows * H * 8;
+  hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (bf16_t*)x, weight,
+                     cosT, sinT, rows, H, hpw, ld, rope_heads);
+  return done();
+}
+
+int k5_launch_gate_sum(const void* x, const void* y, const float* gate, void* out, int rows, int D, hipStream_t s) {
+  if (rows <= 0 || D <= 0) return K5_ERR_ARG;
+  if (D & 7) return K5_ERR_ALIGN;
+  const int64_t nch = (int64_t)rows * (D / 8);
+  hipLaunchKernelGGL(gate_sum_kernel, dim3(grid_for(nch)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)y, gate,
+                     (bf16_t*)out, nch, D / 8);
+  return done();
+}
+
+int k5_launch_gemv_f32(const float* x, const float* W, const float* b, float* y, int N, int K, int silu_in,
+                       const float* add, hipStream_t s) {
+  if (N <= 0 || K <= 0) return K5_ERR_ARG;
+  if (K & 3) return K5_ERR_ALIGN;
+  hipLaunchKernelGGL(gemv_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, W, b, y, N, K, silu_in, add);
+  return done();
+}
+
+int k5_launch_time_features(float t, float* out, int D, hipStream_t s) {
+  if (D <= 0 || (D & 1)) return K5_ERR_ARG;
+  hipLaunchKernelGGL(time_features_kernel, dim3((D / 2 + 255) / 256), dim3(256), 0, s, t, out, D);
+  return done();
+}
+
+int k5_launch_rope_table(float* cosT, float* sinT, const int32_t* p0, const int32_t* p1, const int32_t* p2, int T,
+                         int H, int W, int n0, int n1, int n2, float s0, float s1, float s2, const int32_t* tok_perm,
+                         hipStream_t s) {
+  const int64_t total = (int64_t)T * H * W * (n0 + n1 + n2);
+  if (total <= 0) return K5_ERR_ARG;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cosT, sinT, p0, p1, p2,
+                     T, H, W, n0, n1, n2, s0, s1, s2, tok_perm);
+  return done();
+}
+
+int k5_launch_patchify(const float* x, void* out, int T, int H, int W, int C, int Cin_total, int Kpad,
+                       const int32_t* tok_perm, hipStream_t s) {
+  if (T <= 0 || (H & 1) || (W & 1) || Kpad < 4 * Cin_total || C <= 0 || C > Cin_total) return K5_ERR_ARG;
+  const int64_t total = (int64_t)T * (H / 2) * (W / 2) * Kpad;
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16_t*)out, T, H, W, C, Cin_total, Kpad,
+                     tok_perm);
+  return done();
+}
+
+int k5_launch_unpatchify(const void* x, void* out, int T, int Hp, int Wp, int C, int ldx, const int32_t* tok_perm,
+                         hipStream_t s) {
+  const int64_t total = (int64_t)T * Hp * Wp * 4 * C;
+  if (total <= 0) return K5_ERR_ARG;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, T, Hp, Wp,
+                     C, ldx, tok_perm);
+  return done();
+}
+
+int k5_launch_cfg_euler(float* img, const void* vc, const void* vu, float w, float dt, int64_t n, hipStream_t s) {
+  if (n <= 0) return K5_ERR_ARG;
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid_for(n)), dim3(256), 0, s, img, (const bf16_t*)vc, (const bf16_t*)vu, w,
+                     dt, n);
+  return done();
+}
+
+int k5_launch_cast_f32_bf16(const float* x, void* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return K5_ERR_ARG;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, (bf16_t*)out, n);
+  return done();
+}

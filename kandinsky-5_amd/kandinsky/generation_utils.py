@@ -1,0 +1,160 @@
+"""Sampler — host mirror of kandinsky/generation_utils.py (same function names and signatures).
+
+`generate` keeps the reference's positional signature (generation_utils.py:81-96) and its noise /
+sigma-schedule construction, but runs the Euler / CFG loop on the MI355X engine: in one C call
+(`DiffusionTransformer3D.sample` -> k5_sample) when `model` is the engine-backed DiT, otherwise step by
+step through `model(...)` (duck-typed models, e.g. a MagCache wrapper) with the fused CFG+Euler kernel.
+"""
+import os
+
+os.environ.setdefault("TOKENIZERS_PARALLELISM", "False")
+
+import torch
+
+from . import _engine as E
+
+
+def _attr(obj, name, default=None):
+    if isinstance(obj, dict):
+        return obj.get(name, default)
+    return getattr(obj, name, default)
+
+
+def get_sparse_params(conf, batch_embeds, device):
+    """reference generation_utils.py:10-36.  The STA mask itself is rebuilt on device by the engine from
+    (wT, wH, wW); the dict keeps the reference's keys so callers can introspect it."""
+    patch = conf.model.dit_params.patch_size
+    assert patch[0] == 1
+    T, H, W, _ = batch_embeds["visual"].shape
+    T, H, W = T // patch[0], H // patch[1], W // patch[2]
+    attn = conf.model.attention
+    if _attr(attn, "type") == "nabla":
+        if H % 8 or W % 8:
+            raise ValueError("nabla attention needs latent height/width divisible by 16 (8x8 token tiles)")
+        return {
+            "sta_mask": None,  # built inside the engine
+            "attention_type": _attr(attn, "type"),
+            "to_fractal": True,
+            "P": _attr(attn, "P"),
+            "wT": _attr(attn, "wT"),
+            "wW": _attr(attn, "wW"),
+            "wH": _attr(attn, "wH"),
+            "add_sta": _attr(attn, "add_sta"),
+            "visual_shape": (T, H, W),
+            "method": _attr(attn, "method", "topcdf"),
+        }
+    return None
+
+
+@torch.no_grad()
+def get_velocity(dit, x, t, text_embeds, null_text_embeds, visual_rope_pos, text_rope_pos, null_text_rope_pos,
+                 guidance_weight, conf, sparse_params=None):
+    """reference generation_utils.py:39-77 (two forwards + bf16 CFG combine)."""
+    pred_velocity = dit(x, text_embeds["text_embeds"], text_embeds["pooled_embed"], t * 1000, visual_rope_pos,
+                        text_rope_pos, scale_factor=conf.metrics.scale_factor, sparse_params=sparse_params)
+    if abs(guidance_weight - 1.0) > 1e-6:
+        uncond_pred_velocity = dit(x, null_text_embeds["text_embeds"], null_text_embeds["pooled_embed"], t * 1000,
+                                   visual_rope_pos, null_text_rope_pos, scale_factor=conf.metrics.scale_factor,
+                                   sparse_params=sparse_params)
+        pred_velocity = uncond_pred_velocity + guidance_weight * (pred_velocity - uncond_pred_velocity)
+    return pred_velocity
+
+
+def sigma_schedule(num_steps, scheduler_scale, device="cpu"):
+    """reference generation_utils.py:102-103"""
+    timesteps = torch.linspace(1, 0, num_steps + 1, device=device)
+    return scheduler_scale * timesteps / (1 + (scheduler_scale - 1) * timesteps)
+
+
+@torch.no_grad()
+def generate(model, device, shape, num_steps, text_embeds, null_text_embeds, visual_rope_pos, text_rope_pos,
+             null_text_rope_pos, guidance_weight, scheduler_scale, conf, progress=False, seed=6554, noise=None):
+    """reference generation_utils.py:80-129.  `noise` (optional, extension) overrides the seeded draw."""
+    if noise is None:
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed)
+        img = torch.randn(*shape, device=device, generator=g)
+    else:
+        img = noise.to(device=device, dtype=torch.float32).clone()
+    img = img.contiguous()
+
+    sparse_params = get_sparse_params(conf, {"visual": img}, device)
+    timesteps = sigma_schedule(num_steps, scheduler_scale, device=device).cpu()  # one sync, before the loop
+
+    from .models.dit import DiffusionTransformer3D
+    if type(model) is DiffusionTransformer3D and model.visual_cond in (True, False):
+        # whole loop inside the engine: no per-step host work at all
+        model.sample(img, timesteps.tolist(), text_embeds, null_text_embeds, visual_rope_pos, text_rope_pos,
+                     null_text_rope_pos, guidance_weight, scale_factor=conf.metrics.scale_factor,
+                     sparse_params=sparse_params)
+        return img
+
+    cfg_on = abs(guidance_weight - 1.0) > 1e-6
+    for timestep, timestep_diff in zip(timesteps[:-1].tolist(), torch.diff(timesteps).tolist()):
+        if model.visual_cond:
+            visual_cond = torch.zeros_like(img)
+            visual_cond_mask = torch.zeros([*img.shape[:-1], 1], dtype=img.dtype, device=img.device)
+            model_input = torch.cat([img, visual_cond, visual_cond_mask], dim=-1)
+        else:
+            model_input = img
+        t1000 = torch.tensor([timestep]) * 1000
+        v = model(model_input, text_embeds["text_embeds"], text_embeds["pooled_embed"], t1000, visual_rope_pos,
+                  text_rope_pos, scale_factor=conf.metrics.scale_factor, sparse_params=sparse_params)
+        u = None
+        if cfg_on:
+            u = model(model_input, null_text_embeds["text_embeds"], null_text_embeds["pooled_embed"], t1000,
+                      visual_rope_pos, null_text_rope_pos, scale_factor=conf.metrics.scale_factor,
+                      sparse_params=sparse_params)
+        E.cfg_euler_(img, v.contiguous(), None if u is None else u.contiguous(), guidance_weight, timestep_diff)
+    return img
+
+
+def generate_sample(shape, caption, dit, vae, conf, text_embedder, num_steps=25, guidance_weight=5.0,
+                    scheduler_scale=1, negative_caption="", seed=6554, device="cuda", vae_device="cuda",
+                    text_embedder_device="cuda", progress=True, offload=False):
+    """reference generation_utils.py:132-228: text encode -> generate -> VAE decode -> uint8."""
+    bs, duration, height, width, dim = shape
+    type_of_content = "image" if duration == 1 else "video"
+
+    with torch.no_grad():
+        bs_text_embed, text_cu_seqlens = text_embedder.encode([caption], type_of_content=type_of_content)
+        bs_null_text_embed, null_text_cu_seqlens = text_embedder.encode([negative_caption],
+                                                                         type_of_content=type_of_content)
+    if offload:
+        text_embedder = text_embedder.to("cpu")
+
+    for key in bs_text_embed:
+        bs_text_embed[key] = bs_text_embed[key].to(device=device)
+        bs_null_text_embed[key] = bs_null_text_embed[key].to(device=device)
+    text_cu_seqlens = int(text_cu_seqlens[-1])
+    null_text_cu_seqlens = int(null_text_cu_seqlens[-1])
+
+    patch = conf.model.dit_params.patch_size
+    visual_rope_pos = [torch.arange(duration), torch.arange(shape[-3] // patch[1]), torch.arange(shape[-2] // patch[2])]
+    text_rope_pos = torch.arange(text_cu_seqlens)
+    null_text_rope_pos = torch.arange(null_text_cu_seqlens)
+
+    if offload:
+        dit.to(device, non_blocking=True)
+    with torch.no_grad():
+        latent_visual = generate(dit, device, (bs * duration, height, width, dim), num_steps, bs_text_embed,
+                                 bs_null_text_embed, visual_rope_pos, text_rope_pos, null_text_rope_pos,
+                                 guidance_weight, scheduler_scale, conf, seed=seed, progress=progress)
+    if offload:
+        dit = dit.to("cpu", non_blocking=True)
+    torch.cuda.empty_cache()
+    if offload:
+        vae = vae.to(vae_device, non_blocking=True)
+
+    with torch.no_grad():
+        images = latent_visual.reshape(bs, -1, latent_visual.shape[-3], latent_visual.shape[-2],
+                                       latent_visual.shape[-1])
+        images = images.to(device=vae_device)
+        images = (images / vae.config.scaling_factor).permute(0, 4, 1, 2, 3)
+        images = vae.decode(images).sample
+        images = ((images.clamp(-1.0, 1.0) + 1.0) * 127.5).to(torch.uint8)
+
+    if offload:
+        vae = vae.to("cpu", non_blocking=True)
+    torch.cuda.empty_cache()
+    return images

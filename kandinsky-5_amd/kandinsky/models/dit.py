@@ -1,0 +1,269 @@
+"""DiffusionTransformer3D — host mirror of the reference class (kandinsky/models/dit.py:82-186).
+
+Same constructor kwargs, same `state_dict` keys, same `forward` signature and
+`visual_cond` attribute, so `get_T2V_pipeline`, `generate` and the ComfyUI nodes can use it unchanged.
+The arithmetic is NOT here: `forward` hands raw device pointers to the gfx950 engine in libk5.so
+(kandinsky-5_amd/csrc/engine.hip) through the C ABI (include/k5.h).  There is no eager fallback: without
+the library, or with CPU tensors, `forward` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .. import _engine as E
+from .nn import (FeedForward, Modulation, MultiheadCrossAttention, MultiheadSelfAttentionDec,
+                 MultiheadSelfAttentionEnc, NormWeight, OutLayer, TextEmbeddings, TimeEmbeddings,
+                 VisualEmbeddings, _NoMath)
+
+
+class TransformerEncoderBlock(_NoMath):  # reference dit.py:22-44
+    def __init__(self, model_dim, time_dim, ff_dim, head_dim):
+        super().__init__()
+        self.text_modulation = Modulation(time_dim, model_dim, 6)
+        self.self_attention = MultiheadSelfAttentionEnc(model_dim, head_dim)
+        self.feed_forward = FeedForward(model_dim, ff_dim)
+
+
+class TransformerDecoderBlock(_NoMath):  # reference dit.py:47-79
+    def __init__(self, model_dim, time_dim, ff_dim, head_dim):
+        super().__init__()
+        self.visual_modulation = Modulation(time_dim, model_dim, 9)
+        self.self_attention = MultiheadSelfAttentionDec(model_dim, head_dim)
+        self.cross_attention = MultiheadCrossAttention(model_dim, head_dim)
+        self.feed_forward = FeedForward(model_dim, ff_dim)
+
+
+class DiffusionTransformer3D(nn.Module):
+    def __init__(
+        self,
+        in_visual_dim=4,
+        in_text_dim=3584,
+        in_text_dim2=768,
+        time_dim=512,
+        out_visual_dim=4,
+        patch_size=(1, 2, 2),
+        model_dim=2048,
+        ff_dim=5120,
+        num_text_blocks=2,
+        num_visual_blocks=32,
+        axes_dims=(16, 24, 24),
+        visual_cond=False,
+    ):
+        super().__init__()
+        head_dim = sum(axes_dims)
+        self.in_visual_dim = in_visual_dim
+        self.out_visual_dim = out_visual_dim
+        self.model_dim = model_dim
+        self.patch_size = tuple(patch_size)
+        self.visual_cond = visual_cond
+        self._cfg = dict(in_visual_dim=in_visual_dim, in_text_dim=in_text_dim, in_text_dim2=in_text_dim2,
+                         time_dim=time_dim, out_visual_dim=out_visual_dim, patch_size=tuple(patch_size),
+                         model_dim=model_dim, ff_dim=ff_dim, num_text_blocks=num_text_blocks,
+                         num_visual_blocks=num_visual_blocks, axes_dims=tuple(axes_dims), visual_cond=bool(visual_cond))
+
+        visual_embed_dim = 2 * in_visual_dim + 1 if visual_cond else in_visual_dim
+        self.visual_embed_dim = visual_embed_dim
+        self.time_embeddings = TimeEmbeddings(model_dim, time_dim)
+        self.text_embeddings = TextEmbeddings(in_text_dim, model_dim)
+        self.pooled_text_embeddings = TextEmbeddings(in_text_dim2, time_dim)
+        self.visual_embeddings = VisualEmbeddings(visual_embed_dim, model_dim, patch_size)
+        self.text_transformer_blocks = nn.ModuleList(
+            [TransformerEncoderBlock(model_dim, time_dim, ff_dim, head_dim) for _ in range(num_text_blocks)])
+        self.visual_transformer_blocks = nn.ModuleList(
+            [TransformerDecoderBlock(model_dim, time_dim, ff_dim, head_dim) for _ in range(num_visual_blocks)])
+        self.out_layer = OutLayer(model_dim, time_dim, out_visual_dim, patch_size)
+
+        self._handle = None          # k5_dit*
+        self._handle_device = None
+        self._keepalive = []
+
+    # ---------------------------------------------------------------- engine lifetime
+    def _destroy_engine(self):
+        if self._handle is not None:
+            E.lib().k5_dit_destroy(self._handle)
+        self._handle, self._handle_device = None, None
+
+    def __del__(self):
+        try:
+            self._destroy_engine()
+        except Exception:
+            pass
+
+    def _create_handle(self):
+        c = self._cfg
+        cc = E.DitConfig(c["in_visual_dim"], c["in_text_dim"], c["in_text_dim2"], c["time_dim"], c["out_visual_dim"],
+                         (C.c_int * 3)(*c["patch_size"]), c["model_dim"], c["ff_dim"], c["num_text_blocks"],
+                         c["num_visual_blocks"], (C.c_int * 3)(*c["axes_dims"]), int(c["visual_cond"]))
+        h = C.c_void_p()
+        E.check(E.lib().k5_dit_create(C.byref(cc), C.byref(h)), "k5_dit_create")
+        return h
+
+    @staticmethod
+    def _load_one(handle, name, t):
+        t = t.detach()
+        if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            t = t.float()
+        t = t.contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        E.check(E.lib().k5_dit_load_tensor(handle, name.encode(), t.data_ptr(), E.k5_dtype(t), shape, t.dim()),
+                f"k5_dit_load_tensor({name})")
+
+    def _build_engine(self, device):
+        """Pack the current parameters into the HIP engine on `device` (once; rebuilt if the
+        parameters are replaced or the module is moved)."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the Kandinsky-5 HIP engine runs on an MI355X only (device 'cuda:N'); no CPU path")
+        self._destroy_engine()
+        with torch.cuda.device(device):
+            h = self._create_handle()
+            for name, t in self.state_dict().items():
+                if t.is_meta:
+                    E.lib().k5_dit_destroy(h)
+                    raise RuntimeError(f"parameter {name} is on the meta device: load a checkpoint first")
+                self._load_one(h, name, t)
+            E.check(E.lib().k5_dit_finalize(h), "k5_dit_finalize")
+        self._handle, self._handle_device = h, device
+
+    def init_synthetic(self, device, seed=0, std=0.02):
+        """Random-init weights of this architecture generated ON DEVICE tensor by tensor and handed straight
+        to the engine (no 8 GB host copy).  Linear ~ N(0,std^2) incl. Modulation (reference zero-inits it,
+        nn.py:158-159, which would make every block an identity), norm weights 1, biases N(0,std^2)."""
+        device = torch.device(device)
+        self._destroy_engine()
+        with torch.cuda.device(device):
+            h = self._create_handle()
+            g = torch.Generator(device=device)
+            for idx, (name, p) in enumerate(self.state_dict().items()):
+                g.manual_seed(seed * 1000003 + idx)
+                if name.endswith("norm.weight"):
+                    t = torch.ones(p.shape, device=device)
+                else:
+                    s = std * (2.5 if "modulation" in name else 1.0)
+                    t = torch.randn(p.shape, device=device, generator=g) * s
+                self._load_one(h, name, t)
+            torch.cuda.synchronize(device)
+            E.check(E.lib().k5_dit_finalize(h), "k5_dit_finalize")
+        self._handle, self._handle_device = h, device
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self._destroy_engine()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if self._handle is not None:
+            p = next(self.parameters(), None)
+            if p is not None and p.device != self._handle_device and not p.is_meta:
+                self._destroy_engine()
+        return out
+
+    def engine(self, device):
+        device = torch.device(device)
+        if device.index is None and device.type == "cuda":
+            device = torch.device("cuda", torch.cuda.current_device())
+        if self._handle is None or self._handle_device != device:
+            self._build_engine(device)
+        return self._handle
+
+    # ---------------------------------------------------------------- argument marshalling
+    def _text_cond(self, text_embed, pooled_text_embed, text_rope_pos, keep):
+        if text_embed.dtype != pooled_text_embed.dtype:
+            pooled_text_embed = pooled_text_embed.to(text_embed.dtype)
+        if text_embed.dtype not in (torch.float32, torch.bfloat16):
+            text_embed, pooled_text_embed = text_embed.float(), pooled_text_embed.float()
+        text_embed, pooled_text_embed = text_embed.contiguous(), pooled_text_embed.contiguous()
+        pos = E.i32_array(torch.as_tensor(text_rope_pos).tolist())
+        keep += [text_embed, pooled_text_embed, pos]
+        if len(pos) != text_embed.shape[0]:
+            raise ValueError("text_rope_pos must have one position per text token")
+        return E.TextCond(text_embed.data_ptr(), pooled_text_embed.data_ptr(), E.k5_dtype(text_embed),
+                          text_embed.shape[0], pos)
+
+    def _forward_args(self, x_shape, x_ptr, x_channels, text_embed, pooled_text_embed, time, visual_rope_pos,
+                      text_rope_pos, scale_factor, sparse_params, keep):
+        T, H, W = x_shape
+        pt, ph, pw = self.patch_size
+        pos = [E.i32_array(torch.as_tensor(p).tolist()) for p in visual_rope_pos]
+        if (len(pos[0]), len(pos[1]), len(pos[2])) != (T // pt, H // ph, W // pw):
+            raise ValueError("visual_rope_pos does not match the latent shape")
+        keep += pos
+        a = E.ForwardArgs()
+        a.x, a.T, a.H, a.W, a.x_channels = x_ptr, T, H, W, x_channels
+        a.cond = self._text_cond(text_embed, pooled_text_embed, text_rope_pos, keep)
+        a.time = float(time)
+        a.pos_t, a.pos_h, a.pos_w = pos
+        a.scale_factor = (C.c_float * 3)(*[float(s) for s in scale_factor])
+        if sparse_params is not None:
+            a.attention_type = 1
+            a.nabla_P = float(sparse_params["P"])
+            a.nabla_wT, a.nabla_wH, a.nabla_wW = int(sparse_params["wT"]), int(sparse_params["wH"]), int(sparse_params["wW"])
+        return a
+
+    # ---------------------------------------------------------------- reference API
+    @torch.no_grad()
+    def forward(self, x, text_embed, pooled_text_embed, time, visual_rope_pos, text_rope_pos,
+                scale_factor=(1.0, 1.0, 1.0), sparse_params=None):
+        """Reference signature dit.py:155-165.  x (T,H,W,C_in) ; returns velocity (T,H,W,out_visual_dim) bf16."""
+        if not x.is_cuda:
+            raise RuntimeError("DiffusionTransformer3D.forward needs CUDA (HIP) tensors; there is no CPU fallback")
+        h = self.engine(x.device)
+        x = x.float().contiguous()
+        T, H, W, Cx = x.shape
+        text_embed, pooled_text_embed = text_embed.to(x.device), pooled_text_embed.to(x.device)
+        t_val = float(time.reshape(-1)[0]) if torch.is_tensor(time) else float(time)
+        keep = [x]
+        a = self._forward_args((T, H, W), x.data_ptr(), Cx, text_embed, pooled_text_embed, t_val, visual_rope_pos,
+                               text_rope_pos, scale_factor, sparse_params, keep)
+        out = torch.empty(T, H, W, self.out_visual_dim, dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            E.check(E.lib().k5_dit_forward(h, C.byref(a), out.data_ptr(), E.stream_ptr(x.device)), "k5_dit_forward")
+        return out
+
+    @torch.no_grad()
+    def sample(self, latent, sigmas, text_embeds, null_text_embeds, visual_rope_pos, text_rope_pos,
+               null_text_rope_pos, guidance_weight, scale_factor=(1.0, 1.0, 1.0), sparse_params=None):
+        """Whole Euler/CFG loop on device (generation_utils.py:80-129) in one C call.  `latent` fp32
+        (T,H,W,in_visual_dim) is updated in place; `sigmas` = the sigma schedule (num_steps+1 floats, host)."""
+        if not latent.is_cuda or latent.dtype != torch.float32 or not latent.is_contiguous():
+            raise RuntimeError("latent must be a contiguous fp32 CUDA tensor")
+        h = self.engine(latent.device)
+        dev = latent.device
+        T, H, W, _ = latent.shape
+        keep = []
+        te, pe = text_embeds["text_embeds"].to(dev), text_embeds["pooled_embed"].to(dev)
+        s = E.SampleArgs()
+        s.fwd = self._forward_args((T, H, W), None, self.in_visual_dim, te, pe, 0.0, visual_rope_pos, text_rope_pos,
+                                   scale_factor, sparse_params, keep)
+        if abs(guidance_weight - 1.0) > 1e-6:
+            s.null_cond = self._text_cond(null_text_embeds["text_embeds"].to(dev), null_text_embeds["pooled_embed"].to(dev),
+                                          null_text_rope_pos, keep)
+        sig = [float(v) for v in sigmas]
+        arr = (C.c_float * len(sig))(*sig)
+        s.latent, s.num_steps, s.sigmas, s.guidance_weight = latent.data_ptr(), len(sig) - 1, arr, float(guidance_weight)
+        with torch.cuda.device(dev):
+            E.check(E.lib().k5_sample(h, C.byref(s), E.stream_ptr(dev)), "k5_sample")
+        return latent
+
+    # ---------------------------------------------------------------- profiling (bench.py roofline)
+    def set_profiling(self, on=True):
+        E.check(E.lib().k5_dit_set_profiling(self._handle, int(on)))
+
+    def reset_profile(self):
+        E.check(E.lib().k5_dit_reset_profile(self._handle))
+
+    def get_profile(self, family):
+        ms, n = C.c_double(), C.c_int64()
+        E.check(E.lib().k5_dit_get_profile(self._handle, family.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def get_dit(conf):
+    """reference dit.py:184-186"""
+    conf = dict(conf) if not isinstance(conf, dict) else conf
+    return DiffusionTransformer3D(**conf)

@@ -1,0 +1,98 @@
+"""Factory — host mirror of kandinsky/utils.py:23-198 (`get_T2V_pipeline`, `get_default_conf`).
+
+Keeps the reference signature, the YAML schema and the safetensors checkpoint layout.  What differs:
+no DTensor tensor-parallel wrap (parallelize.py) — multi-GPU is token-sharded sequence parallelism inside
+the engine; the LOCAL_RANK / WORLD_SIZE launch contract (utils.py:40-45) is kept.
+"""
+import os
+from typing import Union
+
+import torch
+
+from .config import Conf, load_config
+from .models.dit import get_dit
+from .t2v_pipeline import Kandinsky5T2VPipeline
+
+
+def get_T2V_pipeline(
+    device_map: Union[str, torch.device, dict],
+    resolution: int = 512,
+    cache_dir: str = "./weights/",
+    dit_path: str = None,
+    text_encoder_path: str = None,
+    text_encoder2_path: str = None,
+    vae_path: str = None,
+    conf_path: str = None,
+    offload: bool = False,
+    magcache: bool = False,
+) -> Kandinsky5T2VPipeline:
+    assert resolution in [512]
+    if not isinstance(device_map, dict):
+        device_map = {"dit": device_map, "vae": device_map, "text_embedder": device_map}
+    try:
+        local_rank, world_size = int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+    except (KeyError, ValueError):
+        local_rank, world_size = 0, 1
+    assert not (world_size > 1 and offload), "Offloading available only with not parallel inference"
+    if world_size > 1:
+        for k in ("dit", "vae", "text_embedder"):
+            device_map[k] = torch.device(f"cuda:{local_rank}")
+    if magcache:
+        raise NotImplementedError("MagCache (reference magcache_utils.py) is a 'next' row (SURVEY.md §8f), not built yet")
+
+    os.makedirs(cache_dir, exist_ok=True)
+    if conf_path is None:
+        # the reference downloads from the HF hub here (utils.py:59-87); offline builds take local paths
+        dit_path = dit_path or os.path.join(cache_dir, "model/kandinsky5lite_t2v_sft_5s.safetensors")
+        vae_path = vae_path or os.path.join(cache_dir, "vae/")
+        text_encoder_path = text_encoder_path or os.path.join(cache_dir, "text_encoder/")
+        text_encoder2_path = text_encoder2_path or os.path.join(cache_dir, "text_encoder2/")
+        conf = get_default_conf(dit_path, vae_path, text_encoder_path, text_encoder2_path)
+    else:
+        conf = load_config(conf_path)
+
+    from .models.text_embedders import get_text_embedder
+    from .models.vae import build_vae
+    from safetensors.torch import load_file
+
+    text_embedder = get_text_embedder(conf.model.text_embedder)
+    if not offload:
+        text_embedder = text_embedder.to(device=device_map["text_embedder"])
+    vae = build_vae(conf.model.vae).eval()
+    if not offload:
+        vae = vae.to(device=device_map["vae"])
+
+    with torch.device("meta"):
+        dit = get_dit(conf.model.dit_params)
+    state_dict = load_file(conf.model.checkpoint_path)
+    dit.load_state_dict(state_dict, assign=True)
+    if not offload:
+        dit = dit.to(device_map["dit"])
+
+    return Kandinsky5T2VPipeline(device_map=device_map, dit=dit, text_embedder=text_embedder, vae=vae,
+                                 resolution=resolution, local_dit_rank=local_rank, world_size=world_size, conf=conf,
+                                 offload=offload)
+
+
+def get_default_conf(dit_path, vae_path, text_encoder_path, text_encoder2_path) -> Conf:
+    """reference utils.py:137-198 (values of the 5 s SFT config)."""
+    return Conf({
+        "model": {
+            "checkpoint_path": dit_path,
+            "vae": {"checkpoint_path": vae_path, "name": "hunyuan"},
+            "text_embedder": {
+                "qwen": {"emb_size": 3584, "checkpoint_path": text_encoder_path, "max_length": 256},
+                "clip": {"checkpoint_path": text_encoder2_path, "emb_size": 768, "max_length": 77},
+            },
+            "dit_params": {
+                "in_visual_dim": 16, "out_visual_dim": 16, "time_dim": 512, "patch_size": [1, 2, 2],
+                "model_dim": 1792, "ff_dim": 7168, "num_text_blocks": 2, "num_visual_blocks": 32,
+                "axes_dims": [16, 24, 24], "visual_cond": True, "in_text_dim": 3584, "in_text_dim2": 768,
+            },
+            "attention": {"type": "flash", "causal": False, "local": False, "glob": False, "window": 3},
+            "num_steps": 50,
+            "guidance_weight": 5.0,
+        },
+        "metrics": {"scale_factor": (1, 2, 2)},
+        "resolution": 512,
+    })

@@ -1,0 +1,120 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/k5.h declares, the host
+mirror keeps the reference's checkpoint layout / config schema, and the product path refuses to run
+without the HIP library or on CPU tensors (no silent fallback)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "kandinsky-5_amd")
+LIB = os.path.join(PKG, "lib", "libk5.so")
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    sys.path.insert(0, PKG)
+    import build as k5build
+    return k5build.build(verbose=False)
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "k5.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(k5_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported(built_lib):
+    import ctypes
+    lib = ctypes.CDLL(built_lib)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/k5.h but not exported by libk5.so"
+
+
+def test_ctypes_table_matches_header(built_lib):
+    from kandinsky import _engine as E
+    assert sorted(E.SYMBOLS) == declared_symbols()
+    L = E.lib()
+    assert L.k5_abi_version() == 1
+
+
+def test_engine_rejects_bad_config_without_gpu(built_lib):
+    """k5_dit_create validates on the host (no GPU work): head_dim must be 64."""
+    import ctypes as C
+    from kandinsky import _engine as E
+    cc = E.DitConfig(16, 96, 48, 64, 16, (C.c_int * 3)(1, 2, 2), 128, 256, 1, 2, (C.c_int * 3)(16, 16, 16), 1)
+    h = C.c_void_p()
+    st = E.lib().k5_dit_create(C.byref(cc), C.byref(h))
+    assert st != 0 and "head_dim" in E.last_error()
+    cc = E.DitConfig(16, 96, 48, 64, 16, (C.c_int * 3)(1, 2, 2), 128, 256, 1, 2, (C.c_int * 3)(16, 24, 24), 1)
+    assert E.lib().k5_dit_create(C.byref(cc), C.byref(h)) == 0
+    # unknown key is rejected before any device work
+    shape = (C.c_int64 * 1)(4)
+    buf = (C.c_float * 4)()
+    assert E.lib().k5_dit_load_tensor(h, b"not.a.key", buf, 0, shape, 1) == 5
+    assert E.lib().k5_dit_missing_keys(h) > 0
+    E.lib().k5_dit_destroy(h)
+
+
+def test_state_dict_layout_matches_reference_manifest():
+    from kandinsky.models.dit import DiffusionTransformer3D
+    from oracle import k5_oracle as O
+    with open(os.path.join(ROOT, "tests", "golden", "dit_lite_manifest.json")) as f:
+        ref = json.load(f)
+    with torch.device("meta"):
+        dit = DiffusionTransformer3D(**O.LITE_2B)
+    sd = dit.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        assert list(v.shape) == ref[k], k
+    assert sum(v.numel() for v in sd.values()) == sum(int(torch.tensor(s).prod()) for s in ref.values())
+    assert dit.visual_cond is True and dit.visual_transformer_blocks[0].self_attention.num_heads == 28
+
+
+def test_load_state_dict_assign_and_no_cpu_fallback(tiny_sd, golden_meta, golden):
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(golden_meta["tiny_config"])
+    dit = DiffusionTransformer3D(**c)
+    dit.load_state_dict(tiny_sd, assign=True)
+    assert torch.equal(dit.state_dict()["out_layer.out_layer.weight"], tiny_sd["out_layer.out_layer.weight"])
+    pos = [torch.arange(3), torch.arange(4), torch.arange(6)]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dit(golden["fwd.x"], golden["fwd.text"], golden["fwd.pooled"], golden["fwd.time"], pos, torch.arange(7))
+    with pytest.raises(RuntimeError, match="parameter container"):
+        dit.visual_transformer_blocks[0].feed_forward(golden["op.ssn.x"])
+
+
+def test_missing_library_fails_loudly():
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['K5_LIB']='/nonexistent/libk5.so';"
+            "from kandinsky import _engine as E\n"
+            "try:\n E.lib()\nexcept RuntimeError as e:\n print('LOUD', e)\n") % PKG
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "LOUD" in out.stdout and "no fallback" in out.stdout, out.stdout + out.stderr
+
+
+def test_config_loader_matches_reference_parse():
+    from kandinsky.config import load_config
+    with open(os.path.join(ROOT, "tests", "golden", "configs_parsed.json")) as f:
+        ref = json.load(f)
+    cdir = os.path.join(PKG, "configs")
+    assert sorted(os.listdir(cdir)) == sorted(ref.keys())
+    for fn, parsed in ref.items():
+        conf = load_config(os.path.join(cdir, fn))
+        assert conf.to_dict() == parsed, fn
+        assert conf.model.dit_params.patch_size == [1, 2, 2]
+        assert conf.model.attention.type in ("flash", "nabla")
+        assert conf["metrics"]["scale_factor"] == [1.0, 2.0, 2.0]
+
+
+def test_sigma_schedule_host():
+    from kandinsky.generation_utils import sigma_schedule
+    from oracle import k5_oracle as O
+    for n, s in ((4, 5.0), (50, 5.0), (100, 10.0)):
+        assert torch.equal(sigma_schedule(n, s), O.sigma_schedule(n, s))
+    assert torch.allclose(sigma_schedule(4, 5.0), torch.tensor([1, .9375, .8333333, .625, 0]), atol=1e-6)

@@ -1,0 +1,250 @@
+"""GPU parity tests (MI355X): every HIP kernel, called through the C ABI, against the CPU oracle
+(oracle/k5_oracle.py, bf16-island arithmetic) on the same seeded inputs.  Tolerances are written here:
+bf16 outputs agree to a few bf16 ulps (eps = 2^-7... relative 7.8e-3 per ulp)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import k5_oracle as O  # noqa: E402
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def E():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X (torch.cuda.is_available() is False)")
+    from kandinsky import _engine as E
+    E.lib()
+    return E
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def bfr(x):
+    return x.to(BF).float()
+
+
+def assert_bf16_close(got, ref, ulps=2, atol=1e-3, what=""):
+    got, ref = got.float().cpu(), ref.float()
+    tol = atol + ulps * 2.0 ** -8 * ref.abs()
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.numel()} off; max abs err {(got - ref).abs().max():.4g}"
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 1792), (200, 72, 136), (7, 128, 96), (1, 64, 48),
+                                   (333, 64, 1792), (1000, 3584, 256)])
+def test_gemm_bias(E, M, N, K):
+    a, w, b = bfr(rnd(M, K, seed=1)), bfr(rnd(N, K, seed=2, scale=0.05)), bfr(rnd(N, seed=3, scale=0.1))
+    ref = bfr(a @ w.t() + b)
+    got = E.gemm(a.cuda().to(BF), w.cuda().to(BF), b.cuda(), E.EPI_BIAS)
+    torch.cuda.synchronize()
+    assert_bf16_close(got, ref, what=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_is_transpose_correct(E):
+    """A = I with an asymmetric W catches any row/col swap in the MFMA C/D mapping (guide rule 16)."""
+    n = 256
+    a = torch.eye(n)
+    w = bfr(rnd(192, n, seed=5))
+    got = E.gemm(a.cuda().to(BF), w.cuda().to(BF), None, E.EPI_BIAS)
+    assert torch.equal(got.float().cpu(), w.t().contiguous())
+
+
+def test_gemm_bias_m_emits_transposed_value(E):
+    """V^T = W_v X^T + b_v[:,None]  (the layout the attention kernel consumes)."""
+    D, S = 128, 300
+    x, wv, bv = bfr(rnd(S, D, seed=1)), bfr(rnd(D, D, seed=2, scale=0.1)), bfr(rnd(D, seed=3))
+    ref = bfr(x @ wv.t() + bv).t()
+    ld = (S + 7) // 8 * 8
+    out = torch.zeros(D, ld, dtype=BF, device="cuda")
+    E.gemm(wv.cuda().to(BF), x.cuda().to(BF), bv.cuda(), E.EPI_BIAS_M, out=out)
+    assert_bf16_close(out[:, :S], ref, what="V^T gemm")
+    assert torch.count_nonzero(out[:, S:]) == 0
+
+
+def test_gemm_gelu_and_gate_epilogues(E):
+    M, D, FF = 300, 128, 256
+    x, w1, w2 = bfr(rnd(M, D, seed=1)), bfr(rnd(FF, D, seed=2, scale=0.1)), bfr(rnd(D, FF, seed=3, scale=0.1))
+    h_ref = bfr(torch.nn.functional.gelu(bfr(x @ w1.t())))
+    h = E.gemm(x.cuda().to(BF), w1.cuda().to(BF), None, E.EPI_GELU)
+    assert_bf16_close(h, h_ref, what="gelu epilogue")
+    resid, gate = bfr(rnd(M, D, seed=4)), rnd(D, seed=5)
+    ref = bfr(resid + gate * bfr(h_ref @ w2.t()))
+    r = resid.cuda().to(BF)
+    got = E.gemm(h_ref.cuda().to(BF), w2.cuda().to(BF), None, E.EPI_GATE, resid=r, gate=gate.cuda(), out=r)  # in place
+    assert_bf16_close(got, ref, ulps=3, what="gate epilogue (in place)")
+
+
+def test_gemm_alignment_error_is_loud(E):
+    a, w = torch.zeros(8, 12, dtype=BF, device="cuda"), torch.zeros(8, 12, dtype=BF, device="cuda")
+    with pytest.raises(RuntimeError, match="status 2"):
+        E.gemm(a, w)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_ref(q, k, v):
+    """oracle sdpa on bf16-valued inputs (fp32 softmax), (S,H,64) layout."""
+    return O.sdpa(q, k, v, "bf16")
+
+
+@pytest.mark.parametrize("Sq,Sk,H", [(72, 72, 2), (256, 256, 1), (300, 77, 3), (513, 7, 2), (1000, 1000, 2),
+                                     (64, 640, 1), (1, 1, 1)])
+def test_attention_matches_oracle(E, Sq, Sk, H):
+    q, k, v = bfr(rnd(Sq, H, 64, seed=1)), bfr(rnd(Sk, H, 64, seed=2)), bfr(rnd(Sk, H, 64, seed=3))
+    ref = attn_ref(q, k, v)
+    ld = (Sk + 7) // 8 * 8
+    vt = torch.zeros(H * 64, ld, dtype=BF, device="cuda")
+    vt[:, :Sk] = v.reshape(Sk, H * 64).t().to(BF)
+    got = E.attention(q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt, H, kv_len=Sk)
+    torch.cuda.synchronize()
+    # P is rounded to bf16 before P.V (as in flash-attn): allow 1e-2 absolute on O(1) outputs
+    assert_bf16_close(got, ref, ulps=4, atol=1e-2, what=f"attention {Sq}x{Sk}x{H}")
+
+
+def test_attention_strided_qk_views(E):
+    """Q and K are column slices of the fused [S][2D] projection buffer (ldq = ldk = 2D)."""
+    S, H = 200, 2
+    qk = bfr(rnd(S, 2 * H * 64, seed=7))
+    v = bfr(rnd(S, H, 64, seed=8))
+    ref = attn_ref(qk[:, :H * 64].reshape(S, H, 64), qk[:, H * 64:].reshape(S, H, 64), v)
+    d = qk.cuda().to(BF)
+    vt = v.reshape(S, -1).t().contiguous().cuda().to(BF)
+    got = E.attention(d[:, :H * 64], d[:, H * 64:], vt, H)
+    assert_bf16_close(got, ref, ulps=4, atol=1e-2, what="strided attention")
+
+
+def test_attention_online_softmax_rescale_branch(E):
+    """Force the running-max rescale late in the key sequence: one key with a huge score at tile 9
+    (guide rule 26: the rare data-dependent branch needs its own test)."""
+    S, H = 1024, 1
+    q, k, v = bfr(rnd(S, H, 64, seed=1)), bfr(rnd(S, H, 64, seed=2)), bfr(rnd(S, H, 64, seed=3))
+    k[600, 0] = q[5, 0] * 4.0  # spikes q5.k600 far above everything seen before
+    k[900, 0] = q[700, 0] * 6.0
+    ref = attn_ref(q, k, v)
+    vt = v.reshape(S, -1).t().contiguous().cuda().to(BF)
+    got = E.attention(q.reshape(S, -1).cuda().to(BF), k.reshape(S, -1).cuda().to(BF), vt, H)
+    assert_bf16_close(got, ref, ulps=4, atol=1e-2, what="rescale branch")
+
+
+def test_attention_full_size_properties(E):
+    """BASELINE config-2 sequence length (N = 47 616 tokens) on 2 heads: size-independent properties
+    (constant V -> constant O; key permutation invariance) + sampled rows against the oracle."""
+    N, H = 47616, 2
+    g = torch.Generator(device="cuda").manual_seed(0)
+    q = torch.randn(N, H * 64, device="cuda", generator=g).to(BF)
+    k = torch.randn(N, H * 64, device="cuda", generator=g).to(BF)
+    v = torch.randn(N, H * 64, device="cuda", generator=g).to(BF)
+    vt = v.t().contiguous()
+    o = E.attention(q, k, vt, H)
+    # (1) sampled query rows vs the CPU oracle
+    rows = torch.tensor([0, 1, 31, 32, 255, 256, 4097, 23808, 47615 - 64, 47615])
+    ref = attn_ref(q[rows].float().cpu().reshape(-1, H, 64), k.float().cpu().reshape(N, H, 64),
+                   v.float().cpu().reshape(N, H, 64))
+    assert_bf16_close(o[rows], ref, ulps=4, atol=5e-3, what="full-size sampled rows")
+    # (2) softmax rows sum to one: V = const  ->  O = const
+    vc = torch.full_like(vt, 0.75)
+    oc = E.attention(q, k, vc, H)
+    assert (oc.float() - 0.75).abs().max().item() <= 2 ** -8
+    # (3) permuting the keys (and values) does not change the result beyond accumulation order
+    perm = torch.randperm(N, device="cuda", generator=g)
+    op = E.attention(q, k[perm].contiguous(), vt[:, perm].contiguous(), H)
+    assert (op.float() - o.float()).abs().max().item() < 2e-2
+    assert not torch.isnan(o.float()).any()
+
+
+# ------------------------------------------------------------------------------------------ elementwise / norms
+@pytest.mark.parametrize("rows,D", [(72, 128), (301, 1792), (5, 2048), (9, 64)])
+def test_ln_modulate(E, rows, D):
+    x = bfr(rnd(rows, D, seed=1, scale=2.0) + 0.3)
+    sc, sh = rnd(1, D, seed=2, scale=0.3), rnd(1, D, seed=3, scale=0.3)
+    ref = O.scale_shift_norm(x, sc, sh, "bf16")
+    got = E.ln_modulate(x.cuda().to(BF), sc.cuda().reshape(-1), sh.cuda().reshape(-1))
+    assert_bf16_close(got, ref, ulps=1, atol=1e-4, what="ln_modulate")
+
+
+def test_rmsnorm_rope_fused_qk(E):
+    S, H = 150, 3
+    qk = bfr(rnd(S, 2 * H * 64, seed=1, scale=3.0))
+    wq, wk = rnd(64, seed=2) * 0.2 + 1, rnd(64, seed=3) * 0.2 + 1
+    ang = rnd(S, 32, seed=4, scale=3.0)
+    cos, sin = torch.cos(ang), torch.sin(ang)
+    q = O.apply_rotary(O.rms_norm_heads(qk[:, :H * 64].reshape(S, H, 64), wq, "bf16"), cos, sin, "bf16")
+    k = O.apply_rotary(O.rms_norm_heads(qk[:, H * 64:].reshape(S, H, 64), wk, "bf16"), cos, sin, "bf16")
+    ref = torch.cat([q.reshape(S, -1), k.reshape(S, -1)], dim=1)
+    d = qk.cuda().to(BF)
+    E.rmsnorm_rope_(d, torch.cat([wq, wk]).cuda(), cos.cuda().contiguous(), sin.cuda().contiguous(), heads=2 * H,
+                    heads_per_weight=H, rope_heads=2 * H)
+    assert_bf16_close(d, ref, ulps=1, atol=1e-4, what="rmsnorm+rope")
+    # no-rope variant (cross-attention q / k, reference nn.py:343-349)
+    d2 = qk[:, :H * 64].contiguous().cuda().to(BF)
+    E.rmsnorm_rope_(d2, wq.cuda())
+    assert_bf16_close(d2, O.rms_norm_heads(qk[:, :H * 64].reshape(S, H, 64), wq, "bf16").reshape(S, -1), ulps=1,
+                      atol=1e-4, what="rmsnorm only")
+
+
+def test_gate_sum(E):
+    x, y, g = bfr(rnd(77, 256, seed=1)), bfr(rnd(77, 256, seed=2)), rnd(256, seed=3)
+    got = E.gate_sum(x.cuda().to(BF), y.cuda().to(BF), g.cuda())
+    assert_bf16_close(got, O.gate_sum(x, y, g, "bf16"), ulps=1, atol=1e-5, what="gate_sum")
+
+
+def test_gemv_f32_modulation(E, tiny_sd):
+    temb = rnd(1, 64, seed=1)
+    ref = O.modulation(tiny_sd, "visual_transformer_blocks.0.visual_modulation", temb)[0]
+    got = E.gemv_f32(temb.cuda().reshape(-1), tiny_sd["visual_transformer_blocks.0.visual_modulation.out_layer.weight"].cuda(),
+                     tiny_sd["visual_transformer_blocks.0.visual_modulation.out_layer.bias"].cuda(), silu_in=True)
+    torch.testing.assert_close(got.cpu(), ref, atol=2e-5, rtol=2e-5)
+
+
+def test_time_features_and_rope_tables(E):
+    import ctypes as C
+    out = torch.empty(1792, device="cuda")
+    E.check(E.lib().k5_time_features_f32(731.25, out.data_ptr(), 1792, E.stream_ptr()))
+    a = torch.outer(torch.tensor([731.25]), O.get_freqs(896))[0]
+    ref = torch.cat([torch.cos(a), torch.sin(a)])
+    torch.testing.assert_close(out.cpu(), ref, atol=5e-4, rtol=0)  # angles up to ~731 rad: fp32 argument ulp 6e-5
+    T, H, W = 3, 4, 6
+    pos = torch.cat([torch.arange(T), torch.arange(H), torch.arange(W)]).int().cuda()
+    cos, sin = torch.empty(T * H * W, 32, device="cuda"), torch.empty(T * H * W, 32, device="cuda")
+    E.check(E.lib().k5_rope_table_f32(cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), pos[T:].data_ptr(),
+                                      pos[T + H:].data_ptr(), T, H, W, 8, 12, 12, 1.0, 2.0, 2.0, None, E.stream_ptr()))
+    args = O.rope_3d_args((T, H, W), [torch.arange(T), torch.arange(H), torch.arange(W)], (16, 24, 24), (1.0, 2.0, 2.0))
+    torch.testing.assert_close(cos.cpu(), torch.cos(args).reshape(-1, 32), atol=2e-6, rtol=0)
+    torch.testing.assert_close(sin.cpu(), torch.sin(args).reshape(-1, 32), atol=2e-6, rtol=0)
+
+
+def test_patchify_unpatchify_orders(E):
+    T, H, W, C = 2, 4, 6, 16
+    x = rnd(T, H, W, C, seed=1)
+    full = torch.cat([x, torch.zeros(T, H, W, C + 1)], dim=-1)
+    ref = bfr(O.patchify(full, (1, 2, 2))).reshape(-1, 4 * 33)
+    out = torch.empty(T * (H // 2) * (W // 2), 136, dtype=BF, device="cuda")
+    xd = x.cuda()
+    E.check(E.lib().k5_patchify_bf16(xd.data_ptr(), out.data_ptr(), T, H, W, C, 33, 136, None, E.stream_ptr()))
+    assert torch.equal(out[:, :132].float().cpu(), ref) and torch.count_nonzero(out[:, 132:]) == 0
+    y = bfr(rnd(T * 2 * 3, 64, seed=2))
+    ref_u = O.unpatchify(y.reshape(T, 2, 3, 64), (1, 2, 2))
+    yo = torch.empty(T, 4, 6, 16, dtype=BF, device="cuda")
+    yd = y.cuda().to(BF)
+    E.check(E.lib().k5_unpatchify_bf16(yd.data_ptr(), yo.data_ptr(), T, 2, 3, 16, 64, None, E.stream_ptr()))
+    assert torch.equal(yo.float().cpu(), ref_u)
+
+
+def test_cfg_euler(E):
+    img, c, u = rnd(1000, seed=1), bfr(rnd(1000, seed=2)), bfr(rnd(1000, seed=3))
+    w, dt = 5.0, -0.0625
+    ref = img + bfr(dt * bfr(u + bfr(w * bfr(c - u))))
+    d = img.cuda()
+    E.cfg_euler_(d, c.cuda().to(BF), u.cuda().to(BF), w, dt)
+    assert torch.equal(d.cpu(), ref)
+    d = img.cuda()
+    E.cfg_euler_(d, c.cuda().to(BF), None, 1.0, dt)
+    assert torch.equal(d.cpu(), img + bfr(dt * c))
