@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py — DiT denoising steps/sec of the MI355X engine on BASELINE.json's metric/config.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" = one Euler update of the flow-matching sampler = one DiT forward (guidance_weight = 1,
+config_5s_nocfg) over the synthetic 5 s 768x512 latent (31,64,96,16) -> N = 47 616 visual tokens,
+L = 256 text tokens, 2B-Lite architecture with random-init weights (no checkpoints offline).
+The latent, text embeddings and weights are resident in HBM before the timed region.
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: dense self-attention, MFMA-bound) and
+`cpu_baseline` (the fp32 CPU oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "kandinsky-5_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+LITE = dict(in_visual_dim=16, out_visual_dim=16, time_dim=512, patch_size=(1, 2, 2), model_dim=1792, ff_dim=7168,
+            num_text_blocks=2, num_visual_blocks=32, axes_dims=(16, 24, 24), visual_cond=True, in_text_dim=3584,
+            in_text_dim2=768)
+WORKLOADS = {
+    # name: latent (T,H,W), text len, null text len, guidance, attention
+    "5s_nocfg": dict(latent=(31, 64, 96), L=256, Lnull=32, w=1.0, attn="flash",
+                     desc="config_5s_nocfg.yaml: 2B Lite, 768x512 5 s latent (31,64,96,16), 47616 tokens, L=256, "
+                          "guidance 1.0 (1 DiT forward per step), NFE=50"),
+    "5s_sft": dict(latent=(31, 64, 96), L=256, Lnull=32, w=5.0, attn="flash",
+                   desc="config_5s_sft.yaml: as 5s_nocfg with CFG (cond + uncond forward per step), NFE=100"),
+    "2s_256": dict(latent=(13, 32, 32), L=256, Lnull=32, w=1.0, attn="flash",
+                   desc="config_5s_distil.yaml plumbing case: 256x256 2 s latent (13,32,32,16), 3328 tokens"),
+}
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def flops_forward(N, L, D=1792, FF=7168, blocks=32):
+    """F_fwd = 32*[2N(6D^2+2D*FF) + 2L*2D^2 + 4N^2 D + 4NLD] + small."""
+    return blocks * (2 * N * (6 * D * D + 2 * D * FF) + 2 * L * 2 * D * D + 4 * N * N * D + 4 * N * L * D) + 0.2e12
+
+
+def cpu_baseline(N, budget_s=12.0):
+    """The CPU oracle (own fp32 restatement pinned against the reference, oracle/k5_oracle.py) on the host
+    cores: ONE full-width decoder block of the 32 at the workload's token count, extrapolated x32 (the text
+    blocks / embeddings are <0.1 % of the FLOPs).  If one block at N would exceed the budget, a query-row
+    slice of the attention is timed and scaled (stated in `sample`)."""
+    from oracle import k5_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.DitConfig(**dict(LITE, num_visual_blocks=1, num_text_blocks=0))
+    names = [k for k in O.state_dict_manifest(cfg) if k.startswith("visual_transformer_blocks.0.")]
+    man = O.state_dict_manifest(cfg)
+    g = torch.Generator().manual_seed(0)
+    sd = {k: torch.randn(man[k], generator=g) * 0.02 for k in names}
+    D, L = cfg.model_dim, 256
+    # calibrate on a small token count to pick the row fraction that fits the budget
+    n_cal = 1024
+    x = torch.randn(n_cal, D, generator=g)
+    text, temb = torch.randn(L, D, generator=g), torch.randn(1, cfg.time_dim, generator=g)
+    cs = torch.ones(n_cal, 32), torch.zeros(n_cal, 32)
+    t0 = time.perf_counter()
+    O.decoder_block(sd, "visual_transformer_blocks.0", x, text, temb, cs[0], cs[1], cfg, "fp32")
+    t_cal = time.perf_counter() - t0
+    fl = lambda n, nq: 2 * nq * (6 * D * D + 2 * D * cfg.ff_dim) + 4 * nq * n * D + 4 * nq * L * D  # noqa: E731
+    rate = fl(n_cal, n_cal) / t_cal
+    frac = min(1.0, budget_s * rate / fl(N, N))
+    nq = max(256, int(N * frac) // 256 * 256)
+    # timed sample: nq query rows of one block against all N keys (all linears on nq rows)
+    x = torch.randn(N, D, generator=g)
+    cos, sin = torch.ones(N, 32), torch.zeros(N, 32)
+    t0 = time.perf_counter()
+    mod = O.modulation(sd, "visual_transformer_blocks.0.visual_modulation", temb)
+    shift, scale, gate = torch.chunk(torch.chunk(mod, 3, dim=-1)[0], 3, dim=-1)
+    h = O.scale_shift_norm(x, scale, shift, "fp32")
+    p = "visual_transformer_blocks.0.self_attention"
+    q, k, v = O._attn_qkv(sd, p, h[:nq], h, "fp32", cfg.num_heads)
+    q, k = O.apply_rotary(q, cos[:nq], sin[:nq], "fp32"), O.apply_rotary(k, cos, sin, "fp32")
+    o = O.sdpa(q, k, v, "fp32")
+    xs = O.gate_sum(x[:nq], O._linear(o, sd[p + ".out_layer.weight"], sd[p + ".out_layer.bias"], "fp32"), gate, "fp32")
+    xs = xs + O.cross_attention(sd, "visual_transformer_blocks.0.cross_attention", xs, text, cfg, "fp32")
+    xs = xs + O.feed_forward(sd, "visual_transformer_blocks.0.feed_forward", xs, "fp32")
+    t_s = time.perf_counter() - t0
+    # k/v projections were done on all N rows; scale the row-proportional part only
+    t_block = t_s * (fl(N, N) / (fl(N, nq) + 2 * (N - nq) * 2 * D * D))
+    return {"value": 1.0 / (32 * t_block), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"fp32 torch-CPU oracle, 1 of 32 decoder blocks, {nq} of {N} query rows against all {N} keys "
+                      f"({t_s:.1f} s measured), scaled to the full block and x32 blocks",
+            "ms_per_step": 32 * t_block * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="5s_nocfg", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blocks", type=int, default=32, help="debug only: fewer visual blocks => INVALID as a bench")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from kandinsky.models.dit import DiffusionTransformer3D
+    wl = WORKLOADS[args.workload]
+    T, H, W = wl["latent"]
+    N, L = T * (H // 2) * (W // 2), wl["L"]
+    cfgd = dict(LITE, num_visual_blocks=args.blocks)
+    with torch.device("meta"):
+        dit = DiffusionTransformer3D(**cfgd)
+    dit.init_synthetic(dev, seed=0)
+    if world > 1:
+        dit.enable_sequence_parallel(rank, world)
+
+    g = torch.Generator(device=dev).manual_seed(6554)
+    latent = torch.randn(T, H, W, 16, device=dev, generator=g)
+    te = {"text_embeds": torch.randn(L, 3584, device=dev, generator=g).bfloat16(),
+          "pooled_embed": torch.randn(1, 768, device=dev, generator=g).bfloat16()}
+    ne = {"text_embeds": torch.randn(wl["Lnull"], 3584, device=dev, generator=g).bfloat16(),
+          "pooled_embed": torch.randn(1, 768, device=dev, generator=g).bfloat16()}
+    vpos = [torch.arange(T), torch.arange(H // 2), torch.arange(W // 2)]
+    tpos, ntpos = torch.arange(L), torch.arange(wl["Lnull"])
+    from kandinsky.generation_utils import sigma_schedule
+    nfe_steps = 50
+    sig = sigma_schedule(nfe_steps, 5.0).tolist()
+
+    def run(k0, k):  # k consecutive Euler steps of the 50-step schedule starting at step k0
+        dit.sample(latent, sig[k0:k0 + k + 1], te, ne, vpos, tpos, ntpos, wl["w"], scale_factor=(1.0, 2.0, 2.0))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    if args.warmup > 0:
+        run(0, args.warmup)
+    barrier()
+    dit.set_profiling(True)
+    dit.reset_profile()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    dit.set_profiling(False)
+
+    fam = {f: dit.get_profile(f) for f in ("attn_self", "attn_cross", "attn_text", "gemm", "elementwise", "prologue",
+                                           "epilogue", "comm")}
+    attn_ms, attn_n = fam["attn_self"]
+    attn_flop = 4.0 * N * N * 64 * 28 / world  # per launch on this rank (queries sharded over ranks)
+    achieved = attn_flop / (attn_ms / max(attn_n, 1) * 1e-3) / 1e12 if attn_n else 0.0
+    fwd_per_step = 2 if abs(wl["w"] - 1.0) > 1e-6 else 1
+    step_flop = fwd_per_step * flops_forward(N, L, blocks=args.blocks)
+    assert torch.isfinite(latent).all(), "latent diverged"
+
+    if rank == 0:
+        out = {
+            "metric": "DiT denoising steps/sec (2B Lite, 5s 768x512 latent)", "value": args.steps / dt, "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": wl["desc"], "tokens": N, "text_len": L, "forwards_per_step": fwd_per_step,
+                       "parallelism": "single GPU" if world == 1 else f"sequence-parallel x{world} (token shards, K/V all-gather)",
+                       "visual_blocks": args.blocks},
+            "nfe_per_s": fwd_per_step * args.steps / dt,
+            "step_tflop": step_flop / 1e12,
+            "model_tflops_per_gpu": step_flop * args.steps / dt / 1e12 / world,
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (dense self-attention, 32 launches per forward)",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                         "traffic": None, "flop_per_launch": attn_flop, "avg_launch_ms": attn_ms / max(attn_n, 1),
+                         "launches": attn_n},
+            "kernel_time_ms_per_step": {k: v[0] / args.steps for k, v in fam.items() if v[1]},
+            "e2e_clip_s_estimate": {"denoise_50_steps_s": 50 * dt / args.steps * (1 if wl["w"] == 1.0 else 1),
+                                    "note": "50 x ms_per_step; VAE decode not included yet"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(N)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,13 @@ int k5_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int
                       int ldq, int ldk, int ldvt, int ldo, const int32_t* kv_nb, const int32_t* kv_idx,
                       int nkb_stride, void* stream);
 
+/* Dense k5_attention_bf16 with a caller-proved bound |q.k| <= score_bound for every (query, key) pair
+ * (after norm_qk nn.py:193-197 every head vector has |x| <= 8*max|weight|).  When 2*bound*log2(e)/8 <= 96
+ * the bound replaces the online running max (same softmax, fewer VALU ops); otherwise, or with
+ * score_bound <= 0, the online-max kernel runs. */
+int k5_attention_bf16_bounded(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+                              int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound, void* stream);
+
 /* apply_scale_shift_norm nn.py:25-28: out = bf16(LayerNorm(x, eps 1e-5, no affine)*(scale+1)+shift). */
 int k5_ln_modulate_bf16(const void* x, const float* scale, const float* shift, void* out, int rows, int D,
                         int ldx, int ldo, void* stream);

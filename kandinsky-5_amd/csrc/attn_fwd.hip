@@ -5,12 +5,9 @@
 // self-attention, :254 visual self-attention, :336 cross-attention; flash-attn itself is a
 // third-party wheel, not part of the reference tree).
 //
-// Structure: one workgroup = 8 waves = 256 query rows of one head; each wave owns 32 query rows.
-// K tile [64 keys][64 d] and V^T tile [64 d][64 keys] are double-buffered in LDS (swizzled 16-B
-// chunks, conflict-free ds_read_b128), register-staged: loads of tile t+1 are issued before the
-// MFMAs of tile t and written to LDS after them (one barrier per tile).
+// Data flow per wave (32 query rows, 64-key tiles):
 //   S^T = K · Q^T   (MFMA A = K rows, B = Q^T)  -> lane (q = l&31) holds 32 scores of ITS query:
-//                   row max / row sum are in-lane + one exchange with lane^32.
+//                   row max / row sum are in-lane + one permlane32 exchange with lane^32.
 //   K rows are fed with bits 2,3 of the row index swapped so that the accumulator registers
 //   [8s, 8s+8) of a lane are 8 CONSECUTIVE keys 16s + 8*(l>>5) + j: they are directly the
 //   B-operand fragment of P^T for the second MFMA — no permlane / LDS round trip for P.
@@ -18,6 +15,17 @@
 //                   softmax rescale is lane-local.
 // V is consumed TRANSPOSED ([H*64][keys]); the engine produces it for free by running the V
 // projection GEMM with operands swapped (W_v · X^T), so no transposing LDS reads are needed.
+//
+// Schedule: one workgroup = 8 waves = 256 query rows of one head; K tile [64][64] and V^T tile
+// [64][64] double-buffered in LDS (swizzled 16-B chunks, zero bank conflicts measured), register
+// staged (tile t+1's global loads are issued before tile t's MFMAs, written to LDS after them), one
+// barrier per tile.  Measured on MI355X (profiles/): a SIMD's time is close to
+// ADDITIVE in MFMA issue cycles (16 x 32 per wave-tile) and VALU issue cycles (~2 per op) — VALU of
+// one wave does not hide under its partner's MFMAs — so phase-shifted ("ping-pong") wave groups
+// bought nothing, while keeping the kernel at <=128 VGPRs (fragments streamed, not hoisted) so that
+// TWO workgroups (4 waves/SIMD) are resident per CU raised issue-port utilisation from 66 % to 85 %.
+// What is left is the VALU op count per score; BOUNDED=true drops the online running max (24 ops
+// per tile + the rescale branch) when the caller proves |score| <= bound (RMS-normalised q, k).
 #include "k5_common.h"
 #include "k5_kernels.h"
 
@@ -30,14 +38,15 @@ constexpr int TILE = 64 * 128;  // bytes of one [64][64] bf16 tile
 struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
   int H, q_len, kv_len, ldq, ldk, ldvt, ldo, nqb;
-  float c;  // softmax scale * log2(e)
+  float c;        // softmax scale * log2(e)
+  float m_fixed;  // BOUNDED: raw-score upper bound used instead of the running max
 };
 
-__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnP p) {
+template <bool BOUNDED>
+__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
-  char* sK = smem;             // 2 buffers
-  char* sV = smem + 2 * TILE;  // 2 buffers
-
+  char* sK = smem;
+  char* sV = smem + 2 * TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int h = lid / p.nqb, qb = lid % p.nqb;
@@ -50,19 +59,20 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + 16 * kk);
   }
-
-  // loader mapping: 512 threads, one 16-B chunk of K and one of V^T each
+  // loader mapping: 512 threads, one 16-B chunk of K and one of V^T each per tile
   const int lrow = tid >> 3, lc = tid & 7;
   const bf16_t* kbase = p.K + h * 64 + 8 * lc;
   const bf16_t* vbase = p.Vt + (size_t)(h * 64 + lrow) * p.ldvt + 8 * lc;
   const int lds_off = lds_swz(lrow, lc);
+  const int T = (p.kv_len + KB - 1) / KB, nfull = p.kv_len / KB;
   u32x4 rk, rv;
-  auto load_tile = [&](int kv0) {
-    rk = *reinterpret_cast<const u32x4*>(kbase + (size_t)min(kv0 + lrow, p.kv_len - 1) * p.ldk);
-    const int key = kv0 + 8 * lc;
-    if (key + 8 <= p.kv_len) {
+  auto load_tile = [&](int t) {
+    rk = *reinterpret_cast<const u32x4*>(kbase + (size_t)min(t * KB + lrow, p.kv_len - 1) * p.ldk);
+    const int kv0 = t * KB;
+    if (t < nfull) {
       rv = *reinterpret_cast<const u32x4*>(vbase + kv0);
-    } else {  // ragged tail: never read past kv_len, zero-fill (P is exactly 0 there)
+    } else {  // ragged last tile: never read past kv_len; zero-fill V^T (P is exactly 0 there)
+      const int key = kv0 + 8 * lc;
       uint16_t e[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
@@ -75,7 +85,6 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnP p) {
     *reinterpret_cast<u32x4*>(sK + buf * TILE + lds_off) = rk;
     *reinterpret_cast<u32x4*>(sV + buf * TILE + lds_off) = rv;
   };
-
   // K row permutation: MFMA row i reads key row pi(i) = i with bits 2 and 3 swapped
   const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
 
@@ -84,62 +93,63 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnP p) {
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
   const float c = p.c;
+  float m_run = BOUNDED ? p.m_fixed : -1e30f, l_run = 0.f;
+  const float mc_fixed = p.m_fixed * c;
 
-  const int ntiles = (p.kv_len + KB - 1) / KB;
   load_tile(0);
   store_tile(0);
   __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = 0; t < T; ++t) {
     const int buf = t & 1;
-    const int kv0 = t * KB;
-    if (t + 1 < ntiles) load_tile(kv0 + KB);
+    if (t + 1 < T) load_tile(t + 1);
     const char* cK = sK + buf * TILE;
     const char* cV = sV + buf * TILE;
-
-    // ---- S^T = K Q^T : two 32-key tiles ----
+    // ---- S^T = K Q^T : two 32-key MFMA tiles, K fragments streamed from LDS ----
     f32x16 st[2];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[tt][r] = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cK + lds_swz(32 * tt + krow, 2 * kk + hi));
-        st[tt] = mfma32(kf, qf[kk], st[tt]);
-      }
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(cK + lds_swz(krow, 2 * kk + hi));
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(cK + lds_swz(32 + krow, 2 * kk + hi));
+      st[0] = mfma32(k0, qf[kk], st[0]);
+      st[1] = mfma32(k1, qf[kk], st[1]);
     }
-    // lane (q=l31, hi) register st[tt][r] is key  kv0 + 32tt + 16(r>>3) + 8hi + (r&7)
-    if (kv0 + KB > p.kv_len) {  // ragged tail tile (wave-uniform branch)
+    // lane (q = l31, hi): st[tt][r] is key  t*64 + 32tt + 16(r>>3) + 8hi + (r&7)
+    if (t >= nfull) {  // ragged last tile (wave-uniform branch)
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + 32 * tt + 16 * (r >> 3) + 8 * hi + (r & 7);
+          const int key = t * KB + 32 * tt + 16 * (r >> 3) + 8 * hi + (r & 7);
           if (key >= p.kv_len) st[tt][r] = -1e30f;
         }
     }
-    // ---- online softmax (raw-score max, exp2 with folded scale) ----
-    float mt = st[0][0];
+    float mc;
+    if (BOUNDED) {
+      mc = mc_fixed;
+    } else {  // online softmax: raw-score running max, rescale only when some row's max grew
+      float mt = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, st[0][r]);
+      for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, st[0][r]), st[1][r]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+      mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // max with the partner lane (l ^ 32)
+      const float m_new = fmaxf(m_run, mt);
+      if (__any(m_new > m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        l_run *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[1][r]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    if (__any(m_new > m_run)) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      l_run *= alpha;
+        for (int d = 0; d < 2; ++d)
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
-      m_run = m_new;
+          for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+        m_run = m_new;
+      }
+      mc = m_run * c;
     }
-    const float mc = m_run * c;
-    bf16x8 pf[4];
+    // ---- P = exp2(S c - m c) -> bf16 fragments; O^T += V^T P^T, V^T fragments streamed ----
     float ls = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -149,26 +159,24 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnP p) {
         e[j] = __builtin_amdgcn_exp2f(fmaf(st[s >> 1][8 * (s & 1) + j], c, -mc));
         ls += e[j];
       }
-      u32x4 pk = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]),
-                  pack_bf16x2(e[6], e[7])};
-      pf[s] = __builtin_bit_cast(bf16x8, pk);
+      u32x4 pk = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
+      const bf16x8 pfs = __builtin_bit_cast(bf16x8, pk);
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(cV + lds_swz(l31, 2 * s + hi));
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(cV + lds_swz(32 + l31, 2 * s + hi));
+      ot[0] = mfma32(v0, pfs, ot[0]);
+      ot[1] = mfma32(v1, pfs, ot[1]);
     }
     l_run += ls;
-    // ---- O^T += V^T P^T ----
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cV + lds_swz(32 * d + l31, 2 * s + hi));
-        ot[d] = mfma32(vf, pf[s], ot[d]);
-      }
-    }
-    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    if (t + 1 < T) store_tile(buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue: normalise, store O[q][h*64 + d] ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot;
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
   const float inv = 1.0f / l_tot;
   const int q = q0 + l31;
   if (q < p.q_len) {
@@ -186,18 +194,36 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnP p) {
 
 }  // namespace
 
-int k5_launch_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
-                             int kv_len, int ldq, int ldk, int ldvt, int ldo, const int32_t* kv_nb,
-                             const int32_t* kv_idx, int nkb_stride, hipStream_t stream) {
+// score_bound > 0: caller guarantees |q.k| <= score_bound for every pair (e.g. RMS-normalised q, k:
+// 64 * max|w_q| * max|w_k|).  If the bound is small enough that exp2 can neither overflow nor flush a
+// whole row to zero, the kernel uses it as a fixed softmax offset and skips the online running max.
+int k5_launch_attention_bf16_bounded(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+                                     int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
+                                     hipStream_t stream) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
-  if (kv_nb || kv_idx) return K5_ERR_UNSUPPORTED;
-  (void)nkb_stride;
   AttnP p;
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
   p.H = H; p.q_len = q_len; p.kv_len = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
   p.nqb = (q_len + QB - 1) / QB;
   p.c = 0.125f * 1.44269504088896340736f;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(H * p.nqb), dim3(512), 0, stream, p);
+  p.m_fixed = 0.f;
+  const dim3 grid(H * p.nqb), block(512);
+  // exponent range used: [-2*bound*c, 0]; fp32 exp2 flushes below -126 -> require 2*bound*c <= 96
+  const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
+  if (bounded) {
+    p.m_fixed = score_bound;
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, stream, p);
+  }
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
+int k5_launch_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+                             int kv_len, int ldq, int ldk, int ldvt, int ldo, const int32_t* kv_nb,
+                             const int32_t* kv_idx, int nkb_stride, hipStream_t stream) {
+  if (kv_nb || kv_idx) return K5_ERR_UNSUPPORTED;
+  (void)nkb_stride;
+  return k5_launch_attention_bf16_bounded(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, 0.f, stream);
 }

@@ -93,6 +93,7 @@ float bf16_round_host(float f) { uint32_t u = (uint32_t)f32_to_bf16_rne(f) << 16
 struct AttnW {  // one attention module, packed
   DevBuf wqk, wq, wk, wv, wo;       // bf16
   DevBuf bqk, bq, bk, bv, bo, norm; // fp32 (bias values bf16-rounded); norm = [q_norm | k_norm]
+  float score_bound = 0.f;          // |q.k| <= 64 max|w_q| max|w_k| after norm_qk (RoPE preserves norms)
 };
 struct BlockW {
   AttnW self_attn, cross_attn;
@@ -247,6 +248,9 @@ int pack_attn(k5_dit* d, const std::string& p, AttnW& a, bool fuse_qk) {
   std::vector<float> n(128);
   memcpy(n.data(), nq->data.data(), 64 * 4); memcpy(n.data() + 64, nk->data.data(), 64 * 4);
   K5CHK(upload_f32(a.norm, n.data(), 128));
+  float mq = 0.f, mk = 0.f;
+  for (int i = 0; i < 64; ++i) { mq = fmaxf(mq, fabsf(n[i])); mk = fmaxf(mk, fabsf(n[64 + i])); }
+  a.score_bound = 64.f * mq * mk * 1.05f;  // 5 % margin for the bf16 roundings after RMSNorm / RoPE
   return K5_OK;
 }
 
@@ -272,7 +276,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   }
   {
     Scope sc(d, s, fam_attn);
-    K5CHK(k5_launch_attention_bf16(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, nullptr, nullptr, 0, s));
+    K5CHK(k5_launch_attention_bf16_bounded(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, s));
   }
   {
     Scope sc(d, s, "gemm");
@@ -298,7 +302,7 @@ int run_cross_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h,
   }
   {
     Scope sc(d, s, "attn_cross");
-    K5CHK(k5_launch_attention_bf16(q, ck, cvt, o, H, rows, L, D, D, ldvt, D, nullptr, nullptr, 0, s));
+    K5CHK(k5_launch_attention_bf16_bounded(q, ck, cvt, o, H, rows, L, D, D, ldvt, D, a.score_bound, s));
   }
   {
     Scope sc(d, s, "gemm");

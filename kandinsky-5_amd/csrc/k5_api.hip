@@ -27,6 +27,12 @@ int k5_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int
                                       (hipStream_t)stream), "k5_attention_bf16");
 }
 
+int k5_attention_bf16_bounded(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len,
+                              int ldq, int ldk, int ldvt, int ldo, float score_bound, void* stream) {
+  return ret(k5_launch_attention_bf16_bounded(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, score_bound,
+                                              (hipStream_t)stream), "k5_attention_bf16_bounded");
+}
+
 int k5_ln_modulate_bf16(const void* x, const float* scale, const float* shift, void* out, int rows, int D, int ldx,
                         int ldo, void* stream) {
   return ret(k5_launch_ln_modulate(x, scale, shift, out, rows, D, ldx, ldo, (hipStream_t)stream), "k5_ln_modulate_bf16");

@@ -18,6 +18,11 @@ int k5_launch_attention_bf16(const void* Q, const void* K, const void* Vt, void*
                              int kv_len, int ldq, int ldk, int ldvt, int ldo, const int32_t* kv_nb,
                              const int32_t* kv_idx, int nkb_stride, hipStream_t stream);
 
+// Dense attention with a caller-proved bound |q.k| <= score_bound (0 = unknown -> online running max).
+int k5_launch_attention_bf16_bounded(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+                                     int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
+                                     hipStream_t stream);
+
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,
                           int D, int ldx, int ldo, hipStream_t stream);

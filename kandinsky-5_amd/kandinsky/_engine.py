@@ -56,6 +56,7 @@ SYMBOLS = {
     "k5_last_error": (C.c_char_p, []),
     "k5_gemm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "k5_attention_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "k5_attention_bf16_bounded": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "k5_ln_modulate_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "k5_rmsnorm_rope_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "k5_gate_sum_bf16": (_I, [_P, _P, _P, _P, _I, _I, _P]),
@@ -151,13 +152,18 @@ def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, out=None):
     return out
 
 
-def attention(q, k, vt, num_heads, q_len=None, kv_len=None, kv_nb=None, kv_idx=None, out=None):
+def attention(q, k, vt, num_heads, q_len=None, kv_len=None, kv_nb=None, kv_idx=None, out=None, score_bound=None):
     """q [Sq, >=H*64] , k [Sk, >=H*64], vt [H*64, >=Sk] bf16 -> out [Sq, H*64]."""
     _need_cuda(q, k, vt)
     q_len = q.shape[0] if q_len is None else q_len
     kv_len = k.shape[0] if kv_len is None else kv_len
     if out is None:
         out = torch.empty(q_len, num_heads * 64, dtype=torch.bfloat16, device=q.device)
+    if score_bound is not None:
+        check(lib().k5_attention_bf16_bounded(ptr(q), ptr(k), ptr(vt), ptr(out), num_heads, q_len, kv_len, q.stride(0),
+                                              k.stride(0), vt.stride(0), out.stride(0), float(score_bound),
+                                              stream_ptr(q.device)), "k5_attention_bf16_bounded")
+        return out
     check(lib().k5_attention_bf16(ptr(q), ptr(k), ptr(vt), ptr(out), num_heads, q_len, kv_len, q.stride(0), k.stride(0),
                                   vt.stride(0), out.stride(0), ptr(kv_nb), ptr(kv_idx),
                                   0 if kv_idx is None else kv_idx.shape[-1], stream_ptr(q.device)), "k5_attention_bf16")

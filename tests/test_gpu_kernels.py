@@ -1,6 +1,7 @@
 """GPU parity tests (MI355X): every HIP kernel, called through the C ABI, against the CPU oracle
 (oracle/k5_oracle.py, bf16-island arithmetic) on the same seeded inputs.  Tolerances are written here:
-bf16 outputs agree to a few bf16 ulps (eps = 2^-7... relative 7.8e-3 per ulp)."""
+bf16 outputs agree to `ulps` bf16 ulps (one ulp <= 2^-7 * |x|: fp32 summation order differs between the
+GPU and the CPU oracle, which can flip a round-to-nearest tie) plus a small absolute term."""
 import math
 
 import pytest
@@ -33,7 +34,7 @@ def bfr(x):
 
 def assert_bf16_close(got, ref, ulps=2, atol=1e-3, what=""):
     got, ref = got.float().cpu(), ref.float()
-    tol = atol + ulps * 2.0 ** -8 * ref.abs()
+    tol = atol + ulps * 2.0 ** -7 * ref.abs()
     bad = (got - ref).abs() > tol
     assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.numel()} off; max abs err {(got - ref).abs().max():.4g}"
 
@@ -182,7 +183,7 @@ def test_rmsnorm_rope_fused_qk(E):
     d = qk.cuda().to(BF)
     E.rmsnorm_rope_(d, torch.cat([wq, wk]).cuda(), cos.cuda().contiguous(), sin.cuda().contiguous(), heads=2 * H,
                     heads_per_weight=H, rope_heads=2 * H)
-    assert_bf16_close(d, ref, ulps=1, atol=1e-4, what="rmsnorm+rope")
+    assert_bf16_close(d, ref, ulps=2, atol=1e-4, what="rmsnorm+rope")  # two chained bf16 roundings
     # no-rope variant (cross-attention q / k, reference nn.py:343-349)
     d2 = qk[:, :H * 64].contiguous().cuda().to(BF)
     E.rmsnorm_rope_(d2, wq.cuda())
@@ -248,3 +249,24 @@ def test_cfg_euler(E):
     d = img.cuda()
     E.cfg_euler_(d, c.cuda().to(BF), None, 1.0, dt)
     assert torch.equal(d.cpu(), img + bfr(dt * c))
+
+
+def test_attention_bounded_scores_equals_online_max(E):
+    """RMS-normalised q,k (|q|=|k|=8 -> |q.k| <= 64): the fixed-offset kernel is the same softmax."""
+    S, H = 700, 2
+    def rmsn(x):
+        return bfr(x / x.pow(2).mean(-1, keepdim=True).sqrt())
+    q, k, v = rmsn(rnd(S, H, 64, seed=1)), rmsn(rnd(S, H, 64, seed=2)), bfr(rnd(S, H, 64, seed=3))
+    ref = attn_ref(q, k, v)
+    vt = torch.zeros(H * 64, 704, dtype=BF, device="cuda")  # leading dimension must be a multiple of 8
+    vt[:, :S] = v.reshape(S, -1).t().to(BF)
+    qd, kd = q.reshape(S, -1).cuda().to(BF), k.reshape(S, -1).cuda().to(BF)
+    with pytest.raises(RuntimeError, match="status 2"):  # unaligned V^T rows are refused loudly
+        E.attention(qd, kd, v.reshape(S, -1).t().contiguous().cuda().to(BF), H, score_bound=64 * 1.05)
+    a = E.attention(qd, kd, vt, H, kv_len=S, score_bound=64 * 1.05)
+    b = E.attention(qd, kd, vt, H, kv_len=S)
+    assert_bf16_close(a, ref, ulps=4, atol=1e-2, what="bounded attention")
+    assert (a.float() - b.float()).abs().max().item() <= 2 ** -7
+    # a bound too large for a fixed offset silently falls back to the online-max kernel (still correct)
+    c = E.attention(qd, kd, vt, H, kv_len=S, score_bound=1e4)
+    assert torch.equal(c, b)

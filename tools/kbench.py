@@ -34,7 +34,7 @@ def rnd(*s):
 
 
 def bench_attn():
-    for (sq, sk, h) in ((N, N, H), (N, 256, H), (3328, 3328, H)):
+    for (sq, sk, h) in ((N, N, H), (N, 256, H), (3328, 3328, H), (N, 4096, H), (N, 16384, H)):
         q, k = rnd(sq, h * 64), rnd(sk, h * 64)
         vt = rnd(h * 64, (sk + 7) // 8 * 8)
         o = torch.empty(sq, h * 64, dtype=BF, device="cuda")
