@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="5s_nocfg", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sp", action="store_true", help="debug: drive the sharded code path through a world=1 RCCL communicator")
     ap.add_argument("--blocks", type=int, default=32, help="debug only: fewer visual blocks => INVALID as a bench")
     args = ap.parse_args()
 
@@ -123,7 +124,7 @@ def main():
     with torch.device("meta"):
         dit = DiffusionTransformer3D(**cfgd)
     dit.init_synthetic(dev, seed=0)
-    if world > 1:
+    if world > 1 or args.force_sp:
         dit.enable_sequence_parallel(rank, world)
 
     g = torch.Generator(device=dev).manual_seed(6554)

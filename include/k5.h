@@ -154,6 +154,14 @@ int k5_dit_forward(k5_dit* dit, const k5_forward_args* args, void* out_velocity,
 /* whole Euler loop on device (generate, generation_utils.py:80-129) */
 int k5_sample(k5_dit* dit, const k5_sample_args* args, void* stream);
 
+/* Sequence parallelism (replaces the reference's DTensor head-parallel plan, kandinsky/models/parallelize.py:11-102,
+ * keeps its launch contract LOCAL_RANK/WORLD_SIZE, kandinsky/utils.py:40-55): one process per GPU, rank r owns the
+ * visual-token rows [r*N/world, (r+1)*N/world) (N a multiple of 64*world); K and V^T of every block are
+ * all-gathered over RCCL/xGMI.  rccl_lib_path: library to dlopen (NULL/"" = default names).  Rank 0 obtains a
+ * 128-byte ncclUniqueId with k5_comm_unique_id, the host broadcasts it, every rank calls k5_dit_comm_init. */
+int k5_comm_unique_id(const char* rccl_lib_path, void* out_unique_id_128);
+int k5_dit_comm_init(k5_dit* dit, const char* rccl_lib_path, int rank, int world, const void* unique_id_128);
+
 /* per-kernel-family accumulated GPU time of the last forward(s), measured with hipEvents on the
  * engine's stream when profiling is enabled.  names: "attn_self","attn_cross","gemm","elementwise",...  */
 int k5_dit_set_profiling(k5_dit* dit, int enabled);

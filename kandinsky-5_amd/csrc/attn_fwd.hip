@@ -40,6 +40,9 @@ struct AttnP {
   int H, q_len, kv_len, ldq, ldk, ldvt, ldo, nqb;
   float c;        // softmax scale * log2(e)
   float m_fixed;  // BOUNDED: raw-score upper bound used instead of the running max
+  // sequence-parallel layout of V^T: keys are split in chunks of vt_chunk_keys (multiple of 64) and chunk c
+  // starts at Vt + c * vt_chunk_stride ([rank][H*64][ldvt] after an in-place all-gather); 0 = one chunk
+  int vt_chunk_keys; long long vt_chunk_stride;
 };
 
 template <bool BOUNDED>
@@ -66,17 +69,20 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   const int lds_off = lds_swz(lrow, lc);
   const int T = (p.kv_len + KB - 1) / KB, nfull = p.kv_len / KB;
   u32x4 rk, rv;
+  const int tiles_per_chunk = p.vt_chunk_keys > 0 ? p.vt_chunk_keys / KB : 0x7fffffff;
   auto load_tile = [&](int t) {
     rk = *reinterpret_cast<const u32x4*>(kbase + (size_t)min(t * KB + lrow, p.kv_len - 1) * p.ldk);
     const int kv0 = t * KB;
+    const int chunk = t / tiles_per_chunk;  // wave-uniform
+    const bf16_t* vsrc = vbase + (long long)chunk * p.vt_chunk_stride + (kv0 - chunk * tiles_per_chunk * KB);
     if (t < nfull) {
-      rv = *reinterpret_cast<const u32x4*>(vbase + kv0);
+      rv = *reinterpret_cast<const u32x4*>(vsrc);
     } else {  // ragged last tile: never read past kv_len; zero-fill V^T (P is exactly 0 there)
       const int key = kv0 + 8 * lc;
       uint16_t e[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        e[j] = (key + j < p.kv_len) ? reinterpret_cast<const uint16_t*>(vbase + kv0)[j] : (uint16_t)0;
+        e[j] = (key + j < p.kv_len) ? reinterpret_cast<const uint16_t*>(vsrc)[j] : (uint16_t)0;
       rv = u32x4{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
                  (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
     }
@@ -197,17 +203,19 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
 // score_bound > 0: caller guarantees |q.k| <= score_bound for every pair (e.g. RMS-normalised q, k:
 // 64 * max|w_q| * max|w_k|).  If the bound is small enough that exp2 can neither overflow nor flush a
 // whole row to zero, the kernel uses it as a fixed softmax offset and skips the online running max.
-int k5_launch_attention_bf16_bounded(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                      int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
-                                     hipStream_t stream) {
+                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
+  if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
   AttnP p;
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
   p.H = H; p.q_len = q_len; p.kv_len = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
   p.nqb = (q_len + QB - 1) / QB;
   p.c = 0.125f * 1.44269504088896340736f;
   p.m_fixed = 0.f;
+  p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   const dim3 grid(H * p.nqb), block(512);
   // exponent range used: [-2*bound*c, 0]; fp32 exp2 flushes below -126 -> require 2*bound*c <= 96
   const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
@@ -218,6 +226,12 @@ int k5_launch_attention_bf16_bounded(const void* Q, const void* K, const void* V
     hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, stream, p);
   }
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
+int k5_launch_attention_bf16_bounded(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+                                     int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
+                                     hipStream_t stream) {
+  return k5_launch_attention_bf16_chunked(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, score_bound, 0, 0, stream);
 }
 
 int k5_launch_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,

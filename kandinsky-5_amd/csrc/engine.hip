@@ -13,6 +13,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types / enums only: the library is dlopen()ed (see Comm)
+
 #include "k5_common.h"
 #include "k5_kernels.h"
 
@@ -103,6 +106,47 @@ struct BlockW {
 
 struct Prof { double ms = 0; int64_t n = 0; };
 
+// RCCL over xGMI, one process per GPU.  The library is dlopen()ed (RTLD_LOCAL) from a path given by the
+// host — normally the librccl.so that torch already mapped — so libk5 has no link-time RCCL dependency
+// and never ends up with a second, conflicting copy of the nccl* symbols in the global namespace.
+struct Comm {
+  void* lib = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  int open(const char* path) {
+    if (lib) return K5_OK;
+    const char* cands[] = {path, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* c : cands) {
+      if (!c || !c[0]) continue;
+      lib = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) { k5_set_error("cannot dlopen RCCL (%s): %s", path ? path : "default names", dlerror()); return K5_ERR_STATE; }
+    GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+    GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) {
+      k5_set_error("RCCL library lacks a required nccl* symbol"); return K5_ERR_STATE;
+    }
+    return K5_OK;
+  }
+  // in-place all-gather: every rank's chunk already sits at buf + rank*count*elem
+  int all_gather_inplace(void* buf, size_t count_per_rank, size_t elem_bytes, hipStream_t s) {
+    char* b = (char*)buf;
+    const ncclResult_t r = AllGather(b + (size_t)rank * count_per_rank * elem_bytes, b, count_per_rank * elem_bytes,
+                                     ncclUint8, comm, s);
+    if (r != ncclSuccess) { k5_set_error("ncclAllGather: %s", GetErrorString(r)); return K5_ERR_HIP; }
+    return K5_OK;
+  }
+};
+
 }  // namespace
 
 struct k5_dit {
@@ -127,6 +171,11 @@ struct k5_dit {
   DevBuf ws_xp, ws_vis, ws_h, ws_qk, ws_vt, ws_o, ws_ff, ws_ck, ws_cvt, ws_y;
   DevBuf ws_vcos, ws_vsin, ws_pos;
   DevBuf ws_vel_c, ws_vel_u;
+  // sequence parallelism (token shards): this rank owns rows [sp_rank*n_loc, (sp_rank+1)*n_loc) of the N visual
+  // tokens; K and V^T of every block are all-gathered in place into ws_kfull [N][D] / ws_vtfull [P][D][n_loc]
+  Comm comm;
+  int sp_rank = 0, sp_world = 1;
+  DevBuf ws_q, ws_kfull, ws_vtfull;
   // rope cache keys
   std::vector<int32_t> key_vpos; float key_scale[3] = {0, 0, 0}; int key_shape[3] = {0, 0, 0};
   struct TextRope { std::vector<int32_t> key; DevBuf cosT, sinT, pos; };
@@ -285,6 +334,49 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   return K5_OK;
 }
 
+// Sequence-parallel visual self-attention: `rows` = this rank's token rows, N = rows * world keys in total.
+// q / k / v^T are projected for the local rows only; k and v^T land directly in this rank's slot of the
+// gather buffers, one in-place all-gather each makes every rank hold all keys, then attention runs for the
+// local query rows.  No head-count constraint (28 heads do not divide by 8), no activation all-reduce.
+int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, void* o, const float* cosT,
+                          const float* sinT, void* resid, const float* gate) {
+  const int D = d->D, H = d->Hh, P = d->sp_world, r = d->sp_rank;
+  const int N = rows * P, ldv = rows;  // rows is a multiple of 64 (checked by the caller)
+  bf16_t* q = d->ws_q.as<bf16_t>();
+  bf16_t* kfull = d->ws_kfull.as<bf16_t>();
+  bf16_t* vtfull = d->ws_vtfull.as<bf16_t>();
+  bf16_t* kloc = kfull + (size_t)r * rows * D;
+  bf16_t* vtloc = vtfull + (size_t)r * D * ldv;
+  const bf16_t* wq = a.wqk.as<bf16_t>();
+  const bf16_t* wk = wq + (size_t)D * D;
+  {
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_bf16(h, wk, a.bqk.as<float>() + D, kloc, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_gemm_bf16(a.wv.p, h, a.bv.as<float>(), vtloc, D, rows, D, D, D, ldv, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_gemm_bf16(h, wq, a.bqk.as<float>(), q, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+  }
+  {
+    Scope sc(d, s, "elementwise");
+    K5CHK(k5_launch_rmsnorm_rope(kloc, a.norm.as<float>() + 64, cosT, sinT, rows, H, D, nullptr, s));
+    K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), cosT, sinT, rows, H, D, nullptr, s));
+  }
+  {
+    Scope sc(d, s, "comm");
+    K5CHK(d->comm.all_gather_inplace(kfull, (size_t)rows * D, 2, s));
+    K5CHK(d->comm.all_gather_inplace(vtfull, (size_t)D * ldv, 2, s));
+  }
+  {
+    Scope sc(d, s, "attn_self");
+    K5CHK(k5_launch_attention_bf16_chunked(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows,
+                                           (long long)D * ldv, s));
+  }
+  {
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_bf16(o, a.wo.p, a.bo.as<float>(), resid, rows, D, D, D, D, D, K5_EPI_GATE, resid, D, gate, s));
+  }
+  return K5_OK;
+}
+
 int run_cross_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, const void* text,
                         int L, void* q, void* ck, void* cvt, void* o, void* resid, const float* gate) {
   const int D = d->D, H = d->Hh;
@@ -374,6 +466,8 @@ int prepare_text_rope(k5_dit* d, hipStream_t s, const k5_text_cond& c, const flo
   if (d->text_rope.size() >= 8) {
     HIPCHK(hipStreamSynchronize(s));
     for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release();
+  if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
     d->text_rope.clear();
   }
   d->text_rope.emplace_back();
@@ -409,7 +503,18 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
   const int Cin = c.visual_cond ? 2 * c.in_visual_dim + 1 : c.in_visual_dim;
   if (N <= 0 || L <= 0 || (a->H & 1) || (a->W & 1)) { k5_set_error("bad shapes"); return K5_ERR_ARG; }
   if (x_channels != Cin && x_channels != c.in_visual_dim) { k5_set_error("x_channels must be %d or %d", Cin, c.in_visual_dim); return K5_ERR_ARG; }
+  const int P = d->sp_world;
+  if (d->comm.comm && (N % (64 * P))) {
+    k5_set_error("sequence parallel x%d needs the token count (%d) to be a multiple of %d", P, N, 64 * P);
+    return K5_ERR_UNSUPPORTED;
+  }
+  const int n = N / P, tok0 = d->sp_rank * n;  // this rank's token rows [tok0, tok0 + n)
+  const bool sp = d->comm.comm != nullptr;  // a communicator (even of size 1) selects the sharded code path
   K5CHK(ensure_workspaces(d, N, L));
+  if (sp) {
+    K5CHK(d->ws_q.ensure((size_t)n * D * 2)); K5CHK(d->ws_kfull.ensure((size_t)N * D * 2));
+    K5CHK(d->ws_vtfull.ensure((size_t)N * D * 2));
+  }
   K5CHK(prepare_rope(d, s, a, Tp, Hp, Wp));
   const float *tcos = nullptr, *tsin = nullptr;
   K5CHK(prepare_text_rope(d, s, cond, &tcos, &tsin));
@@ -437,8 +542,8 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     K5CHK(k5_launch_gemv_f32(d->ws_temb.as<float>(), d->mod_w.as<float>(), d->mod_b.as<float>(), d->ws_mod.as<float>(),
                              (int)d->mod_rows, d->TD, 1, nullptr, s));
     K5CHK(k5_launch_patchify(x, d->ws_xp.p, a->T, a->H, a->W, x_channels, Cin, d->KvisPad, nullptr, s));
-    K5CHK(k5_launch_gemm_bf16(d->ws_xp.p, d->vis_w.p, d->vis_b.as<float>(), d->ws_vis.p, N, D, d->KvisPad, d->KvisPad,
-                              d->KvisPad, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_gemm_bf16(d->ws_xp.as<bf16_t>() + (size_t)tok0 * d->KvisPad, d->vis_w.p, d->vis_b.as<float>(), d->ws_vis.p,
+                              n, D, d->KvisPad, d->KvisPad, d->KvisPad, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   }
   // ---- text blocks (dit.py:170-171, 33-44) ----
   for (int i = 0; i < c.num_text_blocks; ++i) {
@@ -453,22 +558,30 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
   for (int i = 0; i < c.num_visual_blocks; ++i) {
     const BlockW& b = d->vblocks[i];
     const float* m = mod + b.mod_off;
-    K5CHK(ln_mod(d, s, d->ws_vis.p, m, d->ws_h.p, N));
-    K5CHK(run_self_attention(d, s, b.self_attn, d->ws_h.p, N, d->ws_qk.p, d->ws_vt.p, d->ws_o.p, d->ws_vcos.as<float>(),
-                             d->ws_vsin.as<float>(), d->ws_vis.p, m + 2 * D, "attn_self"));
-    K5CHK(ln_mod(d, s, d->ws_vis.p, m + 3 * D, d->ws_h.p, N));
-    K5CHK(run_cross_attention(d, s, b.cross_attn, d->ws_h.p, N, d->ws_text.p, L, d->ws_qk.p, d->ws_ck.p, d->ws_cvt.p,
+    const float* vcos = d->ws_vcos.as<float>() + (size_t)tok0 * 32;
+    const float* vsin = d->ws_vsin.as<float>() + (size_t)tok0 * 32;
+    K5CHK(ln_mod(d, s, d->ws_vis.p, m, d->ws_h.p, n));
+    if (sp) {
+      K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D));
+    } else {
+      K5CHK(run_self_attention(d, s, b.self_attn, d->ws_h.p, n, d->ws_qk.p, d->ws_vt.p, d->ws_o.p, vcos, vsin, d->ws_vis.p,
+                               m + 2 * D, "attn_self"));
+    }
+    K5CHK(ln_mod(d, s, d->ws_vis.p, m + 3 * D, d->ws_h.p, n));
+    K5CHK(run_cross_attention(d, s, b.cross_attn, d->ws_h.p, n, d->ws_text.p, L, d->ws_qk.p, d->ws_ck.p, d->ws_cvt.p,
                               d->ws_o.p, d->ws_vis.p, m + 5 * D));
-    K5CHK(ln_mod(d, s, d->ws_vis.p, m + 6 * D, d->ws_h.p, N));
-    K5CHK(run_ff(d, s, b, d->ws_h.p, N, d->ws_ff.p, d->ws_vis.p, m + 8 * D));
+    K5CHK(ln_mod(d, s, d->ws_vis.p, m + 6 * D, d->ws_h.p, n));
+    K5CHK(run_ff(d, s, b, d->ws_h.p, n, d->ws_ff.p, d->ws_vis.p, m + 8 * D));
   }
   // ---- after_blocks / OutLayer (dit.py:149-153, nn.py:374-400) ----
   {
     Scope sc(d, s, "epilogue");
     const float* m = mod + d->out_mod_off;  // [shift | scale]
-    K5CHK(k5_launch_ln_modulate(d->ws_vis.p, m + D, m, d->ws_h.p, N, D, D, D, s));
-    K5CHK(k5_launch_gemm_bf16(d->ws_h.p, d->out_w.p, d->out_b.as<float>(), d->ws_y.p, N, d->Fout, D, D, D, d->Fout,
-                              K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_ln_modulate(d->ws_vis.p, m + D, m, d->ws_h.p, n, D, D, D, s));
+    K5CHK(k5_launch_gemm_bf16(d->ws_h.p, d->out_w.p, d->out_b.as<float>(), d->ws_y.as<bf16_t>() + (size_t)tok0 * d->Fout, n,
+                              d->Fout, D, D, D, d->Fout, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    // every rank needs the whole velocity: the (replicated) latent is advanced identically on all ranks
+    if (sp) K5CHK(d->comm.all_gather_inplace(d->ws_y.p, (size_t)n * d->Fout, 2, s));
     K5CHK(k5_launch_unpatchify(d->ws_y.p, out_velocity, Tp, Hp, Wp, c.out_visual_dim, d->Fout, nullptr, s));
   }
   return K5_OK;
@@ -512,6 +625,8 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
                    &d->ws_vel_u};
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release();
+  if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
   auto rel_attn = [](AttnW& a) {
     DevBuf* bs[] = {&a.wqk, &a.wq, &a.wk, &a.wv, &a.wo, &a.bqk, &a.bq, &a.bk, &a.bv, &a.bo, &a.norm};
     for (DevBuf* b : bs) b->release();
@@ -658,6 +773,36 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
       K5CHK(k5_launch_cfg_euler(a->latent, d->ws_vel_c.p, cfg_on ? d->ws_vel_u.p : nullptr, a->guidance_weight, dt, n, s));
     }
   }
+  return K5_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: sequence parallelism over RCCL
+// ---------------------------------------------------------------------------------------------
+extern "C" int k5_comm_unique_id(const char* rccl_lib_path, void* out128) {
+  g_err[0] = 0;
+  if (!out128) return K5_ERR_ARG;
+  static Comm probe;  // library handle only
+  K5CHK(probe.open(rccl_lib_path));
+  ncclUniqueId id;
+  const ncclResult_t r = probe.GetUniqueId(&id);
+  if (r != ncclSuccess) { k5_set_error("ncclGetUniqueId: %s", probe.GetErrorString(r)); return K5_ERR_HIP; }
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(out128, &id, 128);
+  return K5_OK;
+}
+
+extern "C" int k5_dit_comm_init(k5_dit* d, const char* rccl_lib_path, int rank, int world, const void* unique_id128) {
+  g_err[0] = 0;
+  if (!d || !unique_id128 || world < 1 || rank < 0 || rank >= world) return K5_ERR_ARG;
+  if (d->comm.comm) { k5_set_error("communicator already initialised"); return K5_ERR_STATE; }
+  K5CHK(d->comm.open(rccl_lib_path));
+  ncclUniqueId id;
+  memcpy(&id, unique_id128, 128);
+  const ncclResult_t r = d->comm.CommInitRank(&d->comm.comm, world, id, rank);
+  if (r != ncclSuccess) { k5_set_error("ncclCommInitRank: %s", d->comm.GetErrorString(r)); return K5_ERR_HIP; }
+  d->comm.rank = rank; d->comm.world = world;
+  d->sp_rank = rank; d->sp_world = world;
   return K5_OK;
 }
 

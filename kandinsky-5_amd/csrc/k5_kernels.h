@@ -23,6 +23,12 @@ int k5_launch_attention_bf16_bounded(const void* Q, const void* K, const void* V
                                      int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                      hipStream_t stream);
 
+// Same, with V^T stored as per-rank chunks (sequence parallelism): keys [c*chunk_keys, (c+1)*chunk_keys) live at
+// Vt + c*chunk_stride, row stride ldvt.
+int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+                                     int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
+                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream);
+
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,
                           int D, int ldx, int ldo, hipStream_t stream);

@@ -74,6 +74,8 @@ SYMBOLS = {
     "k5_dit_missing_keys": (_I, [_P]),
     "k5_dit_forward": (_I, [_P, C.POINTER(ForwardArgs), _P, _P]),
     "k5_sample": (_I, [_P, C.POINTER(SampleArgs), _P]),
+    "k5_comm_unique_id": (_I, [C.c_char_p, _P]),
+    "k5_dit_comm_init": (_I, [_P, C.c_char_p, _I, _I, _P]),
     "k5_dit_set_profiling": (_I, [_P, _I]),
     "k5_dit_get_profile": (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "k5_dit_reset_profile": (_I, [_P]),

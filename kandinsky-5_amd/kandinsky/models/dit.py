@@ -250,6 +250,31 @@ class DiffusionTransformer3D(nn.Module):
             E.check(E.lib().k5_sample(h, C.byref(s), E.stream_ptr(dev)), "k5_sample")
         return latent
 
+    # ---------------------------------------------------------------- multi-GPU
+    def enable_sequence_parallel(self, rank, world, device=None):
+        """Token-sharded sequence parallelism over RCCL (one process per GPU; replaces the reference's DTensor
+        plan, kandinsky/models/parallelize.py).  Rank 0 creates the ncclUniqueId inside libk5, torch.distributed
+        (already initialised by the launcher, kandinsky/utils.py:40-55 contract) only carries its 128 bytes."""
+        import os
+        if self._handle is None:
+            if device is None:
+                raise RuntimeError("build the engine first (forward / init_synthetic) or pass device=")
+            self.engine(device)
+        lib_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = lib_path.encode() if os.path.exists(lib_path) else None
+        payload = [None]
+        if rank == 0:
+            uid = C.create_string_buffer(128)
+            E.check(E.lib().k5_comm_unique_id(path, uid), "k5_comm_unique_id")
+            payload = [uid.raw]
+        if world > 1:
+            import torch.distributed as dist
+            dist.broadcast_object_list(payload, src=0)
+        with torch.cuda.device(self._handle_device):
+            E.check(E.lib().k5_dit_comm_init(self._handle, path, int(rank), int(world), payload[0]), "k5_dit_comm_init")
+        self._sp = (rank, world)
+        return self
+
     # ---------------------------------------------------------------- profiling (bench.py roofline)
     def set_profiling(self, on=True):
         E.check(E.lib().k5_dit_set_profiling(self._handle, int(on)))
