@@ -13,6 +13,8 @@
 // stay in-lane, and the C store is 8 B per lane.  LDS tiles are [128][64] bf16 with the 16-B
 // chunk swizzle of k5_common.h (conflict-free ds_read_b128), double buffered, register staged:
 // the global loads of tile k+1 are issued before the MFMAs of tile k and written to LDS after.
+#include <stdlib.h>
+
 #include "k5_common.h"
 #include "k5_kernels.h"
 
@@ -29,6 +31,70 @@ struct GemmP {
   int M, N, K, lda, ldw, ldc, ldr;
   int tiles_m, tiles_n;
 };
+
+template <int EPI>
+K5_DEV void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int hi, int l31) {
+  // ---- epilogue: lane owns token row m, 4 consecutive n per register group ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wm * 64 + j * 32 + l31;
+    if (m >= p.M) continue;
+    float bias_m = 0.f;
+    if (EPI == K5_EPI_BIAS_M && p.bias) bias_m = p.bias[m];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int n = n0 + wn * 64 + i * 32 + 8 * rg + 4 * hi;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e];
+        const bool full = (n + 3 < p.N);
+        if (EPI == K5_EPI_BIAS_M) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bias_m;
+        } else if (p.bias) {
+          if (full) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
+          }
+        }
+        if (EPI == K5_EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(bf_round(v[e]));
+        }
+        if (EPI == K5_EPI_GATE) {
+          const bf16_t* rp = p.resid + (size_t)m * p.ldr + n;
+          if (full && ((p.ldr & 3) == 0)) {  // one 8-B residual load + one 16-B gate load per 4 outputs
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(p.gate + n);
+            v[0] = __uint_as_float(rr[0] << 16) + gg[0] * bf_round(v[0]);
+            v[1] = __uint_as_float(rr[0] & 0xffff0000u) + gg[1] * bf_round(v[1]);
+            v[2] = __uint_as_float(rr[1] << 16) + gg[2] * bf_round(v[2]);
+            v[3] = __uint_as_float(rr[1] & 0xffff0000u) + gg[3] * bf_round(v[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.N) v[e] = bf2f(rp[e]) + p.gate[n + e] * bf_round(v[e]);
+          }
+        }
+        bf16_t* cp = p.C + (size_t)m * p.ldc + n;
+        if (full && ((p.ldc & 3) == 0)) {
+          u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(cp) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = f2bf(v[e]);
+        }
+      }
+    }
+  }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
@@ -117,57 +183,89 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns token row m, 4 consecutive n per register group ----
+  gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, hi, l31);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (K % 64 == 0): tiles are staged with global_load_lds_dwordx4 — no staging VGPRs and no
+// ds_write pass.  The LDS destination of that instruction is wave-uniform base + lane*16, so the image is
+// lane-linear; the XOR swizzle is therefore applied to the per-lane GLOBAL source address (lane l of a 1-KiB
+// piece fills row l>>3, slot l&7, and fetches the chunk that belongs there: c = slot ^ ((row>>1)&7)); the
+// fragment reads use the same swizzle as the register-staged kernel.  One barrier per K-tile: its implied
+// vmcnt(0) retires tile kt, then tile kt+1's loads are issued and fly under the whole MFMA phase.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  char* sA = smem;
+  char* sW = smem + 2 * TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
+
+  const int nblk = p.tiles_m * p.tiles_n;
+  int lid = xcd_remap(blockIdx.x, nblk);
+  constexpr int GM = 8;
+  const int per_group = GM * p.tiles_n;
+  const int g = lid / per_group, first_m = g * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int tm = first_m + (lid % per_group) % gsz;
+  const int tn = (lid % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // this wave stages pieces wave*4 .. wave*4+3 (8 rows x 128 B each) of both operand tiles
+  const bf16_t* ga[4]; const bf16_t* gw[4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = m0 + wm * 64 + j * 32 + l31;
-    if (m >= p.M) continue;
-    float bias_m = 0.f;
-    if (EPI == K5_EPI_BIAS_M && p.bias) bias_m = p.bias[m];
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (wave * 4 + i) + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + 8 * c;
+    gw[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.ldw + 8 * c;
+  }
+  auto stage = [&](int buf, int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
+      const int piece = (wave * 4 + i) * 1024;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(ga[i] + k0), (lds_void_t*)(sA + buf * TILE_BYTES + piece), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(gw[i] + k0), (lds_void_t*)(sW + buf * TILE_BYTES + piece), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int n = n0 + wn * 64 + i * 32 + 8 * rg + 4 * hi;
-        if (n >= p.N) continue;
-        float v[4];
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e];
-        const bool full = (n + 3 < p.N);
-        if (EPI == K5_EPI_BIAS_M) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bias_m;
-        } else if (p.bias) {
-          if (full) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    __syncthreads();  // vmcnt(0) + barrier: tile kt is in LDS for every wave; buf^1 is no longer being read
+    if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+    const char* cA = sA + buf * TILE_BYTES;
+    const char* cW = sW + buf * TILE_BYTES;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += b[e];
-          } else {
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = 2 * ks + hi;
+      bf16x8 fw[2], fx[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
-          }
-        }
-        if (EPI == K5_EPI_GELU) {
+      for (int i = 0; i < 2; ++i)
+        fw[i] = *reinterpret_cast<const bf16x8*>(cW + lds_swz(wn * 64 + i * 32 + l31, c));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(bf_round(v[e]));
-        }
-        if (EPI == K5_EPI_GATE) {
-          const bf16_t* rp = p.resid + (size_t)m * p.ldr + n;
+      for (int j = 0; j < 2; ++j)
+        fx[j] = *reinterpret_cast<const bf16x8*>(cA + lds_swz(wm * 64 + j * 32 + l31, c));
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) v[e] = bf2f(rp[e]) + p.gate[n + e] * bf_round(v[e]);
-        }
-        bf16_t* cp = p.C + (size_t)m * p.ldc + n;
-        if (full && ((p.ldc & 3) == 0)) {
-          u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(cp) = o;
-        } else {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = f2bf(v[e]);
-        }
-      }
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fw[i], fx[j], acc[i][j]);
     }
   }
+  gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, hi, l31);
 }
 
 }  // namespace
@@ -185,6 +283,17 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  static const int force_v1 = getenv("K5_GEMM_V1") ? atoi(getenv("K5_GEMM_V1")) : 0;  // A/B switch for benchmarking
+  if ((K % BK) == 0 && !force_v1) {
+    switch (epi) {
+      case K5_EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_glds_kernel<K5_EPI_BIAS>, grid, block, 0, stream, p); break;
+      case K5_EPI_BIAS_M: hipLaunchKernelGGL(gemm_bf16_glds_kernel<K5_EPI_BIAS_M>, grid, block, 0, stream, p); break;
+      case K5_EPI_GELU: hipLaunchKernelGGL(gemm_bf16_glds_kernel<K5_EPI_GELU>, grid, block, 0, stream, p); break;
+      case K5_EPI_GATE: hipLaunchKernelGGL(gemm_bf16_glds_kernel<K5_EPI_GATE>, grid, block, 0, stream, p); break;
+      default: return K5_ERR_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+  }
   switch (epi) {
     case K5_EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_kernel<K5_EPI_BIAS>, grid, block, 0, stream, p); break;
     case K5_EPI_BIAS_M: hipLaunchKernelGGL(gemm_bf16_kernel<K5_EPI_BIAS_M>, grid, block, 0, stream, p); break;
