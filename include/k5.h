@@ -27,7 +27,7 @@ typedef enum {
   K5_ERR_UNSUPPORTED = 6
 } k5_status;
 typedef enum { K5_F32 = 0, K5_BF16 = 1, K5_F16 = 2 } k5_dtype;
-typedef enum { K5_EPI_BIAS = 0, K5_EPI_BIAS_M = 1, K5_EPI_GELU = 2, K5_EPI_GATE = 3 } k5_epilogue;
+typedef enum { K5_EPI_BIAS = 0, K5_EPI_BIAS_M = 1, K5_EPI_GELU = 2, K5_EPI_GATE = 3, K5_EPI_F32 = 4 /* internal */ } k5_epilogue;
 
 int k5_abi_version(void);
 const char* k5_last_error(void);
@@ -161,6 +161,40 @@ int k5_sample(k5_dit* dit, const k5_sample_args* args, void* stream);
  * 128-byte ncclUniqueId with k5_comm_unique_id, the host broadcasts it, every rank calls k5_dit_comm_init. */
 int k5_comm_unique_id(const char* rccl_lib_path, void* out_unique_id_128);
 int k5_dit_comm_init(k5_dit* dit, const char* rccl_lib_path, int rank, int world, const void* unique_id_128);
+
+/* ------------------------------------------------------------------------------------------
+ * HunyuanVideo 3D-VAE decoder (kandinsky/models/vae.py): post_quant_conv + HunyuanVideoDecoder3D.forward
+ * (vae.py:684-696, 870) on one latent tile; the tiling policy (vae.py:847-1204) stays on the host mirror.
+ * ---------------------------------------------------------------------------------------- */
+/* HunyuanVideoCausalConv3d (vae.py:125-163, k=3, replicate pad W(1,1) H(1,1) T(2,0)) with the nearest upsample of
+ * HunyuanVideoUpsampleCausal3D (vae.py:187-205) optionally folded in (up_t, up_s in {1,2}); channels-last bf16:
+ * X [Ts][Hs][Ws][Cin] (Cin % 64 == 0), W [Cout][27][Cin] (tap = (dt*3+dh)*3+dw), bias fp32, out [To*Ho*Wo][ldc];
+ * resid (optional) [To*Ho*Wo][ldr]: out = bf16(bf16(conv+bias) + resid) (resnet skip, vae.py:274). */
+int k5_conv3d_bf16(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin, int Cout,
+                   int up_t, int up_s, int ldc, const void* resid, int ldr, void* stream);
+/* nn.GroupNorm(G, C, eps) (+SiLU) on channels-last bf16 rows [M][C] (vae.py:246-263,672-673): fp32 statistics,
+ * bf16 out.  workspace: device scratch of k5_groupnorm_workspace_size(M, G) bytes. */
+int64_t k5_groupnorm_workspace_size(int M, int G);
+int k5_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
+                      int silu, void* workspace, void* stream);
+
+typedef struct k5_vae k5_vae;
+typedef struct k5_vae_config {   /* AutoencoderKLHunyuanVideo.__init__ kwargs, vae.py:709-731 */
+  int latent_channels, out_channels;
+  int block_out_channels[4];
+  int layers_per_block, norm_num_groups;
+} k5_vae_config;
+int k5_vae_create(const k5_vae_config* cfg, k5_vae** out);
+void k5_vae_destroy(k5_vae* vae);
+/* checkpoint tensors by state_dict key (decoder.* and post_quant_conv.*; other keys are ignored), host or device ptr */
+int k5_vae_load_tensor(k5_vae* vae, const char* key, const void* ptr, int dtype, const int64_t* shape, int rank);
+int k5_vae_finalize(k5_vae* vae);
+/* z: device fp32 (latent_channels,T,H,W) (already divided by scaling_factor, generation_utils.py:220) ->
+ * out: device bf16 (out_channels, 4(T-1)+1, 8H, 8W) = self.decoder(self.post_quant_conv(z)) */
+int k5_vae_decode_tile(k5_vae* vae, const float* z, int T, int H, int W, void* out, void* stream);
+/* blend_t / blend_v / blend_h (vae.py:908-936) on contiguous bf16 tensors viewed as [outer][len][inner]:
+ * b[:, y, :] = a[:, len_a-extent+y, :]*(1-y/extent) + b[:, y, :]*(y/extent), y < extent (eager bf16 rounding) */
+int k5_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, void* stream);
 
 /* per-kernel-family accumulated GPU time of the last forward(s), measured with hipEvents on the
  * engine's stream when profiling is enabled.  names: "attn_self","attn_cross","gemm","elementwise",...  */

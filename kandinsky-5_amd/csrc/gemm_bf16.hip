@@ -30,6 +30,7 @@ struct GemmP {
   const float* gate;      // EPI_GATE: per-n gate (fp32)
   int M, N, K, lda, ldw, ldc, ldr;
   int tiles_m, tiles_n;
+  float alpha;            // EPI_F32: C_f32 = alpha * acc
 };
 
 template <int EPI>
@@ -51,6 +52,12 @@ K5_DEV void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], int m0, int n0, i
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e];
         const bool full = (n + 3 < p.N);
+        if (EPI == K5_EPI_F32) {  // raw fp32 scores (VAE mid-block attention): C is float*
+          float* fp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < p.N) fp[e] = v[e] * p.alpha;
+          continue;
+        }
         if (EPI == K5_EPI_BIAS_M) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bias_m;
@@ -282,6 +289,7 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   p.resid = (const bf16_t*)resid; p.gate = gate;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+  p.alpha = 1.f;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
   static const int force_v1 = getenv("K5_GEMM_V1") ? atoi(getenv("K5_GEMM_V1")) : 0;  // A/B switch for benchmarking
   if ((K % BK) == 0 && !force_v1) {
@@ -301,5 +309,20 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
     case K5_EPI_GATE: hipLaunchKernelGGL(gemm_bf16_kernel<K5_EPI_GATE>, grid, block, 0, stream, p); break;
     default: return K5_ERR_ARG;
   }
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
+// C_f32[M][N] = alpha * A[M][K] . W[N][K]^T   (fp32 output; attention scores of the VAE mid block)
+int k5_launch_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc,
+                               float alpha, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return K5_ERR_ARG;
+  if ((K & 7) || (lda & 7) || (ldw & 7)) return K5_ERR_ALIGN;
+  GemmP p;
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = (bf16_t*)C; p.bias = nullptr; p.resid = nullptr; p.gate = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.alpha = alpha;
+  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  if ((K % BK) == 0) hipLaunchKernelGGL(gemm_bf16_glds_kernel<K5_EPI_F32>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(gemm_bf16_kernel<K5_EPI_F32>, grid, block, 0, stream, p);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }

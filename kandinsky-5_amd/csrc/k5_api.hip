@@ -85,4 +85,18 @@ int k5_cfg_euler(float* img, const void* v_cond, const void* v_uncond, float w, 
   return ret(k5_launch_cfg_euler(img, v_cond, v_uncond, w, dt, n, (hipStream_t)stream), "k5_cfg_euler");
 }
 
+int k5_conv3d_bf16(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin, int Cout,
+                   int up_t, int up_s, int ldc, const void* resid, int ldr, void* stream) {
+  return ret(k5_launch_conv3d_bf16(X, W, bias, out, Ts, Hs, Ws, Cin, Cout, up_t, up_s, ldc, resid, ldr, (hipStream_t)stream),
+             "k5_conv3d_bf16");
+}
+
+int64_t k5_groupnorm_workspace_size(int M, int G) { return (int64_t)k5_groupnorm_workspace_bytes(M, G); }
+
+int k5_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
+                      int silu, void* workspace, void* stream) {
+  return ret(k5_launch_groupnorm_bf16(x, gamma, beta, out, M, C, G, eps, silu, C, C, workspace, (hipStream_t)stream),
+             "k5_groupnorm_bf16");
+}
+
 }  // extern "C"

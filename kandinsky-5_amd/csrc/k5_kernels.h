@@ -65,4 +65,16 @@ int k5_launch_cfg_euler(float* img, const void* v_cond, const void* v_uncond, fl
 // fp32 -> bf16 cast, bf16 -> fp32
 int k5_launch_cast_f32_bf16(const float* x, void* out, int64_t n, hipStream_t stream);
 
-const char* k5_hip_error_string();
+int k5_launch_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc,
+                               float alpha, hipStream_t stream);
+
+// ---- VAE decoder kernels (channels-last bf16 activations) ----
+int k5_launch_conv3d_bf16(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin,
+                          int Cout, int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream);
+size_t k5_groupnorm_workspace_bytes(int M, int G);
+int k5_launch_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
+                             int silu, int ldx, int ldo, void* workspace, hipStream_t s);
+int k5_launch_causal_softmax(const float* scores, void* P, int S, int hw, int lds, int ldp, hipStream_t s);
+int k5_launch_nchw_to_mc(const float* z, void* out, int C, int64_t M, int Cpad, hipStream_t s);
+int k5_launch_mc_to_nchw(const void* x, void* out, int C, int64_t M, int ldx, hipStream_t s);
+int k5_launch_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, hipStream_t s);

@@ -1,0 +1,194 @@
+// vae_ops.hip — HBM-bound kernels of the HunyuanVideo VAE decoder on channels-last bf16 activations [M][C].
+//   GroupNorm(32, eps 1e-6) (+SiLU)   vae.py:246-263, 351-355 (attention group_norm), 672-673
+//       two-level statistics: per-block fp32 partial sums -> double-precision combine -> mean / rstd per group,
+//       then one fused normalise*gamma+beta(+SiLU) pass writing bf16 (the fp32 GroupNorm output of autocast is
+//       only ever consumed by a bf16 conv / linear).
+//   frame-causal softmax              prepare_causal_attention_mask vae.py:110-122 + diffusers Attention softmax
+//   layout converters                 (C,T,H,W) fp32 latent -> [M][Cpad] bf16 ; [M][3] bf16 -> (3,T,H,W) bf16
+//   blend_t / blend_v / blend_h       vae.py:908-936 (eager bf16 arithmetic: every op rounds)
+#include "k5_common.h"
+#include "k5_kernels.h"
+
+namespace {
+
+constexpr int GN_ROWS = 512;  // rows per statistics block
+
+// partial[blk][g] = (sum, sumsq) over GN_ROWS rows x (C/G) channels
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int M,
+                                                         int C, int ldx, int G) {
+  __shared__ float red[2][64];  // up to 64 groups
+  const int tid = threadIdx.x;
+  const int nch = C >> 3, cg = C / G;       // 16-B chunks per row; channels per group
+  const int r0 = blockIdx.x * GN_ROWS, r1 = min(r0 + GN_ROWS, M);
+  if (tid < 64) { red[0][tid] = 0.f; red[1][tid] = 0.f; }
+  __syncthreads();
+  // thread -> fixed chunk column (tid % nch), strides over rows: its 8 channels lie in <= 2 groups
+  const int rows_par = 256 / nch > 0 ? 256 / nch : 1;
+  const int ch = tid % nch, rsub = tid / nch;
+  float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
+  const int g0 = (8 * ch) / cg;
+  if (rsub < rows_par) {
+    for (int r = r0 + rsub; r < r1; r += rows_par) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)r * ldx + 8 * ch);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = (j & 1) ? __uint_as_float(raw[j >> 1] & 0xffff0000u) : __uint_as_float(raw[j >> 1] << 16);
+        const int gi = ((8 * ch + j) / cg) - g0;  // 0 or 1 (cg >= 4)
+        s[gi] += v; q[gi] += v * v;
+      }
+    }
+    atomicAdd(&red[0][g0], s[0]); atomicAdd(&red[1][g0], q[0]);
+    if (cg < 8) { atomicAdd(&red[0][g0 + 1], s[1]); atomicAdd(&red[1][g0 + 1], q[1]); }
+  }
+  __syncthreads();
+  if (tid < G) {
+    partial[((size_t)blockIdx.x * G + tid) * 2] = red[0][tid];
+    partial[((size_t)blockIdx.x * G + tid) * 2 + 1] = red[1][tid];
+  }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, int G, double count,
+                                   float eps) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) { s += partial[((size_t)b * G + g) * 2]; q += partial[((size_t)b * G + g) * 2 + 1]; }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0) var = 0;
+  stats[2 * g] = (float)mean;
+  stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       bf16_t* __restrict__ out, int64_t nchunks, int nch, int cg, int ldx, int ldo) {
+  for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < nchunks; gidx += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(gidx % nch);
+    const int64_t row = gidx / nch;
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(x + row * ldx + 8 * ch);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = 8 * ch + j, g = c / cg;
+      const float v = (j & 1) ? __uint_as_float(raw[j >> 1] & 0xffff0000u) : __uint_as_float(raw[j >> 1] << 16);
+      float y = (v - stats[2 * g]) * stats[2 * g + 1] * gamma[c] + beta[c];
+      if (SILU) y = y / (1.0f + expf(-y));
+      o[j] = y;
+    }
+    u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(out + row * ldo + 8 * ch) = pk;
+  }
+}
+
+// scores fp32 [S][lds] (already scaled) -> P bf16 [S][ldp]; row i attends columns j < ((i / hw) + 1) * hw
+__global__ __launch_bounds__(256) void causal_softmax_kernel(const float* __restrict__ sc, bf16_t* __restrict__ P, int S, int hw,
+                                                             int lds, int ldp) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int valid = min(S, (row / hw + 1) * hw);
+  const float* s = sc + (size_t)row * lds;
+  float m = -3.0e38f;
+  for (int j = tid; j < valid; j += 256) m = fmaxf(m, s[j]);
+  m = wave_max(m);
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < valid; j += 256) sum += expf(s[j] - m);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wv] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  bf16_t* p = P + (size_t)row * ldp;
+  for (int j = tid; j < ldp; j += 256) p[j] = f2bf(j < valid ? expf(s[j] - m) * inv : 0.f);
+}
+
+// z (C,T,H,W) fp32 -> [M][Cpad] bf16, channels >= C zero
+__global__ __launch_bounds__(256) void nchw_to_mc_kernel(const float* __restrict__ z, bf16_t* __restrict__ out, int C, int64_t M, int Cpad) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < M * Cpad; g += (int64_t)gridDim.x * 256) {
+    const int c = (int)(g % Cpad);
+    const int64_t m = g / Cpad;
+    out[g] = f2bf(c < C ? z[(int64_t)c * M + m] : 0.f);
+  }
+}
+// [M][ldx] bf16 (first C channels) -> (C, M) bf16
+__global__ __launch_bounds__(256) void mc_to_nchw_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int C, int64_t M, int ldx) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < M * C; g += (int64_t)gridDim.x * 256) {
+    const int64_t m = g % M;
+    const int c = (int)(g / M);
+    out[g] = x[m * ldx + c];
+  }
+}
+
+// b[.., y, ..] = bf16( bf16(a[.., La-extent+y, ..] * (1 - y/extent)) + bf16(b[.., y, ..] * (y/extent)) )  along one axis.
+// tensors are viewed as [outer][len][inner] (contiguous), a and b may have different lengths along the axis.
+__global__ __launch_bounds__(256) void blend_kernel(const bf16_t* __restrict__ a, bf16_t* __restrict__ b, int64_t outer, int la,
+                                                    int lb, int64_t inner, int extent) {
+  const int64_t total = outer * extent * inner;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const int64_t in = g % inner;
+    const int y = (int)((g / inner) % extent);
+    const int64_t o = g / (inner * extent);
+    const float wb = (float)((double)y / (double)extent), wa = (float)(1.0 - (double)y / (double)extent);
+    const float av = bf2f(a[(o * la + (la - extent + y)) * inner + in]);
+    bf16_t* bp = b + (o * lb + y) * inner + in;
+    *bp = f2bf(__fadd_rn(bf_round(__fmul_rn(av, wa)), bf_round(__fmul_rn(bf2f(*bp), wb))));
+  }
+}
+
+inline int grid_for(int64_t n, int cap = 16384) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+inline int done() { return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP; }
+
+}  // namespace
+
+size_t k5_groupnorm_workspace_bytes(int M, int G) { return ((size_t)((M + GN_ROWS - 1) / GN_ROWS) * G * 2 + 2 * G) * sizeof(float); }
+
+int k5_launch_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
+                             int silu, int ldx, int ldo, void* workspace, hipStream_t s) {
+  if (M <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G)) return K5_ERR_ARG;
+  const int cg = C / G;
+  if ((C & 7) || (ldx & 7) || (ldo & 7) || cg < 4 || (cg & (cg - 1)) || (C >> 3) > 256) return K5_ERR_UNSUPPORTED;
+  const int nblk = (M + GN_ROWS - 1) / GN_ROWS;
+  float* partial = (float*)workspace;
+  float* stats = partial + (size_t)nblk * G * 2;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, partial, M, C, ldx, G);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, s, partial, stats, nblk, G, (double)M * cg, eps);
+  const int64_t nchunks = (int64_t)M * (C >> 3);
+  if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid_for(nchunks)), dim3(256), 0, s, (const bf16_t*)x, stats, gamma, beta,
+                               (bf16_t*)out, nchunks, C >> 3, cg, ldx, ldo);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid_for(nchunks)), dim3(256), 0, s, (const bf16_t*)x, stats, gamma, beta,
+                          (bf16_t*)out, nchunks, C >> 3, cg, ldx, ldo);
+  return done();
+}
+
+int k5_launch_causal_softmax(const float* scores, void* P, int S, int hw, int lds, int ldp, hipStream_t s) {
+  if (S <= 0 || hw <= 0 || ldp < S) return K5_ERR_ARG;
+  hipLaunchKernelGGL(causal_softmax_kernel, dim3(S), dim3(256), 0, s, scores, (bf16_t*)P, S, hw, lds, ldp);
+  return done();
+}
+
+int k5_launch_nchw_to_mc(const float* z, void* out, int C, int64_t M, int Cpad, hipStream_t s) {
+  if (C <= 0 || M <= 0 || Cpad < C) return K5_ERR_ARG;
+  hipLaunchKernelGGL(nchw_to_mc_kernel, dim3(grid_for(M * Cpad)), dim3(256), 0, s, z, (bf16_t*)out, C, M, Cpad);
+  return done();
+}
+
+int k5_launch_mc_to_nchw(const void* x, void* out, int C, int64_t M, int ldx, hipStream_t s) {
+  if (C <= 0 || M <= 0) return K5_ERR_ARG;
+  hipLaunchKernelGGL(mc_to_nchw_kernel, dim3(grid_for(M * C)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, C, M, ldx);
+  return done();
+}
+
+int k5_launch_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, hipStream_t s) {
+  if (extent <= 0) return K5_OK;
+  if (extent > len_a || extent > len_b) return K5_ERR_ARG;
+  hipLaunchKernelGGL(blend_kernel, dim3(grid_for(outer * extent * inner)), dim3(256), 0, s, (const bf16_t*)a, (bf16_t*)b, outer,
+                     len_a, len_b, inner, extent);
+  return done();
+}

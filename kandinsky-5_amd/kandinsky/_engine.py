@@ -47,6 +47,11 @@ class SampleArgs(C.Structure):
                 ("sigmas", C.POINTER(C.c_float)), ("guidance_weight", C.c_float)]
 
 
+class VaeConfig(C.Structure):
+    _fields_ = [("latent_channels", C.c_int), ("out_channels", C.c_int), ("block_out_channels", C.c_int * 4),
+                ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int)]
+
+
 _lib: Optional[C.CDLL] = None
 
 # name -> (restype, argtypes); every symbol declared in include/k5.h
@@ -76,6 +81,15 @@ SYMBOLS = {
     "k5_sample": (_I, [_P, C.POINTER(SampleArgs), _P]),
     "k5_comm_unique_id": (_I, [C.c_char_p, _P]),
     "k5_dit_comm_init": (_I, [_P, C.c_char_p, _I, _I, _P]),
+    "k5_conv3d_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "k5_groupnorm_workspace_size": (_I64, [_I, _I]),
+    "k5_groupnorm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P]),
+    "k5_vae_create": (_I, [C.POINTER(VaeConfig), C.POINTER(_P)]),
+    "k5_vae_destroy": (None, [_P]),
+    "k5_vae_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
+    "k5_vae_finalize": (_I, [_P]),
+    "k5_vae_decode_tile": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "k5_blend_bf16": (_I, [_P, _P, _I64, _I, _I, _I64, _I, _P]),
     "k5_dit_set_profiling": (_I, [_P, _I]),
     "k5_dit_get_profile": (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "k5_dit_reset_profile": (_I, [_P]),

@@ -1,0 +1,298 @@
+"""AutoencoderKLHunyuanVideo (decode only) — host mirror of kandinsky/models/vae.py (reference).
+
+Keeps what callers touch: `build_vae(conf)` (vae.py:1276-1282), `.decode(z).sample`, `.config.scaling_factor`, `.eval()`,
+`.to()`, the checkpoint key names of `decoder.*` / `post_quant_conv.*`, and the reference's tiling
+policy — `get_dec_optimal_tiling` tables (data in vae_tiling.json), temporal tiles with a dropped first frame, optional
+spatial tiles, linear cross-fades, including the quirk that `_decode` compares the width with the STRIDE-derived tile
+width (vae.py:854-856).  The arithmetic runs in libk5.so: `k5_vae_decode_tile` per tile, `k5_blend_bf16` for the
+cross-fades; torch only slices / concatenates.  T2V never encodes, so the encoder half is not mirrored.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from .. import _engine as E
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(_HERE, "vae_tiling.json")) as _f:
+    _T = json.load(_f)
+OPT_TEMPORAL_TILING = {int(k): tuple(v) for k, v in _T["temporal"].items()}
+OPT_SPATIAL_TILING = {int(k): tuple(v) for k, v in _T["spatial"].items()}
+
+
+class DecoderOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+def decoder_manifest(latent_channels, out_channels, block_out_channels, layers_per_block):
+    """state_dict names / shapes of post_quant_conv + decoder (vae.py:589-696, 748)."""
+    m = {}
+    boc = list(block_out_channels)
+
+    def conv(n, o, i, k):
+        m[n + ".weight"], m[n + ".bias"] = (o, i, k, k, k), (o,)
+
+    def norm(n, c):
+        m[n + ".weight"], m[n + ".bias"] = (c,), (c,)
+
+    def resnet(p, i, o):
+        norm(p + ".norm1", i); conv(p + ".conv1.conv", o, i, 3); norm(p + ".norm2", o); conv(p + ".conv2.conv", o, o, 3)
+        if i != o:
+            conv(p + ".conv_shortcut.conv", o, i, 1)
+
+    conv("post_quant_conv", latent_channels, latent_channels, 1)
+    top = boc[-1]
+    conv("decoder.conv_in.conv", top, latent_channels, 3)
+    resnet("decoder.mid_block.resnets.0", top, top)
+    a = "decoder.mid_block.attentions.0."
+    norm(a + "group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        m[a + n + ".weight"], m[a + n + ".bias"] = (top, top), (top,)
+    resnet("decoder.mid_block.resnets.1", top, top)
+    prev = top
+    for i, outc in enumerate(reversed(boc)):
+        for j in range(layers_per_block + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else outc, outc)
+        if i < len(boc) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv.conv", outc, outc, 3)
+        prev = outc
+    norm("decoder.conv_norm_out", boc[0])
+    conv("decoder.conv_out.conv", out_channels, boc[0], 3)
+    return m
+
+
+class _Node(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError("VAE parameter container: the decoder runs in the HIP engine (AutoencoderKLHunyuanVideo.decode)")
+
+
+class AutoencoderKLHunyuanVideo(nn.Module):
+    def __init__(self, in_channels=3, out_channels=3, latent_channels=16, down_block_types=None, up_block_types=None,
+                 block_out_channels=(128, 256, 512, 512), layers_per_block=2, act_fn="silu", norm_num_groups=32,
+                 scaling_factor=0.476986, spatial_compression_ratio=8, temporal_compression_ratio=4,
+                 mid_block_add_attention=True, **_ignored):
+        super().__init__()
+        if spatial_compression_ratio != 8 or temporal_compression_ratio != 4 or not mid_block_add_attention:
+            raise NotImplementedError("only the HunyuanVideo 8x/4x decoder with mid-block attention is built")
+        self.config = SimpleNamespace(in_channels=in_channels, out_channels=out_channels, latent_channels=latent_channels,
+                                      block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
+                                      norm_num_groups=norm_num_groups, scaling_factor=scaling_factor,
+                                      spatial_compression_ratio=8, temporal_compression_ratio=4)
+        for name, shape in decoder_manifest(latent_channels, out_channels, block_out_channels, layers_per_block).items():
+            node = self
+            parts = name.split(".")
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape), requires_grad=False))
+        self.spatial_compression_ratio, self.temporal_compression_ratio = 8, 4
+        self.use_tiling = self.use_framewise_decoding = True
+        # defaults of vae.py:765-771, overwritten by apply_tiling
+        self.tile_sample_min_height = self.tile_sample_min_width = 256
+        self.tile_sample_min_num_frames = 16
+        self.tile_sample_stride_height = self.tile_sample_stride_width = 192
+        self.tile_sample_stride_num_frames = 12
+        self.tile_size = None
+        self._handle, self._handle_device = None, None
+
+    # ------------------------------------------------------------------ loading
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **kw):
+        """diffusers-style folder: <path>/<subfolder>/config.json + diffusion_pytorch_model.safetensors (vae.py:1278)."""
+        from safetensors.torch import load_file
+        root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
+        with open(os.path.join(root, "config.json")) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        model = cls(**cfg)
+        files = [f for f in sorted(os.listdir(root)) if f.endswith(".safetensors")]
+        if not files:
+            raise FileNotFoundError(f"no .safetensors checkpoint under {root}")
+        sd = {}
+        for f in files:
+            sd.update(load_file(os.path.join(root, f)))
+        want = model.state_dict().keys()
+        sd = {k: (v.to(torch_dtype) if torch_dtype is not None else v) for k, v in sd.items() if k in want}
+        model.load_state_dict(sd, assign=True)
+        return model
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        state_dict = {k: v for k, v in state_dict.items() if k in self.state_dict()}  # encoder.* / quant_conv.* unused
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self._drop_engine()
+        return out
+
+    def _drop_engine(self):
+        if self._handle is not None:
+            E.lib().k5_vae_destroy(self._handle)
+        self._handle = None
+
+    def _engine(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the VAE decoder runs on the MI355X engine only (no CPU fallback)")
+        if self._handle is not None and self._handle_device == device:
+            return self._handle
+        self._drop_engine()
+        c = self.config
+        cc = E.VaeConfig(c.latent_channels, c.out_channels, (C.c_int * 4)(*c.block_out_channels), c.layers_per_block,
+                         c.norm_num_groups)
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            E.check(E.lib().k5_vae_create(C.byref(cc), C.byref(h)), "k5_vae_create")
+            for name, t in self.state_dict().items():
+                t = t.detach()
+                if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+                    t = t.float()
+                t = t.contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                E.check(E.lib().k5_vae_load_tensor(h, name.encode(), t.data_ptr(), E.k5_dtype(t), shape, t.dim()), name)
+            E.check(E.lib().k5_vae_finalize(h), "k5_vae_finalize")
+        self._handle, self._handle_device = h, device
+        return h
+
+    # ------------------------------------------------------------------ engine calls
+    def _decode_tile(self, z):
+        """z (1,C,t,h,w) -> (1,3,4(t-1)+1,8h,8w) bf16 = decoder(post_quant_conv(z))."""
+        h = self._engine(z.device)
+        zz = z[0].float().contiguous()
+        _, t, hh, ww = zz.shape
+        out = torch.empty(1, self.config.out_channels, 4 * (t - 1) + 1, 8 * hh, 8 * ww, dtype=torch.bfloat16, device=z.device)
+        with torch.cuda.device(z.device):
+            E.check(E.lib().k5_vae_decode_tile(h, zz.data_ptr(), t, hh, ww, out.data_ptr(), E.stream_ptr(z.device)),
+                    "k5_vae_decode_tile")
+        return out
+
+    @staticmethod
+    def _blend(a, b, extent, dim):
+        """blend_t / blend_v / blend_h (vae.py:908-936): cross-fade the first `extent` slices of b with the last of a."""
+        extent = min(a.shape[dim], b.shape[dim], extent)
+        if extent <= 0:
+            return b
+        a, bc = a.contiguous(), b.contiguous()
+        outer = math.prod(b.shape[:dim])
+        inner = math.prod(b.shape[dim + 1:])
+        if math.prod(a.shape[:dim]) != outer or math.prod(a.shape[dim + 1:]) != inner:
+            raise ValueError("blend: tiles differ outside the blended axis")
+        E.check(E.lib().k5_blend_bf16(a.data_ptr(), bc.data_ptr(), outer, a.shape[dim], b.shape[dim], inner, extent,
+                                      E.stream_ptr(b.device)), "k5_blend_bf16")
+        return bc
+
+    # ------------------------------------------------------------------ tiling policy (reference semantics)
+    def get_enc_optimal_tiling(self, shape):
+        _, _, num_frames, height, width = shape
+        if math.sqrt(height * width) < 450 and num_frames <= 97:
+            ft = fs = num_frames
+        else:
+            ft, fs = OPT_TEMPORAL_TILING[num_frames]
+        if math.sqrt(height * width) > 900:
+            (ht, hs), (wt, ws) = OPT_SPATIAL_TILING[height], OPT_SPATIAL_TILING[width]
+        else:
+            ht, hs, wt, ws = height, height, width, width
+        return (1, ft, ht, wt), (fs, hs, ws)
+
+    def get_dec_optimal_tiling(self, shape):
+        b, _, f, h, w = shape
+        return self.get_enc_optimal_tiling([b, 3, 4 * (f - 1) + 1, 8 * h, 8 * w])
+
+    def apply_tiling(self, tile, stride):
+        _, ft, ht, wt = tile
+        fs, hs, ws = stride
+        self.use_tiling = True
+        self.tile_sample_min_num_frames, self.tile_sample_stride_num_frames = ft - 1, fs
+        self.tile_sample_min_height, self.tile_sample_min_width = ht, wt
+        self.tile_sample_stride_height, self.tile_sample_stride_width = hs, ws
+
+    def tiled_decode(self, z, return_dict=True):
+        _, _, _, H, W = z.shape
+        mh, mw = self.tile_sample_min_height // 8, self.tile_sample_min_width // 8
+        sh, sw = self.tile_sample_stride_height // 8, self.tile_sample_stride_width // 8
+        bh = self.tile_sample_min_height - self.tile_sample_stride_height
+        bw = self.tile_sample_min_width - self.tile_sample_stride_width
+        rows = [[self._decode_tile(z[:, :, :, i:i + mh, j:j + mw]) for j in range(0, W - mw + 1, sw)]
+                for i in range(0, H - mh + 1, sh)]
+        out_rows = []
+        for i, row in enumerate(rows):
+            out = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = self._blend(rows[i - 1][j], tile, bh, 3)
+                if j > 0:
+                    tile = self._blend(row[j - 1], tile, bw, 4)
+                rows[i][j] = tile
+                hl = self.tile_sample_min_height if i == len(rows) - 1 else self.tile_sample_stride_height
+                wl = self.tile_sample_min_width if j == len(row) - 1 else self.tile_sample_stride_width
+                out.append(tile[:, :, :, :hl, :wl])
+            out_rows.append(torch.cat(out, dim=-1))
+        dec = torch.cat(out_rows, dim=3)[:, :, :, :H * 8, :W * 8]
+        return DecoderOutput(dec) if return_dict else (dec,)
+
+    def _temporal_tiled_decode(self, z, return_dict=True):
+        nf = z.shape[2]
+        mh, mw = self.tile_sample_min_height // 8, self.tile_sample_min_width // 8
+        mf, sf = self.tile_sample_min_num_frames // 4, self.tile_sample_stride_num_frames // 4
+        bf = self.tile_sample_min_num_frames - self.tile_sample_stride_num_frames
+        row = []
+        for i in range(0, nf - mf + 1, sf):
+            tile = z[:, :, i:i + mf + 1]
+            if self.use_tiling and (tile.shape[-1] > mw or tile.shape[-2] > mh):
+                d = self.tiled_decode(tile).sample
+            else:
+                d = self._decode_tile(tile)
+            row.append(d[:, :, 1:] if i > 0 else d)
+        out = []
+        for i, tile in enumerate(row):
+            if i > 0:
+                tile = self._blend(row[i - 1], tile, bf, 2)
+                row[i] = tile
+                out.append(tile[:, :, :(self.tile_sample_min_num_frames if i == len(row) - 1 else self.tile_sample_stride_num_frames)])
+            else:
+                out.append(tile[:, :, :self.tile_sample_stride_num_frames + 1])
+        dec = torch.cat(out, dim=2)[:, :, :(nf - 1) * 4 + 1]
+        return DecoderOutput(dec) if return_dict else (dec,)
+
+    def _decode(self, z, return_dict=True):
+        _, _, nf, H, W = z.shape
+        mh = self.tile_sample_min_height // 8
+        mw = self.tile_sample_stride_width // 8   # sic: the reference derives this one from the stride (vae.py:854-856)
+        mf = self.tile_sample_min_num_frames // 4
+        if self.use_framewise_decoding and nf > mf + 1:
+            return self._temporal_tiled_decode(z, return_dict)
+        if self.use_tiling and (W > mw or H > mh):
+            return self.tiled_decode(z, return_dict)
+        dec = self._decode_tile(z)
+        return DecoderOutput(dec) if return_dict else (dec,)
+
+    @torch.no_grad()
+    def decode(self, z, return_dict=True):
+        """vae.py:879-906."""
+        if z.shape[0] != 1:
+            outs = [self.decode(z[i:i + 1]).sample for i in range(z.shape[0])]
+            dec = torch.cat(outs, 0)
+            return DecoderOutput(dec) if return_dict else (dec,)
+        tile_size, tile_stride = self.get_dec_optimal_tiling(z.shape)
+        if tile_size != self.tile_size:
+            self.tile_size = tile_size
+            self.apply_tiling(tile_size, tile_stride)
+        dec = self._decode(z).sample
+        return DecoderOutput(dec) if return_dict else (dec,)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("T2V only decodes; the VAE encoder is outside the hot path (SURVEY.md §2 #5)")
+
+
+def build_vae(conf):
+    """reference vae.py:1276-1282"""
+    name = conf["name"] if isinstance(conf, dict) else conf.name
+    path = conf["checkpoint_path"] if isinstance(conf, dict) else conf.checkpoint_path
+    if name == "hunyuan":
+        return AutoencoderKLHunyuanVideo.from_pretrained(path, subfolder="vae", torch_dtype=torch.float16)
+    assert False, f"unknown vae name {name}"

@@ -1,0 +1,158 @@
+"""GPU parity of the VAE decode path (C ABI k5_vae_decode_tile / k5_blend_bf16 + host tiling) against
+oracle/vae_oracle.py in bf16-autocast mode.  Tolerance: relative L2 <= 2e-2 on decoded tiles (bf16 activations through
+~30 conv / GroupNorm layers; the bf16 oracle itself sits ~1e-2 from the fp32 oracle), blends bit-exact."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vae_oracle as V  # noqa: E402
+
+CFG = dict(latent_channels=16, out_channels=3, block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=16)
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture(scope="module")
+def vae():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    from kandinsky.models.vae import AutoencoderKLHunyuanVideo
+    m = AutoencoderKLHunyuanVideo(**CFG)
+    g = torch.Generator().manual_seed(5)
+    sd = {}
+    for k, p in m.state_dict().items():
+        if "norm" in k and k.endswith("weight"):
+            sd[k] = 1.0 + 0.2 * torch.randn(p.shape, generator=g)
+        elif k.endswith("bias"):
+            sd[k] = 0.1 * torch.randn(p.shape, generator=g)
+        else:
+            sd[k] = torch.randn(p.shape, generator=g) * (1.5 / (p[0].numel() ** 0.5))
+    m.load_state_dict(sd, assign=True)
+    return m.to("cuda:0"), sd
+
+
+def bfr(x):
+    return x.bfloat16().float()
+
+
+def test_conv3d_kernel_with_upsample_and_residual(vae):
+    import ctypes as C
+    from kandinsky import _engine as E
+    torch.manual_seed(0)
+    Ts, Hs, Ws, Cin, Cout = 3, 5, 7, 64, 72
+    x = bfr(torch.randn(1, Cin, Ts, Hs, Ws))
+    w = bfr(torch.randn(Cout, Cin, 3, 3, 3) * 0.05)
+    b = bfr(torch.randn(Cout) * 0.1)
+    sd = {"c.conv.weight": w, "c.conv.bias": b}
+    for up_t, up_s in ((1, 1), (1, 2), (2, 2)):
+        xin = x
+        if up_t > 1 or up_s > 1:  # the upsample half of HunyuanVideoUpsampleCausal3D, conv applied below
+            first = torch.nn.functional.interpolate(x[:, :, 0], scale_factor=(up_s, up_s), mode="nearest").unsqueeze(2)
+            rest = torch.nn.functional.interpolate(x[:, :, 1:], scale_factor=(up_t, up_s, up_s), mode="nearest")
+            xin = torch.cat([first, rest], 2)
+        ref = V.causal_conv3d(sd, "c", xin, "bf16")
+        To, Ho, Wo = ref.shape[2:]
+        resid = bfr(torch.randn(To * Ho * Wo, Cout))
+        ref_r = bfr(ref[0].permute(1, 2, 3, 0).reshape(-1, Cout) + resid)
+        xd = x[0].permute(1, 2, 3, 0).contiguous().cuda().bfloat16()          # [T][H][W][C]
+        wd = w.permute(0, 2, 3, 4, 1).reshape(Cout, 27 * Cin).contiguous().cuda().bfloat16()  # [Cout][27][Cin]
+        out = torch.empty(To * Ho * Wo, Cout, dtype=torch.bfloat16, device="cuda")
+        rd, bd = resid.cuda().bfloat16(), b.cuda()
+        for use_res in (False, True):
+            E.check(E.lib().k5_conv3d_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), Ts, Hs, Ws, Cin, Cout,
+                                           up_t, up_s, Cout, rd.data_ptr() if use_res else None, Cout, E.stream_ptr()))
+            torch.cuda.synchronize()
+            want = ref_r if use_res else ref[0].permute(1, 2, 3, 0).reshape(-1, Cout)
+            err = (out.float().cpu() - want).abs().max().item()
+            assert err <= 2.0 ** -6 * max(1.0, want.abs().max().item()), (up_t, up_s, use_res, err)
+
+
+@pytest.mark.parametrize("M,C,G", [(90, 64, 16), (1000, 128, 16), (3000, 512, 32), (77, 256, 32)])
+def test_groupnorm_silu_kernel(M, C, G):
+    from kandinsky import _engine as E
+    g = torch.Generator().manual_seed(M)
+    x = bfr(torch.randn(M, C, generator=g) * 2 + 0.5)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ws = torch.empty(E.lib().k5_groupnorm_workspace_size(M, G), dtype=torch.uint8, device="cuda")
+    out = torch.empty(M, C, dtype=torch.bfloat16, device="cuda")
+    xd, gd, bd = x.cuda().bfloat16(), gamma.cuda(), beta.cuda()
+    for silu in (0, 1):
+        E.check(E.lib().k5_groupnorm_bf16(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), out.data_ptr(), M, C, G, 1e-6, silu,
+                                          ws.data_ptr(), E.stream_ptr()))
+        ref = torch.nn.functional.group_norm(x.t()[None], G, gamma, beta, 1e-6)[0].t()   # stats over (M, C/G) per group
+        if silu:
+            ref = torch.nn.functional.silu(ref)
+        err = (out.float().cpu() - bfr(ref)).abs().max().item()
+        assert err <= 2.0 ** -6 * max(1.0, ref.abs().max().item()), (M, C, G, silu, err)
+
+
+def test_decode_tile_vs_oracle(vae):
+    m, sd = vae
+    z = torch.randn(1, 16, 3, 6, 5, generator=torch.Generator().manual_seed(1))
+    out = m._decode_tile(z.cuda())
+    assert tuple(out.shape) == (1, 3, 9, 48, 40) and out.dtype == torch.bfloat16
+    ref = V.decoder_forward(sd, z, CFG, "bf16")
+    ref32 = V.decoder_forward(sd, z, CFG, "fp32")
+    assert rel(out, ref) <= 2e-2, rel(out, ref)
+    assert rel(out, ref32) <= 4e-2, (rel(out, ref32), rel(ref, ref32))
+
+
+def test_single_frame_tile(vae):
+    m, sd = vae
+    z = torch.randn(1, 16, 1, 4, 4, generator=torch.Generator().manual_seed(2))
+    out = m._decode_tile(z.cuda())
+    assert tuple(out.shape) == (1, 3, 1, 32, 32)
+    assert rel(out, V.decoder_forward(sd, z, CFG, "bf16")) <= 2e-2
+
+
+@pytest.mark.parametrize("shape,tile,stride", [((1, 16, 7, 4, 4), (1, 9, 32, 32), (4, 32, 32)),      # temporal tiles
+                                               ((1, 16, 2, 10, 14), (1, 9, 48, 48), (8, 32, 32)),    # spatial tiles
+                                               ((1, 16, 5, 10, 10), (1, 9, 48, 48), (4, 32, 32))])   # both
+def test_tiled_decode_vs_oracle(vae, shape, tile, stride):
+    m, sd = vae
+    z = torch.randn(*shape, generator=torch.Generator().manual_seed(3))
+    m.apply_tiling(tile, stride)
+    out = m._decode(z.cuda()).sample
+    ref = V.tiled_decode(sd, z, CFG, tile, stride, "bf16")
+    assert out.shape == ref.shape
+    assert rel(out, ref) <= 2e-2, rel(out, ref)
+
+
+def test_blend_kernel_bit_exact(vae):
+    m, _ = vae
+    g = torch.Generator().manual_seed(4)
+    a, b = bfr(torch.randn(1, 3, 5, 6, 7, generator=g)), bfr(torch.randn(1, 3, 5, 6, 7, generator=g))
+    for dim, ext in ((2, 3), (3, 4), (4, 5)):
+        ref = V.blend(a.clone(), b.clone(), ext, dim, "bf16")
+        got = m._blend(a.cuda().bfloat16(), b.cuda().bfloat16(), ext, dim)
+        assert torch.equal(got.float().cpu(), ref), dim
+
+
+def test_decode_picks_reference_tiling(vae):
+    m, _ = vae
+    meta = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vae_meta.json")))
+    for key, (tile, stride) in meta["dec_tiling"].items():
+        shape = [int(x) for x in key.split("x")]
+        a, b = m.get_dec_optimal_tiling(shape)
+        assert list(a) == tile and list(b) == stride
+
+
+def test_generate_sample_postprocess_matches_reference_uint8(vae):
+    m, sd = vae
+    z = torch.randn(1, 16, 2, 4, 4, generator=torch.Generator().manual_seed(6))
+    dec = m.decode(z.cuda()).sample
+    u8 = ((dec.clamp(-1.0, 1.0) + 1.0) * 127.5).to(torch.uint8)           # generation_utils.py:222
+    ref = V.postprocess_uint8(_r16(V.decoder_forward(sd, z, CFG, "bf16")))
+    diff = (u8.int().cpu() - ref.int()).abs()
+    assert diff.float().mean().item() < 1.0 and (diff <= 8).float().mean().item() > 0.99
+
+
+def _r16(x):
+    return x.bfloat16()
