@@ -47,17 +47,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, int G, double count,
-                                   float eps) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= G) return;
+// one 256-thread block per group: strided double-precision sums over the per-block partials, LDS tree
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk,
+                                                          int G, double count, float eps) {
+  __shared__ double rs[256], rq[256];
+  const int g = blockIdx.x, tid = threadIdx.x;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += partial[((size_t)b * G + g) * 2]; q += partial[((size_t)b * G + g) * 2 + 1]; }
-  const double mean = s / count;
-  double var = q / count - mean * mean;
-  if (var < 0) var = 0;
-  stats[2 * g] = (float)mean;
-  stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  for (int b = tid; b < nblk; b += 256) { s += partial[((size_t)b * G + g) * 2]; q += partial[((size_t)b * G + g) * 2 + 1]; }
+  rs[tid] = s; rq[tid] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double mean = rs[0] / count;
+    double var = rq[0] / count - mean * mean;
+    if (var < 0) var = 0;
+    stats[2 * g] = (float)mean;
+    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 template <bool SILU>
@@ -158,7 +167,7 @@ int k5_launch_groupnorm_bf16(const void* x, const float* gamma, const float* bet
   float* partial = (float*)workspace;
   float* stats = partial + (size_t)nblk * G * 2;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, partial, M, C, ldx, G);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, s, partial, stats, nblk, G, (double)M * cg, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G), dim3(256), 0, s, partial, stats, nblk, G, (double)M * cg, eps);
   const int64_t nchunks = (int64_t)M * (C >> 3);
   if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid_for(nchunks)), dim3(256), 0, s, (const bf16_t*)x, stats, gamma, beta,
                                (bf16_t*)out, nchunks, C >> 3, cg, ldx, ldo);
