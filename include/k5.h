@@ -47,11 +47,21 @@ int k5_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M
 /* O[q][h*64+d] = softmax(Q K^T / 8) V per head (head_dim 64, non-causal, fp32 softmax).
  * Replaces FA(q,k,v): nn.py:201 (text self-attn), :254 (visual self-attn), :336 (cross-attn).
  * Q [q_len][ldq], K [kv_len][ldk] with head h at columns h*64..; Vt [H*64][ldvt] is V transposed
- * (row h*64+d, column key).  kv_nb/kv_idx (optional) select 64-key blocks per (head, 64-query block)
- * = flex_attention(block_mask) nn.py:257-280:  counts kv_nb[h*nqb+qb], ids kv_idx[(h*nqb+qb)*nkb_stride+i]. */
+ * (row h*64+d, column key). */
 int k5_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len,
-                      int ldq, int ldk, int ldvt, int ldo, const int32_t* kv_nb, const int32_t* kv_idx,
-                      int nkb_stride, void* stream);
+                      int ldq, int ldk, int ldvt, int ldo, void* stream);
+
+/* NABLA block-sparse attention = nablaT_v2 (kandinsky/models/utils.py:136-163, incl. the STA window of
+ * fast_sta_nabla :108-133) + flex_attention(q,k,v,block_mask) (nn.py:257-280), tokens in fractal order
+ * (utils.py:31-41): N = T*Hb*Wb*64.  k5_nabla_select_bf16 fills `workspace` (k5_nabla_workspace_size bytes) with the
+ * block map of every (head, 64-query block); k5_attention_nabla_bf16 consumes it; k5_nabla_mask_u8 expands the map to
+ * uint8 [H][N/64][N/64] (tests / diagnostics) and k5_nabla_counts copies the kept-block count per row. */
+int64_t k5_nabla_workspace_size(int H, int num_blocks);
+int k5_nabla_select_bf16(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT,
+                         int wH, int wW, float P, void* workspace, void* stream);
+int k5_attention_nabla_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int N, int ldq, int ldk,
+                            int ldvt, int ldo, float score_bound, const void* workspace, void* stream);
+int k5_nabla_mask_u8(const void* workspace, int H, int num_blocks, void* out_u8, void* stream);
 
 /* Dense k5_attention_bf16 with a caller-proved bound |q.k| <= score_bound for every (query, key) pair
  * (after norm_qk nn.py:193-197 every head vector has |x| <= 8*max|weight|).  When 2*bound*log2(e)/8 <= 96

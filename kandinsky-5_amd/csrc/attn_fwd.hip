@@ -43,9 +43,11 @@ struct AttnP {
   // sequence-parallel layout of V^T: keys are split in chunks of vt_chunk_keys (multiple of 64) and chunk c
   // starts at Vt + c * vt_chunk_stride ([rank][H*64][ldvt] after an in-place all-gather); 0 = one chunk
   int vt_chunk_keys; long long vt_chunk_stride;
+  // SPARSE (NABLA): per workgroup (head, 256-query group) a list of kv-block ids | (4-bit membership << 24) and its length
+  const int* sp_list; const int* sp_cnt; int sp_stride;
 };
 
-template <bool BOUNDED>
+template <bool BOUNDED, bool SPARSE>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
   char* sK = smem;
@@ -67,15 +69,19 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   const bf16_t* kbase = p.K + h * 64 + 8 * lc;
   const bf16_t* vbase = p.Vt + (size_t)(h * 64 + lrow) * p.ldvt + 8 * lc;
   const int lds_off = lds_swz(lrow, lc);
-  const int T = (p.kv_len + KB - 1) / KB, nfull = p.kv_len / KB;
+  const int* sp_list = SPARSE ? p.sp_list + (size_t)(h * p.nqb + qb) * p.sp_stride : nullptr;
+  const int T = SPARSE ? p.sp_cnt[h * p.nqb + qb] : (p.kv_len + KB - 1) / KB;
+  const int nfull = SPARSE ? T : p.kv_len / KB;     // NABLA sequences are whole 64-token blocks
+  const int my_bit = 1 << (24 + (wave >> 1));         // this wave's 64-query block inside the 256-query workgroup
   u32x4 rk, rv;
   const int tiles_per_chunk = p.vt_chunk_keys > 0 ? p.vt_chunk_keys / KB : 0x7fffffff;
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int e) {   // e = position in the tile sequence; t = 64-key tile index
+    const int t = SPARSE ? (sp_list[e] & 0xffffff) : e;
     rk = *reinterpret_cast<const u32x4*>(kbase + (size_t)min(t * KB + lrow, p.kv_len - 1) * p.ldk);
     const int kv0 = t * KB;
     const int chunk = t / tiles_per_chunk;  // wave-uniform
     const bf16_t* vsrc = vbase + (long long)chunk * p.vt_chunk_stride + (kv0 - chunk * tiles_per_chunk * KB);
-    if (t < nfull) {
+    if (e < nfull) {
       rv = *reinterpret_cast<const u32x4*>(vsrc);
     } else {  // ragged last tile: never read past kv_len; zero-fill V^T (P is exactly 0 there)
       const int key = kv0 + 8 * lc;
@@ -103,14 +109,14 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   float m_run = BOUNDED ? p.m_fixed : -1e30f, l_run = 0.f;
   const float mc_fixed = p.m_fixed * c;
 
-  load_tile(0);
-  store_tile(0);
+  if (T > 0) { load_tile(0); store_tile(0); }
   __syncthreads();
   for (int t = 0; t < T; ++t) {
     const int buf = t & 1;
     if (t + 1 < T) load_tile(t + 1);
     const char* cK = sK + buf * TILE;
     const char* cV = sV + buf * TILE;
+    if (!SPARSE || (sp_list[t] & my_bit)) {   // wave-uniform: skip kv blocks this query block did not select
     // ---- S^T = K Q^T : two 32-key MFMA tiles, K fragments streamed from LDS ----
     f32x16 st[2];
 #pragma unroll
@@ -173,6 +179,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
       ot[1] = mfma32(v1, pfs, ot[1]);
     }
     l_run += ls;
+    }
     if (t + 1 < T) store_tile(buf ^ 1);
     __syncthreads();
   }
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
-  const float inv = 1.0f / l_tot;
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   const int q = q0 + l31;
   if (q < p.q_len) {
     bf16_t* op = p.O + (size_t)q * p.ldo + h * 64;
@@ -219,11 +226,37 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
   const dim3 grid(H * p.nqb), block(512);
   // exponent range used: [-2*bound*c, 0]; fp32 exp2 flushes below -126 -> require 2*bound*c <= 96
   const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
+  p.sp_list = nullptr; p.sp_cnt = nullptr; p.sp_stride = 0;
   if (bounded) {
     p.m_fixed = score_bound;
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, block, 0, stream, p);
   } else {
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, block, 0, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
+// NABLA block-sparse attention (flex_attention(q,k,v,block_mask) nn.py:257-280): `list`/`cnt` are the per-workgroup
+// union lists produced by k5_launch_nabla_select (stride = number of 64-token blocks).  q_len == kv_len, multiple of 64.
+int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int len, int ldq, int ldk,
+                                    int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
+                                    hipStream_t stream) {
+  if (H <= 0 || len <= 0 || (len % KB) || !list || !cnt) return K5_ERR_ARG;
+  if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
+  AttnP p;
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+  p.H = H; p.q_len = len; p.kv_len = len; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
+  p.nqb = (len + QB - 1) / QB;
+  p.c = 0.125f * 1.44269504088896340736f;
+  p.m_fixed = 0.f; p.vt_chunk_keys = 0; p.vt_chunk_stride = 0;
+  p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride;
+  const dim3 grid(H * p.nqb), block(512);
+  const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
+  if (bounded) {
+    p.m_fixed = score_bound;
+    hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, block, 0, stream, p);
   }
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
@@ -232,12 +265,4 @@ int k5_launch_attention_bf16_bounded(const void* Q, const void* K, const void* V
                                      int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                      hipStream_t stream) {
   return k5_launch_attention_bf16_chunked(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, score_bound, 0, 0, stream);
-}
-
-int k5_launch_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
-                             int kv_len, int ldq, int ldk, int ldvt, int ldo, const int32_t* kv_nb,
-                             const int32_t* kv_idx, int nkb_stride, hipStream_t stream) {
-  if (kv_nb || kv_idx) return K5_ERR_UNSUPPORTED;
-  (void)nkb_stride;
-  return k5_launch_attention_bf16_bounded(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, 0.f, stream);
 }

@@ -176,6 +176,8 @@ struct k5_dit {
   Comm comm;
   int sp_rank = 0, sp_world = 1;
   DevBuf ws_q, ws_kfull, ws_vtfull;
+  // NABLA: fractal token permutation (cached per shape) and the selection workspace
+  DevBuf ws_perm, ws_nabla; int perm_shape[3] = {0, 0, 0}; bool key_fractal = false;
   // rope cache keys
   std::vector<int32_t> key_vpos; float key_scale[3] = {0, 0, 0}; int key_shape[3] = {0, 0, 0};
   struct TextRope { std::vector<int32_t> key; DevBuf cosT, sinT, pos; };
@@ -308,9 +310,11 @@ inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // ---------------------------------------------------------------------------------------------
 // one attention module on `rows` tokens:  x_resid += gate * out_l(attn(...)) fused in the out GEMM
 // ---------------------------------------------------------------------------------------------
+struct NablaArgs { int T, Hb, Wb, wT, wH, wW; float P; };
+
 int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, void* qk, void* vt,
                        void* o, const float* cosT, const float* sinT, void* resid, const float* gate,
-                       const char* fam_attn) {
+                       const char* fam_attn, const NablaArgs* nabla = nullptr) {
   const int D = d->D, H = d->Hh;
   const int ldvt = (int)rup(rows, 8);
   {
@@ -323,7 +327,20 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     const int32_t hc[2] = {H, 2 * H};
     K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s));
   }
-  {
+  if (nabla) {  // nablaT_v2 map (utils.py:136-163) + block-sparse attention (nn.py:257-280)
+    const int nb = rows / 64;
+    K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
+    {
+      Scope sc(d, s, "nabla_map");
+      K5CHK(k5_launch_nabla_select(qk, (const bf16_t*)qk + D, 2 * D, 2 * D, H, rows, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
+                                   nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s));
+    }
+    const int *list, *cnt;
+    k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
+    Scope sc(d, s, fam_attn);
+    K5CHK(k5_launch_attention_bf16_sparse(qk, (const bf16_t*)qk + D, vt, o, H, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, list, cnt,
+                                          nb, s));
+  } else {
     Scope sc(d, s, fam_attn);
     K5CHK(k5_launch_attention_bf16_bounded(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, s));
   }
@@ -437,21 +454,22 @@ int ensure_workspaces(k5_dit* d, int N, int L) {
   return K5_OK;
 }
 
-int prepare_rope(k5_dit* d, hipStream_t s, const k5_forward_args* a, int Tp, int Hp, int Wp) {
+int prepare_rope(k5_dit* d, hipStream_t s, const k5_forward_args* a, int Tp, int Hp, int Wp, const int32_t* tok_perm) {
   // visual tables: recompute only when the (shape, positions, scale) key changes — step-invariant (K15)
   std::vector<int32_t> key;
   key.insert(key.end(), a->pos_t, a->pos_t + Tp); key.insert(key.end(), a->pos_h, a->pos_h + Hp);
   key.insert(key.end(), a->pos_w, a->pos_w + Wp);
   const bool same = key == d->key_vpos && d->key_shape[0] == Tp && d->key_shape[1] == Hp && d->key_shape[2] == Wp &&
-                    !memcmp(d->key_scale, a->scale_factor, 12);
+                    !memcmp(d->key_scale, a->scale_factor, 12) && d->key_fractal == (tok_perm != nullptr);
   if (!same) {
     K5CHK(d->ws_pos.ensure(key.size() * 4));
     HIPCHK(hipMemcpyAsync(d->ws_pos.p, key.data(), key.size() * 4, hipMemcpyHostToDevice, s));
     const int32_t* p = d->ws_pos.as<int32_t>();
     const int n0 = d->cfg.axes_dims[0] / 2, n1 = d->cfg.axes_dims[1] / 2, n2 = d->cfg.axes_dims[2] / 2;
     K5CHK(k5_launch_rope_table(d->ws_vcos.as<float>(), d->ws_vsin.as<float>(), p, p + Tp, p + Tp + Hp, Tp, Hp, Wp, n0, n1,
-                               n2, a->scale_factor[0], a->scale_factor[1], a->scale_factor[2], nullptr, s));
+                               n2, a->scale_factor[0], a->scale_factor[1], a->scale_factor[2], tok_perm, s));
     HIPCHK(hipStreamSynchronize(s));  // key vector is host memory reused below; once per shape only
+    d->key_fractal = tok_perm != nullptr;
     d->key_vpos = key; d->key_shape[0] = Tp; d->key_shape[1] = Hp; d->key_shape[2] = Wp;
     memcpy(d->key_scale, a->scale_factor, 12);
   }
@@ -466,7 +484,7 @@ int prepare_text_rope(k5_dit* d, hipStream_t s, const k5_text_cond& c, const flo
   if (d->text_rope.size() >= 8) {
     HIPCHK(hipStreamSynchronize(s));
     for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release();
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
     d->text_rope.clear();
   }
@@ -496,7 +514,7 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
                  int x_channels, void* out_velocity, hipStream_t s) {
   const k5_dit_config& c = d->cfg;
   if (!d->finalized) { k5_set_error("k5_dit_forward before k5_dit_finalize"); return K5_ERR_STATE; }
-  if (a->attention_type != 0) { k5_set_error("nabla attention not built yet"); return K5_ERR_UNSUPPORTED; }
+  if (a->attention_type != 0 && a->attention_type != 1) { k5_set_error("attention_type must be 0 (flash) or 1 (nabla)"); return K5_ERR_ARG; }
   if (c.patch_size[0] != 1 || c.patch_size[1] != 2 || c.patch_size[2] != 2) return K5_ERR_UNSUPPORTED;
   const int Tp = a->T, Hp = a->H / 2, Wp = a->W / 2;
   const int N = Tp * Hp * Wp, L = cond.text_len, D = d->D;
@@ -515,7 +533,28 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     K5CHK(d->ws_q.ensure((size_t)n * D * 2)); K5CHK(d->ws_kfull.ensure((size_t)N * D * 2));
     K5CHK(d->ws_vtfull.ensure((size_t)N * D * 2));
   }
-  K5CHK(prepare_rope(d, s, a, Tp, Hp, Wp));
+  // NABLA: tokens are processed in fractal order (8x8 spatial tiles contiguous), utils.py:31-41,54-78
+  const bool nabla = a->attention_type == 1;
+  NablaArgs na{};
+  const int32_t* perm = nullptr;
+  if (nabla) {
+    if ((Hp % 8) || (Wp % 8)) { k5_set_error("nabla attention needs latent H, W divisible by 16 (got %d x %d)", a->H, a->W); return K5_ERR_ARG; }
+    if (sp) { k5_set_error("nabla + sequence parallel is not built yet"); return K5_ERR_UNSUPPORTED; }
+    na = NablaArgs{Tp, Hp / 8, Wp / 8, a->nabla_wT, a->nabla_wH, a->nabla_wW, a->nabla_P};
+    if (d->perm_shape[0] != Tp || d->perm_shape[1] != Hp || d->perm_shape[2] != Wp) {
+      std::vector<int32_t> pv((size_t)N);
+      const int Hb = Hp / 8, Wb = Wp / 8;
+      for (int i = 0; i < N; ++i) {
+        const int b = i >> 6, r = i & 63, t = b / (Hb * Wb), hb = (b / Wb) % Hb, wb = b % Wb;
+        pv[i] = (t * Hp + hb * 8 + (r >> 3)) * Wp + wb * 8 + (r & 7);
+      }
+      K5CHK(d->ws_perm.ensure((size_t)N * 4));
+      HIPCHK(hipMemcpy(d->ws_perm.p, pv.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+      d->perm_shape[0] = Tp; d->perm_shape[1] = Hp; d->perm_shape[2] = Wp;
+    }
+    perm = d->ws_perm.as<int32_t>();
+  }
+  K5CHK(prepare_rope(d, s, a, Tp, Hp, Wp, perm));
   const float *tcos = nullptr, *tsin = nullptr;
   K5CHK(prepare_text_rope(d, s, cond, &tcos, &tsin));
 
@@ -541,7 +580,7 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     // every Modulation layer of the network in one GEMV (they all consume the same time_embed)
     K5CHK(k5_launch_gemv_f32(d->ws_temb.as<float>(), d->mod_w.as<float>(), d->mod_b.as<float>(), d->ws_mod.as<float>(),
                              (int)d->mod_rows, d->TD, 1, nullptr, s));
-    K5CHK(k5_launch_patchify(x, d->ws_xp.p, a->T, a->H, a->W, x_channels, Cin, d->KvisPad, nullptr, s));
+    K5CHK(k5_launch_patchify(x, d->ws_xp.p, a->T, a->H, a->W, x_channels, Cin, d->KvisPad, perm, s));
     K5CHK(k5_launch_gemm_bf16(d->ws_xp.as<bf16_t>() + (size_t)tok0 * d->KvisPad, d->vis_w.p, d->vis_b.as<float>(), d->ws_vis.p,
                               n, D, d->KvisPad, d->KvisPad, d->KvisPad, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   }
@@ -565,7 +604,7 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
       K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D));
     } else {
       K5CHK(run_self_attention(d, s, b.self_attn, d->ws_h.p, n, d->ws_qk.p, d->ws_vt.p, d->ws_o.p, vcos, vsin, d->ws_vis.p,
-                               m + 2 * D, "attn_self"));
+                               m + 2 * D, "attn_self", nabla ? &na : nullptr));
     }
     K5CHK(ln_mod(d, s, d->ws_vis.p, m + 3 * D, d->ws_h.p, n));
     K5CHK(run_cross_attention(d, s, b.cross_attn, d->ws_h.p, n, d->ws_text.p, L, d->ws_qk.p, d->ws_ck.p, d->ws_cvt.p,
@@ -582,7 +621,7 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
                               d->Fout, D, D, D, d->Fout, K5_EPI_BIAS, nullptr, 0, nullptr, s));
     // every rank needs the whole velocity: the (replicated) latent is advanced identically on all ranks
     if (sp) K5CHK(d->comm.all_gather_inplace(d->ws_y.p, (size_t)n * d->Fout, 2, s));
-    K5CHK(k5_launch_unpatchify(d->ws_y.p, out_velocity, Tp, Hp, Wp, c.out_visual_dim, d->Fout, nullptr, s));
+    K5CHK(k5_launch_unpatchify(d->ws_y.p, out_velocity, Tp, Hp, Wp, c.out_visual_dim, d->Fout, perm, s));
   }
   return K5_OK;
 }
@@ -625,7 +664,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
                    &d->ws_vel_u};
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release();
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
   auto rel_attn = [](AttnW& a) {
     DevBuf* bs[] = {&a.wqk, &a.wq, &a.wk, &a.wv, &a.wo, &a.bqk, &a.bq, &a.bk, &a.bv, &a.bo, &a.norm};

