@@ -32,6 +32,9 @@ WORKLOADS = {
                           "guidance 1.0 (1 DiT forward per step), NFE=50"),
     "5s_sft": dict(latent=(31, 64, 96), L=256, Lnull=32, w=5.0, attn="flash",
                    desc="config_5s_sft.yaml: as 5s_nocfg with CFG (cond + uncond forward per step), NFE=100"),
+    "10s_nabla": dict(latent=(61, 64, 96), L=256, Lnull=32, w=1.0, attn="nabla",
+                      desc="config_10s_sft.yaml attention (NABLA P=0.9, wT=11, wH=wW=3) on the 768x512 10 s latent (61,64,96,16), "
+                           "93696 tokens, guidance 1.0; map density depends on the (random) weights and is reported"),
     "2s_256": dict(latent=(13, 32, 32), L=256, Lnull=32, w=1.0, attn="flash",
                    desc="config_5s_distil.yaml plumbing case: 256x256 2 s latent (13,32,32,16), 3328 tokens"),
 }
@@ -99,6 +102,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="5s_nocfg", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-for-`value`) VAE decode leg")
     ap.add_argument("--force-sp", action="store_true", help="debug: drive the sharded code path through a world=1 RCCL communicator")
     ap.add_argument("--blocks", type=int, default=32, help="debug only: fewer visual blocks => INVALID as a bench")
     args = ap.parse_args()
@@ -139,8 +143,13 @@ def main():
     nfe_steps = 50
     sig = sigma_schedule(nfe_steps, 5.0).tolist()
 
+    sparse = None
+    if wl["attn"] == "nabla":
+        sparse = {"P": 0.9, "wT": 11, "wH": 3, "wW": 3, "to_fractal": True}
+
     def run(k0, k):  # k consecutive Euler steps of the 50-step schedule starting at step k0
-        dit.sample(latent, sig[k0:k0 + k + 1], te, ne, vpos, tpos, ntpos, wl["w"], scale_factor=(1.0, 2.0, 2.0))
+        dit.sample(latent, sig[k0:k0 + k + 1], te, ne, vpos, tpos, ntpos, wl["w"], scale_factor=(1.0, 2.0, 2.0),
+                   sparse_params=sparse)
 
     def barrier():
         if world > 1:
@@ -163,7 +172,22 @@ def main():
     dit.set_profiling(False)
 
     fam = {f: dit.get_profile(f) for f in ("attn_self", "attn_cross", "attn_text", "gemm", "elementwise", "prologue",
-                                           "epilogue", "comm")}
+                                           "epilogue", "comm", "nabla_map")}
+    # end-to-end leg (not part of `value`): HunyuanVideo VAE decode of the final latent on the same GPU
+    vae_s = None
+    if rank == 0 and not args.no_vae:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from vae_bench import synthetic_vae
+        vae = synthetic_vae(dev)
+        z = (latent / 0.476986).permute(3, 0, 1, 2)[None].contiguous()      # generation_utils.py:220
+        vae._decode_tile(z[:, :, :5]); torch.cuda.synchronize(dev)            # warm-up on one tile (no tiling state touched)
+        tv = time.perf_counter()
+        img = vae.decode(z).sample
+        u8 = ((img.clamp(-1.0, 1.0) + 1.0) * 127.5).to(torch.uint8)          # generation_utils.py:222
+        torch.cuda.synchronize(dev)
+        vae_s = time.perf_counter() - tv
+        assert tuple(u8.shape) == (1, 3, 4 * (T - 1) + 1, 8 * H, 8 * W)
+        del vae, img, u8
     attn_ms, attn_n = fam["attn_self"]
     attn_flop = 4.0 * N * N * 64 * 28 / world  # per launch on this rank (queries sharded over ranks)
     achieved = attn_flop / (attn_ms / max(attn_n, 1) * 1e-3) / 1e12 if attn_n else 0.0
@@ -187,8 +211,10 @@ def main():
                          "traffic": None, "flop_per_launch": attn_flop, "avg_launch_ms": attn_ms / max(attn_n, 1),
                          "launches": attn_n},
             "kernel_time_ms_per_step": {k: v[0] / args.steps for k, v in fam.items() if v[1]},
-            "e2e_clip_s_estimate": {"denoise_50_steps_s": 50 * dt / args.steps * (1 if wl["w"] == 1.0 else 1),
-                                    "note": "50 x ms_per_step; VAE decode not included yet"},
+            "e2e_clip_s": {"denoise_50_steps_s": 50 * dt / args.steps, "vae_decode_s": vae_s,
+                           "total_s": None if vae_s is None else 50 * dt / args.steps + vae_s,
+                           "note": "50 x measured ms_per_step + measured HunyuanVideo VAE decode (14 temporal tiles, uint8 out); "
+                                   "text encoding excluded (no weights offline); reference README: 77 s on 1xH100 incl. text encoder"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N)

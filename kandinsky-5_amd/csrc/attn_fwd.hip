@@ -79,8 +79,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     const int t = SPARSE ? (sp_list[e] & 0xffffff) : e;
     rk = *reinterpret_cast<const u32x4*>(kbase + (size_t)min(t * KB + lrow, p.kv_len - 1) * p.ldk);
     const int kv0 = t * KB;
-    const int chunk = t / tiles_per_chunk;  // wave-uniform
-    const bf16_t* vsrc = vbase + (long long)chunk * p.vt_chunk_stride + (kv0 - chunk * tiles_per_chunk * KB);
+    const bf16_t* vsrc = vbase + kv0;
+    if (!SPARSE && p.vt_chunk_keys > 0) {   // sequence-parallel V^T layout only (uniform branch): per-rank chunks
+      const int chunk = t / tiles_per_chunk;
+      vsrc = vbase + (long long)chunk * p.vt_chunk_stride + (kv0 - chunk * tiles_per_chunk * KB);
+    }
     if (e < nfull) {
       rv = *reinterpret_cast<const u32x4*>(vsrc);
     } else {  // ragged last tile: never read past kv_len; zero-fill V^T (P is exactly 0 there)
