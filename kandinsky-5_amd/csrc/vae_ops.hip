@@ -13,15 +13,14 @@ namespace {
 
 constexpr int GN_ROWS = 512;  // rows per statistics block
 
-// partial[blk][g] = (sum, sumsq) over GN_ROWS rows x (C/G) channels
+// partial[blk][g] = (sum, sumsq) over GN_ROWS rows x (C/G) channels.  Deterministic: per-thread partials go to LDS
+// and each group is summed by one thread in a fixed order (no float atomics -> bit-reproducible decodes).
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int M,
                                                          int C, int ldx, int G) {
-  __shared__ float red[2][64];  // up to 64 groups
+  __shared__ float ps[256][4];  // per thread: (sum, sumsq) for its first group, (sum, sumsq) for its second group
   const int tid = threadIdx.x;
   const int nch = C >> 3, cg = C / G;       // 16-B chunks per row; channels per group
   const int r0 = blockIdx.x * GN_ROWS, r1 = min(r0 + GN_ROWS, M);
-  if (tid < 64) { red[0][tid] = 0.f; red[1][tid] = 0.f; }
-  __syncthreads();
   // thread -> fixed chunk column (tid % nch), strides over rows: its 8 channels lie in <= 2 groups
   const int rows_par = 256 / nch > 0 ? 256 / nch : 1;
   const int ch = tid % nch, rsub = tid / nch;
@@ -37,13 +36,19 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
         s[gi] += v; q[gi] += v * v;
       }
     }
-    atomicAdd(&red[0][g0], s[0]); atomicAdd(&red[1][g0], q[0]);
-    if (cg < 8) { atomicAdd(&red[0][g0 + 1], s[1]); atomicAdd(&red[1][g0 + 1], q[1]); }
   }
+  ps[tid][0] = s[0]; ps[tid][1] = q[0]; ps[tid][2] = s[1]; ps[tid][3] = q[1];
   __syncthreads();
   if (tid < G) {
-    partial[((size_t)blockIdx.x * G + tid) * 2] = red[0][tid];
-    partial[((size_t)blockIdx.x * G + tid) * 2 + 1] = red[1][tid];
+    float ss = 0.f, qq = 0.f;
+    const int used = min(256, rows_par * nch);
+    for (int t = 0; t < used; ++t) {
+      const int tg0 = (8 * (t % nch)) / cg;
+      if (tg0 == tid) { ss += ps[t][0]; qq += ps[t][1]; }
+      else if (cg < 8 && tg0 + 1 == tid) { ss += ps[t][2]; qq += ps[t][3]; }
+    }
+    partial[((size_t)blockIdx.x * G + tid) * 2] = ss;
+    partial[((size_t)blockIdx.x * G + tid) * 2 + 1] = qq;
   }
 }
 
