@@ -275,6 +275,101 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmP p) {
   gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, hi, l31);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x128x64 tile, 8 waves (4 along M x 2 along N, 64x64 each), THREE-stage LDS ring (3 x 48 KB) filled by
+// global_load_lds with a COUNTED vmcnt: when tile kt is consumed, tile kt+1 is still in flight and tile kt+2 is issued
+// right after the barrier, i.e. two K-tiles (~2 x 1024 MFMA cycles per SIMD) of prefetch distance.  Motivation
+// (profiles/r01_gemm_traffic.md): with 128x128 tiles and a single tile of prefetch the FF GEMMs miss L2 for 7-18x their
+// algorithmic bytes (3.5-6.6 GB per launch) and every barrier's vmcnt(0) sat on that latency.  hipcc's __syncthreads()
+// would drain vmcnt(0) (an LDS-DMA is a pending LDS write), so the loop uses a raw s_barrier + explicit s_waitcnt.
+// ---------------------------------------------------------------------------------------------
+constexpr int K3_BM = 256, K3_STAGE = (256 + 128) * 128, K3_STAGES = 3;
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_k3_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
+
+  const int nblk = p.tiles_m * p.tiles_n;
+  int lid = xcd_remap(blockIdx.x, nblk);
+  constexpr int GM = 4;  // 32 resident tiles per XCD = 4 x 8 patch of 256x128 tiles (1024 x 1024 outputs)
+  const int per_group = GM * p.tiles_n;
+  const int g = lid / per_group, first_m = g * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int tm = first_m + (lid % per_group) % gsz;
+  const int tn = (lid % per_group) / gsz;
+  const int m0 = tm * K3_BM, n0 = tn * BN;
+
+  // 48 pieces (8 rows x 128 B) per stage: A pieces 0..31, W pieces 32..47; wave w stages pieces w, w+8, ..., w+40
+  const bf16_t* gsrc[6]; int ldsoff[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int piece = wave + 8 * i;
+    const bool isw = piece >= 32;
+    const int prow = 8 * (isw ? piece - 32 : piece) + (lane >> 3);
+    const int c = (lane & 7) ^ ((prow >> 1) & 7);
+    gsrc[i] = isw ? p.W + (size_t)min(n0 + prow, p.N - 1) * p.ldw + 8 * c
+                  : p.A + (size_t)min(m0 + prow, p.M - 1) * p.lda + 8 * c;
+    ldsoff[i] = piece * 1024;   // A region [0, 32 KB), W region [32 KB, 48 KB) of the stage
+  }
+  auto stage = [&](int st, int k0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(gsrc[i] + k0), (lds_void_t*)(dsm + st * K3_STAGE + ldsoff[i]), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  if (nk > 1) stage(1, BK);
+  int st = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt must have landed; tile kt+1 (6 DMA per wave) may stay in flight
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) stage(st == 0 ? 2 : st - 1, (kt + 2) * BK);   // ring slot (kt+2)%3 == (kt-1)%3: free since the barrier
+    const char* cA = dsm + st * K3_STAGE;
+    const char* cW = cA + 256 * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = 2 * ks + hi;
+      bf16x8 fw[2], fx[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(cW + lds_swz(wn * 64 + i * 32 + l31, c));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fx[j] = *reinterpret_cast<const bf16x8*>(cA + lds_swz(wm * 64 + j * 32 + l31, c));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fw[i], fx[j], acc[i][j]);
+    }
+    st = st == 2 ? 0 : st + 1;
+  }
+  gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, hi, l31);
+}
+
+template <int EPI>
+int launch_k3(GemmP p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_bf16_k3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, K3_STAGES * K3_STAGE) != hipSuccess)
+      return K5_ERR_HIP;
+    attr_set = true;
+  }
+  p.tiles_m = (p.M + K3_BM - 1) / K3_BM;
+  hipLaunchKernelGGL(gemm_bf16_k3_kernel<EPI>, dim3(p.tiles_m * p.tiles_n), dim3(512), K3_STAGES * K3_STAGE, stream, p);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
 }  // namespace
 
 // Host launcher (C++ linkage, used by the C-ABI layer in k5_api.hip and by the engine).
@@ -292,7 +387,18 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   p.alpha = 1.f;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
   static const int force_v1 = getenv("K5_GEMM_V1") ? atoi(getenv("K5_GEMM_V1")) : 0;  // A/B switch for benchmarking
-  if ((K % BK) == 0 && !force_v1) {
+  // K5_GEMM_V1=3 selects the 256x128 3-stage counted-vmcnt variant.  Measured (round 1, model shapes): within +-3 % of the
+  // 128x128 direct-to-LDS kernel (ff2 844 vs 827, ff1 698 vs 719 TFLOP/s) -> L2-miss latency is not the limiter; not default.
+  if ((K % BK) == 0 && M >= 512 && force_v1 == 3) {
+    switch (epi) {
+      case K5_EPI_BIAS: return launch_k3<K5_EPI_BIAS>(p, stream);
+      case K5_EPI_BIAS_M: return launch_k3<K5_EPI_BIAS_M>(p, stream);
+      case K5_EPI_GELU: return launch_k3<K5_EPI_GELU>(p, stream);
+      case K5_EPI_GATE: return launch_k3<K5_EPI_GATE>(p, stream);
+      default: return K5_ERR_ARG;
+    }
+  }
+  if ((K % BK) == 0 && force_v1 != 1) {
     switch (epi) {
       case K5_EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_glds_kernel<K5_EPI_BIAS>, grid, block, 0, stream, p); break;
       case K5_EPI_BIAS_M: hipLaunchKernelGGL(gemm_bf16_glds_kernel<K5_EPI_BIAS_M>, grid, block, 0, stream, p); break;
