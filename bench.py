@@ -46,14 +46,13 @@ def flops_forward(N, L, D=1792, FF=7168, blocks=32):
     return blocks * (2 * N * (6 * D * D + 2 * D * FF) + 2 * L * 2 * D * D + 4 * N * N * D + 4 * N * L * D) + 0.2e12
 
 
-def cpu_baseline(N, budget_s=12.0):
+def cpu_baseline(N, budget_s=5.0):   # the full-size sample runs ~3.5x slower than the 1024-token calibration predicts
     """The CPU oracle (own fp32 restatement pinned against the reference, oracle/k5_oracle.py) on the host
     cores: ONE full-width decoder block of the 32 at the workload's token count, extrapolated x32 (the text
     blocks / embeddings are <0.1 % of the FLOPs).  If one block at N would exceed the budget, a query-row
     slice of the attention is timed and scaled (stated in `sample`)."""
     from oracle import k5_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     cfg = O.DitConfig(**dict(LITE, num_visual_blocks=1, num_text_blocks=0))
     names = [k for k in O.state_dict_manifest(cfg) if k.startswith("visual_transformer_blocks.0.")]
     man = O.state_dict_manifest(cfg)
@@ -65,9 +64,21 @@ def cpu_baseline(N, budget_s=12.0):
     x = torch.randn(n_cal, D, generator=g)
     text, temb = torch.randn(L, D, generator=g), torch.randn(1, cfg.time_dim, generator=g)
     cs = torch.ones(n_cal, 32), torch.zeros(n_cal, 32)
-    t0 = time.perf_counter()
-    O.decoder_block(sd, "visual_transformer_blocks.0", x, text, temb, cs[0], cs[1], cfg, "fp32")
-    t_cal = time.perf_counter() - t0
+    # thread count: the container may be CPU-limited far below os.cpu_count() (256 torch threads on the 2x64-core GPU
+    # host ran 100x slower than 16) -> pick the fastest of a few candidates on the calibration problem
+    best = None
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(th)
+        O.decoder_block(sd, "visual_transformer_blocks.0", x[:128], text, temb, cs[0][:128], cs[1][:128], cfg, "fp32")
+        t0 = time.perf_counter()
+        O.decoder_block(sd, "visual_transformer_blocks.0", x, text, temb, cs[0], cs[1], cfg, "fp32")
+        dtc = time.perf_counter() - t0
+        if best is None or dtc < best[0]:
+            best = (dtc, th)
+        if dtc > 3 * best[0]:
+            break
+    t_cal, cores = best
+    torch.set_num_threads(cores)
     fl = lambda n, nq: 2 * nq * (6 * D * D + 2 * D * cfg.ff_dim) + 4 * nq * n * D + 4 * nq * L * D  # noqa: E731
     rate = fl(n_cal, n_cal) / t_cal
     frac = min(1.0, budget_s * rate / fl(N, N))
@@ -89,7 +100,7 @@ def cpu_baseline(N, budget_s=12.0):
     t_s = time.perf_counter() - t0
     # k/v projections were done on all N rows; scale the row-proportional part only
     t_block = t_s * (fl(N, N) / (fl(N, nq) + 2 * (N - nq) * 2 * D * D))
-    return {"value": 1.0 / (32 * t_block), "unit": "steps/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / (32 * t_block), "unit": "steps/s", "cores": cores, "host_cpus": ncpu, "kind": "port",
             "sample": f"fp32 torch-CPU oracle, 1 of 32 decoder blocks, {nq} of {N} query rows against all {N} keys "
                       f"({t_s:.1f} s measured), scaled to the full block and x32 blocks",
             "ms_per_step": 32 * t_block * 1e3}
@@ -192,6 +203,14 @@ def main():
     attn_flop = 4.0 * N * N * 64 * 28 / world  # per launch on this rank (queries sharded over ranks)
     achieved = attn_flop / (attn_ms / max(attn_n, 1) * 1e-3) / 1e12 if attn_n else 0.0
     fwd_per_step = 2 if abs(wl["w"] - 1.0) > 1e-6 else 1
+    traffic = None   # HBM-side bytes per attention launch from the committed PMC profile (separate --pmc passes; cannot be
+    try:             # collected inside a timed run) — only quoted for the exact workload it was measured on
+        with open(os.path.join(ROOT, "profiles", "r01_attention_traffic.json")) as f:
+            tj = json.load(f)
+        if tj.get("tokens") == N and world == 1 and wl["attn"] == "flash":
+            traffic = tj["bytes_per_launch"]
+    except Exception:
+        pass
     step_flop = fwd_per_step * flops_forward(N, L, blocks=args.blocks)
     assert torch.isfinite(latent).all(), "latent diverged"
 
@@ -208,7 +227,7 @@ def main():
             "model_tflops_per_gpu": step_flop * args.steps / dt / 1e12 / world,
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (dense self-attention, 32 launches per forward)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": None, "flop_per_launch": attn_flop, "avg_launch_ms": attn_ms / max(attn_n, 1),
+                         "traffic": traffic, "flop_per_launch": attn_flop, "avg_launch_ms": attn_ms / max(attn_n, 1),
                          "launches": attn_n},
             "kernel_time_ms_per_step": {k: v[0] / args.steps for k, v in fam.items() if v[1]},
             "e2e_clip_s": {"denoise_50_steps_s": 50 * dt / args.steps, "vae_decode_s": vae_s,
