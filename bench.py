@@ -200,9 +200,12 @@ def main():
         assert tuple(u8.shape) == (1, 3, 4 * (T - 1) + 1, 8 * H, 8 * W)
         del vae, img, u8
     attn_ms, attn_n = fam["attn_self"]
-    attn_flop = 4.0 * N * N * 64 * 28 / world  # per launch on this rank (queries sharded over ranks)
-    achieved = attn_flop / (attn_ms / max(attn_n, 1) * 1e-3) / 1e12 if attn_n else 0.0
     fwd_per_step = 2 if abs(wl["w"] - 1.0) > 1e-6 else 1
+    # algorithmic FLOPs of the dense self-attention on THIS rank per block (queries sharded over ranks); under sequence
+    # parallelism the block's attention is two launches (local chunk, then the gathered chunks) -> rate over their sum
+    attn_flop = 4.0 * N * N * 64 * 28 / world
+    n_blocks_run = args.blocks * fwd_per_step * args.steps
+    achieved = attn_flop * n_blocks_run / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0
     traffic = None   # HBM-side bytes per attention launch from the committed PMC profile (separate --pmc passes; cannot be
     try:             # collected inside a timed run) — only quoted for the exact workload it was measured on
         with open(os.path.join(ROOT, "profiles", "r01_attention_traffic.json")) as f:
@@ -227,7 +230,7 @@ def main():
             "model_tflops_per_gpu": step_flop * args.steps / dt / 1e12 / world,
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (dense self-attention, 32 launches per forward)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": traffic, "flop_per_launch": attn_flop, "avg_launch_ms": attn_ms / max(attn_n, 1),
+                         "traffic": traffic, "flop_per_launch": attn_flop * n_blocks_run / max(attn_n, 1), "avg_launch_ms": attn_ms / max(attn_n, 1),
                          "launches": attn_n},
             "kernel_time_ms_per_step": {k: v[0] / args.steps for k, v in fam.items() if v[1]},
             "e2e_clip_s": {"denoise_50_steps_s": 50 * dt / args.steps, "vae_decode_s": vae_s,

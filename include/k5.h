@@ -51,6 +51,15 @@ int k5_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M
 int k5_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len,
                       int ldq, int ldk, int ldvt, int ldo, void* stream);
 
+/* Split-key form of the dense attention (sequence-parallel overlap): process 64-key tiles e -> e + tile_off0
+ * (+ tile_skip_n once the index reaches tile_skip_at) for e < tile_cnt (-1: to the last tile); flags & 1 resumes from
+ * `state` (fp32 accumulators of an earlier call over other tiles), flags & 2 writes `state` instead of O.
+ * state: k5_attention_state_size(H, q_len) bytes.  Two calls covering disjoint tile sets == one k5_attention_bf16 call. */
+int64_t k5_attention_state_size(int H, int q_len);
+int k5_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len,
+                            int ldq, int ldk, int ldvt, int ldo, float score_bound, int tile_off0, int tile_cnt,
+                            int tile_skip_at, int tile_skip_n, void* state, int flags, void* stream);
+
 /* NABLA block-sparse attention = nablaT_v2 (kandinsky/models/utils.py:136-163, incl. the STA window of
  * fast_sta_nabla :108-133) + flex_attention(q,k,v,block_mask) (nn.py:257-280), tokens in fractal order
  * (utils.py:31-41): N = T*Hb*Wb*64.  k5_nabla_select_bf16 fills `workspace` (k5_nabla_workspace_size bytes) with the

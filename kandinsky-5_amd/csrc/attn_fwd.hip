@@ -45,6 +45,11 @@ struct AttnP {
   int vt_chunk_keys; long long vt_chunk_stride;
   // SPARSE (NABLA): per workgroup (head, 256-query group) a list of kv-block ids | (4-bit membership << 24) and its length
   const int* sp_list; const int* sp_cnt; int sp_stride;
+  // key-tile range of this launch (dense): sequence position e -> tile e + tile_off0, plus tile_skip_n once that reaches
+  // tile_skip_at (lets pass 2 of the sequence-parallel schedule walk "every chunk except mine").  state/flags: resume
+  // from (flags & 1) and/or leave (flags & 2) the fp32 running state {O^T accumulators, m, l} instead of normalising.
+  int tile_off0, tile_cnt, tile_skip_at, tile_skip_n;
+  float* state; int flags;
 };
 
 template <bool BOUNDED, bool SPARSE>
@@ -70,13 +75,19 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   const bf16_t* vbase = p.Vt + (size_t)(h * 64 + lrow) * p.ldvt + 8 * lc;
   const int lds_off = lds_swz(lrow, lc);
   const int* sp_list = SPARSE ? p.sp_list + (size_t)(h * p.nqb + qb) * p.sp_stride : nullptr;
-  const int T = SPARSE ? p.sp_cnt[h * p.nqb + qb] : (p.kv_len + KB - 1) / KB;
-  const int nfull = SPARSE ? T : p.kv_len / KB;     // NABLA sequences are whole 64-token blocks
+  const int T = SPARSE ? p.sp_cnt[h * p.nqb + qb] : p.tile_cnt;
+  const int nfull = p.kv_len / KB;                    // key tiles with all 64 keys valid (NABLA: all of them)
+  auto tile_of = [&](int e) -> int {                  // sequence position -> 64-key tile index (wave-uniform)
+    if (SPARSE) return sp_list[e] & 0xffffff;
+    int t = e + p.tile_off0;
+    if (t >= p.tile_skip_at) t += p.tile_skip_n;
+    return t;
+  };
   const int my_bit = 1 << (24 + (wave >> 1));         // this wave's 64-query block inside the 256-query workgroup
   u32x4 rk, rv;
   const int tiles_per_chunk = p.vt_chunk_keys > 0 ? p.vt_chunk_keys / KB : 0x7fffffff;
   auto load_tile = [&](int e) {   // e = position in the tile sequence; t = 64-key tile index
-    const int t = SPARSE ? (sp_list[e] & 0xffffff) : e;
+    const int t = tile_of(e);
     rk = *reinterpret_cast<const u32x4*>(kbase + (size_t)min(t * KB + lrow, p.kv_len - 1) * p.ldk);
     const int kv0 = t * KB;
     const bf16_t* vsrc = vbase + kv0;
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
       const int chunk = t / tiles_per_chunk;
       vsrc = vbase + (long long)chunk * p.vt_chunk_stride + (kv0 - chunk * tiles_per_chunk * KB);
     }
-    if (e < nfull) {
+    if (SPARSE || t < nfull) {
       rv = *reinterpret_cast<const u32x4*>(vsrc);
     } else {  // ragged last tile: never read past kv_len; zero-fill V^T (P is exactly 0 there)
       const int key = kv0 + 8 * lc;
@@ -111,15 +122,32 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   const float c = p.c;
   float m_run = BOUNDED ? p.m_fixed : -1e30f, l_run = 0.f;
   const float mc_fixed = p.m_fixed * c;
+  // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
+  auto state_o = [&]() { return p.state + (size_t)(q0 + l31) * (p.H * 64) + h * 64 + 4 * hi; };
+  auto state_ml = [&]() { return p.state + (size_t)p.q_len * (p.H * 64) + (((size_t)(q0 + l31) * p.H + h) * 2 + hi) * 2; };
+  if (!SPARSE && (p.flags & 1) && q0 + l31 < p.q_len) {   // resume: accumulators of an earlier launch over other key tiles
+    const float* st_o = state_o(); const float* st_ml = state_ml();
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(st_o + 32 * d + 8 * rg);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ot[d][4 * rg + e] = v[e];
+      }
+    if (!BOUNDED) m_run = st_ml[0];
+    l_run = st_ml[1];
+  }
 
   if (T > 0) { load_tile(0); store_tile(0); }
   __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < T) load_tile(t + 1);
+  for (int e = 0; e < T; ++e) {
+    const int buf = e & 1;
+    if (e + 1 < T) load_tile(e + 1);
+    const int t = tile_of(e);
     const char* cK = sK + buf * TILE;
     const char* cV = sV + buf * TILE;
-    if (!SPARSE || (sp_list[t] & my_bit)) {   // wave-uniform: skip kv blocks this query block did not select
+    if (!SPARSE || (sp_list[e] & my_bit)) {   // wave-uniform: skip kv blocks this query block did not select
     // ---- S^T = K Q^T : two 32-key MFMA tiles, K fragments streamed from LDS ----
     f32x16 st[2];
 #pragma unroll
@@ -134,7 +162,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
       st[1] = mfma32(k1, qf[kk], st[1]);
     }
     // lane (q = l31, hi): st[tt][r] is key  t*64 + 32tt + 16(r>>3) + 8hi + (r&7)
-    if (t >= nfull) {  // ragged last tile (wave-uniform branch)
+    if (!SPARSE && t >= nfull) {  // ragged last tile (wave-uniform branch)
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -183,8 +211,22 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     }
     l_run += ls;
     }
-    if (t + 1 < T) store_tile(buf ^ 1);
+    if (e + 1 < T) store_tile(buf ^ 1);
     __syncthreads();
+  }
+  if (!SPARSE && (p.flags & 2)) {   // leave the running state for a later launch; no output yet
+    if (q0 + l31 < p.q_len) {
+      float* st_o = state_o(); float* st_ml = state_ml();
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const f32x4 v = {ot[d][4 * rg], ot[d][4 * rg + 1], ot[d][4 * rg + 2], ot[d][4 * rg + 3]};
+          *reinterpret_cast<f32x4*>(st_o + 32 * d + 8 * rg) = v;
+        }
+      st_ml[0] = m_run; st_ml[1] = l_run;
+    }
+    return;
   }
 
   // ---- epilogue: normalise, store O[q][h*64 + d] ----
@@ -213,9 +255,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
 // score_bound > 0: caller guarantees |q.k| <= score_bound for every pair (e.g. RMS-normalised q, k:
 // 64 * max|w_q| * max|w_k|).  If the bound is small enough that exp2 can neither overflow nor flush a
 // whole row to zero, the kernel uses it as a fixed softmax offset and skips the online running max.
-int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
-                                     int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
-                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream) {
+size_t k5_attention_state_bytes(int H, int q_len) { return (size_t)q_len * H * (64 + 4) * sizeof(float); }
+
+int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+                                   int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
+                                   int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
+                                   int tile_skip_n, float* state, int flags, hipStream_t stream) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -230,6 +275,12 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
   // exponent range used: [-2*bound*c, 0]; fp32 exp2 flushes below -126 -> require 2*bound*c <= 96
   const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
   p.sp_list = nullptr; p.sp_cnt = nullptr; p.sp_stride = 0;
+  const int total_tiles = (kv_len + KB - 1) / KB;
+  if (tile_cnt < 0) tile_cnt = total_tiles - tile_off0;
+  if (tile_off0 < 0 || tile_skip_n < 0 || tile_off0 + tile_cnt + (tile_skip_at < total_tiles ? tile_skip_n : 0) > total_tiles) return K5_ERR_ARG;
+  if ((flags & 3) && !state) return K5_ERR_ARG;
+  p.tile_off0 = tile_off0; p.tile_cnt = tile_cnt; p.tile_skip_at = tile_skip_at; p.tile_skip_n = tile_skip_n;
+  p.state = state; p.flags = flags;
   if (bounded) {
     p.m_fixed = score_bound;
     hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, block, 0, stream, p);
@@ -237,6 +288,13 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
     hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, block, 0, stream, p);
   }
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
+int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+                                     int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
+                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream) {
+  return k5_launch_attention_bf16_range(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, score_bound, vt_chunk_keys,
+                                        vt_chunk_stride, 0, -1, 0x7fffffff, 0, nullptr, 0, stream);
 }
 
 // NABLA block-sparse attention (flex_attention(q,k,v,block_mask) nn.py:257-280): `list`/`cnt` are the per-workgroup
@@ -253,6 +311,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   p.c = 0.125f * 1.44269504088896340736f;
   p.m_fixed = 0.f; p.vt_chunk_keys = 0; p.vt_chunk_stride = 0;
   p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride;
+  p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;
   const dim3 grid(H * p.nqb), block(512);
   const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
   if (bounded) {

@@ -175,7 +175,9 @@ struct k5_dit {
   // tokens; K and V^T of every block are all-gathered in place into ws_kfull [N][D] / ws_vtfull [P][D][n_loc]
   Comm comm;
   int sp_rank = 0, sp_world = 1;
-  DevBuf ws_q, ws_kfull, ws_vtfull;
+  DevBuf ws_q, ws_kfull, ws_vtfull, ws_attn_state;
+  hipStream_t comm_stream = nullptr;              // all-gathers run here, overlapped with pass 1 of the attention
+  hipEvent_t ev_k = nullptr, ev_v = nullptr, ev_gathered = nullptr;
   // NABLA: fractal token permutation (cached per shape) and the selection workspace
   DevBuf ws_perm, ws_nabla; int perm_shape[3] = {0, 0, 0}; bool key_fractal = false;
   // rope cache keys
@@ -369,23 +371,49 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   {
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(h, wk, a.bqk.as<float>() + D, kloc, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
-    K5CHK(k5_launch_gemm_bf16(a.wv.p, h, a.bv.as<float>(), vtloc, D, rows, D, D, D, ldv, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
-    K5CHK(k5_launch_gemm_bf16(h, wq, a.bqk.as<float>(), q, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   }
   {
     Scope sc(d, s, "elementwise");
     K5CHK(k5_launch_rmsnorm_rope(kloc, a.norm.as<float>() + 64, cosT, sinT, rows, H, D, nullptr, s));
+  }
+  HIPCHK(hipEventRecord(d->ev_k, s));
+  {
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_bf16(a.wv.p, h, a.bv.as<float>(), vtloc, D, rows, D, D, D, ldv, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+  }
+  HIPCHK(hipEventRecord(d->ev_v, s));
+  {
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_bf16(h, wq, a.bqk.as<float>(), q, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+  }
+  {
+    Scope sc(d, s, "elementwise");
     K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), cosT, sinT, rows, H, D, nullptr, s));
   }
+  // all-gathers on the side stream (they only need k / v^T, which are complete at ev_k / ev_v) ...
+  hipStream_t cs = d->comm_stream;
+  HIPCHK(hipStreamWaitEvent(cs, d->ev_k, 0));
   {
-    Scope sc(d, s, "comm");
-    K5CHK(d->comm.all_gather_inplace(kfull, (size_t)rows * D, 2, s));
-    K5CHK(d->comm.all_gather_inplace(vtfull, (size_t)D * ldv, 2, s));
+    Scope sc(d, cs, "comm");
+    K5CHK(d->comm.all_gather_inplace(kfull, (size_t)rows * D, 2, cs));
+    HIPCHK(hipStreamWaitEvent(cs, d->ev_v, 0));
+    K5CHK(d->comm.all_gather_inplace(vtfull, (size_t)D * ldv, 2, cs));
   }
+  HIPCHK(hipEventRecord(d->ev_gathered, cs));
+  // ... while the main stream attends the local query rows to the LOCAL key chunk (pass 1, leaves the fp32 state),
+  // then, once every chunk has arrived, to all the other chunks (pass 2, resumes the state and normalises).
+  const int tpc = rows / 64, total = N / 64;
+  K5CHK(d->ws_attn_state.ensure(k5_attention_state_bytes(H, rows)));
   {
     Scope sc(d, s, "attn_self");
-    K5CHK(k5_launch_attention_bf16_chunked(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows,
-                                           (long long)D * ldv, s));
+    K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
+                                         r * tpc, tpc, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s));
+  }
+  HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
+  {
+    Scope sc(d, s, "attn_self");
+    K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
+                                         0, total - tpc, r * tpc, tpc, d->ws_attn_state.as<float>(), 1, s));
   }
   {
     Scope sc(d, s, "gemm");
@@ -484,7 +512,9 @@ int prepare_text_rope(k5_dit* d, hipStream_t s, const k5_text_cond& c, const flo
   if (d->text_rope.size() >= 8) {
     HIPCHK(hipStreamSynchronize(s));
     for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_perm.release(); d->ws_nabla.release();
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release();
+  if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
+  for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
     d->text_rope.clear();
   }
@@ -664,7 +694,9 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
                    &d->ws_vel_u};
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_perm.release(); d->ws_nabla.release();
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release();
+  if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
+  for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
   auto rel_attn = [](AttnW& a) {
     DevBuf* bs[] = {&a.wqk, &a.wq, &a.wk, &a.wv, &a.wo, &a.bqk, &a.bq, &a.bk, &a.bv, &a.bo, &a.norm};
@@ -842,6 +874,10 @@ extern "C" int k5_dit_comm_init(k5_dit* d, const char* rccl_lib_path, int rank, 
   if (r != ncclSuccess) { k5_set_error("ncclCommInitRank: %s", d->comm.GetErrorString(r)); return K5_ERR_HIP; }
   d->comm.rank = rank; d->comm.world = world;
   d->sp_rank = rank; d->sp_world = world;
+  HIPCHK(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&d->ev_k, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&d->ev_v, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&d->ev_gathered, hipEventDisableTiming));
   return K5_OK;
 }
 

@@ -26,6 +26,16 @@ int k5_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int
              "k5_attention_bf16");
 }
 
+int64_t k5_attention_state_size(int H, int q_len) { return (int64_t)k5_attention_state_bytes(H, q_len); }
+
+int k5_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                            int ldk, int ldvt, int ldo, float score_bound, int tile_off0, int tile_cnt, int tile_skip_at,
+                            int tile_skip_n, void* state, int flags, void* stream) {
+  return ret(k5_launch_attention_bf16_range(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, score_bound, 0, 0, tile_off0,
+                                            tile_cnt, tile_skip_at, tile_skip_n, (float*)state, flags, (hipStream_t)stream),
+             "k5_attention_bf16_range");
+}
+
 int64_t k5_nabla_workspace_size(int H, int num_blocks) { return (int64_t)k5_nabla_workspace_bytes(H, num_blocks); }
 
 int k5_nabla_select_bf16(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,

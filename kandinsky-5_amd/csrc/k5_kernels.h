@@ -22,6 +22,14 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
                                      int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                      int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream);
 
+// General form: process key tiles  e -> e + tile_off0 (+ tile_skip_n once >= tile_skip_at), e < tile_cnt (-1 = to the end);
+// flags & 1: resume from `state`, flags & 2: write `state` instead of O (k5_attention_state_bytes floats-as-bytes).
+size_t k5_attention_state_bytes(int H, int q_len);
+int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
+                                   int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
+                                   int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
+                                   int tile_skip_n, float* state, int flags, hipStream_t stream);
+
 // ---- NABLA (block-sparse) ----
 size_t k5_nabla_workspace_bytes(int H, int nb);
 int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,

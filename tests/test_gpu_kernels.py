@@ -270,3 +270,30 @@ def test_attention_bounded_scores_equals_online_max(E):
     # a bound too large for a fixed offset silently falls back to the online-max kernel (still correct)
     c = E.attention(qd, kd, vt, H, kv_len=S, score_bound=1e4)
     assert torch.equal(c, b)
+
+
+@pytest.mark.parametrize("Sq,Sk,split,bound", [(300, 640, 3, None), (300, 640, 3, 64 * 1.05), (257, 1000, 9, None), (64, 200, 1, 64 * 1.05)])
+def test_attention_split_key_passes_equal_single_pass(E, Sq, Sk, split, bound):
+    """Sequence-parallel overlap building block: pass 1 over key tiles [split, split+n) leaving the fp32 state, pass 2 over
+    all the other tiles resuming it == one pass over all keys (up to fp32 summation order)."""
+    H = 2
+    def rmsn(x):
+        return bfr(x / x.pow(2).mean(-1, keepdim=True).sqrt())
+    q, k, v = rmsn(rnd(Sq, H, 64, seed=1)), rmsn(rnd(Sk, H, 64, seed=2)), bfr(rnd(Sk, H, 64, seed=3))
+    ld = (Sk + 7) // 8 * 8
+    vt = torch.zeros(H * 64, ld, dtype=BF, device="cuda")
+    vt[:, :Sk] = v.reshape(Sk, H * 64).t().to(BF)
+    qd, kd = q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF)
+    one = E.attention(qd, kd, vt, H, kv_len=Sk, score_bound=bound)
+    total = (Sk + 63) // 64
+    n1 = max(1, total // 3)
+    state = torch.zeros(E.lib().k5_attention_state_size(H, Sq), dtype=torch.uint8, device="cuda")
+    out = torch.full((Sq, H * 64), float("nan"), dtype=BF, device="cuda")
+    sb = 0.0 if bound is None else bound
+    args = (qd.data_ptr(), kd.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk, qd.stride(0), kd.stride(0), vt.stride(0),
+            out.stride(0), sb)
+    E.check(E.lib().k5_attention_bf16_range(*args, split, n1, 0x7fffffff, 0, state.data_ptr(), 2, E.stream_ptr()))
+    assert torch.isnan(out.float()).all()                       # pass 1 writes only the state
+    E.check(E.lib().k5_attention_bf16_range(*args, 0, total - n1, split, n1, state.data_ptr(), 1, E.stream_ptr()))
+    assert_bf16_close(out, one.float().cpu(), ulps=2, atol=2e-3, what="two-pass attention")
+    assert_bf16_close(out, attn_ref(q, k, v), ulps=4, atol=1e-2, what="two-pass attention vs oracle")
