@@ -26,6 +26,7 @@
 // TWO workgroups (4 waves/SIMD) are resident per CU raised issue-port utilisation from 66 % to 85 %.
 // What is left is the VALU op count per score; BOUNDED=true drops the online running max (24 ops
 // per tile + the rescale branch) when the caller proves |score| <= bound (RMS-normalised q, k).
+#include <type_traits>
 #include "k5_common.h"
 #include "k5_kernels.h"
 
@@ -52,7 +53,9 @@ struct AttnP {
   float* state; int flags;
 };
 
-template <bool BOUNDED, bool SPARSE>
+// RANGE: key-tile sub-range + resumable fp32 state (sequence-parallel two-pass schedule); kept out of the plain dense
+// instantiation, whose loop is sensitive to every extra live value (128-VGPR budget for 2 workgroups per CU).
+template <bool BOUNDED, bool SPARSE, bool RANGE>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
   char* sK = smem;
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   const int nfull = p.kv_len / KB;                    // key tiles with all 64 keys valid (NABLA: all of them)
   auto tile_of = [&](int e) -> int {                  // sequence position -> 64-key tile index (wave-uniform)
     if (SPARSE) return sp_list[e] & 0xffffff;
+    if (!RANGE) return e;
     int t = e + p.tile_off0;
     if (t >= p.tile_skip_at) t += p.tile_skip_n;
     return t;
@@ -88,13 +92,13 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   const int tiles_per_chunk = p.vt_chunk_keys > 0 ? p.vt_chunk_keys / KB : 0x7fffffff;
   auto load_tile = [&](int e) {   // e = position in the tile sequence; t = 64-key tile index
     const int t = tile_of(e);
-    rk = *reinterpret_cast<const u32x4*>(kbase + (size_t)min(t * KB + lrow, p.kv_len - 1) * p.ldk);
     const int kv0 = t * KB;
     const bf16_t* vsrc = vbase + kv0;
     if (!SPARSE && p.vt_chunk_keys > 0) {   // sequence-parallel V^T layout only (uniform branch): per-rank chunks
       const int chunk = t / tiles_per_chunk;
       vsrc = vbase + (long long)chunk * p.vt_chunk_stride + (kv0 - chunk * tiles_per_chunk * KB);
     }
+    rk = *reinterpret_cast<const u32x4*>(kbase + (size_t)min(kv0 + lrow, p.kv_len - 1) * p.ldk);
     if (SPARSE || t < nfull) {
       rv = *reinterpret_cast<const u32x4*>(vsrc);
     } else {  // ragged last tile: never read past kv_len; zero-fill V^T (P is exactly 0 there)
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
   auto state_o = [&]() { return p.state + (size_t)(q0 + l31) * (p.H * 64) + h * 64 + 4 * hi; };
   auto state_ml = [&]() { return p.state + (size_t)p.q_len * (p.H * 64) + (((size_t)(q0 + l31) * p.H + h) * 2 + hi) * 2; };
-  if (!SPARSE && (p.flags & 1) && q0 + l31 < p.q_len) {   // resume: accumulators of an earlier launch over other key tiles
+  if (RANGE && (p.flags & 1) && q0 + l31 < p.q_len) {   // resume: accumulators of an earlier launch over other key tiles
     const float* st_o = state_o(); const float* st_ml = state_ml();
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -141,8 +145,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
 
   if (T > 0) { load_tile(0); store_tile(0); }
   __syncthreads();
-  for (int e = 0; e < T; ++e) {
-    const int buf = e & 1;
+  // one key tile; BUF (LDS double-buffer half) is a compile-time constant so that every ds_read address is
+  // lane_base + immediate (the loop below is unrolled by two): no per-tile address arithmetic on the VALU
+  auto tile_step = [&](auto BUFC, int e) {
+    constexpr int buf = decltype(BUFC)::value;
     if (e + 1 < T) load_tile(e + 1);
     const int t = tile_of(e);
     const char* cK = sK + buf * TILE;
@@ -213,8 +219,13 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     }
     if (e + 1 < T) store_tile(buf ^ 1);
     __syncthreads();
+  };
+  for (int e = 0; e < T; e += 2) {
+    tile_step(std::integral_constant<int, 0>{}, e);
+    if (e + 1 >= T) break;
+    tile_step(std::integral_constant<int, 1>{}, e + 1);
   }
-  if (!SPARSE && (p.flags & 2)) {   // leave the running state for a later launch; no output yet
+  if (RANGE && (p.flags & 2)) {   // leave the running state for a later launch; no output yet
     if (q0 + l31 < p.q_len) {
       float* st_o = state_o(); float* st_ml = state_ml();
 #pragma unroll
@@ -281,12 +292,12 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   if ((flags & 3) && !state) return K5_ERR_ARG;
   p.tile_off0 = tile_off0; p.tile_cnt = tile_cnt; p.tile_skip_at = tile_skip_at; p.tile_skip_n = tile_skip_n;
   p.state = state; p.flags = flags;
-  if (bounded) {
-    p.m_fixed = score_bound;
-    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, block, 0, stream, p);
-  } else {
-    hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, block, 0, stream, p);
-  }
+  const bool range = tile_off0 != 0 || tile_cnt != total_tiles || (flags & 3);
+  if (bounded) p.m_fixed = score_bound;
+  if (bounded && range) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), grid, block, 0, stream, p);
+  else if (bounded) hipLaunchKernelGGL((attn_fwd_kernel<true, false, false>), grid, block, 0, stream, p);
+  else if (range) hipLaunchKernelGGL((attn_fwd_kernel<false, false, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<false, false, false>), grid, block, 0, stream, p);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -316,9 +327,9 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
   if (bounded) {
     p.m_fixed = score_bound;
-    hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<true, true, false>), grid, block, 0, stream, p);
   } else {
-    hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<false, true, false>), grid, block, 0, stream, p);
   }
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
