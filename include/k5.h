@@ -215,6 +215,18 @@ int k5_vae_decode_tile(k5_vae* vae, const float* z, int T, int H, int W, void* o
  * b[:, y, :] = a[:, len_a-extent+y, :]*(1-y/extent) + b[:, y, :]*(y/extent), y < extent (eager bf16 rounding) */
 int k5_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, void* stream);
 
+/* MagCache — replaces `set_magcache_params` + `magcache_forward` (reference kandinsky/magcache_utils.py:16-101).
+ * `ratio_table` holds 2*num_steps float64 ratios (cond/uncond interleaved, already extended by the two leading 1.0 and
+ * nearest-interpolated as :29-39 does — the host mirror kandinsky/magcache_utils.py does that); table_len == 0
+ * disables.  Afterwards every k5_dit_forward / k5_sample forward runs the reference's decision: after the first
+ * `retention_ratio` of the calls, skip the visual blocks and re-apply the cached bf16 residual of the call's slot
+ * (call parity) while the accumulated |1 - prod ratio| < thresh for at most K consecutive calls.  no_cfg: the call
+ * counter advances by 2 (slot 0 only), :91-94.  Defaults of the reference: thresh 0.12, K 2, retention_ratio 0.2. */
+int k5_dit_set_magcache(k5_dit* dit, const double* ratio_table, int table_len, int no_cfg, double thresh, int K,
+                        double retention_ratio);
+/* introspection: current call counter and how many forwards ran / skipped the visual blocks since set_magcache */
+int k5_dit_magcache_state(k5_dit* dit, int* cnt, long long* n_ran, long long* n_skipped);
+
 /* per-kernel-family accumulated GPU time of the last forward(s), measured with hipEvents on the
  * engine's stream when profiling is enabled.  names: "attn_self","attn_cross","gemm","elementwise",...  */
 int k5_dit_set_profiling(k5_dit* dit, int enabled);

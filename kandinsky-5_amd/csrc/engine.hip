@@ -185,6 +185,20 @@ struct k5_dit {
   struct TextRope { std::vector<int32_t> key; DevBuf cosT, sinT, pos; };
   std::vector<TextRope> text_rope;  // small cache: cond / null-cond position vectors
 
+  // MagCache (reference kandinsky/magcache_utils.py:16-101): skip the visual blocks on some calls and re-apply the
+  // cached bf16 residual of the same cond / uncond slot.  Decisions depend on the ratio table and the call counter only.
+  struct MagCache {
+    bool on = false, no_cfg = false;
+    std::vector<double> table;                     // [2 * num_steps], already interpolated by the host mirror
+    double thresh = 0.12, retention = 0.2;
+    int K = 2, cnt = 0;
+    double acc_err[2] = {0, 0}, acc_ratio[2] = {1, 1};
+    int acc_steps[2] = {0, 0};
+    DevBuf residual[2]; size_t res_elems[2] = {0, 0};
+    DevBuf pm_one;                                 // fp32 [+1 x D | -1 x D]
+    long long n_ran = 0, n_skipped = 0;
+  } mag;
+
   // profiling
   bool profiling = false;
   std::map<std::string, Prof> prof;
@@ -623,8 +637,32 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     K5CHK(ln_mod(d, s, d->ws_text.p, m + 3 * D, d->ws_th.p, L));
     K5CHK(run_ff(d, s, b, d->ws_th.p, L, d->ws_tff.p, d->ws_text.p, m + 5 * D));
   }
+  // ---- MagCache decision (magcache_utils.py:59-76), float64 like the reference's numpy scalars ----
+  auto& mg = d->mag;
+  bool mag_skip = false;
+  const int slot = mg.cnt & 1;
+  const size_t vis_elems = (size_t)n * D;
+  if (mg.on) {
+    if (mg.cnt >= (int)((double)mg.table.size() * mg.retention)) {
+      mg.acc_ratio[slot] *= mg.table[mg.cnt];
+      mg.acc_steps[slot] += 1;
+      mg.acc_err[slot] += std::fabs(1.0 - mg.acc_ratio[slot]);
+      if (mg.acc_err[slot] < mg.thresh && mg.acc_steps[slot] <= mg.K) mag_skip = true;
+      else { mg.acc_err[slot] = 0; mg.acc_steps[slot] = 0; mg.acc_ratio[slot] = 1.0; }
+    }
+    if (mag_skip) {
+      if (mg.res_elems[slot] != vis_elems) { k5_set_error("magcache: skip decided but no cached residual of this shape for the slot"); return K5_ERR_ARG; }
+      Scope sc(d, s, "elementwise");   // visual_embed + residual (bf16 add), :78-79
+      K5CHK(k5_launch_gate_sum(d->ws_vis.p, mg.residual[slot].p, mg.pm_one.as<float>(), d->ws_vis.p, n, D, s));
+      mg.n_skipped++;
+    } else {
+      K5CHK(mg.residual[slot].ensure(vis_elems * 2));
+      HIPCHK(hipMemcpyAsync(mg.residual[slot].p, d->ws_vis.p, vis_elems * 2, hipMemcpyDeviceToDevice, s));  // ori_visual_embed
+      mg.n_ran++;
+    }
+  }
   // ---- visual blocks (dit.py:176-178, 61-79) ----
-  for (int i = 0; i < c.num_visual_blocks; ++i) {
+  for (int i = 0; i < (mag_skip ? 0 : c.num_visual_blocks); ++i) {
     const BlockW& b = d->vblocks[i];
     const float* m = mod + b.mod_off;
     const float* vcos = d->ws_vcos.as<float>() + (size_t)tok0 * 32;
@@ -641,6 +679,18 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
                               d->ws_o.p, d->ws_vis.p, m + 5 * D));
     K5CHK(ln_mod(d, s, d->ws_vis.p, m + 6 * D, d->ws_h.p, n));
     K5CHK(run_ff(d, s, b, d->ws_h.p, n, d->ws_ff.p, d->ws_vis.p, m + 8 * D));
+  }
+  if (mg.on) {
+    if (!mag_skip) {  // residual = visual_embed - ori_visual_embed (bf16), :84
+      Scope sc(d, s, "elementwise");
+      K5CHK(k5_launch_gate_sum(d->ws_vis.p, mg.residual[slot].p, mg.pm_one.as<float>() + D, mg.residual[slot].p, n, D, s));
+      mg.res_elems[slot] = vis_elems;
+    }
+    mg.cnt += mg.no_cfg ? 2 : 1;   // :91-100
+    if (mg.cnt >= (int)mg.table.size()) {
+      mg.cnt = 0;
+      for (int j = 0; j < 2; ++j) { mg.acc_ratio[j] = 1.0; mg.acc_err[j] = 0; mg.acc_steps[j] = 0; }
+    }
   }
   // ---- after_blocks / OutLayer (dit.py:149-153, nn.py:374-400) ----
   {
@@ -814,6 +864,32 @@ extern "C" int k5_dit_finalize(k5_dit* d) {
   K5CHK(upload_f32(d->mod_b, mb.data(), mb.size()));
   d->staged.clear();
   d->finalized = true;
+  return K5_OK;
+}
+
+extern "C" int k5_dit_set_magcache(k5_dit* d, const double* ratio_table, int table_len, int no_cfg, double thresh, int K,
+                                   double retention_ratio) {
+  if (!d || !d->finalized) { k5_set_error("k5_dit_set_magcache: handle not finalized"); return K5_ERR_STATE; }
+  auto& mg = d->mag;
+  mg.cnt = 0; mg.n_ran = mg.n_skipped = 0;
+  for (int j = 0; j < 2; ++j) { mg.acc_ratio[j] = 1.0; mg.acc_err[j] = 0; mg.acc_steps[j] = 0; mg.res_elems[j] = 0; }
+  if (table_len <= 0) { mg.on = false; mg.table.clear(); return K5_OK; }
+  if (!ratio_table || (table_len & 1) || K < 0) { k5_set_error("k5_dit_set_magcache: table of 2*num_steps ratios expected"); return K5_ERR_ARG; }
+  mg.table.assign(ratio_table, ratio_table + table_len);
+  mg.no_cfg = no_cfg != 0; mg.thresh = thresh; mg.K = K; mg.retention = retention_ratio;
+  std::vector<float> pm(2 * (size_t)d->D);
+  for (int i = 0; i < d->D; ++i) { pm[i] = 1.f; pm[d->D + i] = -1.f; }
+  K5CHK(mg.pm_one.ensure(pm.size() * 4));
+  HIPCHK(hipMemcpy(mg.pm_one.p, pm.data(), pm.size() * 4, hipMemcpyHostToDevice));
+  mg.on = true;
+  return K5_OK;
+}
+
+extern "C" int k5_dit_magcache_state(k5_dit* d, int* cnt, long long* n_ran, long long* n_skipped) {
+  if (!d) { k5_set_error("k5_dit_magcache_state: null handle"); return K5_ERR_ARG; }
+  if (cnt) *cnt = d->mag.cnt;
+  if (n_ran) *n_ran = d->mag.n_ran;
+  if (n_skipped) *n_skipped = d->mag.n_skipped;
   return K5_OK;
 }
 

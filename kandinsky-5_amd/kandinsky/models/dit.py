@@ -127,6 +127,9 @@ class DiffusionTransformer3D(nn.Module):
                 self._load_one(h, name, t)
             E.check(E.lib().k5_dit_finalize(h), "k5_dit_finalize")
         self._handle, self._handle_device = h, device
+        if getattr(self, "mag_ratios", None) is not None:   # set_magcache_params() before the weights were loaded
+            from ..magcache_utils import _apply
+            _apply(self)
 
     def init_synthetic(self, device, seed=0, std=0.02):
         """Random-init weights of this architecture generated ON DEVICE tensor by tensor and handed straight

@@ -37,8 +37,6 @@ def get_T2V_pipeline(
     if world_size > 1:
         for k in ("dit", "vae", "text_embedder"):
             device_map[k] = torch.device(f"cuda:{local_rank}")
-    if magcache:
-        raise NotImplementedError("MagCache (reference magcache_utils.py) is a 'next' row (SURVEY.md §8f), not built yet")
 
     os.makedirs(cache_dir, exist_ok=True)
     if conf_path is None:
@@ -64,6 +62,10 @@ def get_T2V_pipeline(
 
     with torch.device("meta"):
         dit = get_dit(conf.model.dit_params)
+    if magcache:  # reference utils.py:107-113
+        from .magcache_utils import set_magcache_params
+        no_cfg = conf.model.guidance_weight == 1.0
+        set_magcache_params(dit, conf.magcache.mag_ratios, conf.model.num_steps, no_cfg)
     state_dict = load_file(conf.model.checkpoint_path)
     dit.load_state_dict(state_dict, assign=True)
     if not offload:

@@ -26,6 +26,7 @@ import math
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -407,10 +408,59 @@ def out_layer(sd, x, temb, cfg, mode):
     return _linear(h, sd["out_layer.out_layer.weight"].float(), sd["out_layer.out_layer.bias"].float(), mode)
 
 
+class MagCache:
+    """MagCache state machine (magcache_utils.py:16-39 `set_magcache_params`, :59-76,91-100 the decision inside
+    `magcache_forward`).  Decisions depend on the ratio table and the call counter only, never on the data: after the
+    first `retention_ratio` of the 2*num_steps calls, the 32 visual blocks are skipped (the cached residual of the same
+    cond/uncond slot is re-applied) while the accumulated |1 - prod(ratios)| stays below `thresh` for at most K
+    consecutive calls of that slot.  All scalar arithmetic is float64 (numpy in the reference)."""
+
+    def __init__(self, mag_ratios, num_steps: int, no_cfg: bool, thresh: float = 0.12, K: int = 2,
+                 retention_ratio: float = 0.2):
+        self.cnt = 0
+        self.num_steps = num_steps * 2
+        self.thresh, self.K, self.retention_ratio, self.no_cfg = thresh, K, retention_ratio, no_cfg
+        self.accumulated_err, self.accumulated_steps, self.accumulated_ratio = [0.0, 0.0], [0, 0], [1.0, 1.0]
+        self.residual_cache = [None, None]
+        r = np.array([1.0] * 2 + list(mag_ratios), dtype=np.float64)
+        if len(r) != num_steps * 2:  # nearest_interp magcache_utils.py:6-13 on the cond / uncond halves
+            r = np.stack([self._nearest(r[0::2], num_steps), self._nearest(r[1::2], num_steps)], axis=1).reshape(-1)
+        self.mag_ratios = r
+        self.ran_blocks = []  # test hook: 1 if the visual blocks ran in that call
+
+    @staticmethod
+    def _nearest(src, n):
+        if n == 1:
+            return np.array([src[-1]])
+        idx = np.round(np.arange(n) * ((len(src) - 1) / (n - 1))).astype(int)  # np.round: half to even
+        return src[idx]
+
+    def decide(self) -> bool:
+        """True = skip the visual blocks in this call (magcache_utils.py:62-76)."""
+        skip, s = False, self.cnt % 2
+        if self.cnt >= int(self.num_steps * self.retention_ratio):
+            self.accumulated_ratio[s] = self.accumulated_ratio[s] * self.mag_ratios[self.cnt]
+            self.accumulated_steps[s] += 1
+            self.accumulated_err[s] += np.abs(1 - self.accumulated_ratio[s])
+            if self.accumulated_err[s] < self.thresh and self.accumulated_steps[s] <= self.K:
+                skip = True
+            else:
+                self.accumulated_err[s], self.accumulated_steps[s], self.accumulated_ratio[s] = 0, 0, 1.0
+        return skip
+
+    def advance(self):
+        """magcache_utils.py:91-100."""
+        self.cnt += 2 if self.no_cfg else 1
+        if self.cnt >= self.num_steps:
+            self.cnt = 0
+            self.accumulated_ratio, self.accumulated_err, self.accumulated_steps = [1.0, 1.0], [0.0, 0.0], [0, 0]
+
+
 def dit_forward(sd, cfg: DitConfig, x, text_embed, pooled_text_embed, time, visual_rope_pos,
                 text_rope_pos, scale_factor=(1.0, 1.0, 1.0), sparse_params=None, mode="fp32",
-                taps: Optional[dict] = None, num_visual_blocks: Optional[int] = None) -> Tensor:
-    """DiffusionTransformer3D.forward dit.py:155-181.
+                taps: Optional[dict] = None, num_visual_blocks: Optional[int] = None,
+                magcache: Optional["MagCache"] = None) -> Tensor:
+    """DiffusionTransformer3D.forward dit.py:155-181 (with `magcache`: magcache_utils.py:42-101).
     x (T,H,W,Cin) fp32; text_embed (L,in_text_dim); pooled (1,in_text_dim2); time (1,) = 1000*sigma.
     Returns velocity (T,H,W,out_visual_dim) (bf16-valued in bf16 mode)."""
     with torch.no_grad():
@@ -439,11 +489,22 @@ def dit_forward(sd, cfg: DitConfig, x, text_embed, pooled_text_embed, time, visu
             perm = fractal_perm((Tp, Hp, Wp))
             vis, vcos, vsin = vis[perm], vcos[perm], vsin[perm]
         nvb = cfg.num_visual_blocks if num_visual_blocks is None else num_visual_blocks
-        for i in range(nvb):
-            vis = decoder_block(sd, f"visual_transformer_blocks.{i}", vis, text, temb, vcos, vsin,
-                                cfg, mode, sparse_params, taps)
-            if taps is not None:
-                taps.setdefault("visual_blocks", []).append(vis)
+        skip = magcache.decide() if magcache is not None else False
+        if skip:  # magcache_utils.py:78-79: bf16 add of the cached residual of this slot
+            residual = magcache.residual_cache[magcache.cnt % 2]
+            vis = _r(vis + residual, mode)
+        else:
+            ori = vis
+            for i in range(nvb):
+                vis = decoder_block(sd, f"visual_transformer_blocks.{i}", vis, text, temb, vcos, vsin,
+                                    cfg, mode, sparse_params, taps)
+                if taps is not None:
+                    taps.setdefault("visual_blocks", []).append(vis)
+            residual = _r(vis - ori, mode) if magcache is not None else None
+        if magcache is not None:  # :86-100
+            magcache.residual_cache[magcache.cnt % 2] = residual
+            magcache.ran_blocks.append(0 if skip else 1)
+            magcache.advance()
         # after_blocks dit.py:149-153
         if to_fractal:
             inv = torch.empty_like(perm)
@@ -472,21 +533,21 @@ def get_sparse_params(attention: dict, latent_shape, patch_size):
 
 
 def get_velocity(sd, cfg, x, t, text_embeds, null_text_embeds, vpos, tpos, ntpos, guidance_weight,
-                 scale_factor, sparse_params, mode):
+                 scale_factor, sparse_params, mode, magcache=None):
     """generation_utils.py:39-77.  CFG combine on bf16 tensors in eager torch: each of
     (c-u), w*(.), u+(.) rounds to bf16."""
     v = dit_forward(sd, cfg, x, text_embeds["text_embeds"], text_embeds["pooled_embed"], t * 1000,
-                    vpos, tpos, scale_factor, sparse_params, mode)
+                    vpos, tpos, scale_factor, sparse_params, mode, magcache=magcache)
     if abs(guidance_weight - 1.0) > 1e-6:
         u = dit_forward(sd, cfg, x, null_text_embeds["text_embeds"], null_text_embeds["pooled_embed"],
-                        t * 1000, vpos, ntpos, scale_factor, sparse_params, mode)
+                        t * 1000, vpos, ntpos, scale_factor, sparse_params, mode, magcache=magcache)
         v = _r(u + _r(guidance_weight * _r(v - u, mode), mode), mode)
     return v
 
 
 def generate(sd, cfg, noise, num_steps, text_embeds, null_text_embeds, vpos, tpos, ntpos,
              guidance_weight, scheduler_scale, scale_factor=(1.0, 2.0, 2.0), attention=None,
-             mode="fp32", return_trajectory=False):
+             mode="fp32", return_trajectory=False, magcache=None):
     """generate generation_utils.py:80-129 with the initial noise passed in explicitly
     (the reference draws it from torch.Generator("cuda"), :97-99 — not reproducible off-CUDA).
     In bf16 mode `timestep_diff * pred_velocity` is (0-dim fp32 tensor) x (bf16 tensor) = bf16
@@ -503,7 +564,7 @@ def generate(sd, cfg, noise, num_steps, text_embeds, null_text_embeds, vpos, tpo
         else:
             x = img
         v = get_velocity(sd, cfg, x, t, text_embeds, null_text_embeds, vpos, tpos, ntpos,
-                         guidance_weight, scale_factor, sparse, mode)
+                         guidance_weight, scale_factor, sparse, mode, magcache=magcache)
         img = img + _r(dt * v, mode)
         if return_trajectory:
             traj.append(img.clone())

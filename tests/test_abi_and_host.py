@@ -7,6 +7,7 @@ import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -118,3 +119,19 @@ def test_sigma_schedule_host():
     for n, s in ((4, 5.0), (50, 5.0), (100, 10.0)):
         assert torch.equal(sigma_schedule(n, s), O.sigma_schedule(n, s))
     assert torch.allclose(sigma_schedule(4, 5.0), torch.tensor([1, .9375, .8333333, .625, 0]), atol=1e-6)
+
+
+def test_magcache_ratio_table_matches_reference_goldens():
+    """Host mirror of set_magcache_params' table preparation (reference magcache_utils.py:6-13,28-39) against the tables
+    the reference derived (tests/golden/magcache_tiny.safetensors, made by oracle/gen_golden_magcache.py)."""
+    import json
+    from safetensors.torch import load_file
+    from kandinsky.magcache_utils import ratio_table, nearest_interp
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    T = load_file(os.path.join(here, "magcache_tiny.safetensors"))
+    for c in json.load(open(os.path.join(here, "magcache_meta.json")))["cases"]:
+        t = ratio_table(c["ratios"], c["num_steps"])
+        assert t.dtype == np.float64 and len(t) == 2 * c["num_steps"]
+        assert np.array_equal(t, T[f"mag.{c['tag']}.table"].numpy()), c["tag"]
+    assert np.array_equal(nearest_interp(np.arange(5.0), 1), np.array([4.0]))
+    assert np.array_equal(nearest_interp(np.arange(5.0), 3), np.array([0.0, 2.0, 4.0]))

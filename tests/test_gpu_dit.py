@@ -129,3 +129,43 @@ def test_full_width_two_blocks_vs_oracle():
     assert rel(out, ref) <= 1.5e-2, rel(out, ref)
     ref32 = O.dit_forward(sd, cfg, xin, text, pooled, t, pos, torch.arange(37), (1.0, 2.0, 2.0), None, "fp32")
     assert rel(out, ref32) <= 3e-2, rel(out, ref32)
+
+
+# ------------------------------------------------------------------------------------------ MagCache
+@pytest.mark.parametrize("tag", ["sft_12", "nocfg_9", "hand_10"])
+def test_magcache_generate(tiny_dit, tiny_sd, cfg, golden, tag):
+    """`set_magcache_params` + generate: the engine's skip pattern is the reference's, the final latent matches the
+    bf16-island oracle running the same state machine and the reference's own fp32 result."""
+    import json
+    import os
+    from types import SimpleNamespace as NS
+    from safetensors.torch import load_file
+    from kandinsky.generation_utils import generate
+    from kandinsky.magcache_utils import set_magcache_params, disable_magcache, magcache_state
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    T = load_file(os.path.join(here, "magcache_tiny.safetensors"))
+    c = [c for c in json.load(open(os.path.join(here, "magcache_meta.json")))["cases"] if c["tag"] == tag][0]
+    conf = NS(model=NS(dit_params=NS(patch_size=(1, 2, 2)), attention=NS(type="flash")),
+              metrics=NS(scale_factor=(1.0, 2.0, 2.0)))
+    te = {"text_embeds": golden["fwd.text"].cuda(), "pooled_embed": golden["fwd.pooled"].cuda()}
+    ne = {"text_embeds": golden["gen.null_text"].cuda(), "pooled_embed": golden["gen.null_pooled"].cuda()}
+    tiny_dit.engine("cuda:0")
+    try:
+        set_magcache_params(tiny_dit, c["ratios"], c["num_steps"], c["no_cfg"])
+        assert torch.equal(torch.from_numpy(tiny_dit.mag_ratios), T[f"mag.{tag}.table"])
+        out = generate(tiny_dit, "cuda:0", (3, 8, 12, 16), c["num_steps"], te, ne, POS, torch.arange(7), torch.arange(4),
+                       c["guidance_weight"], c["scheduler_scale"], conf, noise=golden["gen.noise"])
+        cnt, ran, skipped = magcache_state(tiny_dit)
+        assert (cnt, ran, skipped) == (0, sum(c["ran_blocks"]), len(c["ran_blocks"]) - sum(c["ran_blocks"]))
+    finally:
+        disable_magcache(tiny_dit)
+    mc = O.MagCache(c["ratios"], c["num_steps"], c["no_cfg"])
+    ref16 = O.generate(tiny_sd, O.DitConfig(**cfg), golden["gen.noise"], c["num_steps"], {k: v.cpu() for k, v in te.items()},
+                       {k: v.cpu() for k, v in ne.items()}, POS, torch.arange(7), torch.arange(4), c["guidance_weight"],
+                       c["scheduler_scale"], (1.0, 2.0, 2.0), None, "bf16", magcache=mc)
+    assert rel(out, ref16) <= 1e-2, rel(out, ref16)
+    assert rel(out, T[f"mag.{tag}.final"]) <= 3e-2, rel(out, T[f"mag.{tag}.final"])
+    # and it is a different result from the un-cached run (the cache is really applied)
+    plain = generate(tiny_dit, "cuda:0", (3, 8, 12, 16), c["num_steps"], te, ne, POS, torch.arange(7), torch.arange(4),
+                     c["guidance_weight"], c["scheduler_scale"], conf, noise=golden["gen.noise"])
+    assert rel(out, plain) > 1e-4

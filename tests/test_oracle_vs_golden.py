@@ -218,3 +218,41 @@ def test_bf16_mode_is_close_to_fp32(golden, tiny_sd, cfg):
     rel = (a - ref).norm() / ref.norm()
     assert rel < 2e-2, rel
     assert torch.equal(a, a.bfloat16().float())  # velocity is bf16-valued
+
+
+# ------------------------------------------------------------------------------------------ MagCache
+@pytest.fixture(scope="module")
+def mag_golden():
+    from safetensors.torch import load_file
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return load_file(os.path.join(here, "magcache_tiny.safetensors")), json.load(open(os.path.join(here, "magcache_meta.json")))
+
+
+def test_magcache_tables_and_skip_pattern_match_reference(mag_golden):
+    """Ratio interpolation (np.round half-to-even) and every skip / run decision of the reference's magcache_forward."""
+    T, meta = mag_golden
+    for c in meta["cases"]:
+        mc = O.MagCache(c["ratios"], c["num_steps"], c["no_cfg"])
+        assert np.array_equal(mc.mag_ratios, T[f"mag.{c['tag']}.table"].numpy()), c["tag"]
+        ran = []
+        for _ in c["ran_blocks"]:
+            ran.append(0 if mc.decide() else 1)
+            mc.advance()
+        assert ran == c["ran_blocks"], c["tag"]
+        assert mc.cnt == 0
+        assert 0 < sum(ran) < len(ran)
+
+
+@pytest.mark.parametrize("tag", ["sft_12", "nocfg_9", "hand_10", "sft_50"])
+def test_magcache_generate_matches_reference(mag_golden, golden, tiny_sd, cfg, tag):
+    T, meta = mag_golden
+    c = [c for c in meta["cases"] if c["tag"] == tag][0]
+    te = {"text_embeds": golden["fwd.text"], "pooled_embed": golden["fwd.pooled"]}
+    ne = {"text_embeds": golden["gen.null_text"], "pooled_embed": golden["gen.null_pooled"]}
+    pos = [torch.arange(3), torch.arange(4), torch.arange(6)]
+    mc = O.MagCache(c["ratios"], c["num_steps"], c["no_cfg"])
+    final = O.generate(tiny_sd, cfg, golden["gen.noise"], c["num_steps"], te, ne, pos, torch.arange(7), torch.arange(4),
+                       c["guidance_weight"], c["scheduler_scale"], magcache=mc)
+    assert mc.ran_blocks == c["ran_blocks"]
+    close(final, T[f"mag.{tag}.final"], atol=5e-4, rtol=5e-4)
