@@ -224,6 +224,10 @@ int k5_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, i
  * counter advances by 2 (slot 0 only), :91-94.  Defaults of the reference: thresh 0.12, K 2, retention_ratio 0.2. */
 int k5_dit_set_magcache(k5_dit* dit, const double* ratio_table, int table_len, int no_cfg, double thresh, int K,
                         double retention_ratio);
+/* Which calls of the reference's call sequence (cond, uncond, cond, ...) this handle executes: call indices
+ * first_call, first_call + stride, ...  set_magcache installs (0, 1), or (0, 2) with no_cfg.  CFG-parallel rank groups
+ *  run one branch each: conditional group (0, 2), unconditional group (1, 2). */
+int k5_dit_magcache_calls(k5_dit* dit, int first_call, int stride);
 /* introspection: current call counter and how many forwards ran / skipped the visual blocks since set_magcache */
 int k5_dit_magcache_state(k5_dit* dit, int* cnt, long long* n_ran, long long* n_skipped);
 

@@ -192,6 +192,7 @@ struct k5_dit {
     std::vector<double> table;                     // [2 * num_steps], already interpolated by the host mirror
     double thresh = 0.12, retention = 0.2;
     int K = 2, cnt = 0;
+    int first = 0, stride = 1;                     // which calls of the reference's sequence this handle sees
     double acc_err[2] = {0, 0}, acc_ratio[2] = {1, 1};
     int acc_steps[2] = {0, 0};
     DevBuf residual[2]; size_t res_elems[2] = {0, 0};
@@ -686,9 +687,9 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
       K5CHK(k5_launch_gate_sum(d->ws_vis.p, mg.residual[slot].p, mg.pm_one.as<float>() + D, mg.residual[slot].p, n, D, s));
       mg.res_elems[slot] = vis_elems;
     }
-    mg.cnt += mg.no_cfg ? 2 : 1;   // :91-100
+    mg.cnt += mg.stride;   // :91-100
     if (mg.cnt >= (int)mg.table.size()) {
-      mg.cnt = 0;
+      mg.cnt = mg.first;
       for (int j = 0; j < 2; ++j) { mg.acc_ratio[j] = 1.0; mg.acc_err[j] = 0; mg.acc_steps[j] = 0; }
     }
   }
@@ -877,11 +878,19 @@ extern "C" int k5_dit_set_magcache(k5_dit* d, const double* ratio_table, int tab
   if (!ratio_table || (table_len & 1) || K < 0) { k5_set_error("k5_dit_set_magcache: table of 2*num_steps ratios expected"); return K5_ERR_ARG; }
   mg.table.assign(ratio_table, ratio_table + table_len);
   mg.no_cfg = no_cfg != 0; mg.thresh = thresh; mg.K = K; mg.retention = retention_ratio;
+  mg.first = 0; mg.stride = mg.no_cfg ? 2 : 1;
   std::vector<float> pm(2 * (size_t)d->D);
   for (int i = 0; i < d->D; ++i) { pm[i] = 1.f; pm[d->D + i] = -1.f; }
   K5CHK(mg.pm_one.ensure(pm.size() * 4));
   HIPCHK(hipMemcpy(mg.pm_one.p, pm.data(), pm.size() * 4, hipMemcpyHostToDevice));
   mg.on = true;
+  return K5_OK;
+}
+
+extern "C" int k5_dit_magcache_calls(k5_dit* d, int first_call, int stride) {
+  if (!d || !d->mag.on) { k5_set_error("k5_dit_magcache_calls: MagCache is not enabled on this handle"); return K5_ERR_STATE; }
+  if (first_call < 0 || stride < 1 || first_call >= stride) { k5_set_error("k5_dit_magcache_calls: need 0 <= first < stride"); return K5_ERR_ARG; }
+  d->mag.first = d->mag.cnt = first_call; d->mag.stride = stride;
   return K5_OK;
 }
 

@@ -82,6 +82,23 @@ def generate(model, device, shape, num_steps, text_embeds, null_text_embeds, vis
     timesteps = sigma_schedule(num_steps, scheduler_scale, device=device).cpu()  # one sync, before the loop
 
     from .models.dit import DiffusionTransformer3D
+    cfg_on = abs(guidance_weight - 1.0) > 1e-6
+    cfg_parallel = getattr(model, "_cfg_parallel", None)
+    if cfg_parallel is not None and cfg_on:
+        # CFG-parallel: this rank's group runs ONE of the two forwards; the pair exchanges the velocities
+        # (6 MB at 5 s) and every rank applies the identical bf16 combine + Euler update -> identical latents everywhere
+        from .models.parallelize import exchange_velocity
+        branch, pair_group = cfg_parallel
+        mine, mine_pos = (text_embeds, text_rope_pos) if branch == 0 else (null_text_embeds, null_text_rope_pos)
+        both = None
+        for timestep, timestep_diff in zip(timesteps[:-1].tolist(), torch.diff(timesteps).tolist()):
+            v = model(img, mine["text_embeds"], mine["pooled_embed"], torch.tensor([timestep]) * 1000, visual_rope_pos,
+                      mine_pos, scale_factor=conf.metrics.scale_factor, sparse_params=sparse_params)
+            if both is None:
+                both = torch.empty((2,) + tuple(v.shape), dtype=v.dtype, device=v.device)
+            vc, vu = exchange_velocity(v, pair_group, out=both)
+            E.cfg_euler_(img, vc, vu, guidance_weight, timestep_diff)
+        return img
     if type(model) is DiffusionTransformer3D and model.visual_cond in (True, False):
         # whole loop inside the engine: no per-step host work at all
         model.sample(img, timesteps.tolist(), text_embeds, null_text_embeds, visual_rope_pos, text_rope_pos,
@@ -89,7 +106,6 @@ def generate(model, device, shape, num_steps, text_embeds, null_text_embeds, vis
                      sparse_params=sparse_params)
         return img
 
-    cfg_on = abs(guidance_weight - 1.0) > 1e-6
     for timestep, timestep_diff in zip(timesteps[:-1].tolist(), torch.diff(timesteps).tolist()):
         if model.visual_cond:
             visual_cond = torch.zeros_like(img)

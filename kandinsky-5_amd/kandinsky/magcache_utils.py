@@ -43,6 +43,9 @@ def _apply(dit):
     t = dit.mag_ratios
     E.check(E.lib().k5_dit_set_magcache(dit._handle, t.ctypes.data_as(C.POINTER(C.c_double)), len(t), int(dit.no_cfg),
                                         float(dit.magcache_thresh), int(dit.K), float(dit.retention_ratio)), "set_magcache")
+    cfgp = getattr(dit, "_cfg_parallel", None)
+    if cfgp is not None and not dit.no_cfg:   # this rank group runs one CFG branch only: calls branch, branch+2, ...
+        E.check(E.lib().k5_dit_magcache_calls(dit._handle, int(cfgp[0]), 2), "magcache_calls")
 
 
 def set_magcache_params(dit, mag_ratios, num_steps, no_cfg):

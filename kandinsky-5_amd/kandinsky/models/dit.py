@@ -254,7 +254,7 @@ class DiffusionTransformer3D(nn.Module):
         return latent
 
     # ---------------------------------------------------------------- multi-GPU
-    def enable_sequence_parallel(self, rank, world, device=None):
+    def enable_sequence_parallel(self, rank, world, device=None, group=None, src=0):
         """Token-sharded sequence parallelism over RCCL (one process per GPU; replaces the reference's DTensor
         plan, kandinsky/models/parallelize.py).  Rank 0 creates the ncclUniqueId inside libk5, torch.distributed
         (already initialised by the launcher, kandinsky/utils.py:40-55 contract) only carries its 128 bytes."""
@@ -272,7 +272,7 @@ class DiffusionTransformer3D(nn.Module):
             payload = [uid.raw]
         if world > 1:
             import torch.distributed as dist
-            dist.broadcast_object_list(payload, src=0)
+            dist.broadcast_object_list(payload, src=src, group=group)   # src = global rank of the group's rank 0
         with torch.cuda.device(self._handle_device):
             E.check(E.lib().k5_dit_comm_init(self._handle, path, int(rank), int(world), payload[0]), "k5_dit_comm_init")
         self._sp = (rank, world)

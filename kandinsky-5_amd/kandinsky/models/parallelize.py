@@ -20,8 +20,71 @@ def token_shard(num_tokens: int, world: int, rank: int):
     return rank * n, n
 
 
-def parallelize_dit(model, rank: int, world: int, device=None):
-    """Drop-in for the reference's parallelize_dit(model, tp_mesh): enables sequence parallelism on the engine."""
-    if world > 1:
-        model.enable_sequence_parallel(rank, world, device=device)
+class ParallelLayout:
+    """Rank layout of one node.  Without CFG-parallel: one sequence-parallel group of `world` ranks.  With it
+    (SURVEY.md §8e "CFG-parallel"): two groups of world/2 ranks — ranks [0, world/2) run the conditional forward, ranks
+    [world/2, world) the unconditional one, each group sequence-parallel inside — and rank i of one group is paired with
+    rank i of the other for the single velocity exchange per step."""
+
+    def __init__(self, rank: int, world: int, cfg_parallel: bool = False):
+        if world < 1 or not 0 <= rank < world:
+            raise ValueError("bad rank/world")
+        if cfg_parallel and world % 2:
+            raise ValueError(f"CFG-parallel needs an even number of ranks, got {world}")
+        self.rank, self.world, self.cfg_parallel = rank, world, bool(cfg_parallel)
+        self.sp_world = world // 2 if cfg_parallel else world
+        self.branch = rank // self.sp_world if cfg_parallel else 0       # 0 = conditional, 1 = unconditional
+        self.sp_rank = rank % self.sp_world
+        self.sp_groups = [list(range(b * self.sp_world, (b + 1) * self.sp_world)) for b in range(2 if cfg_parallel else 1)]
+        self.pair_groups = [[i, i + self.sp_world] for i in range(self.sp_world)] if cfg_parallel else []
+
+    @property
+    def sp_ranks(self):
+        return self.sp_groups[self.branch]
+
+    @property
+    def pair_ranks(self):
+        return self.pair_groups[self.sp_rank] if self.cfg_parallel else [self.rank]
+
+
+def make_groups(layout: ParallelLayout):
+    """torch.distributed sub-groups of the layout.  Collective: every rank creates every group, in the same order."""
+    import torch.distributed as dist
+    sp = pair = None
+    for ranks in layout.sp_groups:
+        g = dist.new_group(ranks) if len(ranks) < layout.world or layout.cfg_parallel else None
+        if layout.rank in ranks:
+            sp = g
+    for ranks in layout.pair_groups:
+        g = dist.new_group(ranks)
+        if layout.rank in ranks:
+            pair = g
+    return sp, pair
+
+
+def exchange_velocity(v_mine, pair_group, out=None):
+    """CFG-parallel: one all-gather over the 2-rank pair -> (v_cond, v_uncond) (pair rank order = branch order)."""
+    import torch
+    import torch.distributed as dist
+    if out is None:
+        out = torch.empty((2,) + tuple(v_mine.shape), dtype=v_mine.dtype, device=v_mine.device)
+    # output passed as the dim-0 concatenation (the form every backend accepts)
+    dist.all_gather_into_tensor(out.view((2 * v_mine.shape[0],) + tuple(v_mine.shape[1:])), v_mine.contiguous(), group=pair_group)
+    return out[0], out[1]
+
+
+def parallelize_dit(model, rank: int, world: int, device=None, cfg_parallel: bool = False):
+    """Drop-in for the reference's parallelize_dit(model, tp_mesh): sequence parallelism inside the engine (RCCL), and
+    optionally the conditional / unconditional forwards of classifier-free guidance on two disjoint rank groups."""
+    if world <= 1:
+        return model
+    layout = ParallelLayout(rank, world, cfg_parallel)
+    sp_group, pair_group = make_groups(layout) if cfg_parallel else (None, None)
+    if layout.sp_world > 1:
+        model.enable_sequence_parallel(layout.sp_rank, layout.sp_world, device=device, group=sp_group, src=layout.sp_ranks[0])
+    model._layout = layout
+    model._cfg_parallel = (layout.branch, pair_group) if cfg_parallel else None
+    if getattr(model, "mag_ratios", None) is not None:   # MagCache slot bookkeeping depends on the branch
+        from ..magcache_utils import _apply
+        _apply(model)
     return model

@@ -240,14 +240,20 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         mh, mw = self.tile_sample_min_height // 8, self.tile_sample_min_width // 8
         mf, sf = self.tile_sample_min_num_frames // 4, self.tile_sample_stride_num_frames // 4
         bf = self.tile_sample_min_num_frames - self.tile_sample_stride_num_frames
-        row = []
-        for i in range(0, nf - mf + 1, sf):
+        starts = list(range(0, nf - mf + 1, sf))
+
+        def decode_one(i):
             tile = z[:, :, i:i + mf + 1]
             if self.use_tiling and (tile.shape[-1] > mw or tile.shape[-2] > mh):
-                d = self.tiled_decode(tile).sample
-            else:
-                d = self._decode_tile(tile)
-            row.append(d[:, :, 1:] if i > 0 else d)
+                return self.tiled_decode(tile).sample
+            return self._decode_tile(tile)
+
+        tp = getattr(self, "_tile_parallel", None)
+        if tp is not None and tp[1] > 1 and len(starts) > 1:
+            decoded = self._decode_tiles_distributed(starts, decode_one, *tp)
+        else:
+            decoded = [decode_one(i) for i in starts]
+        row = [d[:, :, 1:] if k > 0 else d for k, d in enumerate(decoded)]
         out = []
         for i, tile in enumerate(row):
             if i > 0:
@@ -258,6 +264,30 @@ class AutoencoderKLHunyuanVideo(nn.Module):
                 out.append(tile[:, :, :self.tile_sample_stride_num_frames + 1])
         dec = torch.cat(out, dim=2)[:, :, :(nf - 1) * 4 + 1]
         return DecoderOutput(dec) if return_dict else (dec,)
+
+    def enable_tile_parallel(self, rank, world, group=None):
+        """Temporal tiles are independent until blend_t: tile k is decoded by rank k % world, one
+        all-gather per round of `world` tiles hands every rank all decoded tiles (40 MB each at 512x768), the cheap
+        cross-fades are then replicated.  Collective: every rank must call decode() with the same latent."""
+        self._tile_parallel = (int(rank), int(world), group)
+        return self
+
+    @staticmethod
+    def _decode_tiles_distributed(starts, decode_one, rank, world, group):
+        import torch.distributed as dist
+        decoded = [None] * len(starts)
+        for r0 in range(0, len(starts), world):
+            k = r0 + rank
+            mine = decode_one(starts[k]) if k < len(starts) else None
+            if mine is None:   # ragged last round: take part in the collective with a dummy of the right shape
+                mine = torch.zeros_like(decoded[0]) if decoded[0] is not None else None
+            if mine is None:
+                raise RuntimeError("tile-parallel decode: the first round cannot be ragged")
+            buf = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(buf.view((world * mine.shape[0],) + tuple(mine.shape[1:])), mine.contiguous(), group=group)
+            for j in range(min(world, len(starts) - r0)):
+                decoded[r0 + j] = buf[j]
+        return decoded
 
     def _decode(self, z, return_dict=True):
         _, _, nf, H, W = z.shape

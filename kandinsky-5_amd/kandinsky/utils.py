@@ -2,7 +2,7 @@
 
 Keeps the reference signature, the YAML schema and the safetensors checkpoint layout.  What differs:
 no DTensor tensor-parallel wrap (parallelize.py) — multi-GPU is token-sharded sequence parallelism inside
-the engine; the LOCAL_RANK / WORLD_SIZE launch contract (utils.py:40-45) is kept.
+the engine (+ CFG-parallel rank groups, VAE tile distribution); the LOCAL_RANK / WORLD_SIZE launch contract (utils.py:40-45) is kept.
 """
 import os
 from typing import Union
@@ -70,6 +70,20 @@ def get_T2V_pipeline(
     dit.load_state_dict(state_dict, assign=True)
     if not offload:
         dit = dit.to(device_map["dit"])
+
+    if world_size > 1:
+        # reference utils.py:47-55,121-122 (init_device_mesh + parallelize_dit): one process per GPU, RCCL.  The token axis
+        # is sharded instead of the heads; with classifier-free guidance and an even rank count the cond / uncond forwards
+        # run on two rank groups (K5_CFG_PARALLEL=0 turns that off); VAE temporal tiles are spread over all ranks.
+        import torch.distributed as dist
+        from .models.parallelize import parallelize_dit
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        cfg_parallel = (conf.model.guidance_weight != 1.0 and world_size % 2 == 0
+                        and os.environ.get("K5_CFG_PARALLEL", "1") != "0")
+        dit = parallelize_dit(dit, local_rank, world_size, device=device_map["dit"], cfg_parallel=cfg_parallel)
+        vae.enable_tile_parallel(local_rank, world_size)
 
     return Kandinsky5T2VPipeline(device_map=device_map, dit=dit, text_embedder=text_embedder, vae=vae,
                                  resolution=resolution, local_dit_rank=local_rank, world_size=world_size, conf=conf,

@@ -133,3 +133,110 @@ def test_engine_sharded_path_world1_rccl_matches_fused(golden, golden_meta, tiny
     with pytest.raises(RuntimeError, match="multiple of 64"):
         dit(golden["fwd.x"].cuda(), text, pooled, torch.tensor([432.0]), [torch.arange(3), torch.arange(4), torch.arange(6)],
             torch.arange(9), scale_factor=(1.0, 2.0, 2.0))
+
+
+# ------------------------------------------------------------------------------------------ CFG-parallel + VAE tile distribution
+def test_parallel_layout_contract():
+    from kandinsky.models.parallelize import ParallelLayout
+    L = ParallelLayout(5, 8, cfg_parallel=True)     # 8 GPUs: CFG(2) x SP(4)
+    assert (L.branch, L.sp_rank, L.sp_world) == (1, 1, 4)
+    assert L.sp_ranks == [4, 5, 6, 7] and L.pair_ranks == [1, 5]
+    assert ParallelLayout(1, 8, True).pair_ranks == [1, 5] and ParallelLayout(1, 8, True).branch == 0
+    L = ParallelLayout(1, 2, cfg_parallel=True)     # 2 GPUs: one forward each, no per-block exchange at all
+    assert (L.branch, L.sp_world, L.sp_ranks, L.pair_ranks) == (1, 1, [1], [0, 1])
+    L = ParallelLayout(3, 4, cfg_parallel=False)
+    assert (L.branch, L.sp_rank, L.sp_world, L.sp_ranks, L.pair_ranks) == (0, 3, 4, [0, 1, 2, 3], [3])
+    with pytest.raises(ValueError):
+        ParallelLayout(0, 3, cfg_parallel=True)
+
+
+def _cfg_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "kandinsky-5_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from kandinsky.models.parallelize import ParallelLayout, make_groups, exchange_velocity
+    cfg = O.DitConfig(in_visual_dim=16, in_text_dim=96, in_text_dim2=48, time_dim=64, out_visual_dim=16,
+                      patch_size=(1, 2, 2), model_dim=128, ff_dim=256, num_text_blocks=1, num_visual_blocks=2,
+                      axes_dims=(16, 24, 24), visual_cond=True)
+    sd = O.synthetic_state_dict(cfg, seed=5, std=0.05)
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(2, 8, 8, 16, generator=g)
+    te = {"text_embeds": torch.randn(9, 96, generator=g), "pooled_embed": torch.randn(1, 48, generator=g)}
+    ne = {"text_embeds": torch.randn(4, 96, generator=g), "pooled_embed": torch.randn(1, 48, generator=g)}
+    vpos = [torch.arange(2), torch.arange(4), torch.arange(4)]
+    w, steps, mode = 3.0, 3, "bf16"
+    layout = ParallelLayout(rank, world, cfg_parallel=True)
+    _, pair = make_groups(layout)
+    # the CFG-parallel loop of kandinsky/generation_utils.py:generate, on the oracle arithmetic
+    mine, mine_pos = (te, torch.arange(9)) if layout.branch == 0 else (ne, torch.arange(4))
+    img = noise.clone()
+    sig = O.sigma_schedule(steps, 5.0)
+    for i in range(steps):
+        x = torch.cat([img, torch.zeros_like(img), torch.zeros(*img.shape[:-1], 1)], dim=-1)
+        v = O.dit_forward(sd, cfg, x, mine["text_embeds"], mine["pooled_embed"], sig[i].unsqueeze(0) * 1000, vpos, mine_pos,
+                          (1.0, 2.0, 2.0), None, mode)
+        vc, vu = exchange_velocity(v.to(torch.bfloat16), pair)
+        vc, vu = vc.float(), vu.float()
+        v = O._r(vu + O._r(w * O._r(vc - vu, mode), mode), mode)
+        img = img + O._r((sig[i + 1] - sig[i]) * v, mode)
+    ref = O.generate(sd, cfg, noise, steps, te, ne, vpos, torch.arange(9), torch.arange(4), w, 5.0, (1.0, 2.0, 2.0), None, mode)
+    q.put((rank, float((img - ref).abs().max()), float(ref.abs().max())))
+    dist.destroy_process_group()
+
+
+def _spawn(worker, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[0] for r in res) == list(range(world))
+    return res
+
+
+def test_cfg_parallel_two_ranks_gloo():
+    """cond on rank 0, uncond on rank 1, one velocity exchange per step: both ranks end with the latent of the
+    sequential two-forward sampler, bit for bit (bf16-island oracle arithmetic)."""
+    for rank, err, scale in _spawn(_cfg_worker):
+        assert err == 0.0, (rank, err, scale)
+
+
+def _vae_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "kandinsky-5_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kandinsky.models.vae import AutoencoderKLHunyuanVideo
+    from oracle import vae_oracle as VO
+
+    def fake_tile(self, z):   # deterministic stand-in for the engine's decoder (the test is about tile bookkeeping)
+        t, h, w = z.shape[2:]
+        up = torch.nn.functional.interpolate(z[:, :3].float(), size=(4 * (t - 1) + 1, 8 * h, 8 * w), mode="nearest")
+        return (up * 0.5 + z.float().mean()).to(torch.bfloat16)
+
+    def fake_blend(a, b, extent, dim):
+        return VO.blend(a.float(), b.float().clone(), extent, dim, "bf16").to(b.dtype)
+
+    outs = []
+    for parallel in (False, True):
+        with torch.device("meta"):
+            vae = AutoencoderKLHunyuanVideo(block_out_channels=(64, 64, 128, 128), norm_num_groups=16)
+        vae._decode_tile = fake_tile.__get__(vae)
+        vae._blend = staticmethod(fake_blend).__get__(None, AutoencoderKLHunyuanVideo)
+        if parallel:
+            vae.enable_tile_parallel(rank, world)
+        z = torch.randn(1, 16, 31, 8, 12, generator=torch.Generator().manual_seed(11))   # 121 frames -> 14 temporal tiles
+        outs.append(vae.decode(z).sample)
+    q.put((rank, float((outs[0].float() - outs[1].float()).abs().max()), tuple(outs[1].shape)))
+    dist.destroy_process_group()
+
+
+def test_vae_temporal_tiles_distributed_two_ranks_gloo():
+    for rank, err, shape in _spawn(_vae_worker):
+        assert err == 0.0 and shape == (1, 3, 121, 64, 96), (rank, err, shape)
