@@ -71,6 +71,17 @@ int k5_nabla_select_bf16(const void* q, const void* k, int ldq, int ldk, int H, 
 int k5_attention_nabla_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int N, int ldq, int ldk,
                             int ldvt, int ldo, float score_bound, const void* workspace, void* stream);
 int k5_nabla_mask_u8(const void* workspace, int H, int num_blocks, void* out_u8, void* stream);
+/* Sequence-parallel form (SURVEY.md §8e "NABLA under SP"): this rank holds the query rows of global blocks
+ * [q_block0, q_block0 + Nq/64) and, after the K / V^T all-gather, all N keys; V^T optionally in per-rank chunks
+ * [chunk][H*64][vt_chunk_keys] (vt_chunk_keys = 0: plain [H*64][ldvt]).  Map rows are indexed by the LOCAL query block;
+ * the workspace is sized by k5_nabla_workspace_size(H, N/64) as above.  Row i of the map equals row q_block0 + i of the
+ * square map. mask: uint8 [H][Nq/64][N/64]. */
+int k5_nabla_select_rect_bf16(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T,
+                              int Hb, int Wb, int wT, int wH, int wW, float P, void* workspace, void* stream);
+int k5_attention_nabla_rect_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int Nq, int N, int ldq,
+                                 int ldk, int ldvt, int ldo, float score_bound, const void* workspace, int vt_chunk_keys,
+                                 int64_t vt_chunk_stride, void* stream);
+int k5_nabla_mask_rect_u8(const void* workspace, int H, int q_blocks, int num_blocks, void* out_u8, void* stream);
 
 /* Dense k5_attention_bf16 with a caller-proved bound |q.k| <= score_bound for every (query, key) pair
  * (after norm_qk nn.py:193-197 every head vector has |x| <= 8*max|weight|).  When 2*bound*log2(e)/8 <= 96

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     const int t = tile_of(e);
     const int kv0 = t * KB;
     const bf16_t* vsrc = vbase + kv0;
-    if (!SPARSE && p.vt_chunk_keys > 0) {   // sequence-parallel V^T layout only (uniform branch): per-rank chunks
+    if (p.vt_chunk_keys > 0) {   // sequence-parallel V^T layout only (uniform branch): per-rank chunks
       const int chunk = t / tiles_per_chunk;
       vsrc = vbase + (long long)chunk * p.vt_chunk_stride + (kv0 - chunk * tiles_per_chunk * KB);
     }
@@ -309,18 +309,20 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
 }
 
 // NABLA block-sparse attention (flex_attention(q,k,v,block_mask) nn.py:257-280): `list`/`cnt` are the per-workgroup
-// union lists produced by k5_launch_nabla_select (stride = number of 64-token blocks).  q_len == kv_len, multiple of 64.
-int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int len, int ldq, int ldk,
-                                    int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
-                                    hipStream_t stream) {
-  if (H <= 0 || len <= 0 || (len % KB) || !list || !cnt) return K5_ERR_ARG;
+// union lists produced by k5_launch_nabla_select[_rect] (stride = number of 64-key blocks).  q_len, kv_len multiples of 64;
+// V^T optionally in per-rank chunks (sequence parallel).
+int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                    int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
+                                    int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream) {
+  if (H <= 0 || q_len <= 0 || kv_len <= 0 || (q_len % KB) || (kv_len % KB) || !list || !cnt) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
+  if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
   AttnP p;
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
-  p.H = H; p.q_len = len; p.kv_len = len; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
-  p.nqb = (len + QB - 1) / QB;
+  p.H = H; p.q_len = q_len; p.kv_len = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
+  p.nqb = (q_len + QB - 1) / QB;
   p.c = 0.125f * 1.44269504088896340736f;
-  p.m_fixed = 0.f; p.vt_chunk_keys = 0; p.vt_chunk_stride = 0;
+  p.m_fixed = 0.f; p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride;
   p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;
   const dim3 grid(H * p.nqb), block(512);

@@ -355,8 +355,8 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     const int *list, *cnt;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
     Scope sc(d, s, fam_attn);
-    K5CHK(k5_launch_attention_bf16_sparse(qk, (const bf16_t*)qk + D, vt, o, H, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, list, cnt,
-                                          nb, s));
+    K5CHK(k5_launch_attention_bf16_sparse(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, list,
+                                          cnt, nb, 0, 0, s));
   } else {
     Scope sc(d, s, fam_attn);
     K5CHK(k5_launch_attention_bf16_bounded(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, s));
@@ -373,7 +373,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
 // gather buffers, one in-place all-gather each makes every rank hold all keys, then attention runs for the
 // local query rows.  No head-count constraint (28 heads do not divide by 8), no activation all-reduce.
 int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, void* o, const float* cosT,
-                          const float* sinT, void* resid, const float* gate) {
+                          const float* sinT, void* resid, const float* gate, const NablaArgs* nabla = nullptr) {
   const int D = d->D, H = d->Hh, P = d->sp_world, r = d->sp_rank;
   const int N = rows * P, ldv = rows;  // rows is a multiple of 64 (checked by the caller)
   bf16_t* q = d->ws_q.as<bf16_t>();
@@ -415,20 +415,39 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     K5CHK(d->comm.all_gather_inplace(vtfull, (size_t)D * ldv, 2, cs));
   }
   HIPCHK(hipEventRecord(d->ev_gathered, cs));
-  // ... while the main stream attends the local query rows to the LOCAL key chunk (pass 1, leaves the fp32 state),
-  // then, once every chunk has arrived, to all the other chunks (pass 2, resumes the state and normalises).
-  const int tpc = rows / 64, total = N / 64;
-  K5CHK(d->ws_attn_state.ensure(k5_attention_state_bytes(H, rows)));
-  {
+  if (nabla) {
+    // NABLA under sequence parallelism: the map rows of this rank's query blocks need the block means of
+    // ALL keys -> wait for the gathered K, then select (local query blocks x all key blocks) and run the list-driven
+    // attention on the chunked V^T layout.  (Single pass: the per-row kept set is not known before the gather.)
+    HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
+    const int nb = N / 64;
+    K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
+    {
+      Scope sc(d, s, "nabla_map");
+      K5CHK(k5_launch_nabla_select_rect(q, kfull, D, D, H, rows, r * (rows / 64), N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
+                                        nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s));
+    }
+    const int *list, *cnt;
+    k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
     Scope sc(d, s, "attn_self");
-    K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
-                                         r * tpc, tpc, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s));
-  }
-  HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
-  {
-    Scope sc(d, s, "attn_self");
-    K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
-                                         0, total - tpc, r * tpc, tpc, d->ws_attn_state.as<float>(), 1, s));
+    K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, list, cnt, nb, rows,
+                                          (long long)D * ldv, s));
+  } else {
+    // ... while the main stream attends the local query rows to the LOCAL key chunk (pass 1, leaves the fp32 state),
+    // then, once every chunk has arrived, to all the other chunks (pass 2, resumes the state and normalises).
+    const int tpc = rows / 64, total = N / 64;
+    K5CHK(d->ws_attn_state.ensure(k5_attention_state_bytes(H, rows)));
+    {
+      Scope sc(d, s, "attn_self");
+      K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
+                                           r * tpc, tpc, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s));
+    }
+    HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
+    {
+      Scope sc(d, s, "attn_self");
+      K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
+                                           0, total - tpc, r * tpc, tpc, d->ws_attn_state.as<float>(), 1, s));
+    }
   }
   {
     Scope sc(d, s, "gemm");
@@ -584,7 +603,6 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
   const int32_t* perm = nullptr;
   if (nabla) {
     if ((Hp % 8) || (Wp % 8)) { k5_set_error("nabla attention needs latent H, W divisible by 16 (got %d x %d)", a->H, a->W); return K5_ERR_ARG; }
-    if (sp) { k5_set_error("nabla + sequence parallel is not built yet"); return K5_ERR_UNSUPPORTED; }
     na = NablaArgs{Tp, Hp / 8, Wp / 8, a->nabla_wT, a->nabla_wH, a->nabla_wW, a->nabla_P};
     if (d->perm_shape[0] != Tp || d->perm_shape[1] != Hp || d->perm_shape[2] != Wp) {
       std::vector<int32_t> pv((size_t)N);
@@ -670,7 +688,7 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     const float* vsin = d->ws_vsin.as<float>() + (size_t)tok0 * 32;
     K5CHK(ln_mod(d, s, d->ws_vis.p, m, d->ws_h.p, n));
     if (sp) {
-      K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D));
+      K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D, nabla ? &na : nullptr));
     } else {
       K5CHK(run_self_attention(d, s, b.self_attn, d->ws_h.p, n, d->ws_qk.p, d->ws_vt.p, d->ws_o.p, vcos, vsin, d->ws_vis.p,
                                m + 2 * D, "attn_self", nabla ? &na : nullptr));

@@ -49,12 +49,33 @@ int k5_attention_nabla_bf16(const void* Q, const void* K, const void* Vt, void* 
   if (!workspace || N <= 0 || (N % 64)) return ret(K5_ERR_ARG, "k5_attention_nabla_bf16");
   const int *list, *cnt;
   k5_nabla_workspace_views(const_cast<void*>(workspace), H, N / 64, nullptr, nullptr, &list, &cnt);
-  return ret(k5_launch_attention_bf16_sparse(Q, K, Vt, O, H, N, ldq, ldk, ldvt, ldo, score_bound, list, cnt, N / 64,
+  return ret(k5_launch_attention_bf16_sparse(Q, K, Vt, O, H, N, N, ldq, ldk, ldvt, ldo, score_bound, list, cnt, N / 64, 0, 0,
                                              (hipStream_t)stream), "k5_attention_nabla_bf16");
 }
 
 int k5_nabla_mask_u8(const void* workspace, int H, int num_blocks, void* out_u8, void* stream) {
-  return ret(k5_launch_nabla_mask_u8(workspace, H, num_blocks, out_u8, (hipStream_t)stream), "k5_nabla_mask_u8");
+  return ret(k5_launch_nabla_mask_u8(workspace, H, num_blocks, num_blocks, out_u8, (hipStream_t)stream), "k5_nabla_mask_u8");
+}
+
+int k5_nabla_select_rect_bf16(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
+                              int Wb, int wT, int wH, int wW, float P, void* workspace, void* stream) {
+  return ret(k5_launch_nabla_select_rect(q, k, ldq, ldk, H, Nq, q_block0, N, T, Hb, Wb, wT, wH, wW, P, workspace,
+                                         (hipStream_t)stream), "k5_nabla_select_rect_bf16");
+}
+
+int k5_attention_nabla_rect_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int Nq, int N, int ldq, int ldk,
+                                 int ldvt, int ldo, float score_bound, const void* workspace, int vt_chunk_keys,
+                                 int64_t vt_chunk_stride, void* stream) {
+  if (!workspace || N <= 0 || (N % 64)) return ret(K5_ERR_ARG, "k5_attention_nabla_rect_bf16");
+  const int *list, *cnt;
+  k5_nabla_workspace_views(const_cast<void*>(workspace), H, N / 64, nullptr, nullptr, &list, &cnt);
+  return ret(k5_launch_attention_bf16_sparse(Q, K, Vt, O, H, Nq, N, ldq, ldk, ldvt, ldo, score_bound, list, cnt, N / 64,
+                                             vt_chunk_keys, (long long)vt_chunk_stride, (hipStream_t)stream),
+             "k5_attention_nabla_rect_bf16");
+}
+
+int k5_nabla_mask_rect_u8(const void* workspace, int H, int q_blocks, int num_blocks, void* out_u8, void* stream) {
+  return ret(k5_launch_nabla_mask_u8(workspace, H, q_blocks, num_blocks, out_u8, (hipStream_t)stream), "k5_nabla_mask_rect_u8");
 }
 
 int k5_attention_bf16_bounded(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len,

@@ -36,10 +36,12 @@ int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H
                            int wW, float P, void* workspace, hipStream_t s);
 void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned long long** bits, const int** kv_nb, const int** list,
                               const int** cnt);
-int k5_launch_nabla_mask_u8(const void* workspace, int H, int nb, void* out, hipStream_t s);
-int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int len, int ldq, int ldk,
-                                    int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
-                                    hipStream_t stream);
+int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
+                                int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s);
+int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void* out, hipStream_t s);
+int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                    int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
+                                    int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream);
 
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,

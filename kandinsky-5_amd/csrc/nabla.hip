@@ -40,6 +40,7 @@ struct SelP {
   unsigned long long* bits;             // [H][nb][nw]
   int* kv_nb;                           // [H][nb] kept blocks per row (diagnostics / density)
   int H, nb, nw, T, Hb, Wb, wT, wH, wW;
+  int nqb, qb0;                         // query blocks handled here: global blocks [qb0, qb0 + nqb) (sequence parallel: the rank's rows)
   float target;                         // 1 - P
 };
 
@@ -50,13 +51,13 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
   extern __shared__ float srow[];   // SEL_WAVES rows of nb floats
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * SEL_WAVES + wave;      // (h, i)
-  if (row >= p.H * p.nb) return;
-  const int h = row / p.nb, i = row % p.nb;
+  if (row >= p.H * p.nqb) return;
+  const int h = row / p.nqb, il = row % p.nqb, i = p.qb0 + il;   // il: local query block, i: its global block index
   float* pr = srow + wave * p.nb;
   // query block mean (broadcast loads)
   float qa[64];
   {
-    const bf16_t* q = p.qa + ((size_t)h * p.nb + i) * 64;
+    const bf16_t* q = p.qa + ((size_t)h * p.nqb + il) * 64;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const u32x4 raw = *reinterpret_cast<const u32x4*>(q + 8 * c);
@@ -125,14 +126,14 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
     tie_seen += __popcll(tmask);
     const unsigned long long w = __ballot(keep);
     kept += __popcll(w);
-    if (lane == 0) p.bits[((size_t)h * p.nb + i) * p.nw + c] = w;
+    if (lane == 0) p.bits[((size_t)h * p.nqb + il) * p.nw + c] = w;
   }
   if (lane == 0 && p.kv_nb) p.kv_nb[row] = kept;
 }
 
 // per (h, group of 4 query blocks): list[(h*ng+g)*nb + e] = kv_block | membership << 24 ; cnt[h*ng+g]
 __global__ __launch_bounds__(256) void nabla_union_kernel(const unsigned long long* __restrict__ bits, int* __restrict__ list,
-                                                          int* __restrict__ cnt, int H, int nb, int nw, int ng) {
+                                                          int* __restrict__ cnt, int H, int nqb, int nb, int nw, int ng) {
   const int lane = threadIdx.x & 63;
   const int gi = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gi >= H * ng) return;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void nabla_union_kernel(const unsigned long lo
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qb = 4 * g + r;
-      w[r] = qb < nb ? bits[((size_t)h * nb + qb) * nw + c] : 0ull;
+      w[r] = qb < nqb ? bits[((size_t)h * nqb + qb) * nw + c] : 0ull;
       u |= w[r];
     }
     if ((u >> lane) & 1ull) {
@@ -168,10 +169,11 @@ __global__ __launch_bounds__(256) void nabla_expand_kernel(const unsigned long l
 
 }  // namespace
 
-int k5_launch_nabla_mask_u8(const void* workspace, int H, int nb, void* out, hipStream_t s) {
+int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void* out, hipStream_t s) {
+  if (H <= 0 || nqb <= 0 || nqb > nb) return K5_ERR_ARG;
   const unsigned long long* bits;
   k5_nabla_workspace_views(const_cast<void*>(workspace), H, nb, &bits, nullptr, nullptr, nullptr);
-  const int64_t rows = (int64_t)H * nb;
+  const int64_t rows = (int64_t)H * nqb;
   int64_t blocks = (rows * nb + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(nabla_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, s, bits, (unsigned char*)out, rows, nb, (nb + 63) / 64);
@@ -187,30 +189,38 @@ size_t k5_nabla_workspace_bytes(int H, int nb) {
          + (size_t)H * ng * 4 + 256;       // counts
 }
 
-// qk: [N][ld] bf16, q heads at columns 0.., k heads at k_col_off.. (both after norm_qk + RoPE, fractal token order).
-// Fills the workspace with: qa|ka means, block bitmap, per-row counts, per-workgroup union lists (layout = NablaWs).
-int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,
-                           int wW, float P, void* workspace, hipStream_t s) {
-  if (H <= 0 || N <= 0 || (N % 64) || T * Hb * Wb * 64 != N) return K5_ERR_ARG;
+// q: [Nq][ldq] bf16 = the query rows handled here (global 64-token blocks [q_block0, q_block0 + Nq/64)), k: [N][ldk] = all
+// keys; both after norm_qk + RoPE, fractal token order.  Fills the workspace (regions sized for Nq == N, rows indexed by
+// the local query block) with: qa|ka means, block bitmap, per-row counts, per-workgroup union lists.
+int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
+                                int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s) {
+  if (H <= 0 || N <= 0 || Nq <= 0 || (N % 64) || (Nq % 64) || T * Hb * Wb * 64 != N) return K5_ERR_ARG;
+  if (q_block0 < 0 || q_block0 * 64 + Nq > N) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7)) return K5_ERR_ALIGN;
-  const int nb = N / 64, nw = (nb + 63) / 64, ng = (nb + 3) / 4;
+  const int nb = N / 64, nqb = Nq / 64, nw = (nb + 63) / 64, ng = (nqb + 3) / 4;
   if (nb > SEL_MAXNB) return K5_ERR_UNSUPPORTED;
   char* ws = (char*)workspace;
   bf16_t* qa = (bf16_t*)ws; ws += (size_t)H * nb * 64 * 2;
   bf16_t* ka = (bf16_t*)ws; ws += (size_t)H * nb * 64 * 2;
   unsigned long long* bits = (unsigned long long*)ws; ws += (size_t)H * nb * nw * 8;
   int* kv_nb = (int*)ws; ws += (size_t)H * nb * 4;
-  int* list = (int*)ws; ws += (size_t)H * ng * nb * 4;
+  int* list = (int*)ws; ws += (size_t)H * ((nb + 3) / 4) * nb * 4;
   int* cnt = (int*)ws;
-  hipLaunchKernelGGL(block_mean_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)q, qa, H, nb, ldq);
+  hipLaunchKernelGGL(block_mean_kernel, dim3(nqb), dim3(256), 0, s, (const bf16_t*)q, qa, H, nqb, ldq);
   hipLaunchKernelGGL(block_mean_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)k, ka, H, nb, ldk);
   SelP p;
   p.qa = qa; p.ka = ka; p.bits = bits; p.kv_nb = kv_nb; p.H = H; p.nb = nb; p.nw = nw; p.T = T; p.Hb = Hb; p.Wb = Wb;
   p.wT = wT; p.wH = wH; p.wW = wW; p.target = (float)(1.0 - (double)P);
-  const int rows = H * nb;
+  p.nqb = nqb; p.qb0 = q_block0;
+  const int rows = H * nqb;
   hipLaunchKernelGGL(nabla_select_kernel, dim3((rows + SEL_WAVES - 1) / SEL_WAVES), dim3(256), (size_t)SEL_WAVES * nb * 4, s, p);
-  hipLaunchKernelGGL(nabla_union_kernel, dim3((H * ng + 3) / 4), dim3(256), 0, s, bits, list, cnt, H, nb, nw, ng);
+  hipLaunchKernelGGL(nabla_union_kernel, dim3((H * ng + 3) / 4), dim3(256), 0, s, bits, list, cnt, H, nqb, nb, nw, ng);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
+int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,
+                           int wW, float P, void* workspace, hipStream_t s) {
+  return k5_launch_nabla_select_rect(q, k, ldq, ldk, H, N, 0, N, T, Hb, Wb, wT, wH, wW, P, workspace, s);
 }
 
 // views into the workspace filled above

@@ -144,3 +144,54 @@ def test_nabla_rejects_unaligned_latent(tiny, golden):
     with pytest.raises(RuntimeError, match="divisible by 16"):
         dit(golden["fwd.x"].cuda(), golden["fwd.text"].cuda(), golden["fwd.pooled"].cuda(), golden["fwd.time"],
             [torch.arange(3), torch.arange(4), torch.arange(6)], torch.arange(7), sparse_params=sparse)
+
+
+# ------------------------------------------------------------------------------------------ NABLA under sequence parallelism
+def test_rect_map_and_chunked_sparse_attention_equal_the_square_rows(E):
+    """A rank holding query blocks [qb0, qb0+nqb) and all keys (V^T in per-rank chunks) gets exactly the rows of the
+    single-GPU map and of the single-GPU block-sparse attention (bit for bit: same kernels, same key order)."""
+    T, Hb, Wb, H, P = 8, 2, 2, 2, 4                      # 32 blocks, 4 "ranks" of 8 blocks
+    nb, N = 32, 2048
+    g = torch.Generator().manual_seed(21)
+    def rmsn(x):
+        return bfr(x / x.pow(2).mean(-1, keepdim=True).sqrt())
+    q, k, v = rmsn(torch.randn(N, H, 64, generator=g)), rmsn(torch.randn(N, H, 64, generator=g)), bfr(torch.randn(N, H, 64, generator=g))
+    qd, kd = q.reshape(N, -1).cuda().to(BF), k.reshape(N, -1).cuda().to(BF)
+    vt = v.reshape(N, -1).t().contiguous().cuda().to(BF)                       # [H*64][N]
+    n = N // P
+    vt_chunks = vt.reshape(H * 64, P, n).permute(1, 0, 2).contiguous()         # [P][H*64][n]
+    ws = E.nabla_select(qd, kd, H, (T, Hb, Wb), (3, 1, 1), 0.6)
+    full_mask = E.nabla_mask(ws, H, nb)
+    full_out = E.attention_nabla(qd, kd, vt, H, ws, score_bound=64 * 1.05)
+    L = E.lib()
+    for r in (0, 2, 3):
+        qb0, nqb = r * (n // 64), n // 64
+        qloc = qd[r * n:(r + 1) * n]
+        wsr = torch.empty(L.k5_nabla_workspace_size(H, nb), dtype=torch.uint8, device="cuda")
+        E.check(L.k5_nabla_select_rect_bf16(qloc.data_ptr(), kd.data_ptr(), qloc.stride(0), kd.stride(0), H, n, qb0, N, T, Hb, Wb,
+                                            3, 1, 1, 0.6, wsr.data_ptr(), E.stream_ptr()))
+        m = torch.empty(H, nqb, nb, dtype=torch.uint8, device="cuda")
+        E.check(L.k5_nabla_mask_rect_u8(wsr.data_ptr(), H, nqb, nb, m.data_ptr(), E.stream_ptr()))
+        assert torch.equal(m.bool(), full_mask[:, qb0:qb0 + nqb])
+        o = torch.empty(n, H * 64, dtype=BF, device="cuda")
+        E.check(L.k5_attention_nabla_rect_bf16(qloc.data_ptr(), kd.data_ptr(), vt_chunks.data_ptr(), o.data_ptr(), H, n, N,
+                                               qloc.stride(0), kd.stride(0), n, o.stride(0), 64 * 1.05, wsr.data_ptr(), n,
+                                               H * 64 * n, E.stream_ptr()))
+        assert torch.equal(o, full_out[r * n:(r + 1) * n])
+
+
+def test_engine_nabla_sharded_path_world1_matches_fused(tiny, golden, golden_meta):
+    """world = 1 RCCL communicator: the sequence-parallel NABLA branch of the engine == the fused NABLA path, bit for bit."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    dit, _ = tiny
+    attn = golden_meta["nabla_attention"]
+    sparse = {"P": attn["P"], "wT": attn["wT"], "wH": attn["wH"], "wW": attn["wW"], "to_fractal": True}
+    pos = [torch.arange(6), torch.arange(16), torch.arange(16)]
+    args = (golden["nabla.fwd.x"].cuda(), golden["fwd.text"].cuda(), golden["fwd.pooled"].cuda(), golden["fwd.time"], pos, torch.arange(7))
+    a = dit(*args, scale_factor=(1.0, 2.0, 2.0), sparse_params=sparse)
+    c = dict(golden_meta["tiny_config"])
+    sp = DiffusionTransformer3D(**c)
+    sp.load_state_dict(dit.state_dict(), assign=True)
+    sp = sp.to("cuda:0").enable_sequence_parallel(0, 1, device="cuda:0")
+    b = sp(*args, scale_factor=(1.0, 2.0, 2.0), sparse_params=sparse)
+    assert torch.equal(a, b)
