@@ -15,6 +15,8 @@
 // the global loads of tile k+1 are issued before the MFMAs of tile k and written to LDS after.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "k5_common.h"
 #include "k5_kernels.h"
 
@@ -31,76 +33,81 @@ struct GemmP {
   int M, N, K, lda, ldw, ldc, ldr;
   int tiles_m, tiles_n;
   float alpha;            // EPI_F32: C_f32 = alpha * acc
+  int dbg;                // benchmarking experiments only (K5_GEMM_DBG); 0 in production
+  unsigned long long* trace;  // -DK8_TRACE builds only
 };
+
+// one 32x32 accumulator tile: this lane owns token row m and, per register group rg, the 4 consecutive
+// output columns n_base + 8 rg + 4 hi .. +3
+template <int EPI>
+K5_DEV void gemm_epilogue_tile(const GemmP& p, const f32x16& acc, int m, int n_base, int hi) {
+  if (m >= p.M) return;
+  float bias_m = 0.f;
+  if (EPI == K5_EPI_BIAS_M && p.bias) bias_m = p.bias[m];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const int n = n_base + 8 * rg + 4 * hi;
+    if (n >= p.N) continue;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = acc[4 * rg + e];
+    const bool full = (n + 3 < p.N);
+    if (EPI == K5_EPI_F32) {  // raw fp32 scores (VAE mid-block attention): C is float*
+      float* fp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) fp[e] = v[e] * p.alpha;
+      continue;
+    }
+    if (EPI == K5_EPI_BIAS_M) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bias_m;
+    } else if (p.bias) {
+      if (full) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
+      }
+    }
+    if (EPI == K5_EPI_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_erf(bf_round(v[e]));
+    }
+    if (EPI == K5_EPI_GATE) {
+      const bf16_t* rp = p.resid + (size_t)m * p.ldr + n;
+      if (full && ((p.ldr & 3) == 0)) {  // one 8-B residual load + one 16-B gate load per 4 outputs
+        const u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(p.gate + n);
+        v[0] = __uint_as_float(rr[0] << 16) + gg[0] * bf_round(v[0]);
+        v[1] = __uint_as_float(rr[0] & 0xffff0000u) + gg[1] * bf_round(v[1]);
+        v[2] = __uint_as_float(rr[1] << 16) + gg[2] * bf_round(v[2]);
+        v[3] = __uint_as_float(rr[1] & 0xffff0000u) + gg[3] * bf_round(v[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) v[e] = bf2f(rp[e]) + p.gate[n + e] * bf_round(v[e]);
+      }
+    }
+    bf16_t* cp = p.C + (size_t)m * p.ldc + n;
+    if (full && ((p.ldc & 3) == 0)) {
+      u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(cp) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = f2bf(v[e]);
+    }
+  }
+}
 
 template <int EPI>
 K5_DEV void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int hi, int l31) {
-  // ---- epilogue: lane owns token row m, 4 consecutive n per register group ----
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = m0 + wm * 64 + j * 32 + l31;
-    if (m >= p.M) continue;
-    float bias_m = 0.f;
-    if (EPI == K5_EPI_BIAS_M && p.bias) bias_m = p.bias[m];
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int n = n0 + wn * 64 + i * 32 + 8 * rg + 4 * hi;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e];
-        const bool full = (n + 3 < p.N);
-        if (EPI == K5_EPI_F32) {  // raw fp32 scores (VAE mid-block attention): C is float*
-          float* fp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < p.N) fp[e] = v[e] * p.alpha;
-          continue;
-        }
-        if (EPI == K5_EPI_BIAS_M) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bias_m;
-        } else if (p.bias) {
-          if (full) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += b[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
-          }
-        }
-        if (EPI == K5_EPI_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(bf_round(v[e]));
-        }
-        if (EPI == K5_EPI_GATE) {
-          const bf16_t* rp = p.resid + (size_t)m * p.ldr + n;
-          if (full && ((p.ldr & 3) == 0)) {  // one 8-B residual load + one 16-B gate load per 4 outputs
-            const u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(p.gate + n);
-            v[0] = __uint_as_float(rr[0] << 16) + gg[0] * bf_round(v[0]);
-            v[1] = __uint_as_float(rr[0] & 0xffff0000u) + gg[1] * bf_round(v[1]);
-            v[2] = __uint_as_float(rr[1] << 16) + gg[2] * bf_round(v[2]);
-            v[3] = __uint_as_float(rr[1] & 0xffff0000u) + gg[3] * bf_round(v[3]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < p.N) v[e] = bf2f(rp[e]) + p.gate[n + e] * bf_round(v[e]);
-          }
-        }
-        bf16_t* cp = p.C + (size_t)m * p.ldc + n;
-        if (full && ((p.ldc & 3) == 0)) {
-          u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(cp) = o;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = f2bf(v[e]);
-        }
-      }
-    }
-  }
+    for (int i = 0; i < 2; ++i)
+      gemm_epilogue_tile<EPI>(p, acc[i][j], m0 + wm * 64 + j * 32 + l31, n0 + wn * 64 + i * 32, hi);
 }
 
 template <int EPI>
@@ -370,6 +377,221 @@ int launch_k3(GemmP p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves in two groups of four (waves w and w+4 share a SIMD), ping-pong by one barrier: while one
+// group issues the 8 MFMAs of a phase the other issues its LDS fragment reads and its share of the next tiles'
+// global_load_lds — so each SIMD's matrix pipe always has a wave feeding it.  Per wave: 128 (n) x 64 (m) outputs =
+// 4 x 2 MFMA 32x32 tiles = 8 independent accumulators; a K-tile is four phases = its four 16-wide k-steps, each phase
+// one MFMA per accumulator and 4 + 2 fragment reads (measured on the first version of this kernel, which walked the
+// output quadrants instead: a phase with 12 reads per wave keeps the CU's LDS busy for ~390 cycles against ~300 cycles of
+// MFMA issue — the read phases must be balanced, LDS bandwidth is the co-limiter of this design).
+// Operand tiles are staged as k-halves: unit = 256 rows x 32 k = 16 KB, LDS row stride 64 B, 16-B chunk swizzle
+// c' = c ^ ((row >> 2) & 3) (16 consecutive rows x one chunk = all 64 banks once).  One unit (2 DMA instructions per
+// thread) is issued per phase, at least one K-tile before its first use:
+//     ph1: W-klo(t+1)    ph2: X-khi(t+1)    ph3: W-khi(t+1)    ph4: X-klo(t+2)
+// and every phase ends with s_waitcnt vmcnt(4) = "all but the two newest units have landed" followed by a barrier.
+// A unit first read in phase R was issued in phase <= R-4, so it is retired by the wait that closes phase R-2 and
+// published by barriers every wave has passed before phase R starts — including the other group, which runs one
+// barrier behind.  Restaging (WAR): a slot's last fragment read is >= 2 phases before its next DMA is issued.
+// LDS: 2 stages x 4 units x 16 KB = 128 KB -> one workgroup per CU, 2 waves per SIMD.
+// ---------------------------------------------------------------------------------------------
+constexpr int K8_BM = 256, K8_BN = 256;
+constexpr int K8_UNIT = 16384, K8_XOFF = 65536, K8_LDS = 131072;   // W units at (2 stage + khalf) * 16 KB, X units 64 KB above
+#ifdef K8_TRACE
+constexpr int K8_TRACE_BYTES = 8 * 128 * 8;
+#else
+constexpr int K8_TRACE_BYTES = 0;
+#endif
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                       // ping-pong group
+  const int wn = wave & 1, wm = ((wave >> 1) & 1) | (grp << 1);   // 2 waves along n, 4 along m
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  // Persistent workgroups (one per CU): XCD x = blockIdx % 8 owns a contiguous range of logical tiles, its (up to 32)
+  // workgroups walk it interleaved, so the tiles in flight on one XCD are neighbours (shared operand panels in its L2).
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7 - xcd) >> 3;   // workgroups on this XCD
+  const int q8 = nblk >> 3, r8 = nblk & 7;
+  const int x_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, x_cnt = q8 + (xcd < r8 ? 1 : 0);
+  constexpr int GM = 4;  // tile order inside a range: 4 m-tiles x all n-tiles groups
+  const int per_group = GM * p.tiles_n;
+  auto tile_origin = [&](int lid, int& m0, int& n0) {
+    const int g = lid / per_group, first_m = g * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    m0 = (first_m + (lid % per_group) % gsz) * K8_BM;
+    n0 = ((lid % per_group) / gsz) * K8_BN;
+  };
+
+  // DMA sources: a unit is 16 pieces of 16 rows x 64 B; this wave stages pieces `wave` and `wave + 8`: rows
+  // 16 wave + (lane>>2) and 128 + 16 wave + (lane>>2); LDS chunk slot lane&3 is filled from source chunk slot ^ swizzle(row).
+  // Per-lane 32-bit byte offsets from the (uniform) operand bases.
+  const int prow = 16 * wave + (lane >> 2);
+  const int pc = (lane & 3) ^ ((prow >> 2) & 3);   // (row>>2)&3 is the same for prow + 128 q
+  uint32_t ow[2], ox[2];
+  auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = 128 * q + prow;
+      ow[q] = (uint32_t)min(n0 + r, p.N - 1) * (uint32_t)p.ldw * 2u + 16u * pc;
+      ox[q] = (uint32_t)min(m0 + r, p.M - 1) * (uint32_t)p.lda * 2u + 16u * pc;
+    }
+  };
+  const char* Wbase = reinterpret_cast<const char*>(p.W);
+  const char* Xbase = reinterpret_cast<const char*>(p.A);
+  const int kmax = p.K - BK;
+  // unit = (stage, k-half kh) of the K-tile starting at k0; tail: k0 is clamped -> redundant (harmless) loads keep the
+  // per-phase DMA count, hence the vmcnt arithmetic, uniform.  (The SGPR-base + VGPR-offset form of the DMA instruction,
+  // via inline asm, measured SLOWER than letting the compiler form 64-bit VGPR addresses: 1062 vs 1164 TFLOP/s at 4096^3.)
+  auto dma_w = [&](int stage, int kh, int k0) {
+    const char* b = Wbase + 2 * (size_t)(min(k0, kmax) + 32 * kh);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b + ow[q]), (lds_void_t*)(dsm + (2 * stage + kh) * K8_UNIT + (8 * q + wave) * 1024), 16, 0, 0);
+  };
+  auto dma_x = [&](int stage, int kh, int k0) {
+    const char* b = Xbase + 2 * (size_t)(min(k0, kmax) + 32 * kh);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b + ox[q]), (lds_void_t*)(dsm + K8_XOFF + (2 * stage + kh) * K8_UNIT + (8 * q + wave) * 1024), 16, 0, 0);
+  };
+  // prologue of a tile: all of K-tile 0 (klo units first) and X-klo of K-tile 1
+  auto prologue = [&]() { dma_w(0, 0, 0); dma_x(0, 0, 0); dma_x(0, 1, 0); dma_w(0, 1, 0); dma_x(1, 0, BK); };
+
+  // fragment read addresses: lane base (row, swizzled chunk) for the two k-steps of a unit; unit / tile offsets are immediates
+  const int sw = (l31 >> 2) & 3;
+  const char* wb[2]; const char* xb[2];
+#pragma unroll
+  for (int ksl = 0; ksl < 2; ++ksl) {
+    const int co = ((2 * ksl + hi) ^ sw) << 4;
+    wb[ksl] = dsm + (128 * wn + l31) * 64 + co;
+    xb[ksl] = dsm + K8_XOFF + (64 * wm + l31) * 64 + co;
+  }
+  const int nk = p.K / BK;
+
+#ifdef K8_TRACE
+  unsigned long long* tr = reinterpret_cast<unsigned long long*>(dsm + K8_LDS) + wave * 128;
+  int tri = 0;
+#define K8_STAMP() do { if (lane == 0 && tri < 128) tr[tri] = __builtin_amdgcn_s_memtime(); ++tri; } while (0)
+#else
+#define K8_STAMP() do {} while (0)
+#endif
+
+  int m0, n0;
+  if (slot < x_cnt) { tile_origin(x_first + slot, m0, n0); set_offsets(m0, n0); prologue(); }
+  for (int ti = slot; ti < x_cnt; ti += per_xcd) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 wf[4], xf[2];
+
+    // this tile's prologue DMAs were issued before the previous tile's epilogue stores (vmcnt also counts those stores,
+    // which may retire out of order with loads -> a full drain here; the DMAs have had the whole epilogue to land)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0 from here on
+
+    // one phase = k-step KS of the K-tile in stage ST: fragment reads, this phase's DMA unit, barrier, 8 MFMAs, wait, barrier
+    auto phase = [&](auto STC, auto KSC, auto&& issue_dma) {
+      constexpr int st = decltype(STC)::value, ks = decltype(KSC)::value;
+      constexpr int uo = (2 * st + (ks >> 1)) * K8_UNIT;
+      __builtin_amdgcn_sched_barrier(0);
+      K8_STAMP();
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb[ks & 1] + uo + j * 32 * 64);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb[ks & 1] + uo + i * 32 * 64);
+      issue_dma();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(wf[i], xf[j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto ktile = [&](auto STC, int t) {
+      constexpr int st = decltype(STC)::value;
+      const int k1 = (t + 1) * BK, k2 = (t + 2) * BK;
+      phase(STC, std::integral_constant<int, 0>{}, [&] { dma_w(st ^ 1, 0, k1); });
+      phase(STC, std::integral_constant<int, 1>{}, [&] { dma_x(st ^ 1, 1, k1); });
+      phase(STC, std::integral_constant<int, 2>{}, [&] { dma_w(st ^ 1, 1, k1); });
+      phase(STC, std::integral_constant<int, 3>{}, [&] { dma_x(st, 0, k2); });
+    };
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      ktile(std::integral_constant<int, 0>{}, t);
+      ktile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (nk & 1) ktile(std::integral_constant<int, 0>{}, t);
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier: every fragment read of this tile is done
+    // the tail's redundant DMAs must have landed before the same slots are restaged for the next tile (and before exit)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int cm0 = m0, cn0 = n0;
+    if (ti + per_xcd < x_cnt) {   // next tile's prologue flies under this tile's epilogue
+      tile_origin(x_first + ti + per_xcd, m0, n0);
+      set_offsets(m0, n0);
+      prologue();
+    }
+    // epilogue indices are re-derived from a laundered thread id so that none of the address math is hoisted above the
+    // K loop (where it would push the accumulators into scratch)
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int e_l31 = tid2 & 31, e_hi = (tid2 >> 5) & 1, e_wave = tid2 >> 6;
+    const int e_wn = e_wave & 1, e_wm = ((e_wave >> 1) & 1) | ((e_wave >> 2) << 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        gemm_epilogue_tile<EPI>(p, acc[i][j], cm0 + 64 * e_wm + 32 * j + e_l31, cn0 + 128 * e_wn + 32 * i, e_hi);
+  }
+#undef K8_STAMP
+#ifdef K8_TRACE
+  __syncthreads();
+  if (blockIdx.x == 0 && p.trace) for (int i = tid; i < 8 * 128; i += 512) p.trace[i] = reinterpret_cast<unsigned long long*>(dsm + K8_LDS)[i];
+#endif
+}
+
+template <int EPI>
+int launch_k8(GemmP p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_bf16_k8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, K8_LDS + K8_TRACE_BYTES) != hipSuccess)
+      return K5_ERR_HIP;
+    attr_set = true;
+  }
+  p.tiles_m = (p.M + K8_BM - 1) / K8_BM; p.tiles_n = (p.N + K8_BN - 1) / K8_BN;
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  static const bool full_grid = getenv("K5_GEMM_FULLGRID") != nullptr;   // A/B: one workgroup per tile instead of per CU
+  const int grid = full_grid ? p.tiles_m * p.tiles_n : min(p.tiles_m * p.tiles_n, num_cu);   // persistent: one workgroup per CU (128 KB of LDS each)
+#ifdef K8_TRACE
+  p.trace = getenv("K5_GEMM_TRACE") ? (unsigned long long*)strtoull(getenv("K5_GEMM_TRACE"), nullptr, 16) : nullptr;
+#endif
+  hipLaunchKernelGGL(gemm_bf16_k8_kernel<EPI>, dim3(grid), dim3(512), K8_LDS + K8_TRACE_BYTES, stream, p);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
 }  // namespace
 
 // Host launcher (C++ linkage, used by the C-ABI layer in k5_api.hip and by the engine).
@@ -384,11 +606,23 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   p.resid = (const bf16_t*)resid; p.gate = gate;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
-  p.alpha = 1.f;
+  p.alpha = 1.f; p.trace = nullptr;
+  static const int dbg = getenv("K5_GEMM_DBG") ? atoi(getenv("K5_GEMM_DBG")) : 0;
+  p.dbg = dbg;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
   static const int force_v1 = getenv("K5_GEMM_V1") ? atoi(getenv("K5_GEMM_V1")) : 0;  // A/B switch for benchmarking
   // K5_GEMM_V1=3 selects the 256x128 3-stage counted-vmcnt variant.  Measured (round 1, model shapes): within +-3 % of the
   // 128x128 direct-to-LDS kernel (ff2 844 vs 827, ff1 698 vs 719 TFLOP/s) -> L2-miss latency is not the limiter; not default.
+  // default for the model's large projections: the 256x256 two-group ping-pong kernel (K5_GEMM_V1=2 keeps the 128x128 one)
+  if ((K % BK) == 0 && K >= 2 * BK && M >= 512 && N >= 256 && (force_v1 == 0 || force_v1 == 8)) {
+    switch (epi) {
+      case K5_EPI_BIAS: return launch_k8<K5_EPI_BIAS>(p, stream);
+      case K5_EPI_BIAS_M: return launch_k8<K5_EPI_BIAS_M>(p, stream);
+      case K5_EPI_GELU: return launch_k8<K5_EPI_GELU>(p, stream);
+      case K5_EPI_GATE: return launch_k8<K5_EPI_GATE>(p, stream);
+      default: return K5_ERR_ARG;
+    }
+  }
   if ((K % BK) == 0 && M >= 512 && force_v1 == 3) {
     switch (epi) {
       case K5_EPI_BIAS: return launch_k3<K5_EPI_BIAS>(p, stream);
@@ -425,7 +659,7 @@ int k5_launch_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, in
   if ((K & 7) || (lda & 7) || (ldw & 7)) return K5_ERR_ALIGN;
   GemmP p;
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = (bf16_t*)C; p.bias = nullptr; p.resid = nullptr; p.gate = nullptr;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.alpha = alpha;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.alpha = alpha; p.dbg = 0; p.trace = nullptr;
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
   if ((K % BK) == 0) hipLaunchKernelGGL(gemm_bf16_glds_kernel<K5_EPI_F32>, grid, block, 0, stream, p);
