@@ -59,6 +59,12 @@ int64_t k5_attention_state_size(int H, int q_len);
 int k5_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len,
                             int ldq, int ldk, int ldvt, int ldo, float score_bound, int tile_off0, int tile_cnt,
                             int tile_skip_at, int tile_skip_n, void* state, int flags, void* stream);
+/* k5_attention_bf16[_bounded] with load balancing: the (head, 256-query) jobs that do not fill a whole round of the
+ * device's resident workgroups are split 2-4 ways along the keys and merged (same result up to fp32 summation order).
+ * workspace: k5_attention_balance_size(H, q_len) bytes.  The engine uses this for every large self-attention. */
+int64_t k5_attention_balance_size(int H, int q_len);
+int k5_attention_bf16_balanced(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len,
+                               int ldq, int ldk, int ldvt, int ldo, float score_bound, void* workspace, void* stream);
 
 /* NABLA block-sparse attention = nablaT_v2 (kandinsky/models/utils.py:136-163, incl. the STA window of
  * fast_sta_nabla :108-133) + flex_attention(q,k,v,block_mask) (nn.py:257-280), tokens in fractal order

@@ -26,6 +26,8 @@
 // TWO workgroups (4 waves/SIMD) are resident per CU raised issue-port utilisation from 66 % to 85 %.
 // What is left is the VALU op count per score; BOUNDED=true drops the online running max (24 ops
 // per tile + the rescale branch) when the caller proves |score| <= bound (RMS-normalised q, k).
+#include <stdlib.h>
+
 #include <type_traits>
 #include "k5_common.h"
 #include "k5_kernels.h"
@@ -51,6 +53,11 @@ struct AttnP {
   // from (flags & 1) and/or leave (flags & 2) the fp32 running state {O^T accumulators, m, l} instead of normalising.
   int tile_off0, tile_cnt, tile_skip_at, tile_skip_n;
   float* state; int flags;
+  // job = (head, 256-query block) = job0 + workgroup index; RANGE launches may split every job's tile sequence `splits`
+  // ways (workgroup g -> job job0 + g / splits, part g % splits): part 0 uses `state` (and is the only one that resumes),
+  // part s >= 1 leaves its state at split_state + (s - 1) * split_stride floats.  Used to cut the last, partially filled
+  // round of workgroups into short pieces (k5_launch_attention_bf16_balanced).
+  int job0, splits; float* split_state; long long split_stride;
 };
 
 // RANGE: key-tile sub-range + resumable fp32 state (sequence-parallel two-pass schedule); kept out of the plain dense
@@ -61,7 +68,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   char* sK = smem;
   char* sV = smem + 2 * TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int gid = xcd_remap(blockIdx.x, gridDim.x);
+  const int part = RANGE ? gid % p.splits : 0;
+  const int lid = p.job0 + (RANGE ? gid / p.splits : gid);
   const int h = lid / p.nqb, qb = lid % p.nqb;
   const int q0 = qb * QB + wave * 32;
 
@@ -78,7 +87,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   const bf16_t* vbase = p.Vt + (size_t)(h * 64 + lrow) * p.ldvt + 8 * lc;
   const int lds_off = lds_swz(lrow, lc);
   const int* sp_list = SPARSE ? p.sp_list + (size_t)(h * p.nqb + qb) * p.sp_stride : nullptr;
-  const int T = SPARSE ? p.sp_cnt[h * p.nqb + qb] : p.tile_cnt;
+  const int Tall = SPARSE ? p.sp_cnt[h * p.nqb + qb] : p.tile_cnt;
+  // this workgroup's share of the tile sequence: positions [E0, T)  (everything unless the job is split)
+  const int E0 = RANGE ? (int)(((long long)Tall * part) / p.splits) : 0;
+  const int T = RANGE ? (int)(((long long)Tall * (part + 1)) / p.splits) : Tall;
   const int nfull = p.kv_len / KB;                    // key tiles with all 64 keys valid (NABLA: all of them)
   auto tile_of = [&](int e) -> int {                  // sequence position -> 64-key tile index (wave-uniform)
     if (SPARSE) return sp_list[e] & 0xffffff;
@@ -127,9 +139,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   float m_run = BOUNDED ? p.m_fixed : -1e30f, l_run = 0.f;
   const float mc_fixed = p.m_fixed * c;
   // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
-  auto state_o = [&]() { return p.state + (size_t)(q0 + l31) * (p.H * 64) + h * 64 + 4 * hi; };
-  auto state_ml = [&]() { return p.state + (size_t)p.q_len * (p.H * 64) + (((size_t)(q0 + l31) * p.H + h) * 2 + hi) * 2; };
-  if (RANGE && (p.flags & 1) && q0 + l31 < p.q_len) {   // resume: accumulators of an earlier launch over other key tiles
+  auto state_base = [&]() { return part == 0 ? p.state : p.split_state + (size_t)(part - 1) * p.split_stride; };
+  auto state_o = [&]() { return state_base() + (size_t)(q0 + l31) * (p.H * 64) + h * 64 + 4 * hi; };
+  auto state_ml = [&]() { return state_base() + (size_t)p.q_len * (p.H * 64) + (((size_t)(q0 + l31) * p.H + h) * 2 + hi) * 2; };
+  if (RANGE && (p.flags & 1) && part == 0 && q0 + l31 < p.q_len) {   // resume: accumulators of an earlier launch over other key tiles
     const float* st_o = state_o(); const float* st_ml = state_ml();
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     l_run = st_ml[1];
   }
 
-  if (T > 0) { load_tile(0); store_tile(0); }
+  if (T > E0) { load_tile(E0); store_tile(0); }
   __syncthreads();
   // one key tile; BUF (LDS double-buffer half) is a compile-time constant so that every ds_read address is
   // lane_base + immediate (the loop below is unrolled by two): no per-tile address arithmetic on the VALU
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     if (e + 1 < T) store_tile(buf ^ 1);
     __syncthreads();
   };
-  for (int e = 0; e < T; e += 2) {
+  for (int e = E0; e < T; e += 2) {
     tile_step(std::integral_constant<int, 0>{}, e);
     if (e + 1 >= T) break;
     tile_step(std::integral_constant<int, 1>{}, e + 1);
@@ -261,6 +274,45 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   }
 }
 
+// Merge the per-part running states of the split jobs [job0, job0 + njobs) and write their normalised rows of O.
+// One workgroup per job, one thread per query: O = sum_s w_s O_s / sum_s w_s l_s,  w_s = exp2((m_s - max m) c)  (w_s = 1 when
+// the softmax offset is fixed).  State layout as written by attn_fwd_kernel: O^T accumulators [q][H*64] fp32 in natural d
+// order, then (m, l) per (q, h, half-lane) — l is the half-lane's partial sum, m is common to both halves.
+template <bool BOUNDED>
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, const float* split_state, long long split_stride,
+                                                         int splits, int job0, int H, int q_len, int nqb, float c, bf16_t* O, int ldo) {
+  const int job = job0 + blockIdx.x, h = job / nqb, qb = job % nqb;
+  const int q = qb * QB + threadIdx.x;
+  if (q >= q_len) return;
+  const size_t o_off = (size_t)q * (H * 64) + h * 64;
+  const size_t ml_off = (size_t)q_len * (H * 64) + ((size_t)q * H + h) * 4;
+  float w[8], m = -3.0e38f, l = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float* st = s == 0 ? state0 : split_state + (size_t)(s - 1) * split_stride;
+    w[s] = st[ml_off];                       // m_s for now
+    if (!BOUNDED) m = fmaxf(m, w[s]);
+  }
+  for (int s = 0; s < splits; ++s) {
+    const float* st = s == 0 ? state0 : split_state + (size_t)(s - 1) * split_stride;
+    w[s] = BOUNDED ? 1.f : __builtin_amdgcn_exp2f((w[s] - m) * c);
+    l += w[s] * (st[ml_off + 1] + st[ml_off + 3]);
+  }
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  bf16_t* op = O + (size_t)q * ldo + h * 64;
+#pragma unroll 4
+  for (int d = 0; d < 64; d += 4) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) {
+      const float* st = s == 0 ? state0 : split_state + (size_t)(s - 1) * split_stride;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(st + o_off + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += w[s] * v[e];
+    }
+    u32x2 o = {pack_bf16x2(a[0] * inv, a[1] * inv), pack_bf16x2(a[2] * inv, a[3] * inv)};
+    *reinterpret_cast<u32x2*>(op + d) = o;
+  }
+}
+
 }  // namespace
 
 // score_bound > 0: caller guarantees |q.k| <= score_bound for every pair (e.g. RMS-normalised q, k:
@@ -268,10 +320,32 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
 // whole row to zero, the kernel uses it as a fixed softmax offset and skips the online running max.
 size_t k5_attention_state_bytes(int H, int q_len) { return (size_t)q_len * H * (64 + 4) * sizeof(float); }
 
+// Workspace of the balanced launcher below: up to K5_ATTN_MAX_SPLITS - 1 extra states + (when the caller passes no state
+// of its own) one base state.
+constexpr int K5_ATTN_MAX_SPLITS = 4;
+size_t k5_attention_balance_bytes(int H, int q_len) { return (size_t)K5_ATTN_MAX_SPLITS * k5_attention_state_bytes(H, q_len); }
+
+namespace {
+int g_attn_slots = 0;   // concurrently resident attention workgroups on the device: 2 per CU (128 VGPRs x 8 waves)
+int attn_slots() {
+  if (!g_attn_slots) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 512;
+    g_attn_slots = 2 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+  }
+  return g_attn_slots;
+}
+}  // namespace
+
+// Dense attention over a key-tile range (see AttnP).  With a workspace `ws` (k5_attention_balance_bytes) and final output
+// requested (flags & 2 == 0), the launch is BALANCED: the jobs that fill whole rounds of the device's resident-workgroup
+// slots run as usual; the jobs of the last, partially filled round are split 2-4 ways along the key sequence into short
+// workgroups that fill the slots, and a merge kernel combines their states.  5208 jobs on 512 slots: 10.25 rounds instead
+// of 11; an 8-GPU shard's 672 jobs: 1.33 instead of 2.
 int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
-                                   int tile_skip_n, float* state, int flags, hipStream_t stream) {
+                                   int tile_skip_n, float* state, int flags, hipStream_t stream, float* ws) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -282,7 +356,7 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.c = 0.125f * 1.44269504088896340736f;
   p.m_fixed = 0.f;
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
-  const dim3 grid(H * p.nqb), block(512);
+  const dim3 block(512);
   // exponent range used: [-2*bound*c, 0]; fp32 exp2 flushes below -126 -> require 2*bound*c <= 96
   const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
   p.sp_list = nullptr; p.sp_cnt = nullptr; p.sp_stride = 0;
@@ -292,12 +366,35 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   if ((flags & 3) && !state) return K5_ERR_ARG;
   p.tile_off0 = tile_off0; p.tile_cnt = tile_cnt; p.tile_skip_at = tile_skip_at; p.tile_skip_n = tile_skip_n;
   p.state = state; p.flags = flags;
+  p.job0 = 0; p.splits = 1; p.split_state = nullptr; p.split_stride = 0;
   const bool range = tile_off0 != 0 || tile_cnt != total_tiles || (flags & 3);
   if (bounded) p.m_fixed = score_bound;
-  if (bounded && range) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), grid, block, 0, stream, p);
-  else if (bounded) hipLaunchKernelGGL((attn_fwd_kernel<true, false, false>), grid, block, 0, stream, p);
-  else if (range) hipLaunchKernelGGL((attn_fwd_kernel<false, false, true>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<false, false, false>), grid, block, 0, stream, p);
+  auto launch = [&](int njobs, bool use_range) {
+    const dim3 grid(njobs);
+    if (bounded && use_range) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), grid, block, 0, stream, p);
+    else if (bounded) hipLaunchKernelGGL((attn_fwd_kernel<true, false, false>), grid, block, 0, stream, p);
+    else if (use_range) hipLaunchKernelGGL((attn_fwd_kernel<false, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, false, false>), grid, block, 0, stream, p);
+  };
+  const int jobs = H * p.nqb, slots = attn_slots();
+  const int full = jobs / slots * slots, rem = jobs - full;
+  int S = rem > 0 ? slots / rem : 1;
+  if (S > K5_ATTN_MAX_SPLITS) S = K5_ATTN_MAX_SPLITS;
+  if (S > tile_cnt / 8) S = tile_cnt / 8;          // keep >= 8 key tiles per part
+  static const bool no_balance = getenv("K5_ATTN_NO_BALANCE") != nullptr;   // A/B switch for benchmarking
+  if (!ws || (flags & 2) || S < 2 || no_balance) {
+    launch(jobs, range);
+    return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+  }
+  if (full > 0) launch(full, range);
+  // tail jobs, S parts each: part 0 resumes the caller's state if there is one, every part leaves its state
+  const long long stride = (long long)(k5_attention_state_bytes(H, q_len) / sizeof(float));
+  float* base = (flags & 1) ? state : ws;
+  p.job0 = full; p.splits = S; p.state = base; p.split_state = ws + stride; p.split_stride = stride;
+  p.flags = (flags & 1) | 2;
+  launch(rem * S, true);
+  if (bounded) hipLaunchKernelGGL(attn_merge_kernel<true>, dim3(rem), dim3(256), 0, stream, base, ws + stride, stride, S, full, H, q_len, p.nqb, p.c, (bf16_t*)O, ldo);
+  else hipLaunchKernelGGL(attn_merge_kernel<false>, dim3(rem), dim3(256), 0, stream, base, ws + stride, stride, S, full, H, q_len, p.nqb, p.c, (bf16_t*)O, ldo);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -305,7 +402,7 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
                                      int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                      int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream) {
   return k5_launch_attention_bf16_range(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, score_bound, vt_chunk_keys,
-                                        vt_chunk_stride, 0, -1, 0x7fffffff, 0, nullptr, 0, stream);
+                                        vt_chunk_stride, 0, -1, 0x7fffffff, 0, nullptr, 0, stream, nullptr);
 }
 
 // NABLA block-sparse attention (flex_attention(q,k,v,block_mask) nn.py:257-280): `list`/`cnt` are the per-workgroup
@@ -325,6 +422,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   p.m_fixed = 0.f; p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride;
   p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;
+  p.job0 = 0; p.splits = 1; p.split_state = nullptr; p.split_stride = 0;
   const dim3 grid(H * p.nqb), block(512);
   const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
   if (bounded) {

@@ -176,6 +176,7 @@ struct k5_dit {
   Comm comm;
   int sp_rank = 0, sp_world = 1;
   DevBuf ws_q, ws_kfull, ws_vtfull, ws_attn_state;
+  DevBuf ws_attn_bal;                              // states of the split tail jobs (k5_launch_attention_bf16_range, balanced)
   hipStream_t comm_stream = nullptr;              // all-gathers run here, overlapped with pass 1 of the attention
   hipEvent_t ev_k = nullptr, ev_v = nullptr, ev_gathered = nullptr;
   // NABLA: fractal token permutation (cached per shape) and the selection workspace
@@ -358,8 +359,10 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     K5CHK(k5_launch_attention_bf16_sparse(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, list,
                                           cnt, nb, 0, 0, s));
   } else {
+    K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     Scope sc(d, s, fam_attn);
-    K5CHK(k5_launch_attention_bf16_bounded(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, s));
+    K5CHK(k5_launch_attention_bf16_range(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, 0, 0, 0, -1,
+                                         0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>()));
   }
   {
     Scope sc(d, s, "gemm");
@@ -437,6 +440,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     // then, once every chunk has arrived, to all the other chunks (pass 2, resumes the state and normalises).
     const int tpc = rows / 64, total = N / 64;
     K5CHK(d->ws_attn_state.ensure(k5_attention_state_bytes(H, rows)));
+    K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     {
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
@@ -446,7 +450,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     {
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
-                                           0, total - tpc, r * tpc, tpc, d->ws_attn_state.as<float>(), 1, s));
+                                           0, total - tpc, r * tpc, tpc, d->ws_attn_state.as<float>(), 1, s, d->ws_attn_bal.as<float>()));
     }
   }
   {
@@ -546,7 +550,7 @@ int prepare_text_rope(k5_dit* d, hipStream_t s, const k5_text_cond& c, const flo
   if (d->text_rope.size() >= 8) {
     HIPCHK(hipStreamSynchronize(s));
     for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release();
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release();
   if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
   for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
@@ -763,7 +767,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
                    &d->ws_vel_u};
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release();
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release();
   if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
   for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);

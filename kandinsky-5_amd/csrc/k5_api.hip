@@ -36,6 +36,15 @@ int k5_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* 
              "k5_attention_bf16_range");
 }
 
+int64_t k5_attention_balance_size(int H, int q_len) { return (int64_t)k5_attention_balance_bytes(H, q_len); }
+
+int k5_attention_bf16_balanced(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                               int ldk, int ldvt, int ldo, float score_bound, void* workspace, void* stream) {
+  if (!workspace) return ret(K5_ERR_ARG, "k5_attention_bf16_balanced");
+  return ret(k5_launch_attention_bf16_range(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, score_bound, 0, 0, 0, -1, 0x7fffffff, 0,
+                                            nullptr, 0, (hipStream_t)stream, (float*)workspace), "k5_attention_bf16_balanced");
+}
+
 int64_t k5_nabla_workspace_size(int H, int num_blocks) { return (int64_t)k5_nabla_workspace_bytes(H, num_blocks); }
 
 int k5_nabla_select_bf16(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,

@@ -28,7 +28,8 @@ size_t k5_attention_state_bytes(int H, int q_len);
 int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
-                                   int tile_skip_n, float* state, int flags, hipStream_t stream);
+                                   int tile_skip_n, float* state, int flags, hipStream_t stream, float* balance_ws = nullptr);
+size_t k5_attention_balance_bytes(int H, int q_len);
 
 // ---- NABLA (block-sparse) ----
 size_t k5_nabla_workspace_bytes(int H, int nb);

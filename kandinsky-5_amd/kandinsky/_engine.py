@@ -63,6 +63,8 @@ SYMBOLS = {
     "k5_attention_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k5_attention_state_size": (_I64, [_I, _I]),
     "k5_attention_bf16_range": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P, _I, _P]),
+    "k5_attention_balance_size": (_I64, [_I, _I]),
+    "k5_attention_bf16_balanced": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "k5_nabla_workspace_size": (_I64, [_I, _I]),
     "k5_nabla_select_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "k5_attention_nabla_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),

@@ -313,3 +313,27 @@ def test_attention_split_key_passes_equal_single_pass(E, Sq, Sk, split, bound):
     E.check(E.lib().k5_attention_bf16_range(*args, 0, total - n1, split, n1, state.data_ptr(), 1, E.stream_ptr()))
     assert_bf16_close(out, one.float().cpu(), ulps=2, atol=2e-3, what="two-pass attention")
     assert_bf16_close(out, attn_ref(q, k, v), ulps=4, atol=1e-2, what="two-pass attention vs oracle")
+
+
+@pytest.mark.parametrize("Sq,Sk,H,bound", [(47616 // 8, 47616, 28, 64 * 1.05), (5952, 8192, 28, None), (2600, 1500, 9, None),
+                                           (300, 640, 2, 64 * 1.05)])
+def test_attention_balanced_tail_split_equals_single_launch(E, Sq, Sk, H, bound):
+    """Jobs of the last, partially filled round are split along the keys and merged: same result as one launch up to
+    fp32 summation order (an 8-GPU shard's shape: 672 jobs on 512 slots -> 160 jobs split 3 ways)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    def rmsn(x):
+        return (x / x.pow(2).mean(-1, keepdim=True).sqrt())
+    q = rmsn(torch.randn(Sq, H, 64, device="cuda", generator=g)).reshape(Sq, -1).to(BF)
+    k = rmsn(torch.randn(Sk, H, 64, device="cuda", generator=g)).reshape(Sk, -1).to(BF)
+    ld = (Sk + 7) // 8 * 8
+    vt = torch.zeros(H * 64, ld, dtype=BF, device="cuda")
+    vt[:, :Sk] = torch.randn(H * 64, Sk, device="cuda", generator=g).to(BF)
+    one = E.attention(q, k, vt, H, kv_len=Sk, score_bound=bound)
+    L = E.lib()
+    ws = torch.empty(L.k5_attention_balance_size(H, Sq), dtype=torch.uint8, device="cuda")
+    out = torch.full((Sq, H * 64), float("nan"), dtype=BF, device="cuda")
+    E.check(L.k5_attention_bf16_balanced(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk, q.stride(0),
+                                         k.stride(0), vt.stride(0), out.stride(0), 0.0 if bound is None else bound,
+                                         ws.data_ptr(), E.stream_ptr()))
+    assert not torch.isnan(out.float()).any()
+    assert_bf16_close(out, one.float().cpu(), ulps=2, atol=2e-3, what="balanced attention")
