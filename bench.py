@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-for-`value`) VAE decode leg")
     ap.add_argument("--force-sp", action="store_true", help="debug: drive the sharded code path through a world=1 RCCL communicator")
+    ap.add_argument("--emulate-shard", type=int, default=0, metavar="P",
+                    help="debug only (INVALID as a bench): per-rank compute of a P-GPU run on one GPU, collectives move nothing")
     ap.add_argument("--blocks", type=int, default=32, help="debug only: fewer visual blocks => INVALID as a bench")
     args = ap.parse_args()
 
@@ -139,7 +141,9 @@ def main():
     with torch.device("meta"):
         dit = DiffusionTransformer3D(**cfgd)
     dit.init_synthetic(dev, seed=0)
-    if world > 1 or args.force_sp:
+    if args.emulate_shard > 1:
+        os.environ["K5_SP_EMULATE_WORLD"] = str(args.emulate_shard)
+    if world > 1 or args.force_sp or args.emulate_shard > 1:
         dit.enable_sequence_parallel(rank, world)
 
     g = torch.Generator(device=dev).manual_seed(6554)

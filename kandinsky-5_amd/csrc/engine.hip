@@ -981,6 +981,10 @@ extern "C" int k5_dit_comm_init(k5_dit* d, const char* rccl_lib_path, int rank, 
   if (r != ncclSuccess) { k5_set_error("ncclCommInitRank: %s", d->comm.GetErrorString(r)); return K5_ERR_HIP; }
   d->comm.rank = rank; d->comm.world = world;
   d->sp_rank = rank; d->sp_world = world;
+  // timing aid (bench.py --emulate-shard P, one GPU): lay the work out as rank 0 of a P-rank group while the communicator has
+  // one rank, i.e. the collectives move nothing and the other ranks' key chunks are never filled -> per-rank COMPUTE time of a
+  // P-GPU run; the numbers it produces are garbage
+  if (world == 1 && getenv("K5_SP_EMULATE_WORLD")) { const int e = atoi(getenv("K5_SP_EMULATE_WORLD")); if (e > 1) d->sp_world = e; }
   HIPCHK(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&d->ev_k, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&d->ev_v, hipEventDisableTiming));

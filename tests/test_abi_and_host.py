@@ -135,3 +135,21 @@ def test_magcache_ratio_table_matches_reference_goldens():
         assert np.array_equal(t, T[f"mag.{c['tag']}.table"].numpy()), c["tag"]
     assert np.array_equal(nearest_interp(np.arange(5.0), 1), np.array([4.0]))
     assert np.array_equal(nearest_interp(np.arange(5.0), 3), np.array([0.0, 2.0, 4.0]))
+
+
+def test_cli_keeps_the_reference_flags():
+    """kandinsky-5_amd/test.py: flags / defaults of the reference CLI (reference test.py:32-122) and its size check."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("k5_cli", os.path.join(ROOT, "kandinsky-5_amd", "test.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    a = cli.build_parser().parse_args([])
+    assert (a.config, a.prompt, a.width, a.height, a.video_duration, a.expand_prompt, a.sample_steps, a.guidance_weight,
+            a.scheduler_scale, a.output_filename, a.offload, a.magcache) == \
+        ("./configs/config_5s_sft.yaml", "a cat in a blue hat", 768, 512, 5, 1, None, None, 5.0, "./test.mp4", False, False)
+    a = cli.build_parser().parse_args(["--local-rank", "3", "--magcache", "--width", "512", "--height", "512"])
+    assert a.local_rank == 3 and a.magcache
+    cli.validate_args(a)
+    a.width, a.height = 768, 768
+    with pytest.raises(NotImplementedError):
+        cli.validate_args(a)

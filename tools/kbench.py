@@ -56,6 +56,21 @@ def bench_gemm():
         print(f"gemm {name:9s} M={m} N={n} K={k}: {ms:8.3f} ms  {2.0 * m * n * k / ms / 1e9:8.1f} TFLOP/s", flush=True)
 
 
+def bench_gemm_sp():
+    """the same projections on an 8-GPU / 4-GPU / 2-GPU token shard"""
+    for P in (8, 4, 2):
+        n = N // P
+        for (m, nn, k, epi, name) in ((n, D, D, E.EPI_BIAS, f"k/q P={P}"), (D, n, D, E.EPI_BIAS_M, f"v^T P={P}"),
+                                      (n, FF, D, E.EPI_GELU, f"ff1 P={P}"), (n, D, FF, E.EPI_GATE, f"ff2 P={P}")):
+            a, w = rnd(m, k), rnd(nn, k) * 0.05
+            bias = torch.randn(m if epi == E.EPI_BIAS_M else nn, device="cuda")
+            out = torch.empty(m, nn, dtype=BF, device="cuda")
+            resid = rnd(m, nn) if epi == E.EPI_GATE else None
+            gate = torch.randn(nn, device="cuda") if epi == E.EPI_GATE else None
+            ms = timeit(lambda: E.gemm(a, w, bias, epi, resid=resid, gate=gate, out=out), iters=10)
+            print(f"gemm {name:10s} M={m} N={nn} K={k}: {ms:8.3f} ms  {2.0 * m * nn * k / ms / 1e9:8.1f} TFLOP/s", flush=True)
+
+
 def bench_elem():
     x = rnd(N, D)
     sc, sh = torch.randn(D, device="cuda"), torch.randn(D, device="cuda")
@@ -77,6 +92,8 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), flush=True)
     if "attn" in which:
         bench_attn()
+    if "gemm_sp" in which:
+        bench_gemm_sp()
     if "gemm" in which:
         bench_gemm()
     if "elem" in which:
