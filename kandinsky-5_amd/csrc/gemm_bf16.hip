@@ -37,6 +37,59 @@ struct GemmP {
   unsigned long long* trace;  // -DK8_TRACE builds only
 };
 
+// four consecutive output columns n .. n+3 of token row m (v = fp32 accumulators)
+template <int EPI>
+K5_DEV void gemm_epilogue_quad(const GemmP& p, float (&v)[4], int m, int n, float bias_m) {
+  if (n >= p.N) return;
+  const bool full = (n + 3 < p.N);
+  if (EPI == K5_EPI_F32) {  // raw fp32 scores (VAE mid-block attention): C is float*
+    float* fp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (n + e < p.N) fp[e] = v[e] * p.alpha;
+    return;
+  }
+  if (EPI == K5_EPI_BIAS_M) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += bias_m;
+  } else if (p.bias) {
+    if (full) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += b[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
+    }
+  }
+  if (EPI == K5_EPI_GELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(bf_round(v[e]));
+  }
+  if (EPI == K5_EPI_GATE) {
+    const bf16_t* rp = p.resid + (size_t)m * p.ldr + n;
+    if (full && ((p.ldr & 3) == 0)) {  // one 8-B residual load + one 16-B gate load per 4 outputs
+      const u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(p.gate + n);
+      v[0] = __uint_as_float(rr[0] << 16) + gg[0] * bf_round(v[0]);
+      v[1] = __uint_as_float(rr[0] & 0xffff0000u) + gg[1] * bf_round(v[1]);
+      v[2] = __uint_as_float(rr[1] << 16) + gg[2] * bf_round(v[2]);
+      v[3] = __uint_as_float(rr[1] & 0xffff0000u) + gg[3] * bf_round(v[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < p.N) v[e] = bf2f(rp[e]) + p.gate[n + e] * bf_round(v[e]);
+    }
+  }
+  bf16_t* cp = p.C + (size_t)m * p.ldc + n;
+  if (full && ((p.ldc & 3) == 0)) {
+    u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(cp) = o;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = f2bf(v[e]);
+  }
+}
+
 // one 32x32 accumulator tile: this lane owns token row m and, per register group rg, the 4 consecutive
 // output columns n_base + 8 rg + 4 hi .. +3
 template <int EPI>
@@ -46,58 +99,10 @@ K5_DEV void gemm_epilogue_tile(const GemmP& p, const f32x16& acc, int m, int n_b
   if (EPI == K5_EPI_BIAS_M && p.bias) bias_m = p.bias[m];
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) {
-    const int n = n_base + 8 * rg + 4 * hi;
-    if (n >= p.N) continue;
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = acc[4 * rg + e];
-    const bool full = (n + 3 < p.N);
-    if (EPI == K5_EPI_F32) {  // raw fp32 scores (VAE mid-block attention): C is float*
-      float* fp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) if (n + e < p.N) fp[e] = v[e] * p.alpha;
-      continue;
-    }
-    if (EPI == K5_EPI_BIAS_M) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bias_m;
-    } else if (p.bias) {
-      if (full) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += b[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
-      }
-    }
-    if (EPI == K5_EPI_GELU) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_erf(bf_round(v[e]));
-    }
-    if (EPI == K5_EPI_GATE) {
-      const bf16_t* rp = p.resid + (size_t)m * p.ldr + n;
-      if (full && ((p.ldr & 3) == 0)) {  // one 8-B residual load + one 16-B gate load per 4 outputs
-        const u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
-        const f32x4 gg = *reinterpret_cast<const f32x4*>(p.gate + n);
-        v[0] = __uint_as_float(rr[0] << 16) + gg[0] * bf_round(v[0]);
-        v[1] = __uint_as_float(rr[0] & 0xffff0000u) + gg[1] * bf_round(v[1]);
-        v[2] = __uint_as_float(rr[1] << 16) + gg[2] * bf_round(v[2]);
-        v[3] = __uint_as_float(rr[1] & 0xffff0000u) + gg[3] * bf_round(v[3]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < p.N) v[e] = bf2f(rp[e]) + p.gate[n + e] * bf_round(v[e]);
-      }
-    }
-    bf16_t* cp = p.C + (size_t)m * p.ldc + n;
-    if (full && ((p.ldc & 3) == 0)) {
-      u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      *reinterpret_cast<u32x2*>(cp) = o;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = f2bf(v[e]);
-    }
+    gemm_epilogue_quad<EPI>(p, v, m, n_base + 8 * rg + 4 * hi, bias_m);
   }
 }
 
@@ -381,10 +386,9 @@ int launch_k3(GemmP p, hipStream_t stream) {
 // 256x256x64 tile, 8 waves in two groups of four (waves w and w+4 share a SIMD), ping-pong by one barrier: while one
 // group issues the 8 MFMAs of a phase the other issues its LDS fragment reads and its share of the next tiles'
 // global_load_lds — so each SIMD's matrix pipe always has a wave feeding it.  Per wave: 128 (n) x 64 (m) outputs =
-// 4 x 2 MFMA 32x32 tiles = 8 independent accumulators; a K-tile is four phases = its four 16-wide k-steps, each phase
-// one MFMA per accumulator and 4 + 2 fragment reads (measured on the first version of this kernel, which walked the
-// output quadrants instead: a phase with 12 reads per wave keeps the CU's LDS busy for ~390 cycles against ~300 cycles of
-// MFMA issue — the read phases must be balanced, LDS bandwidth is the co-limiter of this design).
+// 8 x 4 MFMA 16x16x32 tiles (this shape sustains 1962 TFLOP/s on random operands against 1695 for 32x32x16 —
+// tools/probes/mfma_peak.hip).  A K-tile (64) is four phases = (k-half, n-half): 16 MFMAs on 16 independent
+// accumulators and 8 / 4 / 8 / 4 fragment reads (the m-side fragments of a k-half are kept for its second phase).
 // Operand tiles are staged as k-halves: unit = 256 rows x 32 k = 16 KB, LDS row stride 64 B, 16-B chunk swizzle
 // c' = c ^ ((row >> 2) & 3) (16 consecutive rows x one chunk = all 64 banks once).  One unit (2 DMA instructions per
 // thread) is issued per phase, at least one K-tile before its first use:
@@ -461,15 +465,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
   // prologue of a tile: all of K-tile 0 (klo units first) and X-klo of K-tile 1
   auto prologue = [&]() { dma_w(0, 0, 0); dma_x(0, 0, 0); dma_x(0, 1, 0); dma_w(0, 1, 0); dma_x(1, 0, BK); };
 
-  // fragment read addresses: lane base (row, swizzled chunk) for the two k-steps of a unit; unit / tile offsets are immediates
-  const int sw = (l31 >> 2) & 3;
-  const char* wb[2]; const char* xb[2];
-#pragma unroll
-  for (int ksl = 0; ksl < 2; ++ksl) {
-    const int co = ((2 * ksl + hi) ^ sw) << 4;
-    wb[ksl] = dsm + (128 * wn + l31) * 64 + co;
-    xb[ksl] = dsm + K8_XOFF + (64 * wm + l31) * 64 + co;
-  }
+  // fragment read addresses (MFMA 16x16x32 operand: lane holds row lane&15, k-chunk lane>>4 of a 32-wide k-slab = one
+  // 64-B unit row): one lane base per operand, unit / tile offsets are immediates
+  const int l15 = lane & 15, lc = lane >> 4;
+  const int fco = (lc ^ ((l15 >> 2) & 3)) << 4;
+  const char* wb = dsm + (128 * wn + l15) * 64 + fco;
+  const char* xb = dsm + K8_XOFF + (64 * wm + l15) * 64 + fco;
   const int nk = p.K / BK;
 
 #ifdef K8_TRACE
@@ -483,14 +484,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
   int m0, n0;
   if (slot < x_cnt) { tile_origin(x_first + slot, m0, n0); set_offsets(m0, n0); prologue(); }
   for (int ti = slot; ti < x_cnt; ti += per_xcd) {
-    f32x16 acc[4][2];
+    f32x4 acc[8][4];   // [n-tile of 16][m-tile of 16]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8 wf[4], xf[2];
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wf[4], xf[4];
 
     // this tile's prologue DMAs were issued before the previous tile's epilogue stores (vmcnt also counts those stores,
     // which may retire out of order with loads -> a full drain here; the DMAs have had the whole epilogue to land)
@@ -498,16 +497,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0 from here on
 
-    // one phase = k-step KS of the K-tile in stage ST: fragment reads, this phase's DMA unit, barrier, 8 MFMAs, wait, barrier
-    auto phase = [&](auto STC, auto KSC, auto&& issue_dma) {
-      constexpr int st = decltype(STC)::value, ks = decltype(KSC)::value;
-      constexpr int uo = (2 * st + (ks >> 1)) * K8_UNIT;
+    // one phase = (k-half KH, n-half NH) of the K-tile in stage ST: fragment reads, this phase's DMA unit, barrier,
+    // 16 MFMAs, wait, barrier
+    auto phase = [&](auto STC, auto KHC, auto NHC, auto&& issue_dma) {
+      constexpr int st = decltype(STC)::value, kh = decltype(KHC)::value, nh = decltype(NHC)::value;
+      constexpr int uo = (2 * st + kh) * K8_UNIT;
       __builtin_amdgcn_sched_barrier(0);
       K8_STAMP();
+      if (nh == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb[ks & 1] + uo + j * 32 * 64);
+        for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + uo + j * 16 * 64);
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb[ks & 1] + uo + i * 32 * 64);
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + uo + (4 * nh + i) * 16 * 64);
       issue_dma();
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -515,9 +517,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(wf[i], xf[j], acc[i][j]);
+        for (int i = 0; i < 4; ++i)
+          acc[4 * nh + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[4 * nh + i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -527,10 +530,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
     auto ktile = [&](auto STC, int t) {
       constexpr int st = decltype(STC)::value;
       const int k1 = (t + 1) * BK, k2 = (t + 2) * BK;
-      phase(STC, std::integral_constant<int, 0>{}, [&] { dma_w(st ^ 1, 0, k1); });
-      phase(STC, std::integral_constant<int, 1>{}, [&] { dma_x(st ^ 1, 1, k1); });
-      phase(STC, std::integral_constant<int, 2>{}, [&] { dma_w(st ^ 1, 1, k1); });
-      phase(STC, std::integral_constant<int, 3>{}, [&] { dma_x(st, 0, k2); });
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+      phase(STC, I0{}, I0{}, [&] { dma_w(st ^ 1, 0, k1); });
+      phase(STC, I0{}, I1{}, [&] { dma_x(st ^ 1, 1, k1); });
+      phase(STC, I1{}, I0{}, [&] { dma_w(st ^ 1, 1, k1); });
+      phase(STC, I1{}, I1{}, [&] { dma_x(st, 0, k2); });
     };
     int t = 0;
     for (; t + 1 < nk; t += 2) {
@@ -553,13 +557,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
     // K loop (where it would push the accumulators into scratch)
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));
-    const int e_l31 = tid2 & 31, e_hi = (tid2 >> 5) & 1, e_wave = tid2 >> 6;
+    const int e_l15 = tid2 & 15, e_lc = (tid2 >> 4) & 3, e_wave = tid2 >> 6;
     const int e_wn = e_wave & 1, e_wm = ((e_wave >> 1) & 1) | ((e_wave >> 2) << 1);
+    // accumulator tile (i, j): this lane holds token row m = 16 j + lane&15 and output columns n = 16 i + 4 (lane>>4) + 0..3
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const int m = cm0 + 64 * e_wm + 16 * j + e_l15;
+      if (m >= p.M) continue;
+      float bias_m = 0.f;
+      if (EPI == K5_EPI_BIAS_M && p.bias) bias_m = p.bias[m];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        gemm_epilogue_tile<EPI>(p, acc[i][j], cm0 + 64 * e_wm + 32 * j + e_l31, cn0 + 128 * e_wn + 32 * i, e_hi);
+      for (int i = 0; i < 8; ++i) {
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        gemm_epilogue_quad<EPI>(p, v, m, cn0 + 128 * e_wn + 16 * i + 4 * e_lc, bias_m);
+      }
+    }
   }
 #undef K8_STAMP
 #ifdef K8_TRACE
