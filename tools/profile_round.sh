@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round profile: everything the numbers in bench.py / DESIGN.md are checked against.  Run on the GPU box from the repo root:
+#     tools/profile_round.sh r01
+# writes gpurun_out/prof_<tag>/... (scratch) and the summaries gpurun_out/<tag>_*.{md,json} to copy into profiles/.
+TAG=${1:-r01}
+export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT; cd /tmp
+# 1. kernel trace + stats of the bench command (no counters in this pass)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae > $OUT/${TAG}_bench_under_rocprof.log 2>&1
+# 2. HBM traffic counters, one per pass (2 visual blocks are enough: per-launch numbers)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-vae --blocks 2 > /dev/null 2>&1
+done
+# 3. issue / wait counters of the attention kernel
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_sq -o p -- python $R/tools/attn_only.py 2 > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_lds -o p -- python $R/tools/attn_only.py 2 > /dev/null 2>&1
+# 4. VAE decode kernel stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_vae -o vae -- python $R/tools/vae_bench.py > $OUT/${TAG}_vae_under_rocprof.log 2>&1
+cd $R
+python tools/profile_summarize.py $TAG

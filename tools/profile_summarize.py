@@ -1,0 +1,91 @@
+"""Summaries of tools/profile_round.sh for profiles/ (markdown + the traffic json bench.py reads)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1]
+OUT = "gpurun_out"
+
+
+def stats_md(src, dst, title, top=22):
+    files = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)
+    if not files:
+        print("no kernel stats in", src)
+        return None
+    rows = list(csv.DictReader(open(files[0])))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    with open(dst, "w") as f:
+        f.write(f"# {title}\n\nsource: `rocprofv3 --kernel-trace --stats --output-format csv`; total GPU kernel time {tot / 1e6:.1f} ms\n\n"
+                "| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
+        for r in rows[:top]:
+            name = r["Name"].replace("(anonymous namespace)::", "").replace("|", "/")
+            name = name if len(name) <= 96 else name[:93] + "..."
+            f.write(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+    return rows
+
+
+def counters(d, want=None):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    names = {}
+    for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fn)):
+            if want and r["Counter_Name"] not in want:
+                continue
+            acc[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+            names[r["Dispatch_Id"]] = r["Kernel_Name"]
+    return acc, names
+
+
+rows = stats_md(f"{OUT}/prof_{tag}", f"{OUT}/{tag}_bench_kernel_stats.md",
+                f"bench.py --steps 2 --warmup 1 (config_5s_nocfg, 1x MI355X): rocprofv3 kernel stats")
+stats_md(f"{OUT}/prof_{tag}_vae", f"{OUT}/{tag}_vae_kernel_stats.md", "HunyuanVideo VAE decode of one 5 s clip (tools/vae_bench.py): rocprofv3 kernel stats")
+
+# ---- HBM traffic per launch (FETCH_SIZE x2 on gfx950, KB units) ----
+traffic = {}
+per_kernel = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc, names = counters(f"{OUT}/pmc_{tag}_{c}", {c})
+    for d, v in acc.items():
+        per_kernel[names[d]][c].append(v[c])
+md = ["# HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 per MI355X_MICROARCH.md; KB -> MB)", "",
+      "| kernel | launches | fetch MB (x2) | write MB |", "|---|---:|---:|---:|"]
+attn_main = None
+for k, d in sorted(per_kernel.items(), key=lambda kv: -max(kv[1]["FETCH_SIZE"] or [0])):
+    if not any(t in k for t in ("attn_fwd", "attn_merge", "gemm_bf16", "ln_kernel", "rmsnorm")):
+        continue
+    f = max(d["FETCH_SIZE"]) if d["FETCH_SIZE"] else 0.0
+    w = max(d["WRITE_SIZE"]) if d["WRITE_SIZE"] else 0.0
+    short = k.replace("(anonymous namespace)::", "")[:80]
+    md.append(f"| `{short}` | {len(d['FETCH_SIZE'])} | {2 * f / 1024:.1f} | {w / 1024:.1f} |")
+    if "attn_fwd_kernel<true, false, false>" in k or (attn_main is None and "attn_fwd" in k):
+        attn_main = (k, f, w)
+open(f"{OUT}/{tag}_hbm_traffic.md", "w").write("\n".join(md) + "\n")
+if attn_main:
+    k, f, w = attn_main
+    N, H = 47616, 28
+    json.dump({"kernel": k.replace("(anonymous namespace)::", "")[:60], "tokens": N, "heads": H, "fetch_size_kb_raw": f,
+               "fetch_bytes_x2_gfx950": 2 * f * 1024, "write_bytes": w * 1024, "bytes_per_launch": 2 * f * 1024 + w * 1024,
+               "algorithmic_bytes": 4 * N * H * 64 * 2,
+               "source": "tools/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes), FETCH x2 per "
+                         "MI355X_MICROARCH.md; fabric-side counter: Infinity-Cache hits included"},
+              open(f"{OUT}/{tag}_attention_traffic.json", "w"))
+
+# ---- attention issue / wait counters ----
+md = ["# Attention kernel SQ counters (tools/attn_only.py: N = 47 616 tokens, 28 heads, N(0,1) data; last dispatch)", ""]
+for sub in ("sq", "lds"):
+    acc, names = counters(f"{OUT}/pmc_{tag}_{sub}")
+    sel = [d for d in acc if "attn_fwd" in names[d]]
+    if sel:
+        d = acc[sel[-1]]
+        md.append("`" + names[sel[-1]].replace("(anonymous namespace)::", "")[:70] + "`")
+        md += [f"* {k}: {v:.0f}" for k, v in sorted(d.items())]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d:
+            md.append(f"* MFMA instructions {d.get('SQ_INSTS_MFMA', 0):.0f}, VALU instructions {d.get('SQ_INSTS_VALU', 0):.0f} "
+                      f"(ratio {d.get('SQ_INSTS_VALU', 0) / max(d.get('SQ_INSTS_MFMA', 1), 1):.2f} VALU per MFMA)")
+        md.append("")
+open(f"{OUT}/{tag}_attention_pmc.md", "w").write("\n".join(md) + "\n")
+for fn in sorted(glob.glob(f"{OUT}/{tag}_*")):
+    print(fn, os.path.getsize(fn))
