@@ -60,10 +60,284 @@ struct AttnP {
   int job0, splits; float* split_state; long long split_stride;
 };
 
+// MFMA 16x16x32 bf16 (1962 TFLOP/s sustained on random operands vs 1695 for 32x32x16, tools/probes/mfma_peak.hip):
+//   A operand: lane l holds A[i = l&15][k = 8*(l>>4) + 0..7];  B operand: lane l holds B[k = 8*(l>>4) + 0..7][j = l&15]
+//   C/D: lane l, reg r holds D[i = 4*(l>>4) + r][j = l&15]
+K5_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// K tile swizzle.  The S^T MFMA reads, per 16-lane group, the permuted key rows {8a + b (+4, +32) : a, b in 0..3} at one
+// 16-B chunk: XOR the chunk with row bits (4,3,1) so that those 16 rows (x row&1) hit 16 distinct 16-B bank slots.
+K5_DEV int lds_swz_k(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 4); }
+
 // RANGE: key-tile sub-range + resumable fp32 state (sequence-parallel two-pass schedule); kept out of the plain dense
 // instantiation, whose loop is sensitive to every extra live value (128-VGPR budget for 2 workgroups per CU).
 template <bool BOUNDED, bool SPARSE, bool RANGE>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
+  char* sK = smem;
+  char* sV = smem + 2 * TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int gid = xcd_remap(blockIdx.x, gridDim.x);
+  const int part = RANGE ? gid % p.splits : 0;
+  const int lid = p.job0 + (RANGE ? gid / p.splits : gid);
+  const int h = lid / p.nqb, qb = lid % p.nqb;
+  const int q0 = qb * QB + wave * 32;   // this wave: queries q0 .. q0+31 = two 16-query MFMA tiles (qt = 0, 1)
+
+  // Q^T fragments (MFMA 16x16x32 B operand): lane (l15, g) holds Q[q0 + 16 qt + l15][32 ks + 8 g .. +8]
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const bf16_t* qp = p.Q + (size_t)min(q0 + 16 * qt + l15, p.q_len - 1) * p.ldq + h * 64 + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+  }
+  // loader mapping: 512 threads, one 16-B chunk of K and one of V^T each per tile
+  const int lrow = tid >> 3, lc = tid & 7;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // global addresses as uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset: two VGPRs instead of two pointers
+  const char* Kb = reinterpret_cast<const char*>(p.K);
+  const char* Vb = reinterpret_cast<const char*>(p.Vt);
+  // Tiles go global -> LDS by DMA (global_load_lds, 16 B per lane, wave w fills rows 8w..8w+7 = 1 KB): the LDS slot
+  // (lrow, lc) receives SOURCE chunk lc ^ swizzle(lrow), so position p of a row holds logical chunk p ^ swizzle(row)
+  const uint32_t kstride = (uint32_t)p.ldk * 2u;
+  const uint32_t klane = (uint32_t)(h * 64 + 8 * (lc ^ (((lrow >> 1) & 1) | (((lrow >> 3) & 3) << 1)))) * 2u;
+  const uint32_t vlane = ((uint32_t)(h * 64 + lrow) * (uint32_t)p.ldvt + 8u * (lc ^ ((lrow >> 1) & 7))) * 2u;
+  const uint32_t vlane_lin = ((uint32_t)(h * 64 + lrow) * (uint32_t)p.ldvt + 8u * lc) * 2u;   // ragged tile: register path
+  const int* sp_list = SPARSE ? p.sp_list + (size_t)(h * p.nqb + qb) * p.sp_stride : nullptr;
+  const int Tall = SPARSE ? p.sp_cnt[h * p.nqb + qb] : p.tile_cnt;
+  // this workgroup's share of the tile sequence: positions [E0, T)  (everything unless the job is split)
+  const int E0 = RANGE ? (int)(((long long)Tall * part) / p.splits) : 0;
+  const int T = RANGE ? (int)(((long long)Tall * (part + 1)) / p.splits) : Tall;
+  const int nfull = p.kv_len / KB;                    // key tiles with all 64 keys valid (NABLA: all of them)
+  auto tile_of = [&](int e) -> int {                  // sequence position -> 64-key tile index (wave-uniform)
+    if (SPARSE) return sp_list[e] & 0xffffff;
+    if (!RANGE) return e;
+    int t = e + p.tile_off0;
+    if (t >= p.tile_skip_at) t += p.tile_skip_n;
+    return t;
+  };
+  const int my_bit = 1 << (24 + (wave >> 1));         // this wave's 64-query block inside the 256-query workgroup
+  const int tiles_per_chunk = p.vt_chunk_keys > 0 ? p.vt_chunk_keys / KB : 0x7fffffff;
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef const __attribute__((address_space(1))) void gbl_void_t;
+  auto load_tile = [&](int e, int buf) {   // e = position in the tile sequence; tile t = tile_of(e) -> LDS buffer `buf`
+    const int t = tile_of(e);
+    const int kv0 = t * KB;
+    const char* vsrc = Vb + 2 * (long long)kv0;     // uniform
+    if (p.vt_chunk_keys > 0) {   // sequence-parallel V^T layout only (uniform branch): per-rank chunks
+      const int chunk = t / tiles_per_chunk;
+      vsrc = Vb + 2 * ((long long)chunk * p.vt_chunk_stride + (kv0 - chunk * tiles_per_chunk * KB));
+    }
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(Kb + ((uint32_t)min(kv0 + lrow, p.kv_len - 1) * kstride + klane)),
+                                     (lds_void_t*)(sK + buf * TILE + wave_u * 1024), 16, 0, 0);
+    if (SPARSE || t < nfull) {
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(vsrc + vlane), (lds_void_t*)(sV + buf * TILE + wave_u * 1024), 16, 0, 0);
+    } else {  // ragged last tile: never read past the padded row; zero the keys >= kv_len (P is exactly 0 there anyway)
+      const int rem = p.kv_len - (kv0 + 8 * lc);    // valid keys in this lane's 8-key chunk (<= 0: none)
+      u32x4 rv = {0u, 0u, 0u, 0u};
+      if (rem > 0) rv = *reinterpret_cast<const u32x4*>(vsrc + vlane_lin);   // the chunk lies inside the 8-padded row
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rv[j] = rem >= 2 * j + 2 ? rv[j] : (rem == 2 * j + 1 ? (rv[j] & 0xffffu) : 0u);
+      *reinterpret_cast<u32x4*>(sV + buf * TILE + lds_swz(lrow, lc)) = rv;
+    }
+  };
+  // K row permutation.  S^T tile kt (16 keys) row i of lane group g' = i>>2 must be the key that the P^T operand of the
+  // second MFMA wants in this lane: P^T (B operand, k = 32 keys) lane (query, g) holds keys 8g..8g+7 of the 32-key group,
+  // the accumulator lane (query, g) holds rows 4g..4g+3 of tiles 2ks2 and 2ks2+1 -> tile kt row i <-> key
+  // 32 (kt>>1) + 8 (i>>2) + 4 (kt&1) + (i&3): the two tiles' registers of a lane ARE its 8 consecutive keys.
+  const int krow = 8 * (l15 >> 2) + (l15 & 3);        // + 32 (kt>>1) + 4 (kt&1): immediates
+
+  f32x4 ot[4][2];   // O^T accumulators: [d tile of 16][query tile]: lane (l15, g) holds d = 16 dt + 4 g + r, query 16 qt + l15
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) ot[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float c = p.c;
+  float m_run[2] = {BOUNDED ? p.m_fixed : -1e30f, BOUNDED ? p.m_fixed : -1e30f}, l_run[2] = {0.f, 0.f};
+  const float mc_fixed = p.m_fixed * c;
+  // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
+  auto state_base = [&]() { return part == 0 ? p.state : p.split_state + (size_t)(part - 1) * p.split_stride; };
+  auto state_o = [&](int qt) { return state_base() + (size_t)(q0 + 16 * qt + l15) * (p.H * 64) + h * 64 + 4 * g; };
+  auto state_ml = [&](int qt) { return state_base() + (size_t)p.q_len * (p.H * 64) + (((size_t)(q0 + 16 * qt + l15) * p.H + h) * 4 + g) * 2; };
+  if (RANGE && (p.flags & 1) && part == 0) {   // resume: accumulators of an earlier launch over other key tiles
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+      if (q0 + 16 * qt + l15 < p.q_len) {
+        const float* st_o = state_o(qt); const float* st_ml = state_ml(qt);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ot[dt][qt] = *reinterpret_cast<const f32x4*>(st_o + 16 * dt);
+        if (!BOUNDED) m_run[qt] = st_ml[0];
+        l_run[qt] = st_ml[1];
+      }
+  }
+
+  if (T > E0) load_tile(E0, 0);
+  __syncthreads();   // drains the DMA (vmcnt) and publishes the tile
+  // one key tile; BUF (LDS double-buffer half) is a compile-time constant so that every ds_read address is
+  // lane_base + immediate (the loop below is unrolled by two): no per-tile address arithmetic on the VALU
+  auto tile_step = [&](auto BUFC, int e) {
+    constexpr int buf = decltype(BUFC)::value;
+    if (e + 1 < T) load_tile(e + 1, buf ^ 1);   // buffer buf^1 was last read before the barrier that ended tile e-1
+    const int t = tile_of(e);
+    const char* cK = sK + buf * TILE;
+    const char* cV = sV + buf * TILE;
+    if (!SPARSE || (sp_list[e] & my_bit)) {   // wave-uniform: skip kv blocks this query block did not select
+    if (!BOUNDED) {
+      // Online-max variant: the running max adds live state (m, m c per query tile + the rescale temporaries) that does not
+      // fit next to 64 accumulator + 16 Q registers under the 128-VGPR budget, so the two query tiles are processed one
+      // after the other (K / V^T fragments are read twice from LDS; the fixed-offset variant below reads them once).
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x4 st[4];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), g));
+          const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), 4 + g));
+          st[kt] = mfma16(k1, qf[qt][1], mfma16(k0, qf[qt][0], zero4));
+        }
+        if (!SPARSE && t >= nfull) {  // ragged last tile (wave-uniform branch)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (t * KB + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= p.kv_len) st[kt][r] = -1e30f;
+        }
+        float mt = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+#pragma unroll
+        for (int kt = 1; kt < 4; ++kt) mt = fmaxf(fmaxf(fmaxf(mt, st[kt][0]), fmaxf(st[kt][1], st[kt][2])), st[kt][3]);
+        // max over the four lanes (g = 0..3) that share this query: lanes l ^ 16 and l ^ 32
+        auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+        mt = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+        auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+        mt = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+        const float m_new = fmaxf(m_run[qt], mt);
+        if (__any(m_new > m_run[qt])) {   // rescale only when some row's max grew
+          const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c);
+          l_run[qt] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[dt][qt][r] *= alpha;
+          m_run[qt] = m_new;
+        }
+        const float mcq = m_run[qt] * c;
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          float ev[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            ev[j] = __builtin_amdgcn_exp2f(fmaf(st[2 * ks2 + (j >> 2)][j & 3], c, -mcq));
+            l_run[qt] += ev[j];
+          }
+          u32x4 pk = {pack_bf16x2(ev[0], ev[1]), pack_bf16x2(ev[2], ev[3]), pack_bf16x2(ev[4], ev[5]), pack_bf16x2(ev[6], ev[7])};
+          const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cV + lds_swz(16 * dt + l15, 4 * ks2 + g));
+            ot[dt][qt] = mfma16(vf, pf, ot[dt][qt]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the two passes sequential (their live ranges must not overlap)
+      }
+    } else {
+    // ---- S^T = K Q^T : four 16-key x two 16-query MFMA tiles, two k-steps over d; K fragments streamed from LDS ----
+    f32x4 st[4][2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {   // first k-step starts from the constant 0 (no accumulator initialisation moves)
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), g));
+      st[kt][0] = mfma16(kf, qf[0][0], zero4);
+      st[kt][1] = mfma16(kf, qf[1][0], zero4);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), 4 + g));
+      st[kt][0] = mfma16(kf, qf[0][1], st[kt][0]);
+      st[kt][1] = mfma16(kf, qf[1][1], st[kt][1]);
+    }
+    // lane (query l15 of tile qt, g): st[kt][qt][r] is key  t*64 + 32 (kt>>1) + 8 g + 4 (kt&1) + r
+    if (!SPARSE && t >= nfull) {  // ragged last tile (wave-uniform branch)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = t * KB + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r;
+          if (key >= p.kv_len) { st[kt][0][r] = -1e30f; st[kt][1][r] = -1e30f; }
+        }
+    }
+    const float mc[2] = {mc_fixed, mc_fixed};
+    // ---- P = exp2(S c - m c) -> bf16 fragments; O^T += V^T P^T (two k-steps of 32 keys), V^T fragments streamed ----
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        bf16x8 vf[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vf[dt] = *reinterpret_cast<const bf16x8*>(cV + lds_swz(16 * dt + l15, 4 * ks2 + g));
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {   // 8 exponentials, then the 4 MFMAs they feed: fine-grained VALU / MFMA interleave
+          float e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            e[j] = __builtin_amdgcn_exp2f(fmaf(st[2 * ks2 + (j >> 2)][qt][j & 3], c, -mc[qt]));
+            l_run[qt] += e[j];
+          }
+          u32x4 pk = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
+          const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) ot[dt][qt] = mfma16(vf[dt], pf, ot[dt][qt]);
+        }
+      }
+    }
+    }
+    __syncthreads();   // vmcnt(0) + barrier: tile e+1 has landed for every wave, tile e's buffer is free
+  };
+  for (int e = E0; e < T; e += 2) {
+    tile_step(std::integral_constant<int, 0>{}, e);
+    if (e + 1 >= T) break;
+    tile_step(std::integral_constant<int, 1>{}, e + 1);
+  }
+  if (RANGE && (p.flags & 2)) {   // leave the running state for a later launch; no output yet
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+      if (q0 + 16 * qt + l15 < p.q_len) {
+        float* st_o = state_o(qt); float* st_ml = state_ml(qt);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(st_o + 16 * dt) = ot[dt][qt];
+        st_ml[0] = m_run[qt]; st_ml[1] = l_run[qt];
+      }
+    return;
+  }
+
+  // ---- epilogue: normalise, store O[q][h*64 + d] ----
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l_tot = l_run[qt];   // sum of the four lanes' partial row sums
+    auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+    l_tot = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+    auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+    l_tot = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int q = q0 + 16 * qt + l15;
+    if (q < p.q_len) {
+      bf16_t* op = p.O + (size_t)q * p.ldo + h * 64 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        u32x2 o = {pack_bf16x2(ot[dt][qt][0] * inv, ot[dt][qt][1] * inv), pack_bf16x2(ot[dt][qt][2] * inv, ot[dt][qt][3] * inv)};
+        *reinterpret_cast<u32x2*>(op + 16 * dt) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA 32x32x16 formulation (one query per lane: S^T = K Q^T with key rows permuted so that the accumulator registers
+// of a lane are its P^T operand).  Used for the ONLINE-max instantiations only: with the running max the 16x16x32
+// formulation above has to take its two query tiles one after the other (register budget) and loses to this one
+// (832 vs 966 TFLOP/s on N(0,1) data); with the fixed softmax offset the 16x16x32 kernel wins (1095 vs 1032).
+// Register-staged tile loads (global -> VGPR -> LDS) as before.  State: slots 0,1 of the four (m, l) pairs per (q, h).
+// ---------------------------------------------------------------------------------------------
+template <bool BOUNDED, bool SPARSE, bool RANGE>
+__global__ __launch_bounds__(512, 4) void attn_fwd32_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
   char* sK = smem;
   char* sV = smem + 2 * TILE;
@@ -141,7 +415,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
   auto state_base = [&]() { return part == 0 ? p.state : p.split_state + (size_t)(part - 1) * p.split_stride; };
   auto state_o = [&]() { return state_base() + (size_t)(q0 + l31) * (p.H * 64) + h * 64 + 4 * hi; };
-  auto state_ml = [&]() { return state_base() + (size_t)p.q_len * (p.H * 64) + (((size_t)(q0 + l31) * p.H + h) * 2 + hi) * 2; };
+  auto state_ml = [&]() { return state_base() + (size_t)p.q_len * (p.H * 64) + (((size_t)(q0 + l31) * p.H + h) * 4 + hi) * 2; };
   if (RANGE && (p.flags & 1) && part == 0 && q0 + l31 < p.q_len) {   // resume: accumulators of an earlier launch over other key tiles
     const float* st_o = state_o(); const float* st_ml = state_ml();
 #pragma unroll
@@ -249,6 +523,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
           *reinterpret_cast<f32x4*>(st_o + 32 * d + 8 * rg) = v;
         }
       st_ml[0] = m_run; st_ml[1] = l_run;
+      st_ml[4] = m_run; st_ml[5] = 0.f;   // slots 2, 3 (the 16x16 kernel's lane groups): no contribution
     }
     return;
   }
@@ -277,7 +552,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
 // Merge the per-part running states of the split jobs [job0, job0 + njobs) and write their normalised rows of O.
 // One workgroup per job, one thread per query: O = sum_s w_s O_s / sum_s w_s l_s,  w_s = exp2((m_s - max m) c)  (w_s = 1 when
 // the softmax offset is fixed).  State layout as written by attn_fwd_kernel: O^T accumulators [q][H*64] fp32 in natural d
-// order, then (m, l) per (q, h, half-lane) — l is the half-lane's partial sum, m is common to both halves.
+// order, then (m, l) per (q, h, lane group g = 0..3) — l is that lane's partial sum, m is common to the four.
 template <bool BOUNDED>
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, const float* split_state, long long split_stride,
                                                          int splits, int job0, int H, int q_len, int nqb, float c, bf16_t* O, int ldo) {
@@ -285,7 +560,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
   const int q = qb * QB + threadIdx.x;
   if (q >= q_len) return;
   const size_t o_off = (size_t)q * (H * 64) + h * 64;
-  const size_t ml_off = (size_t)q_len * (H * 64) + ((size_t)q * H + h) * 4;
+  const size_t ml_off = (size_t)q_len * (H * 64) + ((size_t)q * H + h) * 8;
   float w[8], m = -3.0e38f, l = 0.f;
   for (int s = 0; s < splits; ++s) {
     const float* st = s == 0 ? state0 : split_state + (size_t)(s - 1) * split_stride;
@@ -295,7 +570,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
   for (int s = 0; s < splits; ++s) {
     const float* st = s == 0 ? state0 : split_state + (size_t)(s - 1) * split_stride;
     w[s] = BOUNDED ? 1.f : __builtin_amdgcn_exp2f((w[s] - m) * c);
-    l += w[s] * (st[ml_off + 1] + st[ml_off + 3]);
+    l += w[s] * ((st[ml_off + 1] + st[ml_off + 3]) + (st[ml_off + 5] + st[ml_off + 7]));
   }
   const float inv = l > 0.f ? 1.0f / l : 0.f;
   bf16_t* op = O + (size_t)q * ldo + h * 64;
@@ -318,7 +593,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
 // score_bound > 0: caller guarantees |q.k| <= score_bound for every pair (e.g. RMS-normalised q, k:
 // 64 * max|w_q| * max|w_k|).  If the bound is small enough that exp2 can neither overflow nor flush a
 // whole row to zero, the kernel uses it as a fixed softmax offset and skips the online running max.
-size_t k5_attention_state_bytes(int H, int q_len) { return (size_t)q_len * H * (64 + 4) * sizeof(float); }
+size_t k5_attention_state_bytes(int H, int q_len) { return (size_t)q_len * H * (64 + 8) * sizeof(float); }
 
 // Workspace of the balanced launcher below: up to K5_ATTN_MAX_SPLITS - 1 extra states + (when the caller passes no state
 // of its own) one base state.
@@ -373,8 +648,8 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
     const dim3 grid(njobs);
     if (bounded && use_range) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), grid, block, 0, stream, p);
     else if (bounded) hipLaunchKernelGGL((attn_fwd_kernel<true, false, false>), grid, block, 0, stream, p);
-    else if (use_range) hipLaunchKernelGGL((attn_fwd_kernel<false, false, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<false, false, false>), grid, block, 0, stream, p);
+    else if (use_range) hipLaunchKernelGGL((attn_fwd32_kernel<false, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd32_kernel<false, false, false>), grid, block, 0, stream, p);
   };
   const int jobs = H * p.nqb, slots = attn_slots();
   const int full = jobs / slots * slots, rem = jobs - full;
@@ -429,7 +704,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
     p.m_fixed = score_bound;
     hipLaunchKernelGGL((attn_fwd_kernel<true, true, false>), grid, block, 0, stream, p);
   } else {
-    hipLaunchKernelGGL((attn_fwd_kernel<false, true, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((attn_fwd32_kernel<false, true, false>), grid, block, 0, stream, p);
   }
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }

@@ -8,6 +8,20 @@ BF = torch.bfloat16
 q, k = torch.randn(N, H * 64, device="cuda").to(BF), torch.randn(N, H * 64, device="cuda").to(BF)
 vt = torch.randn(H * 64, N, device="cuda").to(BF)
 o = torch.empty(N, H * 64, dtype=BF, device="cuda")
+bound = None
+if os.environ.get("BOUNDED"):   # RMS-normalised heads, as after norm_qk: |q.k| <= 64
+    def rmsn(x):
+        x = x.float().reshape(N, H, 64)
+        return (x / x.pow(2).mean(-1, keepdim=True).sqrt()).reshape(N, H * 64).to(BF)
+    q, k, bound = rmsn(q), rmsn(k), 64 * 1.05
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
-    E.attention(q, k, vt, H, out=o)
+    E.attention(q, k, vt, H, out=o, score_bound=bound)
 torch.cuda.synchronize()
+if os.environ.get("TIME"):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        E.attention(q, k, vt, H, out=o, score_bound=bound)
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 5
+    print(f"attention N={N} bounded={bound is not None}: {ms:.3f} ms  {4.0 * N * N * 64 * H / ms / 1e9:.1f} TFLOP/s")
