@@ -43,6 +43,41 @@ rows = stats_md(f"{OUT}/prof_{tag}", f"{OUT}/{tag}_bench_kernel_stats.md",
                 f"bench.py --steps 2 --warmup 1 (config_5s_nocfg, 1x MI355X): rocprofv3 kernel stats")
 stats_md(f"{OUT}/prof_{tag}_vae", f"{OUT}/{tag}_vae_kernel_stats.md", "HunyuanVideo VAE decode of one 5 s clip (tools/vae_bench.py): rocprofv3 kernel stats")
 
+# ---- self-attention of one block from the kernel trace: the three launches bench.py's roofline sums ----
+def attention_block_md():
+    files = glob.glob(f"{OUT}/prof_{tag}/**/*kernel_trace.csv", recursive=True)
+    if not files:
+        return
+    groups = collections.defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        n = r["Kernel_Name"]
+        if "attn_fwd" in n or "attn_merge" in n:
+            key = (n.replace("(anonymous namespace)::", "")[:64], int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1))
+            groups[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    lines = ["", "## Attention launches by grid (kernel trace of the same run)", "",
+             "| kernel | workgroups | launches | avg us | role |", "|---|---:|---:|---:|---|"]
+    block_us = 0.0
+    for (name, wgs), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+        avg = sum(v) / len(v)
+        role = ""
+        if wgs == 5120:
+            role = "self-attention, 5120 whole-round jobs"; block_us += avg
+        elif "merge" in name:
+            role = "merge of the split tail jobs"; block_us += avg
+        elif wgs in (352, 264, 176):
+            role = "self-attention, 88 tail jobs x parts"; block_us += avg
+        elif wgs == 5208:
+            role = "cross-attention (N queries x 256 text keys) / unbalanced launch"
+        lines.append(f"| `{name}` | {wgs} | {len(v)} | {avg:.1f} | {role} |")
+    lines.append("")
+    lines.append(f"Self-attention of one block = {block_us / 1e3:.2f} ms (sum of the three rows above) -> "
+                 f"{4.0 * 47616 * 47616 * 64 * 28 / (block_us * 1e-6) / 1e12:.0f} TFLOP/s; bench.py's `roofline.avg_launch_ms` is the HIP-event "
+                 "time of the same three launches.")
+    open(f"{OUT}/{tag}_bench_kernel_stats.md", "a").write("\n".join(lines) + "\n")
+
+
+attention_block_md()
+
 # ---- HBM traffic per launch (FETCH_SIZE x2 on gfx950, KB units) ----
 traffic = {}
 per_kernel = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
