@@ -34,6 +34,9 @@ struct GemmP {
   int tiles_m, tiles_n;
   float alpha;            // EPI_F32: C_f32 = alpha * acc
   int dbg;                // benchmarking experiments only (K5_GEMM_DBG); 0 in production
+  // 256x256 kernel: logical tiles [0, lid_limit) only.  128x128 kernel in tail mode (tail_base >= 0): workgroup b computes
+  // quadrant b & 3 of the 256x256 logical tile tail_base + b / 4 (tiles256_m/n = that grid's extent).
+  int lid_limit, tail_base, tiles256_m, tiles256_n;
   unsigned long long* trace;  // -DK8_TRACE builds only
 };
 
@@ -232,7 +235,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmP p) {
   const int gsz = min(p.tiles_m - first_m, GM);
   const int tm = first_m + (lid % per_group) % gsz;
   const int tn = (lid % per_group) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
+  int m0 = tm * BM, n0 = tn * BN;
+  if (p.tail_base >= 0) {   // quadrant of a 256x256 logical tile left over by the persistent kernel's whole rounds
+    const int plid = p.tail_base + (int)(blockIdx.x >> 2), q = blockIdx.x & 3;
+    const int pg = plid / (4 * p.tiles256_n), pfirst = pg * 4, pgsz = min(p.tiles256_m - pfirst, 4);
+    m0 = (pfirst + (plid % (4 * p.tiles256_n)) % pgsz) * 256 + 128 * (q >> 1);
+    n0 = ((plid % (4 * p.tiles256_n)) / pgsz) * 256 + 128 * (q & 1);
+    if (m0 >= p.M || n0 >= p.N) return;
+  }
 
   // this wave stages pieces wave*4 .. wave*4+3 (8 rows x 128 B each) of both operand tiles
   const bf16_t* ga[4]; const bf16_t* gw[4];
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
 
   // Persistent workgroups (one per CU): XCD x = blockIdx % 8 owns a contiguous range of logical tiles, its (up to 32)
   // workgroups walk it interleaved, so the tiles in flight on one XCD are neighbours (shared operand panels in its L2).
-  const int nblk = p.tiles_m * p.tiles_n;
+  const int nblk = p.lid_limit;   // logical tiles of this launch (the rest, if any, goes to the 128x128 kernel)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7 - xcd) >> 3;   // workgroups on this XCD
   const int q8 = nblk >> 3, r8 = nblk & 7;
   const int x_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, x_cnt = q8 + (xcd < r8 ? 1 : 0);
@@ -596,11 +606,25 @@ int launch_k8(GemmP p, hipStream_t stream) {
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   static const bool full_grid = getenv("K5_GEMM_FULLGRID") != nullptr;   // A/B: one workgroup per tile instead of per CU
-  const int grid = full_grid ? p.tiles_m * p.tiles_n : min(p.tiles_m * p.tiles_n, num_cu);   // persistent: one workgroup per CU (128 KB of LDS each)
+  const int tiles = p.tiles_m * p.tiles_n;
+  // Whole rounds of num_cu tiles go to the persistent kernel; a last round that would fill less than half of the CUs is
+  // computed as 128x128 quadrants by the small kernel instead (1302 tiles of an N = 1792 projection: 5 rounds + 88 small
+  // workgroups instead of 6 rounds).
+  static const bool no_tail = getenv("K5_GEMM_NO_TAIL") != nullptr;   // A/B switch for benchmarking
+  const int full = tiles / num_cu * num_cu, rem = tiles - full;
+  const bool split_tail = !no_tail && !full_grid && full > 0 && rem > 0 && 2 * rem < num_cu;
+  p.lid_limit = split_tail ? full : tiles;
+  p.tiles256_m = p.tiles_m; p.tiles256_n = p.tiles_n;
+  const int grid = full_grid ? tiles : min(p.lid_limit, num_cu);   // persistent: one workgroup per CU (128 KB of LDS each)
 #ifdef K8_TRACE
   p.trace = getenv("K5_GEMM_TRACE") ? (unsigned long long*)strtoull(getenv("K5_GEMM_TRACE"), nullptr, 16) : nullptr;
 #endif
   hipLaunchKernelGGL(gemm_bf16_k8_kernel<EPI>, dim3(grid), dim3(512), K8_LDS + K8_TRACE_BYTES, stream, p);
+  if (split_tail) {
+    p.tail_base = full;
+    p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL(gemm_bf16_glds_kernel<EPI>, dim3(4 * rem), dim3(256), 0, stream, p);
+  }
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -618,7 +642,7 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   p.resid = (const bf16_t*)resid; p.gate = gate;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
-  p.alpha = 1.f; p.trace = nullptr;
+  p.alpha = 1.f; p.trace = nullptr; p.lid_limit = 0; p.tail_base = -1; p.tiles256_m = p.tiles256_n = 0;
   static const int dbg = getenv("K5_GEMM_DBG") ? atoi(getenv("K5_GEMM_DBG")) : 0;
   p.dbg = dbg;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
@@ -671,7 +695,7 @@ int k5_launch_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, in
   if ((K & 7) || (lda & 7) || (ldw & 7)) return K5_ERR_ALIGN;
   GemmP p;
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = (bf16_t*)C; p.bias = nullptr; p.resid = nullptr; p.gate = nullptr;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.alpha = alpha; p.dbg = 0; p.trace = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.alpha = alpha; p.dbg = 0; p.trace = nullptr; p.lid_limit = 0; p.tail_base = -1; p.tiles256_m = p.tiles256_n = 0;
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
   if ((K % BK) == 0) hipLaunchKernelGGL(gemm_bf16_glds_kernel<K5_EPI_F32>, grid, block, 0, stream, p);

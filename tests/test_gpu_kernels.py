@@ -66,6 +66,24 @@ def test_gemm_256_tile_kernel_is_race_free_and_deterministic(E):
         assert_bf16_close(first, ref, what=f"k8 gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("epi", ["bias", "gate"])
+def test_gemm_tail_round_as_128_quadrants(E, epi):
+    """More 256x256 tiles than CUs with a small remainder (264 = 256 + 8): the persistent kernel takes the whole round, the
+    8 leftover tiles are computed as 32 quadrants by the 128x128 kernel; incl. a ragged edge (M, N not multiples of 256)."""
+    M, N, K = 33 * 256 - 40, 8 * 256 - 24, 128
+    a, w = bfr(rnd(M, K, seed=21)), bfr(rnd(N, K, seed=22, scale=0.05))
+    b = bfr(rnd(N, seed=23, scale=0.1))
+    if epi == "bias":
+        ref = bfr(a @ w.t() + b)
+        got = E.gemm(a.cuda().to(BF), w.cuda().to(BF), b.cuda(), E.EPI_BIAS)
+    else:
+        resid, gate = bfr(rnd(M, N, seed=24)), rnd(N, seed=25)
+        ref = bfr(resid + gate * bfr(a @ w.t() + b))
+        r = resid.cuda().to(BF)
+        got = E.gemm(a.cuda().to(BF), w.cuda().to(BF), b.cuda(), E.EPI_GATE, resid=r, gate=gate.cuda(), out=r)
+    assert_bf16_close(got, ref, ulps=3, what=f"tail-split gemm {epi}")
+
+
 def test_gemm_is_transpose_correct(E):
     """A = I with an asymmetric W catches any row/col swap in the MFMA C/D mapping (guide rule 16)."""
     n = 256
