@@ -182,65 +182,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     const char* cK = sK + buf * TILE;
     const char* cV = sV + buf * TILE;
     if (!SPARSE || (sp_list[e] & my_bit)) {   // wave-uniform: skip kv blocks this query block did not select
-    if (!BOUNDED) {
-      // Online-max variant: the running max adds live state (m, m c per query tile + the rescale temporaries) that does not
-      // fit next to 64 accumulator + 16 Q registers under the 128-VGPR budget, so the two query tiles are processed one
-      // after the other (K / V^T fragments are read twice from LDS; the fixed-offset variant below reads them once).
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        f32x4 st[4];
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-          const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), g));
-          const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), 4 + g));
-          st[kt] = mfma16(k1, qf[qt][1], mfma16(k0, qf[qt][0], zero4));
-        }
-        if (!SPARSE && t >= nfull) {  // ragged last tile (wave-uniform branch)
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (t * KB + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= p.kv_len) st[kt][r] = -1e30f;
-        }
-        float mt = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
-#pragma unroll
-        for (int kt = 1; kt < 4; ++kt) mt = fmaxf(fmaxf(fmaxf(mt, st[kt][0]), fmaxf(st[kt][1], st[kt][2])), st[kt][3]);
-        // max over the four lanes (g = 0..3) that share this query: lanes l ^ 16 and l ^ 32
-        auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-        mt = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
-        auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-        mt = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
-        const float m_new = fmaxf(m_run[qt], mt);
-        if (__any(m_new > m_run[qt])) {   // rescale only when some row's max grew
-          const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c);
-          l_run[qt] *= alpha;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ot[dt][qt][r] *= alpha;
-          m_run[qt] = m_new;
-        }
-        const float mcq = m_run[qt] * c;
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-          float ev[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            ev[j] = __builtin_amdgcn_exp2f(fmaf(st[2 * ks2 + (j >> 2)][j & 3], c, -mcq));
-            l_run[qt] += ev[j];
-          }
-          u32x4 pk = {pack_bf16x2(ev[0], ev[1]), pack_bf16x2(ev[2], ev[3]), pack_bf16x2(ev[4], ev[5]), pack_bf16x2(ev[6], ev[7])};
-          const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cV + lds_swz(16 * dt + l15, 4 * ks2 + g));
-            ot[dt][qt] = mfma16(vf, pf, ot[dt][qt]);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the two passes sequential (their live ranges must not overlap)
-      }
-    } else {
+    static_assert(BOUNDED, "the 16x16x32 formulation is instantiated for the fixed softmax offset only (attn_fwd32_kernel has the online max)");
+    {
     // ---- S^T = K Q^T : four 16-key x two 16-query MFMA tiles, two k-steps over d; K fragments streamed from LDS ----
     f32x4 st[4][2];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
