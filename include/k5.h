@@ -232,6 +232,11 @@ int k5_vae_decode_tile(k5_vae* vae, const float* z, int T, int H, int W, void* o
  * b[:, y, :] = a[:, len_a-extent+y, :]*(1-y/extent) + b[:, y, :]*(y/extent), y < extent (eager bf16 rounding) */
 int k5_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, void* stream);
 
+/* k5_sample replays ONE hipGraph-captured sampler step (forwards + CFG/Euler, per-step scalars read from device tables at a
+ * device-side step counter) instead of launching ~500 kernels per step from the host; results are bit-identical.  Ignored
+ * while MagCache or profiling is on, and for fewer than 3 steps. */
+int k5_dit_set_graph(k5_dit* dit, int enabled);
+
 /* MagCache — replaces `set_magcache_params` + `magcache_forward` (reference kandinsky/magcache_utils.py:16-101).
  * `ratio_table` holds 2*num_steps float64 ratios (cond/uncond interleaved, already extended by the two leading 1.0 and
  * nearest-interpolated as :29-39 does — the host mirror kandinsky/magcache_utils.py does that); table_len == 0

@@ -176,6 +176,10 @@ struct k5_dit {
   Comm comm;
   int sp_rank = 0, sp_world = 1;
   DevBuf ws_q, ws_kfull, ws_vtfull, ws_attn_state;
+  DevBuf ws_sched;                                 // sampler tables on the device: t*1000 [steps] | dt [steps] | step counter
+  bool use_graph = false;                          // k5_sample replays one captured step (k5_dit_set_graph)
+  hipStream_t graph_stream = nullptr;              // capture needs a real stream: the caller's may be the legacy null stream
+  hipEvent_t ev_graph = nullptr;
   DevBuf ws_attn_bal;                              // states of the split tail jobs (k5_launch_attention_bf16_range, balanced)
   hipStream_t comm_stream = nullptr;              // all-gathers run here, overlapped with pass 1 of the attention
   hipEvent_t ev_k = nullptr, ev_v = nullptr, ev_gathered = nullptr;
@@ -550,10 +554,6 @@ int prepare_text_rope(k5_dit* d, hipStream_t s, const k5_text_cond& c, const flo
   if (d->text_rope.size() >= 8) {
     HIPCHK(hipStreamSynchronize(s));
     for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release();
-  if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
-  for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
-  if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
     d->text_rope.clear();
   }
   d->text_rope.emplace_back();
@@ -579,7 +579,7 @@ int to_bf16(k5_dit* d, hipStream_t s, const void* src, int dtype, size_t n, DevB
 }
 
 int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, float time, const float* x,
-                 int x_channels, void* out_velocity, hipStream_t s) {
+                 int x_channels, void* out_velocity, hipStream_t s, const float* tvec = nullptr, const int* step = nullptr) {
   const k5_dit_config& c = d->cfg;
   if (!d->finalized) { k5_set_error("k5_dit_forward before k5_dit_finalize"); return K5_ERR_STATE; }
   if (a->attention_type != 0 && a->attention_type != 1) { k5_set_error("attention_type must be 0 (flash) or 1 (nabla)"); return K5_ERR_ARG; }
@@ -639,7 +639,7 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
                               c.in_text_dim2, c.in_text_dim2, d->TD, K5_EPI_BIAS, nullptr, 0, nullptr, s));
     K5CHK(k5_launch_ln_affine(d->ws_pool_lin.p, d->pool_lnw.as<float>(), d->pool_lnb.as<float>(), nullptr,
                               d->ws_pool_f32.as<float>(), 1, d->TD, s));
-    K5CHK(k5_launch_time_features(time, d->ws_tfeat.as<float>(), D, s));
+    K5CHK(k5_launch_time_features(time, d->ws_tfeat.as<float>(), D, s, tvec, step));
     K5CHK(k5_launch_gemv_f32(d->ws_tfeat.as<float>(), d->time_w1.as<float>(), d->time_b1.as<float>(), d->ws_th1.as<float>(),
                              d->TD, D, 0, nullptr, s));
     K5CHK(k5_launch_gemv_f32(d->ws_th1.as<float>(), d->time_w2.as<float>(), d->time_b2.as<float>(), d->ws_temb.as<float>(),
@@ -767,7 +767,8 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
                    &d->ws_vel_u};
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release();
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_sched.release();
+  if (d->graph_stream) { (void)hipStreamSynchronize(d->graph_stream); (void)hipStreamDestroy(d->graph_stream); (void)hipEventDestroy(d->ev_graph); }
   if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
   for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
@@ -941,18 +942,70 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
   K5CHK(d->ws_vel_c.ensure(n * 2));
   const bool cfg_on = fabsf(a->guidance_weight - 1.0f) > 1e-6f;  // generation_utils.py:63
   if (cfg_on) K5CHK(d->ws_vel_u.ensure(n * 2));
+  // hipGraph mode (BASELINE config 5 "hipGraph-captured step"): the per-step scalars live in device tables indexed by a
+  // device-side step counter, so ONE captured step (forward(s) + CFG/Euler + counter increment) replays for every step.
+  // Step 0 runs eagerly (it sizes every workspace and fills the RoPE / permutation caches), step 1 is captured, steps 1..
+  // are launches of the instantiated graph.  Not with MagCache (its skip pattern changes the launch sequence per step)
+  // or while profiling (events).
+  const bool graph = d->use_graph && !d->mag.on && !d->profiling && a->num_steps > 2;
+  std::vector<float> host_tab(2 * (size_t)a->num_steps);
   for (int i = 0; i < a->num_steps; ++i) {
-    const float t1000 = a->sigmas[i] * 1000.0f;          // t * 1000, fp32 (:57)
-    const float dt = a->sigmas[i + 1] - a->sigmas[i];    // torch.diff(timesteps) (:105)
-    K5CHK(forward_impl(d, &a->fwd, a->fwd.cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_c.p, s));
-    if (cfg_on) K5CHK(forward_impl(d, &a->fwd, a->null_cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_u.p, s));
+    host_tab[i] = a->sigmas[i] * 1000.0f;                        // t * 1000, fp32 (:57)
+    host_tab[a->num_steps + i] = a->sigmas[i + 1] - a->sigmas[i];  // torch.diff(timesteps) (:105)
+  }
+  const float* tvec = nullptr; const float* dtvec = nullptr; int* step = nullptr;
+  hipStream_t caller = s;
+  if (graph) {
+    if (!d->graph_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&d->graph_stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&d->ev_graph, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(d->ev_graph, caller));          // everything the caller enqueued so far happens before the sampler
+    s = d->graph_stream;
+    HIPCHK(hipStreamWaitEvent(s, d->ev_graph, 0));
+    K5CHK(d->ws_sched.ensure(host_tab.size() * 4 + 16));
+    HIPCHK(hipMemcpyAsync(d->ws_sched.p, host_tab.data(), host_tab.size() * 4, hipMemcpyHostToDevice, s));
+    step = reinterpret_cast<int*>(d->ws_sched.as<float>() + host_tab.size());
+    HIPCHK(hipMemsetAsync(step, 0, 4, s));
+    HIPCHK(hipStreamSynchronize(s));   // host_tab is a local
+    tvec = d->ws_sched.as<float>(); dtvec = tvec + a->num_steps;
+  }
+  auto one_step = [&](int i) -> int {
+    const float t1000 = host_tab[i], dt = host_tab[a->num_steps + i];
+    K5CHK(forward_impl(d, &a->fwd, a->fwd.cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_c.p, s, tvec, step));
+    if (cfg_on) K5CHK(forward_impl(d, &a->fwd, a->null_cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_u.p, s, tvec, step));
     {
       Scope sc(d, s, "elementwise");
-      K5CHK(k5_launch_cfg_euler(a->latent, d->ws_vel_c.p, cfg_on ? d->ws_vel_u.p : nullptr, a->guidance_weight, dt, n, s));
+      K5CHK(k5_launch_cfg_euler(a->latent, d->ws_vel_c.p, cfg_on ? d->ws_vel_u.p : nullptr, a->guidance_weight, dt, n, s, dtvec, step));
     }
+    if (step) K5CHK(k5_launch_step_inc(step, s));
+    return K5_OK;
+  };
+  if (!graph) {
+    for (int i = 0; i < a->num_steps; ++i) K5CHK(one_step(i));
+    return K5_OK;
   }
-  return K5_OK;
+  K5CHK(one_step(0));
+  hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+  HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  const int rc = one_step(1);
+  const hipError_t ec = hipStreamEndCapture(s, &g);
+  if (rc != K5_OK || ec != hipSuccess || !g) {
+    if (g) (void)hipGraphDestroy(g);
+    if (rc == K5_OK) k5_set_error("hipStreamEndCapture: %s", hipGetErrorString(ec));
+    return rc != K5_OK ? rc : K5_ERR_HIP;
+  }
+  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); k5_set_error("hipGraphInstantiate failed"); return K5_ERR_HIP; }
+  int status = K5_OK;
+  for (int i = 1; i < a->num_steps && status == K5_OK; ++i)
+    if (hipGraphLaunch(ge, s) != hipSuccess) { k5_set_error("hipGraphLaunch failed"); status = K5_ERR_HIP; }
+  (void)hipStreamSynchronize(s);   // the executable graph must outlive its launches (this also orders the caller's stream after us)
+  (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+  (void)caller;
+  return status;
 }
+
+extern "C" int k5_dit_set_graph(k5_dit* d, int enabled) { if (!d) return K5_ERR_ARG; d->use_graph = enabled != 0; return K5_OK; }
 
 // ---------------------------------------------------------------------------------------------
 // C ABI: sequence parallelism over RCCL

@@ -63,7 +63,9 @@ int k5_launch_gate_sum(const void* x, const void* y, const float* gate, void* ou
 int k5_launch_gemv_f32(const float* x, const float* W, const float* b, float* y, int N, int K, int silu_in,
                        const float* add, hipStream_t stream);
 // sinusoidal time features (K12): out[0..D/2) = cos(t f_i), out[D/2..D) = sin(t f_i)
-int k5_launch_time_features(float t, float* out, int D, hipStream_t stream);
+// tvec/step (both or neither): read the time from tvec[*step] on the device (hipGraph-replayable sampler step)
+int k5_launch_time_features(float t, float* out, int D, hipStream_t stream, const float* tvec = nullptr, const int* step = nullptr);
+int k5_launch_step_inc(int* step, hipStream_t stream);
 // LayerNorm with affine over bf16 rows (K13): out = bf16(LN(x) * w + b); also fp32 output option
 int k5_launch_ln_affine(const void* x, const float* w, const float* b, void* out_bf16, float* out_f32, int rows,
                         int D, hipStream_t stream);
@@ -76,7 +78,7 @@ int k5_launch_unpatchify(const void* x, void* out, int T, int Hp, int Wp, int C,
                          const int32_t* tok_perm, hipStream_t stream);
 // K18: CFG combine + Euler.  v = cond (bf16) or bf16(u + bf16(w * bf16(c-u))); img += float(bf16(dt*v))
 int k5_launch_cfg_euler(float* img, const void* v_cond, const void* v_uncond, float w, float dt, int64_t n,
-                        hipStream_t stream);
+                        hipStream_t stream, const float* dtvec = nullptr, const int* step = nullptr);
 // fp32 -> bf16 cast, bf16 -> fp32
 int k5_launch_cast_f32_bf16(const float* x, void* out, int64_t n, hipStream_t stream);
 

@@ -173,10 +173,12 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__
   }
 }
 
-__global__ void time_features_kernel(float t, float* __restrict__ out, int D) {
+// tvec / step: hipGraph-replayable form — the time is read from a device table at the device-side step counter
+__global__ void time_features_kernel(float t, const float* __restrict__ tvec, const int* __restrict__ step, float* __restrict__ out, int D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int half = D / 2;
   if (i >= half) return;
+  if (tvec) t = tvec[*step];
   // get_freqs(models/utils.py:21-28): exp(-ln(1e4) * i / half) in fp32
   const float f = expf(__fdiv_rn(__fmul_rn(-9.210340371976184f, (float)i), (float)half));
   const float a = __fmul_rn(t, f);
@@ -242,7 +244,9 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const bf16_t* __restric
 }
 
 __global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ img, const bf16_t* __restrict__ vc,
-                                                        const bf16_t* __restrict__ vu, float w, float dt, int64_t n) {
+                                                        const bf16_t* __restrict__ vu, float w, float dt,
+                                                        const float* __restrict__ dtvec, const int* __restrict__ step, int64_t n) {
+  if (dtvec) dt = dtvec[*step];
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) {
     float v = bf2f(vc[g]);
     if (vu) {  // uncond + w * (cond - uncond), each eager bf16 op rounds (generation_utils.py:74-76)
@@ -252,6 +256,8 @@ __global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ img,
     img[g] = __fadd_rn(img[g], bf_round(__fmul_rn(dt, v)));  // :128, (0-dim fp32)*(bf16) -> bf16
   }
 }
+
+__global__ void step_inc_kernel(int* step) { *step += 1; }
 
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int64_t n) {
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) out[g] = f2bf(x[g]);
@@ -315,9 +321,14 @@ int k5_launch_gemv_f32(const float* x, const float* W, const float* b, float* y,
   return done();
 }
 
-int k5_launch_time_features(float t, float* out, int D, hipStream_t s) {
-  if (D <= 0 || (D & 1)) return K5_ERR_ARG;
-  hipLaunchKernelGGL(time_features_kernel, dim3((D / 2 + 255) / 256), dim3(256), 0, s, t, out, D);
+int k5_launch_time_features(float t, float* out, int D, hipStream_t s, const float* tvec, const int* step) {
+  if (D <= 0 || (D & 1) || ((tvec != nullptr) != (step != nullptr))) return K5_ERR_ARG;
+  hipLaunchKernelGGL(time_features_kernel, dim3((D / 2 + 255) / 256), dim3(256), 0, s, t, tvec, step, out, D);
+  return done();
+}
+
+int k5_launch_step_inc(int* step, hipStream_t s) {
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step);
   return done();
 }
 
@@ -349,10 +360,11 @@ int k5_launch_unpatchify(const void* x, void* out, int T, int Hp, int Wp, int C,
   return done();
 }
 
-int k5_launch_cfg_euler(float* img, const void* vc, const void* vu, float w, float dt, int64_t n, hipStream_t s) {
-  if (n <= 0) return K5_ERR_ARG;
+int k5_launch_cfg_euler(float* img, const void* vc, const void* vu, float w, float dt, int64_t n, hipStream_t s,
+                        const float* dtvec, const int* step) {
+  if (n <= 0 || ((dtvec != nullptr) != (step != nullptr))) return K5_ERR_ARG;
   hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid_for(n)), dim3(256), 0, s, img, (const bf16_t*)vc, (const bf16_t*)vu, w,
-                     dt, n);
+                     dt, dtvec, step, n);
   return done();
 }
 

@@ -278,6 +278,11 @@ class DiffusionTransformer3D(nn.Module):
         self._sp = (rank, world)
         return self
 
+    def set_graph(self, on=True):
+        """sample() replays one hipGraph-captured step (k5_dit_set_graph); bit-identical results"""
+        E.check(E.lib().k5_dit_set_graph(self._handle, int(on)))
+        return self
+
     # ---------------------------------------------------------------- profiling (bench.py roofline)
     def set_profiling(self, on=True):
         E.check(E.lib().k5_dit_set_profiling(self._handle, int(on)))

@@ -169,3 +169,48 @@ def test_magcache_generate(tiny_dit, tiny_sd, cfg, golden, tag):
     plain = generate(tiny_dit, "cuda:0", (3, 8, 12, 16), c["num_steps"], te, ne, POS, torch.arange(7), torch.arange(4),
                      c["guidance_weight"], c["scheduler_scale"], conf, noise=golden["gen.noise"])
     assert rel(out, plain) > 1e-4
+
+
+# ------------------------------------------------------------------------------------------ hipGraph-captured step
+@pytest.mark.parametrize("w,sp", [(1.0, False), (5.0, False), (3.0, True)])
+def test_graph_captured_step_is_bit_identical(cfg, tiny_sd, golden, w, sp):
+    """k5_dit_set_graph: one captured sampler step replayed for steps 1..n-1 (device-side step counter) == the eager loop,
+    bit for bit; also through the sequence-parallel path (side stream + RCCL inside the capture, world = 1 communicator)."""
+    from types import SimpleNamespace as NS
+    from kandinsky.generation_utils import generate
+    from kandinsky.models.dit import DiffusionTransformer3D
+    conf = NS(model=NS(dit_params=NS(patch_size=(1, 2, 2)), attention=NS(type="flash")), metrics=NS(scale_factor=(1.0, 2.0, 2.0)))
+    te = {"text_embeds": golden["fwd.text"].cuda(), "pooled_embed": golden["fwd.pooled"].cuda()}
+    ne = {"text_embeds": golden["gen.null_text"].cuda(), "pooled_embed": golden["gen.null_pooled"].cuda()}
+    shape, pos = ((3, 8, 12, 16), POS) if not sp else ((2, 16, 16, 16), [torch.arange(2), torch.arange(8), torch.arange(8)])
+    noise = golden["gen.noise"] if not sp else torch.randn(*shape, generator=torch.Generator().manual_seed(9))
+    outs = []
+    for graph in (False, True):
+        dit = DiffusionTransformer3D(**cfg)
+        dit.load_state_dict(tiny_sd, assign=True)
+        dit = dit.to("cuda:0")
+        dit.engine("cuda:0")
+        if sp:
+            dit.enable_sequence_parallel(0, 1, device="cuda:0")
+        dit.set_graph(graph)
+        outs.append(generate(dit, "cuda:0", shape, 6, te, ne, pos, torch.arange(7), torch.arange(4), w, 5.0, conf, noise=noise))
+        del dit
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_text_rope_cache_eviction_keeps_the_handle_intact(tiny_dit, golden):
+    """More than 8 distinct prompt lengths on one handle evict the RoPE1D cache — and nothing else (regression: the
+    eviction once released the sequence-parallel buffers and the communicator)."""
+    x = golden["fwd.x"].cuda()
+    g = torch.Generator().manual_seed(4)
+    first = None
+    for L in list(range(3, 14)) + [3]:
+        out = tiny_dit(x, torch.randn(L, 96, generator=g).cuda() if L != 3 else golden["fwd.text"][:3].cuda(),
+                       golden["fwd.pooled"].cuda(), golden["fwd.time"], POS, torch.arange(L), scale_factor=(1.0, 2.0, 2.0))
+        assert torch.isfinite(out.float()).all()
+        if L == 3:
+            if first is None:
+                first = out.clone()
+            else:
+                assert torch.equal(out, first)
