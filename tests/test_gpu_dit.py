@@ -129,6 +129,15 @@ def test_full_width_two_blocks_vs_oracle():
     assert rel(out, ref) <= 1.5e-2, rel(out, ref)
     ref32 = O.dit_forward(sd, cfg, xin, text, pooled, t, pos, torch.arange(37), (1.0, 2.0, 2.0), None, "fp32")
     assert rel(out, ref32) <= 3e-2, rel(out, ref32)
+    # and against the REFERENCE's own output on the same inputs / seeded weights (tests/golden/dit_fullwidth.*)
+    import json
+    import os
+    from safetensors.torch import load_file
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    G, meta = load_file(os.path.join(here, "dit_fullwidth.safetensors")), json.load(open(os.path.join(here, "dit_fullwidth_meta.json")))
+    assert meta["weights_seed"] == 3 and torch.equal(G["x"], x) and torch.equal(G["text"], text)
+    got = out.float().cpu().reshape(-1)[G["sample_idx"]]
+    assert rel(got, G["sample_val"]) <= 3e-2, rel(got, G["sample_val"])
 
 
 # ------------------------------------------------------------------------------------------ MagCache
