@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-for-`value`) VAE decode leg")
     ap.add_argument("--force-sp", action="store_true", help="debug: drive the sharded code path through a world=1 RCCL communicator")
+    ap.add_argument("--fp8", action="store_true", help="opt-in lossy mode (feed-forward GEMMs in W8A8 e4m3): NOT the headline number, reported as dtype bf16+fp8ff")
     ap.add_argument("--emulate-shard", type=int, default=0, metavar="P",
                     help="debug only (INVALID as a bench): per-rank compute of a P-GPU run on one GPU, collectives move nothing")
     ap.add_argument("--blocks", type=int, default=32, help="debug only: fewer visual blocks => INVALID as a bench")
@@ -141,6 +142,8 @@ def main():
     with torch.device("meta"):
         dit = DiffusionTransformer3D(**cfgd)
     dit.init_synthetic(dev, seed=0)
+    if args.fp8:
+        dit.set_fp8(True)
     if args.emulate_shard > 1:
         os.environ["K5_SP_EMULATE_WORLD"] = str(args.emulate_shard)
     if world > 1 or args.force_sp or args.emulate_shard > 1:
@@ -225,7 +228,7 @@ def main():
         out = {
             "metric": "DiT denoising steps/sec (2B Lite, 5s 768x512 latent)", "value": args.steps / dt, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16+fp8ff (REDUCED PRECISION, not the headline)" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": wl["desc"], "tokens": N, "text_len": L, "forwards_per_step": fwd_per_step,
                        "parallelism": "single GPU" if world == 1 else f"sequence-parallel x{world} (token shards, K/V all-gather)",
                        "visual_blocks": args.blocks},

@@ -232,6 +232,22 @@ int k5_vae_decode_tile(k5_vae* vae, const float* z, int T, int H, int W, void* o
  * b[:, y, :] = a[:, len_a-extent+y, :]*(1-y/extent) + b[:, y, :]*(y/extent), y < extent (eager bf16 rounding) */
 int k5_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, void* stream);
 
+/* fp8 (OCP e4m3) W8A8 GEMM, opt-in (BASELINE config 5 "fp8 MFMA weights"): C = epilogue(w_scale[n] * A8 . W8^T) with fp32
+ * accumulation on v_mfma_scale_f32_16x16x128_f8f6f4.  A8 [M][lda] and W8 [N][ldw] are fp8 bytes (K a multiple of 128, >= 256,
+ * rows 16-byte aligned).  epi: K5_EPI_BIAS -> C bf16 (no bias term: the feed-forward layers have none, nn.py:352-361);
+ * K5_EPI_GELU -> C fp8 = e4m3(GELU(bf16(.))) (the input of the second feed-forward GEMM); K5_EPI_GATE -> gated residual as
+ * k5_gemm_bf16.  k5_quant_rows_fp8: x bf16 [rows][K] -> e4m3 with a per-row scale max|x|/448 written to `scale`, or with the
+ * static scale 1 when scale == NULL (activations).  This is a LOSSY mode (3 mantissa bits per operand); the engine uses it
+ * only after k5_dit_set_fp8(dit, 1). */
+int k5_gemm_fp8(const void* A8, const void* W8, const float* w_scale, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                int epi, const void* resid, int ldr, const float* gate, void* stream);
+int k5_quant_rows_fp8(const void* x_bf16, void* out_fp8, float* scale, int rows, int K, int ldx, int ldo, void* stream);
+
+/* Run the feed-forward GEMMs of the visual blocks in W8A8 e4m3 (weights quantised per output channel on first enable,
+ * activations with the static scale 1).  LOSSY and off by default: ~3e-2 relative L2 on a velocity against the bf16 path
+ * (stated with the parity test tests/test_gpu_dit.py::test_fp8_feed_forward_mode); +30 % on those GEMMs. */
+int k5_dit_set_fp8(k5_dit* dit, int enabled);
+
 /* k5_sample replays ONE hipGraph-captured sampler step (forwards + CFG/Euler, per-step scalars read from device tables at a
  * device-side step counter) instead of launching ~500 kernels per step from the host; results are bit-identical.  Ignored
  * while MagCache or profiling is on, and for fewer than 3 steps. */

@@ -101,6 +101,7 @@ struct AttnW {  // one attention module, packed
 struct BlockW {
   AttnW self_attn, cross_attn;
   DevBuf w1, w2;  // feed_forward in/out, bf16
+  DevBuf w1_f8, w2_f8, s1_f8, s2_f8;  // opt-in fp8 copies (k5_dit_set_fp8): e4m3 weights + per-output-channel scales
   size_t mod_off = 0;  // offset (floats) of this block's modulation vector in mod_all
 };
 
@@ -176,6 +177,8 @@ struct k5_dit {
   Comm comm;
   int sp_rank = 0, sp_world = 1;
   DevBuf ws_q, ws_kfull, ws_vtfull, ws_attn_state;
+  bool use_fp8 = false;                            // visual feed-forward GEMMs in W8A8 e4m3 (k5_dit_set_fp8)
+  DevBuf ws_h8, ws_ff8;                            // fp8 activations of that path
   DevBuf ws_sched;                                 // sampler tables on the device: t*1000 [steps] | dt [steps] | step counter
   bool use_graph = false;                          // k5_sample replays one captured step (k5_dit_set_graph)
   hipStream_t graph_stream = nullptr;              // capture needs a real stream: the caller's may be the legacy null stream
@@ -492,6 +495,19 @@ int run_cross_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h,
 
 int run_ff(k5_dit* d, hipStream_t s, const BlockW& b, const void* h, int rows, void* ff, void* resid, const float* gate) {
   const int D = d->D, FF = d->FF;
+  if (d->use_fp8 && b.w1_f8.p && rows >= 256) {
+    // opt-in lossy path: h -> e4m3 (static scale), FF1 on the fp8 MFMA with the GELU epilogue writing e4m3, FF2 likewise
+    // with the gated-residual epilogue (gemm_fp8.hip)
+    K5CHK(d->ws_h8.ensure((size_t)rows * D)); K5CHK(d->ws_ff8.ensure((size_t)rows * FF));
+    {
+      Scope sc(d, s, "elementwise");
+      K5CHK(k5_launch_quant_rows_fp8(h, d->ws_h8.p, nullptr, rows, D, D, D, s));
+    }
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_fp8(d->ws_h8.p, b.w1_f8.p, b.s1_f8.as<float>(), d->ws_ff8.p, rows, FF, D, D, D, FF, K5_EPI_GELU, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_gemm_fp8(d->ws_ff8.p, b.w2_f8.p, b.s2_f8.as<float>(), resid, rows, D, FF, FF, FF, D, K5_EPI_GATE, resid, D, gate, s));
+    return K5_OK;
+  }
   Scope sc(d, s, "gemm");
   K5CHK(k5_launch_gemm_bf16(h, b.w1.p, nullptr, ff, rows, FF, D, D, D, FF, K5_EPI_GELU, nullptr, 0, nullptr, s));
   K5CHK(k5_launch_gemm_bf16(ff, b.w2.p, nullptr, resid, rows, D, FF, FF, FF, D, K5_EPI_GATE, resid, D, gate, s));
@@ -767,7 +783,8 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
                    &d->ws_vel_u};
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_sched.release();
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
+  for (auto& b : d->vblocks) { b.w1_f8.release(); b.w2_f8.release(); b.s1_f8.release(); b.s2_f8.release(); }
   if (d->graph_stream) { (void)hipStreamSynchronize(d->graph_stream); (void)hipStreamDestroy(d->graph_stream); (void)hipEventDestroy(d->ev_graph); }
   if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
   for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
@@ -1003,6 +1020,26 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
   (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
   (void)caller;
   return status;
+}
+
+// W8A8 e4m3 feed-forward (BASELINE config 5).  Quantises W1 / W2 of every visual block per output channel on first enable.
+extern "C" int k5_dit_set_fp8(k5_dit* d, int enabled) {
+  g_err[0] = 0;
+  if (!d || !d->finalized) { k5_set_error("k5_dit_set_fp8: handle not finalized"); return K5_ERR_STATE; }
+  if (enabled && ((d->D % 128) || (d->FF % 128) || d->D < 256 || d->FF < 256)) {
+    k5_set_error("k5_dit_set_fp8: model_dim and ff_dim must be multiples of 128 and >= 256"); return K5_ERR_UNSUPPORTED;
+  }
+  if (enabled)
+    for (auto& b : d->vblocks) {
+      if (b.w1_f8.p) continue;
+      K5CHK(b.w1_f8.ensure((size_t)d->FF * d->D)); K5CHK(b.s1_f8.ensure((size_t)d->FF * 4));
+      K5CHK(b.w2_f8.ensure((size_t)d->D * d->FF)); K5CHK(b.s2_f8.ensure((size_t)d->D * 4));
+      K5CHK(k5_launch_quant_rows_fp8(b.w1.p, b.w1_f8.p, b.s1_f8.as<float>(), d->FF, d->D, d->D, d->D, nullptr));
+      K5CHK(k5_launch_quant_rows_fp8(b.w2.p, b.w2_f8.p, b.s2_f8.as<float>(), d->D, d->FF, d->FF, d->FF, nullptr));
+    }
+  HIPCHK(hipDeviceSynchronize());
+  d->use_fp8 = enabled != 0;
+  return K5_OK;
 }
 
 extern "C" int k5_dit_set_graph(k5_dit* d, int enabled) { if (!d) return K5_ERR_ARG; d->use_graph = enabled != 0; return K5_OK; }

@@ -36,6 +36,15 @@ int k5_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* 
              "k5_attention_bf16_range");
 }
 
+int k5_gemm_fp8(const void* A8, const void* W8, const float* w_scale, void* C, int M, int N, int K, int lda, int ldw, int ldc, int epi,
+                const void* resid, int ldr, const float* gate, void* stream) {
+  return ret(k5_launch_gemm_fp8(A8, W8, w_scale, C, M, N, K, lda, ldw, ldc, epi, resid, ldr, gate, (hipStream_t)stream), "k5_gemm_fp8");
+}
+
+int k5_quant_rows_fp8(const void* x, void* out, float* scale, int rows, int K, int ldx, int ldo, void* stream) {
+  return ret(k5_launch_quant_rows_fp8(x, out, scale, rows, K, ldx, ldo, (hipStream_t)stream), "k5_quant_rows_fp8");
+}
+
 int64_t k5_attention_balance_size(int H, int q_len) { return (int64_t)k5_attention_balance_bytes(H, q_len); }
 
 int k5_attention_bf16_balanced(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,

@@ -31,6 +31,11 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* balance_ws = nullptr);
 size_t k5_attention_balance_bytes(int H, int q_len);
 
+// ---- fp8 (e4m3) feed-forward path, opt-in (gemm_fp8.hip) ----
+int k5_launch_gemm_fp8(const void* A8, const void* W8, const float* w_scale, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                       int epi, const void* resid, int ldr, const float* gate, hipStream_t stream);
+int k5_launch_quant_rows_fp8(const void* x, void* out, float* scale, int rows, int K, int ldx, int ldo, hipStream_t stream);
+
 // ---- NABLA (block-sparse) ----
 size_t k5_nabla_workspace_bytes(int H, int nb);
 int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,

@@ -63,6 +63,8 @@ SYMBOLS = {
     "k5_attention_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k5_attention_state_size": (_I64, [_I, _I]),
     "k5_attention_bf16_range": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P, _I, _P]),
+    "k5_gemm_fp8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "k5_quant_rows_fp8": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "k5_attention_balance_size": (_I64, [_I, _I]),
     "k5_attention_bf16_balanced": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "k5_nabla_workspace_size": (_I64, [_I, _I]),
@@ -102,6 +104,7 @@ SYMBOLS = {
     "k5_vae_decode_tile": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "k5_blend_bf16": (_I, [_P, _P, _I64, _I, _I, _I64, _I, _P]),
     "k5_dit_set_graph": (_I, [_P, _I]),
+    "k5_dit_set_fp8": (_I, [_P, _I]),
     "k5_dit_set_magcache": (_I, [_P, C.POINTER(C.c_double), _I, _I, C.c_double, _I, C.c_double]),
     "k5_dit_magcache_calls": (_I, [_P, _I, _I]),
     "k5_dit_magcache_state": (_I, [_P, C.POINTER(_I), C.POINTER(_I64), C.POINTER(_I64)]),

@@ -278,6 +278,11 @@ class DiffusionTransformer3D(nn.Module):
         self._sp = (rank, world)
         return self
 
+    def set_fp8(self, on=True):
+        """opt-in, lossy: visual feed-forward GEMMs in W8A8 e4m3 (k5_dit_set_fp8; BASELINE config 5)"""
+        E.check(E.lib().k5_dit_set_fp8(self._handle, int(on)), "k5_dit_set_fp8")
+        return self
+
     def set_graph(self, on=True):
         """sample() replays one hipGraph-captured step (k5_dit_set_graph); bit-identical results"""
         E.check(E.lib().k5_dit_set_graph(self._handle, int(on)))

@@ -284,8 +284,22 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, mode: str, block_mask: Optional[Tensor
     return _r(out.transpose(0, 1).reshape(Sq, H * d), mode)
 
 
+FP8_FF = False   # test switch: restate the engine's opt-in W8A8 e4m3 feed-forward (csrc/gemm_fp8.hip) in bf16 mode
+
+
+def _q8(x: Tensor) -> Tensor:
+    """saturating e4m3 round trip"""
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
 def feed_forward(sd, prefix: str, x: Tensor, mode: str) -> Tensor:
     """nn.py:352-361: Linear(no bias) -> exact-erf GELU (on the bf16 GEMM output) -> Linear."""
+    if FP8_FF and mode == "bf16" and x.shape[0] >= 256 and prefix.startswith("visual_transformer_blocks"):
+        w1, w2 = _r(sd[f"{prefix}.in_layer.weight"].float(), mode), _r(sd[f"{prefix}.out_layer.weight"].float(), mode)
+        s1, s2 = w1.abs().amax(1) / 448.0, w2.abs().amax(1) / 448.0          # per output channel
+        h = _r((_q8(x) @ _q8(w1 / s1[:, None]).t()) * s1, mode)
+        h = _q8(F.gelu(h))
+        return _r((h @ _q8(w2 / s2[:, None]).t()) * s2, mode)
     h = _linear(x, sd[f"{prefix}.in_layer.weight"].float(), None, mode)
     h = _r(F.gelu(h), mode)
     return _linear(h, sd[f"{prefix}.out_layer.weight"].float(), None, mode)

@@ -355,3 +355,67 @@ def test_attention_balanced_tail_split_equals_single_launch(E, Sq, Sk, H, bound)
                                          ws.data_ptr(), E.stream_ptr()))
     assert not torch.isnan(out.float()).any()
     assert_bf16_close(out, one.float().cpu(), ulps=2, atol=2e-3, what="balanced attention")
+
+
+# ------------------------------------------------------------------------------------------ fp8 (e4m3) GEMM, opt-in path
+F8 = torch.float8_e4m3fn
+
+
+def _to_f8_bytes(x):
+    return x.to(F8).view(torch.uint8)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (512, 768, 1792), (600, 300, 384), (1024, 7168, 1792)])
+def test_gemm_fp8_matches_fp8_reference(E, M, N, K):
+    """W8A8 e4m3 GEMM on v_mfma_scale_f32_16x16x128_f8f6f4: operands already in fp8 -> the only difference to an fp32
+    matmul of the de-quantised operands is the accumulation order."""
+    a8 = _to_f8_bytes(rnd(M, K, seed=31) * 2.0)
+    w8 = _to_f8_bytes(rnd(N, K, seed=32))
+    ws = (rnd(N, seed=33).abs() * 0.01 + 0.001)
+    ref = bfr((a8.view(F8).float() @ w8.view(F8).float().t()) * ws)
+    out = torch.empty(M, N, dtype=BF, device="cuda")
+    L = E.lib()
+    ad, wd, sd = a8.cuda(), w8.cuda(), ws.cuda()
+    E.check(L.k5_gemm_fp8(ad.data_ptr(), wd.data_ptr(), sd.data_ptr(), out.data_ptr(), M, N, K, K, K, N, E.EPI_BIAS, None, 0, None, E.stream_ptr()))
+    assert_bf16_close(out, ref, ulps=2, atol=1e-3, what=f"fp8 gemm {M}x{N}x{K}")
+    for _ in range(10):   # race screen of the DMA / barrier schedule
+        o2 = torch.empty_like(out)
+        E.check(L.k5_gemm_fp8(ad.data_ptr(), wd.data_ptr(), sd.data_ptr(), o2.data_ptr(), M, N, K, K, K, N, E.EPI_BIAS, None, 0, None, E.stream_ptr()))
+        assert torch.equal(o2, out)
+
+
+def test_gemm_fp8_epilogues_and_row_quantisation(E):
+    M, D, FF = 512, 256, 512
+    L = E.lib()
+    x = bfr(rnd(M, D, seed=41))
+    w1, w2 = bfr(rnd(FF, D, seed=42, scale=0.05)), bfr(rnd(D, FF, seed=43, scale=0.05))
+    # per-channel weight quantisation and static-scale activation quantisation done by the library
+    def quant(t, per_row):
+        src = t.cuda().to(BF)
+        out = torch.empty(t.shape, dtype=torch.uint8, device="cuda")
+        sc = torch.empty(t.shape[0], dtype=torch.float32, device="cuda") if per_row else None
+        E.check(L.k5_quant_rows_fp8(src.data_ptr(), out.data_ptr(), sc.data_ptr() if per_row else None, t.shape[0], t.shape[1],
+                                    t.shape[1], t.shape[1], E.stream_ptr()))
+        return out, sc
+    x8, _ = quant(x, False)
+    w18, s1 = quant(w1, True)
+    w28, s2 = quant(w2, True)
+    # reference of the quantisers themselves
+    assert torch.equal(x8.cpu(), _to_f8_bytes(x.clamp(-448, 448)))
+    s1_ref = w1.abs().amax(1) / 448
+    assert torch.allclose(s1.cpu(), s1_ref, rtol=1e-6)
+    assert torch.equal(w18.cpu(), _to_f8_bytes(w1 / s1.cpu()[:, None]))
+    # FF1: fp8 out = e4m3(GELU(bf16(acc * s)))
+    h8 = torch.empty(M, FF, dtype=torch.uint8, device="cuda")
+    E.check(L.k5_gemm_fp8(x8.data_ptr(), w18.data_ptr(), s1.data_ptr(), h8.data_ptr(), M, FF, D, D, D, FF, E.EPI_GELU, None, 0, None, E.stream_ptr()))
+    pre = bfr((x8.cpu().view(F8).float() @ w18.cpu().view(F8).float().t()) * s1.cpu())
+    h_ref = torch.nn.functional.gelu(pre)
+    got = h8.cpu().view(F8).float()
+    assert ((got - h_ref.to(F8).float()).abs() <= 0.13 * h_ref.abs() + 2e-3).all()       # at most one e4m3 step (bf16 tie flips)
+    # FF2: gated residual, in place
+    resid, gate = bfr(rnd(M, D, seed=44)), rnd(D, seed=45)
+    r = resid.cuda().to(BF)
+    E.check(L.k5_gemm_fp8(h8.data_ptr(), w28.data_ptr(), s2.data_ptr(), r.data_ptr(), M, D, FF, FF, FF, D, E.EPI_GATE, r.data_ptr(), D,
+                          gate.cuda().data_ptr(), E.stream_ptr()))
+    ref = bfr(resid + gate * bfr((got @ w28.cpu().view(F8).float().t()) * s2.cpu()))
+    assert_bf16_close(r, ref, ulps=4, atol=4e-3, what="fp8 ff2 gate")   # bf16 tie flips of the inner rounding, times the gate

@@ -71,6 +71,23 @@ def bench_gemm_sp():
             print(f"gemm {name:10s} M={m} N={nn} K={k}: {ms:8.3f} ms  {2.0 * m * nn * k / ms / 1e9:8.1f} TFLOP/s", flush=True)
 
 
+def bench_gemm_fp8():
+    L = E.lib()
+    for (m, n, k, epi, name) in ((N, FF, D, E.EPI_GELU, "ff1+gelu fp8"), (N, D, FF, E.EPI_GATE, "ff2+gate fp8"), (4096, 4096, 4096, E.EPI_BIAS, "4096^3 fp8")):
+        a = torch.randint(0, 255, (m, k), dtype=torch.uint8, device="cuda") & 0x77    # finite e4m3 patterns of both signs
+        a |= torch.randint(0, 2, (m, k), dtype=torch.uint8, device="cuda") << 7
+        w = torch.randint(0, 255, (n, k), dtype=torch.uint8, device="cuda") & 0x77
+        sc = torch.full((n,), 1e-3, device="cuda")
+        out = torch.empty(m, n, dtype=torch.uint8 if epi == E.EPI_GELU else BF, device="cuda")
+        resid = rnd(m, n) if epi == E.EPI_GATE else None
+        gate = torch.randn(n, device="cuda") if epi == E.EPI_GATE else None
+        def run():
+            E.check(L.k5_gemm_fp8(a.data_ptr(), w.data_ptr(), sc.data_ptr(), out.data_ptr(), m, n, k, k, k, n, epi,
+                                  resid.data_ptr() if resid is not None else None, n, gate.data_ptr() if gate is not None else None, E.stream_ptr()))
+        ms = timeit(run)
+        print(f"gemm {name:13s} M={m} N={n} K={k}: {ms:8.3f} ms  {2.0 * m * n * k / ms / 1e9:8.1f} TFLOP/s", flush=True)
+
+
 def bench_elem():
     x = rnd(N, D)
     sc, sh = torch.randn(D, device="cuda"), torch.randn(D, device="cuda")
@@ -92,6 +109,8 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), flush=True)
     if "attn" in which:
         bench_attn()
+    if "gemm_fp8" in which:
+        bench_gemm_fp8()
     if "gemm_sp" in which:
         bench_gemm_sp()
     if "gemm" in which:
