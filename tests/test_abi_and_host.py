@@ -153,3 +153,44 @@ def test_cli_keeps_the_reference_flags():
     a.width, a.height = 768, 768
     with pytest.raises(NotImplementedError):
         cli.validate_args(a)
+
+
+def test_package_surface_used_by_the_reference_comfyui_nodes_and_cli():
+    """Drop-in seams: every name the reference's comfyui/nodes_kandinsky.py:3-7,26,49-52,98-99,102-106,131 and
+    test.py:8,131-151 import or call exists here with a compatible call shape."""
+    import inspect
+    import kandinsky
+    from kandinsky import get_T2V_pipeline
+    from kandinsky.generation_utils import generate, generate_sample, get_velocity, get_sparse_params
+    from kandinsky.models.dit import get_dit, DiffusionTransformer3D
+    from kandinsky.models.text_embedders import Kandinsky5TextEmbedder, get_text_embedder
+    from kandinsky.models.vae import build_vae, AutoencoderKLHunyuanVideo
+    from kandinsky.magcache_utils import set_magcache_params
+    from kandinsky.t2v_pipeline import Kandinsky5T2VPipeline
+    assert kandinsky.get_T2V_pipeline is get_T2V_pipeline
+    p = inspect.signature(get_T2V_pipeline).parameters
+    assert list(p)[:1] == ["device_map"] and {"conf_path", "offload", "magcache", "cache_dir", "dit_path", "vae_path"} <= set(p)
+    g = list(inspect.signature(generate).parameters)
+    assert g[:12] == ["model", "device", "shape", "num_steps", "text_embeds", "null_text_embeds", "visual_rope_pos", "text_rope_pos",
+                      "null_text_rope_pos", "guidance_weight", "scheduler_scale", "conf"]
+    assert list(inspect.signature(Kandinsky5TextEmbedder.__init__).parameters)[:3] == ["self", "conf", "device"]
+    for name in ("encode", "to"):
+        assert callable(getattr(Kandinsky5TextEmbedder, name))
+    c = inspect.signature(Kandinsky5T2VPipeline.__call__).parameters
+    assert {"time_length", "width", "height", "num_steps", "guidance_weight", "scheduler_scale", "expand_prompts", "save_path",
+            "seed", "negative_caption"} <= set(c)
+    # get_dit(conf.model.dit_params) -> .to(device=) -> .load_state_dict(sd) (no assign=) ; attributes touched by callers
+    with torch.device("meta"):
+        dit = get_dit(dict(in_visual_dim=16, out_visual_dim=16, time_dim=64, patch_size=(1, 2, 2), model_dim=128, ff_dim=256,
+                           num_text_blocks=1, num_visual_blocks=1, axes_dims=(16, 24, 24), visual_cond=True, in_text_dim=96,
+                           in_text_dim2=48))
+    assert isinstance(dit, DiffusionTransformer3D) and dit.visual_cond is True
+    for attr in ("visual_transformer_blocks", "text_transformer_blocks", "time_embeddings", "text_embeddings",
+                 "pooled_text_embeddings", "visual_embeddings", "out_layer"):
+        assert hasattr(dit, attr), attr
+    assert "assign" in inspect.signature(dit.load_state_dict).parameters
+    with torch.device("meta"):
+        vae = AutoencoderKLHunyuanVideo()
+    assert hasattr(vae, "decode") and hasattr(vae.config, "scaling_factor") and callable(vae.eval)
+    assert callable(build_vae) and callable(get_text_embedder) and callable(set_magcache_params)
+    assert callable(generate_sample) and callable(get_velocity) and callable(get_sparse_params)
