@@ -99,11 +99,12 @@ def test_missing_library_fails_loudly():
     assert "LOUD" in out.stdout and "no fallback" in out.stdout, out.stdout + out.stderr
 
 
-def test_config_loader_matches_reference_parse():
-    from kandinsky.config import load_config
+def test_config_loader_matches_reference_parse(tmp_path):
+    from kandinsky.config import load_config, write_default_configs
     with open(os.path.join(ROOT, "tests", "golden", "configs_parsed.json")) as f:
         ref = json.load(f)
-    cdir = os.path.join(PKG, "configs")
+    cdir = str(tmp_path / "configs")
+    write_default_configs(cdir)
     assert sorted(os.listdir(cdir)) == sorted(ref.keys())
     for fn, parsed in ref.items():
         conf = load_config(os.path.join(cdir, fn))
@@ -194,3 +195,16 @@ def test_package_surface_used_by_the_reference_comfyui_nodes_and_cli():
     assert hasattr(vae, "decode") and hasattr(vae.config, "scaling_factor") and callable(vae.eval)
     assert callable(build_vae) and callable(get_text_embedder) and callable(set_magcache_params)
     assert callable(generate_sample) and callable(get_velocity) and callable(get_sparse_params)
+
+
+def test_default_configs_equal_the_reference_configs_and_materialise(tmp_path):
+    """kandinsky/default_configs.json == the parsed reference YAMLs (tests/golden/configs_parsed.json, G10); a missing default
+    config path is written on first load."""
+    from kandinsky.config import default_configs, load_config, DEFAULT_CONFIG_NAMES
+    with open(os.path.join(ROOT, "tests", "golden", "configs_parsed.json")) as f:
+        ref = json.load(f)
+    assert default_configs() == ref and set(DEFAULT_CONFIG_NAMES) == set(ref)
+    conf = load_config(str(tmp_path / "configs" / "config_10s_sft.yaml"))
+    assert conf.model.attention.type == "nabla" and conf.model.num_steps == 50 and len(conf.magcache.mag_ratios) == 98
+    assert conf.to_dict() == ref["config_10s_sft.yaml"]
+    assert sorted(os.listdir(tmp_path / "configs")) == sorted(DEFAULT_CONFIG_NAMES)
