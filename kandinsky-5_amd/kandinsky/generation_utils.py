@@ -125,52 +125,52 @@ def generate(model, device, shape, num_steps, text_embeds, null_text_embeds, vis
     return img
 
 
+def _encode_prompts(text_embedder, prompts, kind, device):
+    """[(embeds dict on `device`, number of text tokens)] for each prompt (reference generation_utils.py:153-176)."""
+    out = []
+    with torch.no_grad():
+        for prompt in prompts:
+            embeds, cu = text_embedder.encode([prompt], type_of_content=kind)
+            out.append(({name: t.to(device=device) for name, t in embeds.items()}, int(cu[-1])))
+    return out
+
+
+def latent_to_uint8(latent, vae, batch, vae_device):
+    """Latent (batch*T, H, W, C) -> uint8 frames (batch, 3, F, 8H, 8W): un-scale, channels first, VAE decode, clamp to [-1, 1],
+    map to 0..255 (reference generation_utils.py:209-222)."""
+    T = latent.shape[0] // batch
+    z = latent.reshape(batch, T, *latent.shape[1:]).to(device=vae_device)
+    z = (z / vae.config.scaling_factor).permute(0, 4, 1, 2, 3)
+    frames = vae.decode(z).sample
+    return ((frames.clamp(-1.0, 1.0) + 1.0) * 127.5).to(torch.uint8)
+
+
 def generate_sample(shape, caption, dit, vae, conf, text_embedder, num_steps=25, guidance_weight=5.0,
                     scheduler_scale=1, negative_caption="", seed=6554, device="cuda", vae_device="cuda",
                     text_embedder_device="cuda", progress=True, offload=False):
-    """reference generation_utils.py:132-228: text encode -> generate -> VAE decode -> uint8."""
-    bs, duration, height, width, dim = shape
-    type_of_content = "image" if duration == 1 else "video"
-
-    with torch.no_grad():
-        bs_text_embed, text_cu_seqlens = text_embedder.encode([caption], type_of_content=type_of_content)
-        bs_null_text_embed, null_text_cu_seqlens = text_embedder.encode([negative_caption],
-                                                                         type_of_content=type_of_content)
+    """reference generation_utils.py:132-228 (same signature): text encode -> generate -> VAE decode -> uint8.
+    With `offload` each of the three models visits the GPU only for its own stage."""
+    batch, frames, height, width, channels = shape
+    kind = "image" if frames == 1 else "video"
+    (cond, n_cond), (uncond, n_uncond) = _encode_prompts(text_embedder, (caption, negative_caption), kind, device)
     if offload:
         text_embedder = text_embedder.to("cpu")
 
-    for key in bs_text_embed:
-        bs_text_embed[key] = bs_text_embed[key].to(device=device)
-        bs_null_text_embed[key] = bs_null_text_embed[key].to(device=device)
-    text_cu_seqlens = int(text_cu_seqlens[-1])
-    null_text_cu_seqlens = int(null_text_cu_seqlens[-1])
-
     patch = conf.model.dit_params.patch_size
-    visual_rope_pos = [torch.arange(duration), torch.arange(shape[-3] // patch[1]), torch.arange(shape[-2] // patch[2])]
-    text_rope_pos = torch.arange(text_cu_seqlens)
-    null_text_rope_pos = torch.arange(null_text_cu_seqlens)
-
+    grid = [torch.arange(frames), torch.arange(height // patch[1]), torch.arange(width // patch[2])]
     if offload:
         dit.to(device, non_blocking=True)
     with torch.no_grad():
-        latent_visual = generate(dit, device, (bs * duration, height, width, dim), num_steps, bs_text_embed,
-                                 bs_null_text_embed, visual_rope_pos, text_rope_pos, null_text_rope_pos,
-                                 guidance_weight, scheduler_scale, conf, seed=seed, progress=progress)
+        latent = generate(dit, device, (batch * frames, height, width, channels), num_steps, cond, uncond, grid,
+                          torch.arange(n_cond), torch.arange(n_uncond), guidance_weight, scheduler_scale, conf, seed=seed,
+                          progress=progress)
     if offload:
-        dit = dit.to("cpu", non_blocking=True)
-    torch.cuda.empty_cache()
-    if offload:
-        vae = vae.to(vae_device, non_blocking=True)
-
+        dit.to("cpu", non_blocking=True)
+        torch.cuda.empty_cache()
+        vae.to(vae_device, non_blocking=True)
     with torch.no_grad():
-        images = latent_visual.reshape(bs, -1, latent_visual.shape[-3], latent_visual.shape[-2],
-                                       latent_visual.shape[-1])
-        images = images.to(device=vae_device)
-        images = (images / vae.config.scaling_factor).permute(0, 4, 1, 2, 3)
-        images = vae.decode(images).sample
-        images = ((images.clamp(-1.0, 1.0) + 1.0) * 127.5).to(torch.uint8)
-
+        images = latent_to_uint8(latent, vae, batch, vae_device)
     if offload:
-        vae = vae.to("cpu", non_blocking=True)
-    torch.cuda.empty_cache()
+        vae.to("cpu", non_blocking=True)
+        torch.cuda.empty_cache()
     return images

@@ -29,62 +29,67 @@ class Kandinsky5T2VPipeline:
         Delegated to the text embedder wrapper, which owns the HF model."""
         return self.text_embedder.expand_prompt(prompt)
 
+    # ------------------------------------------------------------------ helpers of __call__
+    def _agree_on(self, value_fn, as_object=False):
+        """rank 0 computes `value_fn()`, every rank returns the same value (reference t2v_pipeline.py:108-118,131-141)."""
+        mine = value_fn() if self.local_dit_rank == 0 else None
+        if self.world_size <= 1:
+            return mine
+        if as_object:
+            box = [mine]
+            torch.distributed.broadcast_object_list(box, 0)
+            return box[0]
+        t = (torch.tensor([mine], dtype=torch.int64) if mine is not None else torch.empty(1, dtype=torch.int64)).to(self.local_dit_rank)
+        torch.distributed.broadcast(t, 0)
+        return int(t.item())
+
+    def _check_size(self, height, width):
+        if self.resolution != 512:
+            raise NotImplementedError("Only 512 resolution is available for now")
+        allowed = self.RESOLUTIONS[self.resolution]
+        if (height, width) not in allowed:
+            raise ValueError(f"Wrong height, width pair. Available (height, width) are: {allowed}")
+
+    def _beautified(self, prompt):
+        if self.offload:
+            self.text_embedder = self.text_embedder.to(self.device_map["text_embedder"])
+        return self.expand_prompt(prompt)
+
+    @staticmethod
+    def _save(images, time_length, save_path):
+        """uint8 (B,3,F,H,W) -> PIL list (image mode) or the tensor itself; optional PNG / video files (reference :166-189)."""
+        paths = None if save_path is None else ([save_path] if isinstance(save_path, str) else list(save_path))
+        if time_length == 0:
+            from .video_io import to_pil_images
+            pics = to_pil_images(images.squeeze(2).cpu())
+            if paths is not None and len(paths) == len(pics):
+                for path, pic in zip(paths, pics):
+                    pic.save(path)
+            return pics
+        if paths is not None and len(paths) == len(images):
+            from .video_io import write_video
+            for path, clip in zip(paths, images):
+                write_video(path, clip.permute(1, 2, 3, 0).cpu(), fps=24)
+        return images
+
     def __call__(self, text: str, time_length: int = 5, width: int = 768, height: int = 512, seed: int = None,
                  num_steps: int = None, guidance_weight: float = None, scheduler_scale: float = 10.0,
                  negative_caption: str = _NEG, expand_prompts: bool = True, save_path: str = None,
                  progress: bool = True):
-        num_steps = self.num_steps if num_steps is None else num_steps
-        guidance_weight = self.guidance_weight if guidance_weight is None else guidance_weight
-        if seed is None:  # rank 0 draws, everyone agrees (reference :108-118)
-            if self.local_dit_rank == 0:
-                seed = torch.randint(2 ** 63 - 1, (1,)).to(self.local_dit_rank)
-            else:
-                seed = torch.empty((1,), dtype=torch.int64).to(self.local_dit_rank)
-            if self.world_size > 1:
-                torch.distributed.broadcast(seed, 0)
-            seed = seed.item()
-        if self.resolution != 512:
-            raise NotImplementedError("Only 512 resolution is available for now")
-        if (height, width) not in self.RESOLUTIONS[self.resolution]:
-            raise ValueError(
-                f"Wrong height, width pair. Available (height, width) are: {self.RESOLUTIONS[self.resolution]}")
+        """reference t2v_pipeline.py:90-189 (same arguments, defaults, errors and return values: uint8 tensor (1,3,F,H,W) on
+        rank 0 / list of PIL images for time_length = 0, None on the other ranks)."""
+        steps = self.num_steps if num_steps is None else num_steps
+        weight = self.guidance_weight if guidance_weight is None else guidance_weight
+        if seed is None:
+            seed = self._agree_on(lambda: int(torch.randint(2 ** 63 - 1, (1,)).item()))
+        self._check_size(height, width)
+        frames = 1 if time_length == 0 else time_length * 24 // 4 + 1
+        caption = self._agree_on(lambda: self._beautified(text), as_object=True) if expand_prompts else text
 
-        num_frames = 1 if time_length == 0 else time_length * 24 // 4 + 1
-        caption = text
-        if expand_prompts:
-            if self.local_dit_rank == 0:
-                if self.offload:
-                    self.text_embedder = self.text_embedder.to(self.device_map["text_embedder"])
-                caption = self.expand_prompt(caption)
-            if self.world_size > 1:
-                caption = [caption]
-                torch.distributed.broadcast_object_list(caption, 0)
-                caption = caption[0]
-        shape = (1, num_frames, height // 8, width // 8, 16)
-
-        images = generate_sample(shape, caption, self.dit, self.vae, self.conf, text_embedder=self.text_embedder,
-                                 num_steps=num_steps, guidance_weight=guidance_weight, scheduler_scale=scheduler_scale,
-                                 negative_caption=negative_caption, seed=seed, device=self.device_map["dit"],
-                                 vae_device=self.device_map["vae"],
-                                 text_embedder_device=self.device_map["text_embedder"], progress=progress,
-                                 offload=self.offload)
+        images = generate_sample((1, frames, height // 8, width // 8, 16), caption, self.dit, self.vae, self.conf,
+                                 text_embedder=self.text_embedder, num_steps=steps, guidance_weight=weight,
+                                 scheduler_scale=scheduler_scale, negative_caption=negative_caption, seed=seed,
+                                 device=self.device_map["dit"], vae_device=self.device_map["vae"],
+                                 text_embedder_device=self.device_map["text_embedder"], progress=progress, offload=self.offload)
         torch.cuda.empty_cache()
-
-        if self.local_dit_rank != 0:
-            return None
-        if time_length == 0:
-            from .video_io import to_pil_images
-            return_images = to_pil_images(images.squeeze(2).cpu())
-            if save_path is not None:
-                save_path = [save_path] if isinstance(save_path, str) else save_path
-                if len(save_path) == len(return_images):
-                    for path, image in zip(save_path, return_images):
-                        image.save(path)
-            return return_images
-        if save_path is not None:
-            from .video_io import write_video
-            save_path = [save_path] if isinstance(save_path, str) else save_path
-            if len(save_path) == len(images):
-                for path, video in zip(save_path, images):
-                    write_video(path, video.permute(1, 2, 3, 0).cpu(), fps=24)
-        return images
+        return self._save(images, time_length, save_path) if self.local_dit_rank == 0 else None
