@@ -91,24 +91,13 @@ def get_T2V_pipeline(
 
 
 def get_default_conf(dit_path, vae_path, text_encoder_path, text_encoder2_path) -> Conf:
-    """reference utils.py:137-198 (values of the 5 s SFT config)."""
-    return Conf({
-        "model": {
-            "checkpoint_path": dit_path,
-            "vae": {"checkpoint_path": vae_path, "name": "hunyuan"},
-            "text_embedder": {
-                "qwen": {"emb_size": 3584, "checkpoint_path": text_encoder_path, "max_length": 256},
-                "clip": {"checkpoint_path": text_encoder2_path, "emb_size": 768, "max_length": 77},
-            },
-            "dit_params": {
-                "in_visual_dim": 16, "out_visual_dim": 16, "time_dim": 512, "patch_size": [1, 2, 2],
-                "model_dim": 1792, "ff_dim": 7168, "num_text_blocks": 2, "num_visual_blocks": 32,
-                "axes_dims": [16, 24, 24], "visual_cond": True, "in_text_dim": 3584, "in_text_dim2": 768,
-            },
-            "attention": {"type": "flash", "causal": False, "local": False, "glob": False, "window": 3},
-            "num_steps": 50,
-            "guidance_weight": 5.0,
-        },
-        "metrics": {"scale_factor": (1, 2, 2)},
-        "resolution": 512,
-    })
+    """reference utils.py:137-198: the configuration used when no `conf_path` is given = the 5 s SFT model (dense attention,
+    50 steps, guidance 5) with the four checkpoint locations filled in."""
+    from .config import default_configs
+    base = default_configs()["config_5s_sft.yaml"]
+    model = dict(base["model"])
+    model["checkpoint_path"] = dit_path
+    model["vae"] = dict(model["vae"], checkpoint_path=vae_path)
+    model["text_embedder"] = {"qwen": dict(model["text_embedder"]["qwen"], checkpoint_path=text_encoder_path),
+                              "clip": dict(model["text_embedder"]["clip"], checkpoint_path=text_encoder2_path)}
+    return Conf({"model": model, "metrics": {"scale_factor": (1, 2, 2)}, "resolution": 512})

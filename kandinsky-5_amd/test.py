@@ -22,20 +22,20 @@ NEGATIVE = ("Static, 2D cartoon, cartoon, 2d animation, paintings, images, worst
 
 def build_parser():
     p = argparse.ArgumentParser(description="Generate a video with Kandinsky 5 (MI355X engine)")
-    p.add_argument("--local-rank", type=int, help="local rank")
-    p.add_argument("--config", type=str, default="./configs/config_5s_sft.yaml", help="The config file of the model")
-    p.add_argument("--prompt", type=str, default="a cat in a blue hat", help="The prompt to generate video")
-    p.add_argument("--negative_prompt", type=str, default=NEGATIVE, help="Negative prompt for classifier-free guidance")
-    p.add_argument("--width", type=int, default=768, choices=[768, 512], help="Width of the video in pixels")
-    p.add_argument("--height", type=int, default=512, choices=[768, 512], help="Height of the video in pixels")
-    p.add_argument("--video_duration", type=int, default=5, help="Duration of the video in seconds")
-    p.add_argument("--expand_prompt", type=int, default=1, help="Whether to use prompt expansion.")
-    p.add_argument("--sample_steps", type=int, default=None, help="The sampling steps number.")
-    p.add_argument("--guidance_weight", type=float, default=None, help="Guidance weight.")
-    p.add_argument("--scheduler_scale", type=float, default=5.0, help="Scheduler scale.")
-    p.add_argument("--output_filename", type=str, default="./test.mp4", help="Name of the resulting file")
-    p.add_argument("--offload", action="store_true", default=False, help="Offload models to save memory or not")
-    p.add_argument("--magcache", action="store_true", default=False, help="Using MagCache (for 50 steps models only)")
+    p.add_argument("--local-rank", type=int, help="set by the launcher (one process per GPU)")
+    p.add_argument("--config", type=str, default="./configs/config_5s_sft.yaml", help="YAML config (reference schema); a missing default name is created")
+    p.add_argument("--prompt", type=str, default="a cat in a blue hat", help="text prompt")
+    p.add_argument("--negative_prompt", type=str, default=NEGATIVE, help="negative prompt of the unconditional branch")
+    p.add_argument("--width", type=int, default=768, choices=[768, 512], help="frame width in pixels")
+    p.add_argument("--height", type=int, default=512, choices=[768, 512], help="frame height in pixels")
+    p.add_argument("--video_duration", type=int, default=5, help="clip length in seconds (0 = a single image)")
+    p.add_argument("--expand_prompt", type=int, default=1, help="1 = rewrite the prompt with the Qwen2.5-VL chat model first")
+    p.add_argument("--sample_steps", type=int, default=None, help="number of Euler steps (default: the config's)")
+    p.add_argument("--guidance_weight", type=float, default=None, help="classifier-free guidance weight (default: the config's)")
+    p.add_argument("--scheduler_scale", type=float, default=5.0, help="sigma-schedule scale s in s*t/(1+(s-1)*t)")
+    p.add_argument("--output_filename", type=str, default="./test.mp4", help="output path (.mp4 / .avi / .png)")
+    p.add_argument("--offload", action="store_true", default=False, help="keep only the active model on the GPU")
+    p.add_argument("--magcache", action="store_true", default=False, help="MagCache: skip the visual blocks on low-error steps (50-step configs)")
     return p
 
 
