@@ -417,7 +417,9 @@ constexpr int K8_TRACE_BYTES = 8 * 128 * 8;
 constexpr int K8_TRACE_BYTES = 0;
 #endif
 
-template <int EPI>
+// MT = 16-row m-tiles per wave: 4 -> 256 x 256 block tile, 3 -> 192 (m) x 256 (n): same staging (the X units still carry 256
+// rows, the last 64 unused), 3/4 of the MFMAs — for token-shard shapes whose 256-row tiles would fill only 2/3 of the CUs.
+template <int EPI, int MT>
 __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
   auto tile_origin = [&](int lid, int& m0, int& n0) {
     const int g = lid / per_group, first_m = g * GM;
     const int gsz = min(p.tiles_m - first_m, GM);
-    m0 = (first_m + (lid % per_group) % gsz) * K8_BM;
+    m0 = (first_m + (lid % per_group) % gsz) * (64 * MT);
     n0 = ((lid % per_group) / gsz) * K8_BN;
   };
 
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
   const int l15 = lane & 15, lc = lane >> 4;
   const int fco = (lc ^ ((l15 >> 2) & 3)) << 4;
   const char* wb = dsm + (128 * wn + l15) * 64 + fco;
-  const char* xb = dsm + K8_XOFF + (64 * wm + l15) * 64 + fco;
+  const char* xb = dsm + K8_XOFF + (16 * MT * wm + l15) * 64 + fco;
   const int nk = p.K / BK;
 
 #ifdef K8_TRACE
@@ -494,12 +496,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
   int m0, n0;
   if (slot < x_cnt) { tile_origin(x_first + slot, m0, n0); set_offsets(m0, n0); prologue(); }
   for (int ti = slot; ti < x_cnt; ti += per_xcd) {
-    f32x4 acc[8][4];   // [n-tile of 16][m-tile of 16]
+    f32x4 acc[8][MT];   // [n-tile of 16][m-tile of 16]
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wf[4], xf[4];
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wf[4], xf[MT];
 
     // this tile's prologue DMAs were issued before the previous tile's epilogue stores (vmcnt also counts those stores,
     // which may retire out of order with loads -> a full drain here; the DMAs have had the whole epilogue to land)
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
       K8_STAMP();
       if (nh == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + uo + j * 16 * 64);
+        for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + uo + j * 16 * 64);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + uo + (4 * nh + i) * 16 * 64);
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < MT; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           acc[4 * nh + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[4 * nh + i][j], 0, 0, 0);
@@ -571,8 +573,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
     const int e_wn = e_wave & 1, e_wm = ((e_wave >> 1) & 1) | ((e_wave >> 2) << 1);
     // accumulator tile (i, j): this lane holds token row m = 16 j + lane&15 and output columns n = 16 i + 4 (lane>>4) + 0..3
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = cm0 + 64 * e_wm + 16 * j + e_l15;
+    for (int j = 0; j < MT; ++j) {
+      const int m = cm0 + 16 * MT * e_wm + 16 * j + e_l15;
       if (m >= p.M) continue;
       float bias_m = 0.f;
       if (EPI == K5_EPI_BIAS_M && p.bias) bias_m = p.bias[m];
@@ -590,15 +592,38 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
 #endif
 }
 
-template <int EPI>
-int launch_k8(GemmP p, hipStream_t stream) {
+template <int EPI, int MT>
+int launch_k8_mt(GemmP p, hipStream_t stream, int num_cu, bool full_grid, bool no_tail) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_k8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, K8_LDS + K8_TRACE_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bf16_k8_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, K8_LDS + K8_TRACE_BYTES) != hipSuccess)
       return K5_ERR_HIP;
     attr_set = true;
   }
-  p.tiles_m = (p.M + K8_BM - 1) / K8_BM; p.tiles_n = (p.N + K8_BN - 1) / K8_BN;
+  p.tiles_m = (p.M + 64 * MT - 1) / (64 * MT); p.tiles_n = (p.N + K8_BN - 1) / K8_BN;
+  const int tiles = p.tiles_m * p.tiles_n;
+  // Whole rounds of num_cu tiles go to the persistent kernel; a last round that would fill less than half of the CUs is
+  // computed as 128x128 quadrants by the small kernel instead (1302 tiles of an N = 1792 projection: 5 rounds + 88 small
+  // workgroups instead of 6 rounds).  (256-row tiles only.)
+  const int full = tiles / num_cu * num_cu, rem = tiles - full;
+  const bool split_tail = MT == 4 && !no_tail && !full_grid && full > 0 && rem > 0 && 2 * rem < num_cu;
+  p.lid_limit = split_tail ? full : tiles;
+  p.tiles256_m = p.tiles_m; p.tiles256_n = p.tiles_n;
+  const int grid = full_grid ? tiles : min(p.lid_limit, num_cu);   // persistent: one workgroup per CU (128 KB of LDS each)
+#ifdef K8_TRACE
+  p.trace = getenv("K5_GEMM_TRACE") ? (unsigned long long*)strtoull(getenv("K5_GEMM_TRACE"), nullptr, 16) : nullptr;
+#endif
+  hipLaunchKernelGGL((gemm_bf16_k8_kernel<EPI, MT>), dim3(grid), dim3(512), K8_LDS + K8_TRACE_BYTES, stream, p);
+  if (split_tail) {
+    p.tail_base = full;
+    p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL(gemm_bf16_glds_kernel<EPI>, dim3(4 * rem), dim3(256), 0, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
+template <int EPI>
+int launch_k8(GemmP p, hipStream_t stream) {
   static int num_cu = 0;
   if (!num_cu) {
     int dev = 0; hipDeviceProp_t prop;
@@ -606,26 +631,17 @@ int launch_k8(GemmP p, hipStream_t stream) {
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   static const bool full_grid = getenv("K5_GEMM_FULLGRID") != nullptr;   // A/B: one workgroup per tile instead of per CU
-  const int tiles = p.tiles_m * p.tiles_n;
-  // Whole rounds of num_cu tiles go to the persistent kernel; a last round that would fill less than half of the CUs is
-  // computed as 128x128 quadrants by the small kernel instead (1302 tiles of an N = 1792 projection: 5 rounds + 88 small
-  // workgroups instead of 6 rounds).
-  static const bool no_tail = getenv("K5_GEMM_NO_TAIL") != nullptr;   // A/B switch for benchmarking
-  const int full = tiles / num_cu * num_cu, rem = tiles - full;
-  const bool split_tail = !no_tail && !full_grid && full > 0 && rem > 0 && 2 * rem < num_cu;
-  p.lid_limit = split_tail ? full : tiles;
-  p.tiles256_m = p.tiles_m; p.tiles256_n = p.tiles_n;
-  const int grid = full_grid ? tiles : min(p.lid_limit, num_cu);   // persistent: one workgroup per CU (128 KB of LDS each)
-#ifdef K8_TRACE
-  p.trace = getenv("K5_GEMM_TRACE") ? (unsigned long long*)strtoull(getenv("K5_GEMM_TRACE"), nullptr, 16) : nullptr;
-#endif
-  hipLaunchKernelGGL(gemm_bf16_k8_kernel<EPI>, dim3(grid), dim3(512), K8_LDS + K8_TRACE_BYTES, stream, p);
-  if (split_tail) {
-    p.tail_base = full;
-    p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(gemm_bf16_glds_kernel<EPI>, dim3(4 * rem), dim3(256), 0, stream, p);
-  }
-  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+  static const bool no_tail = getenv("K5_GEMM_NO_TAIL") != nullptr;      // A/B switches for benchmarking
+  static const int force_mt = getenv("K5_GEMM_MT") ? atoi(getenv("K5_GEMM_MT")) : 0;
+  // 192-row tiles when they need fewer (cost-weighted) rounds of the CUs than 256-row tiles: a round of 192-row tiles costs
+  // 3/4; a last round that the tail split handles costs ~0.3.  An 8-GPU shard's N = 1792 projections: 217 tiles x 0.75 vs 168 x 1.
+  auto cost = [&](int bm, double w, bool tail_ok) {
+    const int tiles = ((p.M + bm - 1) / bm) * ((p.N + K8_BN - 1) / K8_BN);
+    const int full = tiles / num_cu, rem = tiles % num_cu;
+    return w * (full + (rem == 0 ? 0.0 : (tail_ok && full > 0 && 2 * rem < num_cu ? 0.3 : 1.0)));
+  };
+  const bool mt3 = force_mt ? force_mt == 3 : cost(192, 0.75, false) < 0.97 * cost(256, 1.0, !no_tail);
+  return mt3 ? launch_k8_mt<EPI, 3>(p, stream, num_cu, full_grid, no_tail) : launch_k8_mt<EPI, 4>(p, stream, num_cu, full_grid, no_tail);
 }
 
 }  // namespace
