@@ -666,7 +666,10 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   // K5_GEMM_V1=3 selects the 256x128 3-stage counted-vmcnt variant.  Measured (round 1, model shapes): within +-3 % of the
   // 128x128 direct-to-LDS kernel (ff2 844 vs 827, ff1 698 vs 719 TFLOP/s) -> L2-miss latency is not the limiter; not default.
   // default for the model's large projections: the 256x256 two-group ping-pong kernel (K5_GEMM_V1=2 keeps the 128x128 one)
-  if ((K % BK) == 0 && K >= 2 * BK && M >= 512 && N >= 256 && (force_v1 == 0 || force_v1 == 8)) {
+  // ... once its 256x256 tiles fill at least half of the CUs (measured crossover, tools/gemm_small.py: 91-112 tiles lose to the
+  // 128x128 kernel by 5-10 %, 42 tiles by 40 %; 168 tiles win by 15 %)
+  const long long tiles256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  if ((K % BK) == 0 && K >= 2 * BK && M >= 512 && N >= 256 && (force_v1 == 8 || (force_v1 == 0 && tiles256 >= 128))) {
     switch (epi) {
       case K5_EPI_BIAS: return launch_k8<K5_EPI_BIAS>(p, stream);
       case K5_EPI_BIAS_M: return launch_k8<K5_EPI_BIAS_M>(p, stream);

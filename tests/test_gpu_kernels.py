@@ -42,7 +42,7 @@ def assert_bf16_close(got, ref, ulps=2, atol=1e-3, what=""):
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 1792), (200, 72, 136), (7, 128, 96), (1, 64, 48),
                                    (333, 64, 1792), (1000, 3584, 256), (768, 512, 1792), (600, 300, 192), (512, 256, 128),
-                                   (1024, 1792, 7168)])
+                                   (1024, 1792, 7168), (4100, 2048, 192), (5952, 1792, 1792)])
 def test_gemm_bias(E, M, N, K):
     a, w, b = bfr(rnd(M, K, seed=1)), bfr(rnd(N, K, seed=2, scale=0.05)), bfr(rnd(N, seed=3, scale=0.1))
     ref = bfr(a @ w.t() + b)
@@ -56,7 +56,7 @@ def test_gemm_256_tile_kernel_is_race_free_and_deterministic(E):
     repeating a multi-tile problem (odd and even K-tile counts) and demanding bit-identical results every time, equal to
     the 128x128 kernel's (same fp32 accumulation order along K)."""
     import os
-    for (M, N, K) in ((2048, 1024, 1792), (1536, 768, 448), (4096, 512, 128)):
+    for (M, N, K) in ((4096, 2048, 1792), (3072, 3072, 448), (8192, 1024, 128)):   # >= 128 tiles of 256x256: the persistent kernel's range
         a, w = bfr(rnd(M, K, seed=11)).cuda().to(BF), bfr(rnd(N, K, seed=12, scale=0.05)).cuda().to(BF)
         b = bfr(rnd(N, seed=13)).cuda()
         first = E.gemm(a, w, b, E.EPI_BIAS).clone()
@@ -116,6 +116,15 @@ def test_gemm_gelu_and_gate_epilogues(E):
     r = resid.cuda().to(BF)
     got = E.gemm(h_ref.cuda().to(BF), w2.cuda().to(BF), None, E.EPI_GATE, resid=r, gate=gate.cuda(), out=r)  # in place
     assert_bf16_close(got, ref, ulps=3, what="gate epilogue (in place)")
+
+
+def test_gemm_gelu_epilogue_persistent_kernel(E):
+    """GELU epilogue at a size the 256x256 persistent kernel takes (>= 128 tiles), ragged in M and N."""
+    M, D, FF = 4000, 256, 2040
+    x, w1 = bfr(rnd(M, D, seed=51)), bfr(rnd(FF, D, seed=52, scale=0.1))
+    ref = bfr(torch.nn.functional.gelu(bfr(x @ w1.t())))
+    got = E.gemm(x.cuda().to(BF), w1.cuda().to(BF), None, E.EPI_GELU)
+    assert_bf16_close(got, ref, what="gelu epilogue (k8)")
 
 
 def test_gemm_alignment_error_is_loud(E):
