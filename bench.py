@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-for-`value`) VAE decode leg")
     ap.add_argument("--force-sp", action="store_true", help="debug: drive the sharded code path through a world=1 RCCL communicator")
+    ap.add_argument("--magcache", action="store_true", help="MagCache with the config's ratio table (changes the work per step: not the headline metric)")
     ap.add_argument("--fp8", action="store_true", help="opt-in lossy mode (feed-forward GEMMs in W8A8 e4m3): NOT the headline number, reported as dtype bf16+fp8ff")
     ap.add_argument("--emulate-shard", type=int, default=0, metavar="P",
                     help="debug only (INVALID as a bench): per-rank compute of a P-GPU run on one GPU, collectives move nothing")
@@ -142,6 +143,14 @@ def main():
     with torch.device("meta"):
         dit = DiffusionTransformer3D(**cfgd)
     dit.init_synthetic(dev, seed=0)
+    if args.magcache:
+        from kandinsky.config import default_configs
+        from kandinsky.magcache_utils import set_magcache_params
+        cname = {"5s_nocfg": "config_5s_nocfg.yaml", "5s_sft": "config_5s_sft.yaml", "10s_nabla": "config_10s_sft.yaml"}.get(args.workload)
+        if cname is None:
+            raise SystemExit("--magcache needs a 50-step workload (5s_nocfg, 5s_sft, 10s_nabla)")
+        dit.engine(dev)
+        set_magcache_params(dit, default_configs()[cname]["magcache"]["mag_ratios"], 50, abs(wl["w"] - 1.0) <= 1e-6)
     if args.fp8:
         dit.set_fp8(True)
     if args.emulate_shard > 1:
@@ -231,7 +240,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16+fp8ff (REDUCED PRECISION, not the headline)" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": wl["desc"], "tokens": N, "text_len": L, "forwards_per_step": fwd_per_step,
                        "parallelism": "single GPU" if world == 1 else f"sequence-parallel x{world} (token shards, K/V all-gather)",
-                       "visual_blocks": args.blocks},
+                       "visual_blocks": args.blocks, "magcache": bool(args.magcache)},
             "nfe_per_s": fwd_per_step * args.steps / dt,
             "step_tflop": step_flop / 1e12,
             "model_tflops_per_gpu": step_flop * args.steps / dt / 1e12 / world,
