@@ -59,6 +59,12 @@ int64_t k5_attention_state_size(int H, int q_len);
 int k5_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len,
                             int ldq, int ldk, int ldvt, int ldo, float score_bound, int tile_off0, int tile_cnt,
                             int tile_skip_at, int tile_skip_n, void* state, int flags, void* stream);
+/* The same attention with the keys ALREADY multiplied by the softmax scale in the exp2 domain: Kc = bf16(log2(e)/8 * k)
+ * (one rounding, done by the producer: the engine's rmsnorm/RoPE kernel).  The scores are then the exp2 arguments up to the
+ * fixed offset score_bound * log2(e)/8, which rides in the MFMA accumulator's initial value: no per-score multiply-add.
+ * Needs the fixed-offset softmax: score_bound > 0 with 2 * score_bound * log2(e)/8 <= 96 (else K5_ERR_ARG). */
+int k5_attention_bf16_prescaled(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len,
+                                int ldq, int ldk, int ldvt, int ldo, float score_bound, void* stream);
 /* k5_attention_bf16[_bounded] with load balancing: the (head, 256-query) jobs that do not fill a whole round of the
  * device's resident workgroups are split 2-4 ways along the keys and merged (same result up to fp32 summation order).
  * workspace: k5_attention_balance_size(H, q_len) bytes.  The engine uses this for every large self-attention. */

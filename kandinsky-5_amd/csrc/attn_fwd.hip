@@ -71,7 +71,9 @@ K5_DEV int lds_swz_k(int row, int chunk) { return row * 128 + ((chunk ^ (((row >
 
 // RANGE: key-tile sub-range + resumable fp32 state (sequence-parallel two-pass schedule); kept out of the plain dense
 // instantiation, whose loop is sensitive to every extra live value (128-VGPR budget for 2 workgroups per CU).
-template <bool BOUNDED, bool SPARSE, bool RANGE>
+// PRE: K arrives pre-multiplied by log2(e)/8 (rounded to bf16 once, by the rmsnorm/RoPE kernel): the scores ARE the exp2
+// arguments up to the fixed offset, which rides in the MFMA accumulator's initial value -> no per-score fma at all.
+template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
   char* sK = smem;
@@ -186,9 +188,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     {
     // ---- S^T = K Q^T : four 16-key x two 16-query MFMA tiles, two k-steps over d; K fragments streamed from LDS ----
     f32x4 st[4][2];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = PRE ? f32x4{-mc_fixed, -mc_fixed, -mc_fixed, -mc_fixed} : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {   // first k-step starts from the constant 0 (no accumulator initialisation moves)
+    for (int kt = 0; kt < 4; ++kt) {   // first k-step starts from a constant (0, or the softmax offset when PRE)
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), g));
       st[kt][0] = mfma16(kf, qf[0][0], zero4);
       st[kt][1] = mfma16(kf, qf[1][0], zero4);
@@ -221,7 +223,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
           float e[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            e[j] = __builtin_amdgcn_exp2f(fmaf(st[2 * ks2 + (j >> 2)][qt][j & 3], c, -mc[qt]));
+            e[j] = PRE ? __builtin_amdgcn_exp2f(st[2 * ks2 + (j >> 2)][qt][j & 3])
+                       : __builtin_amdgcn_exp2f(fmaf(st[2 * ks2 + (j >> 2)][qt][j & 3], c, -mc[qt]));
             l_run[qt] += e[j];
           }
           u32x4 pk = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
@@ -563,7 +566,7 @@ int attn_slots() {
 int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
-                                   int tile_skip_n, float* state, int flags, hipStream_t stream, float* ws) {
+                                   int tile_skip_n, float* state, int flags, hipStream_t stream, float* ws, bool k_prescaled) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -586,10 +589,13 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.state = state; p.flags = flags;
   p.job0 = 0; p.splits = 1; p.split_state = nullptr; p.split_stride = 0;
   const bool range = tile_off0 != 0 || tile_cnt != total_tiles || (flags & 3);
+  if (k_prescaled && !bounded) return K5_ERR_ARG;   // pre-scaled keys need the fixed-offset softmax (caller checks the bound)
   if (bounded) p.m_fixed = score_bound;
   auto launch = [&](int njobs, bool use_range) {
     const dim3 grid(njobs);
-    if (bounded && use_range) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), grid, block, 0, stream, p);
+    if (bounded && k_prescaled && use_range) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true>), grid, block, 0, stream, p);
+    else if (bounded && k_prescaled) hipLaunchKernelGGL((attn_fwd_kernel<true, false, false, true>), grid, block, 0, stream, p);
+    else if (bounded && use_range) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), grid, block, 0, stream, p);
     else if (bounded) hipLaunchKernelGGL((attn_fwd_kernel<true, false, false>), grid, block, 0, stream, p);
     else if (use_range) hipLaunchKernelGGL((attn_fwd32_kernel<false, false, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((attn_fwd32_kernel<false, false, false>), grid, block, 0, stream, p);
@@ -620,7 +626,7 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
                                      int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                      int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream) {
   return k5_launch_attention_bf16_range(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, score_bound, vt_chunk_keys,
-                                        vt_chunk_stride, 0, -1, 0x7fffffff, 0, nullptr, 0, stream, nullptr);
+                                        vt_chunk_stride, 0, -1, 0x7fffffff, 0, nullptr, 0, stream, nullptr, false);
 }
 
 // NABLA block-sparse attention (flex_attention(q,k,v,block_mask) nn.py:257-280): `list`/`cnt` are the per-workgroup

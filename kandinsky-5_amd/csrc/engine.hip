@@ -332,6 +332,15 @@ int pack_attn(k5_dit* d, const std::string& p, AttnW& a, bool fuse_qk) {
 
 inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Dense visual self-attention runs with the keys pre-multiplied by log2(e)/8 (attn_fwd_kernel<.., PRE>) whenever the fixed
+// softmax offset is usable (2 * bound * c <= 96, the same condition the attention launcher applies); NABLA keeps unscaled
+// keys (its block map is computed from them).  K5_NO_PRESCALE=1: A/B switch.
+constexpr float K5_SOFTMAX_C = 0.125f * 1.44269504088896340736f;
+inline bool use_prescale(const AttnW& a) {
+  static const bool off = getenv("K5_NO_PRESCALE") != nullptr;
+  return !off && a.score_bound > 0.f && 2.f * a.score_bound * K5_SOFTMAX_C <= 96.f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // one attention module on `rows` tokens:  x_resid += gate * out_l(attn(...)) fused in the out GEMM
 // ---------------------------------------------------------------------------------------------
@@ -350,7 +359,8 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   {
     Scope sc(d, s, "elementwise");
     const int32_t hc[2] = {H, 2 * H};
-    K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s));
+    const bool pre = !nabla && !strcmp(fam_attn, "attn_self") && use_prescale(a);   // visual blocks only (not the text blocks)
+    K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff));
   }
   if (nabla) {  // nablaT_v2 map (utils.py:136-163) + block-sparse attention (nn.py:257-280)
     const int nb = rows / 64;
@@ -369,7 +379,8 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     Scope sc(d, s, fam_attn);
     K5CHK(k5_launch_attention_bf16_range(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, 0, 0, 0, -1,
-                                         0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>()));
+                                         0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(),
+                                         !strcmp(fam_attn, "attn_self") && use_prescale(a)));
   }
   {
     Scope sc(d, s, "gemm");
@@ -399,7 +410,8 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   }
   {
     Scope sc(d, s, "elementwise");
-    K5CHK(k5_launch_rmsnorm_rope(kloc, a.norm.as<float>() + 64, cosT, sinT, rows, H, D, nullptr, s));
+    const bool pre = !nabla && use_prescale(a);
+    K5CHK(k5_launch_rmsnorm_rope(kloc, a.norm.as<float>() + 64, cosT, sinT, rows, H, D, nullptr, s, K5_SOFTMAX_C, pre ? 0 : 0x7fffffff));
   }
   HIPCHK(hipEventRecord(d->ev_k, s));
   {
@@ -451,13 +463,14 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     {
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
-                                           r * tpc, tpc, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s));
+                                           r * tpc, tpc, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s, nullptr, use_prescale(a)));
     }
     HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
     {
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
-                                           0, total - tpc, r * tpc, tpc, d->ws_attn_state.as<float>(), 1, s, d->ws_attn_bal.as<float>()));
+                                           0, total - tpc, r * tpc, tpc, d->ws_attn_state.as<float>(), 1, s, d->ws_attn_bal.as<float>(),
+                                         use_prescale(a)));
     }
   }
   {

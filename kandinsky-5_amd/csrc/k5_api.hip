@@ -45,6 +45,12 @@ int k5_quant_rows_fp8(const void* x, void* out, float* scale, int rows, int K, i
   return ret(k5_launch_quant_rows_fp8(x, out, scale, rows, K, ldx, ldo, (hipStream_t)stream), "k5_quant_rows_fp8");
 }
 
+int k5_attention_bf16_prescaled(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                int ldk, int ldvt, int ldo, float score_bound, void* stream) {
+  return ret(k5_launch_attention_bf16_range(Q, Kc, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, score_bound, 0, 0, 0, -1, 0x7fffffff, 0,
+                                            nullptr, 0, (hipStream_t)stream, nullptr, true), "k5_attention_bf16_prescaled");
+}
+
 int64_t k5_attention_balance_size(int H, int q_len) { return (int64_t)k5_attention_balance_bytes(H, q_len); }
 
 int k5_attention_bf16_balanced(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,

@@ -28,7 +28,7 @@ size_t k5_attention_state_bytes(int H, int q_len);
 int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
-                                   int tile_skip_n, float* state, int flags, hipStream_t stream, float* balance_ws = nullptr);
+                                   int tile_skip_n, float* state, int flags, hipStream_t stream, float* balance_ws = nullptr, bool k_prescaled = false);
 size_t k5_attention_balance_bytes(int H, int q_len);
 
 // ---- fp8 (e4m3) feed-forward path, opt-in (gemm_fp8.hip) ----
@@ -56,7 +56,8 @@ int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift,
 //   x holds H heads per row; head h uses weight[(h / heads_per_weight)*64 ..]; RoPE (cos/sin [rows][32]) on heads
 //   < rope_heads.  heads_cfg = host pointer to {heads_per_weight, rope_heads} or null (= {H, H}).
 int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cos, const float* sin, int rows,
-                           int H, int ld, const int32_t* heads_cfg, hipStream_t stream);
+                           int H, int ld, const int32_t* heads_cfg, hipStream_t stream,
+                           float out_scale = 1.f, int scale_from_head = 0x7fffffff);  // heads >= scale_from_head are multiplied by out_scale before the bf16 rounding
 // K15: cos/sin tables [T*H*W][n0+n1+n2] for RoPE3D (RoPE1D: H=W=1, n1=n2=0), optional token permutation
 int k5_launch_rope_table(float* cosT, float* sinT, const int32_t* p0, const int32_t* p1, const int32_t* p2, int T,
                          int H, int W, int n0, int n1, int n2, float s0, float s1, float s2, const int32_t* tok_perm,

@@ -65,6 +65,7 @@ SYMBOLS = {
     "k5_attention_bf16_range": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P, _I, _P]),
     "k5_gemm_fp8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "k5_quant_rows_fp8": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "k5_attention_bf16_prescaled": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "k5_attention_balance_size": (_I64, [_I, _I]),
     "k5_attention_bf16_balanced": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "k5_nabla_workspace_size": (_I64, [_I, _I]),

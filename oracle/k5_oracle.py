@@ -227,7 +227,12 @@ def rope_3d_args(shape, pos, axes_dims, scale_factor=(1.0, 1.0, 1.0)) -> Tensor:
     ], dim=-1)
 
 
-def apply_rotary(x: Tensor, cos: Tensor, sin: Tensor, mode: str) -> Tensor:
+PRESCALE_K = False   # test switch: the engine's dense visual self-attention hands the softmax keys pre-multiplied by
+#                      log2(e)/8 (one bf16 rounding, csrc/small_ops.hip rmsnorm_rope_kernel) and exponentiates in base 2
+SOFTMAX_C = 0.125 * 1.44269504088896340736
+
+
+def apply_rotary(x: Tensor, cos: Tensor, sin: Tensor, mode: str, out_scale: float = 1.0) -> Tensor:
     """nn.py:35-40 with rope = [[cos,-sin],[sin,cos]] (nn.py:112-116): adjacent pairs
     (x0,x1) -> (c*x0 - s*x1, s*x0 + c*x1), fp32 math, bf16 rounding.
     x (S,H,hd); cos/sin (S, hd/2)."""
@@ -237,7 +242,10 @@ def apply_rotary(x: Tensor, cos: Tensor, sin: Tensor, mode: str) -> Tensor:
     s = sin[:, None, :]
     o0 = c * xp[..., 0] + (-s) * xp[..., 1]
     o1 = s * xp[..., 0] + c * xp[..., 1]
-    return _r(torch.stack([o0, o1], dim=-1).reshape(S, H, hd), mode)
+    rot = torch.stack([o0, o1], dim=-1).reshape(S, H, hd)
+    if out_scale != 1.0:
+        rot = rot * torch.tensor(out_scale, dtype=torch.float32)
+    return _r(rot, mode)
 
 
 def modulation(sd, prefix: str, temb: Tensor) -> Tensor:
@@ -265,14 +273,14 @@ def rms_norm_heads(x: Tensor, w: Tensor, mode: str) -> Tensor:
     return _r(y, mode)
 
 
-def sdpa(q: Tensor, k: Tensor, v: Tensor, mode: str, block_mask: Optional[Tensor] = None) -> Tensor:
+def sdpa(q: Tensor, k: Tensor, v: Tensor, mode: str, block_mask: Optional[Tensor] = None, base2: bool = False) -> Tensor:
     """FA(q,k,v) nn.py:201,254,336 — third-party flash-attn (absent from the reference tree):
     softmax(q k^T / sqrt(d)) v, non-causal, fp32 softmax, bf16 output.
     q (Sq,H,d), k,v (Sk,H,d) -> (Sq, H*d).  block_mask (H, Sq/64, Sk/64) bool for NABLA."""
     Sq, H, d = q.shape
     qh, kh, vh = q.float().transpose(0, 1), k.float().transpose(0, 1), v.float().transpose(0, 1)
     out = torch.empty(H, Sq, d)
-    scale = 1.0 / math.sqrt(d)
+    scale = math.log(2.0) if base2 else 1.0 / math.sqrt(d)   # base2: k already carries log2(e)/sqrt(d); 2^x = e^(x ln 2)
     chunk = 2048
     for h in range(H):
         for s0 in range(0, Sq, chunk):
@@ -365,9 +373,13 @@ def _attn_qkv(sd, prefix, xq, xkv, mode, H):
 def self_attention(sd, prefix, x, cos, sin, cfg, mode, sparse=None, taps=None):
     """MultiheadSelfAttentionEnc/Dec.forward nn.py:208-217,286-298."""
     q, k, v = _attn_qkv(sd, prefix, x, x, mode, cfg.num_heads)
+    pre = PRESCALE_K and mode == "bf16" and sparse is None and prefix.startswith("visual_transformer_blocks")
     q = apply_rotary(q, cos, sin, mode)
-    k = apply_rotary(k, cos, sin, mode)
+    k = apply_rotary(k, cos, sin, mode, SOFTMAX_C if pre else 1.0)
     bm = None
+    if pre:
+        o = sdpa(q, k, v, mode, None, base2=True)
+        return _linear(o, sd[f"{prefix}.out_layer.weight"].float(), sd[f"{prefix}.out_layer.bias"].float(), mode)
     if sparse is not None:
         bm = nabla_block_mask(q, k, sparse["sta_mask"], sparse["P"], mode)
         if taps is not None:

@@ -129,6 +129,15 @@ def test_full_width_two_blocks_vs_oracle():
     assert rel(out, ref) <= 1.5e-2, rel(out, ref)
     ref32 = O.dit_forward(sd, cfg, xin, text, pooled, t, pos, torch.arange(37), (1.0, 2.0, 2.0), None, "fp32")
     assert rel(out, ref32) <= 3e-2, rel(out, ref32)
+    # the engine's dense visual self-attention uses keys pre-multiplied by log2(e)/8 (one bf16 rounding): the oracle with the
+    # same rounding point is closer still
+    O.PRESCALE_K = True
+    try:
+        refp = O.dit_forward(sd, cfg, xin, text, pooled, t, pos, torch.arange(37), (1.0, 2.0, 2.0), None, "bf16")
+    finally:
+        O.PRESCALE_K = False
+    print(f"full width: engine vs bf16-island oracle {rel(out, ref):.3e}, vs oracle with pre-scaled keys {rel(out, refp):.3e}, vs fp32 {rel(out, ref32):.3e}")
+    assert rel(out, refp) <= 1.5e-2, rel(out, refp)
     # and against the REFERENCE's own output on the same inputs / seeded weights (tests/golden/dit_fullwidth.*)
     import json
     import os

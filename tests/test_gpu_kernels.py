@@ -428,3 +428,27 @@ def test_gemm_fp8_epilogues_and_row_quantisation(E):
                           gate.cuda().data_ptr(), E.stream_ptr()))
     ref = bfr(resid + gate * bfr((got @ w28.cpu().view(F8).float().t()) * s2.cpu()))
     assert_bf16_close(r, ref, ulps=4, atol=4e-3, what="fp8 ff2 gate")   # bf16 tie flips of the inner rounding, times the gate
+
+
+def test_attention_prescaled_keys(E):
+    """k5_attention_bf16_prescaled: keys pre-multiplied by log2(e)/8 and rounded once.  Exactly the softmax (base 2) of those
+    keys — checked against the oracle fed the same rounded keys — and within bf16 noise of the unscaled formulation."""
+    H, Sq, Sk = 3, 700, 1100
+    def rmsn(x):
+        return bfr(x / x.pow(2).mean(-1, keepdim=True).sqrt())
+    q, k, v = rmsn(rnd(Sq, H, 64, seed=61)), rmsn(rnd(Sk, H, 64, seed=62)), bfr(rnd(Sk, H, 64, seed=63))
+    kc = bfr(k * torch.tensor(O.SOFTMAX_C, dtype=torch.float32))
+    ld = (Sk + 7) // 8 * 8
+    vt = torch.zeros(H * 64, ld, dtype=BF, device="cuda")
+    vt[:, :Sk] = v.reshape(Sk, H * 64).t().to(BF)
+    qd, kd, kcd = q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), kc.reshape(Sk, -1).cuda().to(BF)
+    out = torch.empty(Sq, H * 64, dtype=BF, device="cuda")
+    L = E.lib()
+    E.check(L.k5_attention_bf16_prescaled(qd.data_ptr(), kcd.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk, qd.stride(0),
+                                          kcd.stride(0), vt.stride(0), out.stride(0), 64 * 1.05, E.stream_ptr()))
+    assert_bf16_close(out, O.sdpa(q, kc, v, "bf16", None, base2=True), ulps=4, atol=1e-2, what="prescaled attention vs base-2 oracle")
+    plain = E.attention(qd, kd, vt, H, kv_len=Sk, score_bound=64 * 1.05)
+    assert (out.float() - plain.float()).abs().max().item() <= 3e-2        # re-rounded keys: bf16-level differences only
+    with pytest.raises(RuntimeError):                                       # needs the fixed-offset softmax
+        E.check(L.k5_attention_bf16_prescaled(qd.data_ptr(), kcd.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk, qd.stride(0),
+                                              kcd.stride(0), vt.stride(0), out.stride(0), 0.0, E.stream_ptr()))
