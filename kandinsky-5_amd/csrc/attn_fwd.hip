@@ -634,7 +634,7 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
 // V^T optionally in per-rank chunks (sequence parallel).
 int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
-                                    int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream) {
+                                    int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0 || (q_len % KB) || (kv_len % KB) || !list || !cnt) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -649,7 +649,11 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   p.job0 = 0; p.splits = 1; p.split_state = nullptr; p.split_stride = 0;
   const dim3 grid(H * p.nqb), block(512);
   const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
-  if (bounded) {
+  if (k_prescaled && !bounded) return K5_ERR_ARG;
+  if (bounded && k_prescaled) {
+    p.m_fixed = score_bound;
+    hipLaunchKernelGGL((attn_fwd_kernel<true, true, false, true>), grid, block, 0, stream, p);
+  } else if (bounded) {
     p.m_fixed = score_bound;
     hipLaunchKernelGGL((attn_fwd_kernel<true, true, false>), grid, block, 0, stream, p);
   } else {

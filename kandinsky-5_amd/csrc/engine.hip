@@ -183,6 +183,7 @@ struct k5_dit {
   bool use_graph = false;                          // k5_sample replays one captured step (k5_dit_set_graph)
   hipStream_t graph_stream = nullptr;              // capture needs a real stream: the caller's may be the legacy null stream
   hipEvent_t ev_graph = nullptr;
+  DevBuf ws_kc;                                    // NABLA: keys pre-multiplied by the softmax scale (separate from the map's keys)
   DevBuf ws_attn_bal;                              // states of the split tail jobs (k5_launch_attention_bf16_range, balanced)
   hipStream_t comm_stream = nullptr;              // all-gathers run here, overlapped with pass 1 of the attention
   hipEvent_t ev_k = nullptr, ev_v = nullptr, ev_gathered = nullptr;
@@ -359,8 +360,10 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   {
     Scope sc(d, s, "elementwise");
     const int32_t hc[2] = {H, 2 * H};
-    const bool pre = !nabla && !strcmp(fam_attn, "attn_self") && use_prescale(a);   // visual blocks only (not the text blocks)
-    K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff));
+    const bool pre = !strcmp(fam_attn, "attn_self") && use_prescale(a);   // visual blocks only (not the text blocks)
+    void* kc = nullptr;   // NABLA: the block map needs the unscaled keys -> the scaled copy goes to its own buffer
+    if (pre && nabla) { K5CHK(d->ws_kc.ensure((size_t)rows * D * 2)); kc = d->ws_kc.p; }
+    K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D));
   }
   if (nabla) {  // nablaT_v2 map (utils.py:136-163) + block-sparse attention (nn.py:257-280)
     const int nb = rows / 64;
@@ -373,8 +376,9 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     const int *list, *cnt;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
     Scope sc(d, s, fam_attn);
-    K5CHK(k5_launch_attention_bf16_sparse(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, list,
-                                          cnt, nb, 0, 0, s));
+    const bool pre = !strcmp(fam_attn, "attn_self") && use_prescale(a);
+    K5CHK(k5_launch_attention_bf16_sparse(qk, pre ? d->ws_kc.as<bf16_t>() : (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, pre ? D : 2 * D,
+                                          ldvt, D, a.score_bound, list, cnt, nb, 0, 0, s, pre));
   } else {
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     Scope sc(d, s, fam_attn);
@@ -796,7 +800,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
                    &d->ws_vel_u};
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_kc.release(); d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
   for (auto& b : d->vblocks) { b.w1_f8.release(); b.w2_f8.release(); b.s1_f8.release(); b.s2_f8.release(); }
   if (d->graph_stream) { (void)hipStreamSynchronize(d->graph_stream); (void)hipStreamDestroy(d->graph_stream); (void)hipEventDestroy(d->ev_graph); }
   if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }

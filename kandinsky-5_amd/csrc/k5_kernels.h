@@ -47,7 +47,7 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
 int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void* out, hipStream_t s);
 int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
-                                    int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream);
+                                    int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled = false);
 
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,
@@ -57,7 +57,9 @@ int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift,
 //   < rope_heads.  heads_cfg = host pointer to {heads_per_weight, rope_heads} or null (= {H, H}).
 int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cos, const float* sin, int rows,
                            int H, int ld, const int32_t* heads_cfg, hipStream_t stream,
-                           float out_scale = 1.f, int scale_from_head = 0x7fffffff);  // heads >= scale_from_head are multiplied by out_scale before the bf16 rounding
+                           float out_scale = 1.f, int scale_from_head = 0x7fffffff, void* scaled_out = nullptr, int ld_scaled = 0);
+// heads >= scale_from_head are multiplied by out_scale before the bf16 rounding — in place, or (scaled_out != null) into
+// scaled_out[row][(head - scale_from_head) * 64 ...] while the unscaled values stay in place
 // K15: cos/sin tables [T*H*W][n0+n1+n2] for RoPE3D (RoPE1D: H=W=1, n1=n2=0), optional token permutation
 int k5_launch_rope_table(float* cosT, float* sinT, const int32_t* p0, const int32_t* p1, const int32_t* p2, int T,
                          int H, int W, int n0, int n1, int n2, float s0, float s1, float s2, const int32_t* tok_perm,

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, c
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                            const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                            int rows, int H, int heads_per_weight, int ld, int rope_heads,
-                                                           float out_scale, int scale_from_head) {
+                                                           float out_scale, int scale_from_head, bf16_t* __restrict__ scaled_out,
+                                                           int ld_scaled) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)rows * H * 8;
   const bool valid = gid < total;
@@ -121,8 +122,16 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
     }
   }
   if (head >= scale_from_head) {   // keys handed to the pre-scaled softmax: k' = bf16(log2(e)/8 * k), one rounding
+    if (scaled_out) {              // NABLA: the unscaled keys stay in place (block map), the scaled copy goes to its own buffer
+      if (valid) {
+        u32x4 pks = {pack_bf16x2(__fmul_rn(y[0], out_scale), __fmul_rn(y[1], out_scale)), pack_bf16x2(__fmul_rn(y[2], out_scale), __fmul_rn(y[3], out_scale)),
+                     pack_bf16x2(__fmul_rn(y[4], out_scale), __fmul_rn(y[5], out_scale)), pack_bf16x2(__fmul_rn(y[6], out_scale), __fmul_rn(y[7], out_scale))};
+        *reinterpret_cast<u32x4*>(scaled_out + (size_t)row * ld_scaled + (head - scale_from_head) * 64 + 8 * c) = pks;
+      }
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) y[j] = __fmul_rn(y[j], out_scale);
+      for (int j = 0; j < 8; ++j) y[j] = __fmul_rn(y[j], out_scale);
+    }
   }
   if (valid) {
     u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
@@ -297,7 +306,8 @@ int k5_launch_ln_affine(const void* x, const float* w, const float* b, void* out
 }
 
 int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, const float* sinT, int rows, int H,
-                           int ld, const int32_t* heads_cfg, hipStream_t s, float out_scale, int scale_from_head) {
+                           int ld, const int32_t* heads_cfg, hipStream_t s, float out_scale, int scale_from_head, void* scaled_out,
+                           int ld_scaled) {
   // heads_cfg (host pointer, optional): {heads_per_weight, rope_heads}; default: one weight, rope on all heads
   if (rows <= 0 || H <= 0) return K5_ERR_ARG;
   if (ld & 7) return K5_ERR_ALIGN;
@@ -305,7 +315,7 @@ int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, cons
   const int rope_heads = heads_cfg ? heads_cfg[1] : H;
   const int64_t total = (int64_t)rows * H * 8;
   hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (bf16_t*)x, weight,
-                     cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head);
+                     cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled);
   return done();
 }
 

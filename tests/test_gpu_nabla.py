@@ -181,7 +181,10 @@ def test_rect_map_and_chunked_sparse_attention_equal_the_square_rows(E):
 
 
 def test_engine_nabla_sharded_path_world1_matches_fused(tiny, golden, golden_meta):
-    """world = 1 RCCL communicator: the sequence-parallel NABLA branch of the engine == the fused NABLA path, bit for bit."""
+    """world = 1 RCCL communicator: the sequence-parallel NABLA branch of the engine vs the fused NABLA path.  Same block map
+    and same attention kernel; the fused path hands the attention keys pre-multiplied by the softmax scale (one bf16 rounding
+    of c*k instead of k), the sharded path keeps one set of (unscaled) gathered keys for map and attention -> bf16-level
+    differences only."""
     from kandinsky.models.dit import DiffusionTransformer3D
     dit, _ = tiny
     attn = golden_meta["nabla_attention"]
@@ -194,4 +197,4 @@ def test_engine_nabla_sharded_path_world1_matches_fused(tiny, golden, golden_met
     sp.load_state_dict(dit.state_dict(), assign=True)
     sp = sp.to("cuda:0").enable_sequence_parallel(0, 1, device="cuda:0")
     b = sp(*args, scale_factor=(1.0, 2.0, 2.0), sparse_params=sparse)
-    assert torch.equal(a, b)
+    assert rel(b, a) <= 5e-3, rel(b, a)
