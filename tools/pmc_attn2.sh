@@ -2,8 +2,8 @@
 # usage: tools/pmc_attn2.sh <tag> [env assignments...] — VALU / MFMA / LDS counters of the (bounded) attention kernel
 TAG=$1; shift
 export TMPDIR=/tmp; R=$PWD; cd /tmp
-env BOUNDED=1 "$@" rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/pmca_$TAG -o p -- python $R/tools/attn_only.py 2 > /dev/null 2>&1
-env BOUNDED=1 "$@" rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $R/gpurun_out/pmca_${TAG}b -o p -- python $R/tools/attn_only.py 2 > /dev/null 2>&1
+env BOUNDED=1 PRESCALED=1 "$@" rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/pmca_$TAG -o p -- python $R/tools/attn_only.py 2 > /dev/null 2>&1
+env BOUNDED=1 PRESCALED=1 "$@" rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $R/gpurun_out/pmca_${TAG}b -o p -- python $R/tools/attn_only.py 2 > /dev/null 2>&1
 cd $R
 python - <<PY
 import csv, collections, glob
