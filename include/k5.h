@@ -62,7 +62,8 @@ int k5_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* 
 /* The same attention with the keys ALREADY multiplied by the softmax scale in the exp2 domain: Kc = bf16(log2(e)/8 * k)
  * (one rounding, done by the producer: the engine's rmsnorm/RoPE kernel).  The scores are then the exp2 arguments up to the
  * fixed offset score_bound * log2(e)/8, which rides in the MFMA accumulator's initial value: no per-score multiply-add.
- * Needs the fixed-offset softmax: score_bound > 0 with 2 * score_bound * log2(e)/8 <= 96 (else K5_ERR_ARG). */
+ * Needs the fixed-offset softmax (score_bound > 0 with 2 * score_bound * log2(e)/8 <= 96) and whole key tiles
+ * (kv_len % 64 == 0: this entry carries no ragged-tile masking); K5_ERR_ARG otherwise. */
 int k5_attention_bf16_prescaled(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len,
                                 int ldq, int ldk, int ldvt, int ldo, float score_bound, void* stream);
 /* k5_attention_bf16[_bounded] with load balancing: the (head, 256-query) jobs that do not fill a whole round of the

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     }
     __builtin_amdgcn_global_load_lds((gbl_void_t*)(Kb + ((uint32_t)min(kv0 + lrow, p.kv_len - 1) * kstride + klane)),
                                      (lds_void_t*)(sK + buf * TILE + wave_u * 1024), 16, 0, 0);
-    if (SPARSE || t < nfull) {
+    if (SPARSE || PRE || t < nfull) {   // PRE launches require kv_len % 64 == 0 (checked by the launcher): no ragged tile
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(vsrc + vlane), (lds_void_t*)(sV + buf * TILE + wave_u * 1024), 16, 0, 0);
     } else {  // ragged last tile: never read past the padded row; zero the keys >= kv_len (P is exactly 0 there anyway)
       const int rem = p.kv_len - (kv0 + 8 * lc);    // valid keys in this lane's 8-key chunk (<= 0: none)
@@ -155,8 +155,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) ot[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float c = p.c;
-  float m_run[2] = {BOUNDED ? p.m_fixed : -1e30f, BOUNDED ? p.m_fixed : -1e30f}, l_run[2] = {0.f, 0.f};
+  float m_run[2] = {BOUNDED ? p.m_fixed : -1e30f, BOUNDED ? p.m_fixed : -1e30f};
   const float mc_fixed = p.m_fixed * c;
+  f32x4 lt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const bf16x8 onesf = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
   // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
   auto state_base = [&]() { return part == 0 ? p.state : p.split_state + (size_t)(part - 1) * p.split_stride; };
   auto state_o = [&](int qt) { return state_base() + (size_t)(q0 + 16 * qt + l15) * (p.H * 64) + h * 64 + 4 * g; };
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) ot[dt][qt] = *reinterpret_cast<const f32x4*>(st_o + 16 * dt);
         if (!BOUNDED) m_run[qt] = st_ml[0];
-        l_run[qt] = st_ml[1];
+        { const float* b4 = st_ml - 2 * g; const float L = (b4[1] + b4[3]) + (b4[5] + b4[7]); lt[qt] = f32x4{L, L, L, L}; }   // the four slots' row sums
       }
   }
 
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
       st[kt][1] = mfma16(kf, qf[1][1], st[kt][1]);
     }
     // lane (query l15 of tile qt, g): st[kt][qt][r] is key  t*64 + 32 (kt>>1) + 8 g + 4 (kt&1) + r
-    if (!SPARSE && t >= nfull) {  // ragged last tile (wave-uniform branch)
+    if (!SPARSE && !PRE && t >= nfull) {  // ragged last tile (wave-uniform branch)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -214,23 +216,25 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     const float mc[2] = {mc_fixed, mc_fixed};
     // ---- P = exp2(S c - m c) -> bf16 fragments; O^T += V^T P^T (two k-steps of 32 keys), V^T fragments streamed ----
 #pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-        bf16x8 vf[4];
+      for (int ks2 = 0; ks2 < 2; ++ks2) {   // both query tiles' probabilities first (8 live registers), V^T fragments streamed
+        bf16x8 pf[2];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vf[dt] = *reinterpret_cast<const bf16x8*>(cV + lds_swz(16 * dt + l15, 4 * ks2 + g));
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {   // 8 exponentials, then the 4 MFMAs they feed: fine-grained VALU / MFMA interleave
+        for (int qt = 0; qt < 2; ++qt) {
           float e[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             e[j] = PRE ? __builtin_amdgcn_exp2f(st[2 * ks2 + (j >> 2)][qt][j & 3])
                        : __builtin_amdgcn_exp2f(fmaf(st[2 * ks2 + (j >> 2)][qt][j & 3], c, -mc[qt]));
-            l_run[qt] += e[j];
           }
           u32x4 pk = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
-          const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+          pf[qt] = __builtin_bit_cast(bf16x8, pk);
+          lt[qt] = mfma16(onesf, pf[qt], lt[qt]);   // every row = sum over the 32 keys of bf16(p) for query l15
+        }
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) ot[dt][qt] = mfma16(vf[dt], pf, ot[dt][qt]);
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cV + lds_swz(16 * dt + l15, 4 * ks2 + g));
+          ot[dt][0] = mfma16(vf, pf[0], ot[dt][0]);
+          ot[dt][1] = mfma16(vf, pf[1], ot[dt][1]);
         }
       }
     }
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
         float* st_o = state_o(qt); float* st_ml = state_ml(qt);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(st_o + 16 * dt) = ot[dt][qt];
-        st_ml[0] = m_run[qt]; st_ml[1] = l_run[qt];
+        st_ml[0] = m_run[qt]; st_ml[1] = g == 0 ? lt[qt][0] : 0.f;   // slot 0 carries the whole row sum
       }
     return;
   }
@@ -257,11 +261,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   // ---- epilogue: normalise, store O[q][h*64 + d] ----
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l_tot = l_run[qt];   // sum of the four lanes' partial row sums
-    auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
-    l_tot = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
-    auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
-    l_tot = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+    const float l_tot = lt[qt][0];   // the ones-MFMA left the whole row sum in every lane of the query's column
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int q = q0 + 16 * qt + l15;
     if (q < p.q_len) {
@@ -589,14 +589,13 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.state = state; p.flags = flags;
   p.job0 = 0; p.splits = 1; p.split_state = nullptr; p.split_stride = 0;
   const bool range = tile_off0 != 0 || tile_cnt != total_tiles || (flags & 3);
-  if (k_prescaled && !bounded) return K5_ERR_ARG;   // pre-scaled keys need the fixed-offset softmax (caller checks the bound)
+  if (k_prescaled && (!bounded || (kv_len % KB))) return K5_ERR_ARG;   // pre-scaled keys: fixed-offset softmax, whole key tiles only
   if (bounded) p.m_fixed = score_bound;
   auto launch = [&](int njobs, bool use_range) {
     const dim3 grid(njobs);
-    if (bounded && k_prescaled && use_range) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true>), grid, block, 0, stream, p);
-    else if (bounded && k_prescaled) hipLaunchKernelGGL((attn_fwd_kernel<true, false, false, true>), grid, block, 0, stream, p);
-    else if (bounded && use_range) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), grid, block, 0, stream, p);
-    else if (bounded) hipLaunchKernelGGL((attn_fwd_kernel<true, false, false>), grid, block, 0, stream, p);
+    // fixed-offset softmax: always the RANGE instantiation (a superset; with the plain one the register allocator spills)
+    if (bounded && k_prescaled) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true>), grid, block, 0, stream, p);
+    else if (bounded) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), grid, block, 0, stream, p);
     else if (use_range) hipLaunchKernelGGL((attn_fwd32_kernel<false, false, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((attn_fwd32_kernel<false, false, false>), grid, block, 0, stream, p);
   };

@@ -341,6 +341,7 @@ inline bool use_prescale(const AttnW& a) {
   static const bool off = getenv("K5_NO_PRESCALE") != nullptr;
   return !off && a.score_bound > 0.f && 2.f * a.score_bound * K5_SOFTMAX_C <= 96.f;
 }
+// (the pre-scaled instantiations have no ragged-tile code: callers add `keys % 64 == 0`)
 
 // ---------------------------------------------------------------------------------------------
 // one attention module on `rows` tokens:  x_resid += gate * out_l(attn(...)) fused in the out GEMM
@@ -360,7 +361,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   {
     Scope sc(d, s, "elementwise");
     const int32_t hc[2] = {H, 2 * H};
-    const bool pre = !strcmp(fam_attn, "attn_self") && use_prescale(a);   // visual blocks only (not the text blocks)
+    const bool pre = !strcmp(fam_attn, "attn_self") && use_prescale(a) && rows % 64 == 0;   // visual blocks only (not the text blocks)
     void* kc = nullptr;   // NABLA: the block map needs the unscaled keys -> the scaled copy goes to its own buffer
     if (pre && nabla) { K5CHK(d->ws_kc.ensure((size_t)rows * D * 2)); kc = d->ws_kc.p; }
     K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D));
@@ -376,7 +377,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     const int *list, *cnt;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
     Scope sc(d, s, fam_attn);
-    const bool pre = !strcmp(fam_attn, "attn_self") && use_prescale(a);
+    const bool pre = !strcmp(fam_attn, "attn_self") && use_prescale(a) && rows % 64 == 0;
     K5CHK(k5_launch_attention_bf16_sparse(qk, pre ? d->ws_kc.as<bf16_t>() : (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, pre ? D : 2 * D,
                                           ldvt, D, a.score_bound, list, cnt, nb, 0, 0, s, pre));
   } else {
@@ -384,7 +385,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     Scope sc(d, s, fam_attn);
     K5CHK(k5_launch_attention_bf16_range(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, 0, 0, 0, -1,
                                          0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(),
-                                         !strcmp(fam_attn, "attn_self") && use_prescale(a)));
+                                         !strcmp(fam_attn, "attn_self") && use_prescale(a) && rows % 64 == 0));
   }
   {
     Scope sc(d, s, "gemm");

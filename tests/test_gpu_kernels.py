@@ -433,7 +433,7 @@ def test_gemm_fp8_epilogues_and_row_quantisation(E):
 def test_attention_prescaled_keys(E):
     """k5_attention_bf16_prescaled: keys pre-multiplied by log2(e)/8 and rounded once.  Exactly the softmax (base 2) of those
     keys — checked against the oracle fed the same rounded keys — and within bf16 noise of the unscaled formulation."""
-    H, Sq, Sk = 3, 700, 1100
+    H, Sq, Sk = 3, 700, 1088          # whole 64-key tiles: the pre-scaled entry has no ragged-tile path
     def rmsn(x):
         return bfr(x / x.pow(2).mean(-1, keepdim=True).sqrt())
     q, k, v = rmsn(rnd(Sq, H, 64, seed=61)), rmsn(rnd(Sk, H, 64, seed=62)), bfr(rnd(Sk, H, 64, seed=63))
@@ -452,3 +452,6 @@ def test_attention_prescaled_keys(E):
     with pytest.raises(RuntimeError):                                       # needs the fixed-offset softmax
         E.check(L.k5_attention_bf16_prescaled(qd.data_ptr(), kcd.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk, qd.stride(0),
                                               kcd.stride(0), vt.stride(0), out.stride(0), 0.0, E.stream_ptr()))
+    with pytest.raises(RuntimeError):                                       # ... and whole key tiles
+        E.check(L.k5_attention_bf16_prescaled(qd.data_ptr(), kcd.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk - 8, qd.stride(0),
+                                              kcd.stride(0), vt.stride(0), out.stride(0), 64 * 1.05, E.stream_ptr()))
