@@ -644,6 +644,257 @@ int launch_k8(GemmP p, hipStream_t stream) {
   return mt3 ? launch_k8_mt<EPI, 3>(p, stream, num_cu, full_grid, no_tail) : launch_k8_mt<EPI, 4>(p, stream, num_cu, full_grid, no_tail);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x256x64 tile, FOUR waves, one per SIMD, each a 128 x 128 quadrant = 8 x 8 MFMA 16x16x32 tiles on 64 independent
+// accumulators (256 registers; with one wave per SIMD the wave owns all 512).  Against the 8-wave kernel above: 2/3 of
+// the LDS fragment traffic (32 KB instead of 48 KB per 128 MFMAs), 2 barriers per K-tile instead of 8, and the
+// global -> LDS stream costs no VALU at all: `buffer_load_dwordx4 ... lds` with a per-lane offset register that is
+// bumped once per K-tile, per-instruction SGPR row offsets, and hardware range checking (rows past M / N read as zero).
+// This is the shape the vendor library's hand-scheduled kernels use on this chip (same macro tile, same wave count);
+// the schedule below is ours.  STATUS: experimental, K5_GEMM_V1=4 only.  Measured (4096 x 4096 x 32768, steady state):
+// this kernel 1100 TFLOP/s, the 8-wave kernel 1000, hipBLASLt 1350; compile-time ablations of THIS loop: MFMA stream alone
+// 1860, DMA stream alone (no barriers) 0.63 ms = 13.6 TB/s L2->LDS = "1745", DMA + barriers without any MFMA 0.92-0.96 ms
+// = the full kernel's time.  I.e. the matrix pipe is ~50 % idle and the global->LDS stream (64 KB per K-tile and CU, whose
+// round trip under load is ~1.8 us against a 1.2 us K-tile) sets the pace; issuing the DMAs in a burst is worse (938-1046)
+// than spread over the K-tile (1100), more lead does not help, a staggered K start loses.  On the model's shapes it does
+// not beat the 8-wave kernel yet (FF2 1000 vs 1064; K = 1792 shapes lose to its unoptimised epilogue), so it is not the default.
+//
+// LDS: an operand tile (256 rows x 64 k, 128 B per row) is 32 pieces; piece d = 16 h + r holds rows 128 h + 16 i + r
+// (i = 0..7) back to back, 1024 B + 16 B pad, i.e. row -> (16 h + r) * 1040 + 128 i.  One DMA instruction fills one piece
+// (lane j: row-tile i = j >> 3, 16-B chunk j & 7: eight 128-B global segments).  A fragment read (16 rows r = lane & 15 of
+// row-tile i, k-chunk 4 s + lane>>4) is lane_base + 128 i + 64 s: every offset an immediate, and the 16 lanes of a
+// ds_read_b128 quarter are 1040 B apart = 4 banks apart: conflict-free.  2 stages x 2 operands x 33 280 B = 133 120 B.
+//
+// Pipeline (K-tile t in stage t & 1; there are no staging registers, so a stage is free as soon as its fragments are in
+// registers, and a third fragment buffer lets ALL of K-tile t+1's fragments be read during the last quarter of K-tile t):
+//   top of K-tile t: barrier (everyone holds K-tile t's fragments); DMA K-tile t+2 into stage t&1, all 16 instructions early
+//   m = 88:          vmcnt(16) = K-tile t+1 landed; barrier; its 32 fragment reads under the last 32 MFMAs
+// The K-tile stream runs on across output tiles (persistent workgroup): the DMAs of the last two iterations already
+// fetch the next tile, whose first fragments are read while the current tile's last MFMAs run; the epilogue sits between.
+// ---------------------------------------------------------------------------------------------
+constexpr int W4_PAD = 1040, W4_OP = 32 * W4_PAD, W4_STAGE = 2 * W4_OP, W4_LDS = 2 * W4_STAGE;
+typedef __attribute__((address_space(3))) void w4_lds_t;
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;
+  const int l15 = lane & 15, lc = lane >> 4;
+
+  // persistent walk over logical tiles, as in the 8-wave kernel
+  const int nblk = p.lid_limit;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7 - xcd) >> 3;
+  const int q8 = nblk >> 3, r8 = nblk & 7;
+  const int x_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, x_cnt = q8 + (xcd < r8 ? 1 : 0);
+  constexpr int GM = 4;
+  const int per_group = GM * p.tiles_n;
+  auto tile_origin = [&](int lid, int& m0, int& n0) {
+    const int g = lid / per_group, first_m = g * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    m0 = (first_m + (lid % per_group) % gsz) * K8_BM;
+    n0 = ((lid % per_group) / gsz) * K8_BN;
+  };
+  if (slot >= x_cnt) return;
+
+  const int nk = p.K / BK;                     // even, >= 4 (launcher)
+  const uint32_t ldw2 = (uint32_t)p.ldw * 2u, lda2 = (uint32_t)p.lda * 2u;
+  const uint32_t vw0 = (uint32_t)(16 * (lane >> 3)) * ldw2 + (uint32_t)(lane & 7) * 16u;
+  const uint32_t vx0 = (uint32_t)(16 * (lane >> 3)) * lda2 + (uint32_t)(lane & 7) * 16u;
+  const int drow = 128 * (wave >> 1) + 8 * (wave & 1);   // first row of this wave's 8 DMA instructions per operand
+  const int dslot = 8 * wave;                            // ... and their LDS piece
+  uint32_t vw = vw0, vx = vx0;                           // lane offsets incl. the K advance of the DMA cursor
+  __amdgpu_buffer_rsrc_t rW, rX;
+  int d_ti = slot, d_kt = 0, d_cnt = 0;                  // DMA cursor: tile (index into this workgroup's walk), K-tile, K-tiles done
+#ifndef W4_STAGGER
+#define W4_STAGGER 0   // measured: 1, 2, 4 K-tiles per tile index all LOSE 1-6 % (lockstep workgroups share L2 fills)
+#endif
+  auto set_dma_tile = [&](int ti) {
+    int m0, n0;
+    tile_origin(x_first + ti, m0, n0);
+    const int rows_w = min(p.N - n0, K8_BN), rows_x = min(p.M - m0, K8_BM);
+    rW = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.W) + (size_t)n0 * ldw2), 0,
+                                           (int)(((uint32_t)(rows_w - 1) * (uint32_t)p.ldw + (uint32_t)p.K) * 2u), 0x00020000);
+    rX = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.A) + (size_t)m0 * lda2), 0,
+                                           (int)(((uint32_t)(rows_x - 1) * (uint32_t)p.lda + (uint32_t)p.K) * 2u), 0x00020000);
+    // staggered start: each tile walks K from its own offset and wraps (the sum is order-independent up to fp32 rounding), so
+    // the workgroups that run in lockstep do not all pull the same K columns - i.e. the same few L2 channels - at once
+    d_kt = W4_STAGGER ? (int)((unsigned)(W4_STAGGER * (m0 / K8_BM + n0 / K8_BN)) % (unsigned)nk) : 0;
+    d_cnt = 0;
+    vw = vw0 + (uint32_t)d_kt * (2 * BK); vx = vx0 + (uint32_t)d_kt * (2 * BK);
+  };
+  auto dma_w = [&](int stage) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + stage * W4_STAGE + (dslot + jj) * W4_PAD), 16, vw,
+                                               (uint32_t)(drow + jj) * ldw2, 0, 0);
+  };
+  auto dma_x = [&](int stage) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + stage * W4_STAGE + W4_OP + (dslot + jj) * W4_PAD), 16, vx,
+                                               (uint32_t)(drow + jj) * lda2, 0, 0);
+  };
+  // after a K-tile's 16 DMAs: move the cursor; past the last tile it wraps onto the same tile (harmless loads that keep
+  // the vmcnt arithmetic uniform; nothing reads them)
+  auto dma_advance = [&]() {
+    vw += 2 * BK; vx += 2 * BK;
+    if (++d_kt == nk) { d_kt = 0; vw = vw0; vx = vx0; }
+    if (++d_cnt == nk) {
+      if (d_ti + per_xcd < x_cnt) d_ti += per_xcd;
+      set_dma_tile(d_ti);
+    }
+  };
+
+  // fragment read addresses (LDS byte addresses; one base register per operand and stage, everything else an immediate)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(w4_lds_t*)dsm;
+  uint32_t wbs[2], xbs[2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    wbs[st] = lds0 + st * W4_STAGE + (16 * wn + l15) * W4_PAD + lc * 16;
+    xbs[st] = lds0 + st * W4_STAGE + W4_OP + (16 * wm + l15) * W4_PAD + lc * 16;
+    asm volatile("" : "+v"(wbs[st]), "+v"(xbs[st]));   // keep them in registers: the stage offset does not fit the 16-bit immediate
+  }
+  // fragment registers: k-step 0 of the current K-tile, and k-step 1 in one of two buffers (the other one receives the NEXT
+  // K-tile's k-step 1 while this one is in use; k-step 0 of the next K-tile goes to wf0/xf0, dead after the first 64 MFMAs)
+  bf16x8 wf0[8], xf0[8], wf1[2][8], xf1[2][8];
+  f32x4 acc[8][8];   // [n-tile][m-tile]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ds_read_b128 as asm: the compiler would otherwise guard every fragment read with s_waitcnt vmcnt(..) against the LDS-DMA
+  // writes in flight (it cannot tell the stages apart) and serialise the prefetch.  All waits are explicit below.
+#define W4_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+  // The matrix instructions are inline asm with the accumulators pinned to the AGPR file: with the builtin the register
+  // allocator mixes the two files and shuffles ~500 registers per two K-tiles.  volatile asm statements keep their order, and
+  // loads cannot cross them, so the source order below IS the instruction schedule: fragment reads and DMAs are placed
+  // between the MFMAs by hand.  (An accumulator is revisited 64 MFMAs later: no dependent-issue hazard inside the stream.)
+#define W4_MF(WF, XF, Q) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(Q) & 7][(Q) >> 3]) : "v"(WF[(Q) & 7]), "v"(XF[(Q) >> 3]))
+#ifndef W4_DBG
+#define W4_DBG 0
+#endif
+  constexpr int dbg = W4_DBG;   // compile-time ablations (benchmarking only): 1 no DMA, 2 no fragment reads, 4 no barriers, 8 no MFMA
+  auto dma1 = [&](int stage, int d) {
+    if (dbg & 1) return;
+    if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + stage * W4_STAGE + (dslot + d) * W4_PAD), 16, vw,
+                                                        (uint32_t)(drow + d) * ldw2, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + stage * W4_STAGE + W4_OP + (dslot + d - 8) * W4_PAD), 16, vx,
+                                                  (uint32_t)(drow + d - 8) * lda2, 0, 0);
+  };
+
+  set_dma_tile(slot);
+  dma_w(0); dma_x(0); dma_advance();
+  dma_w(1); dma_x(1); dma_advance();
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { W4_RD(wf0[i], wbs[0], i * 128); W4_RD(wf1[0][i], wbs[0], i * 128 + 64); }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { W4_RD(xf0[j], xbs[0], j * 128); W4_RD(xf1[0][j], xbs[0], j * 128 + 64); }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // One K-tile t (stage st = t & 1) = 128 MFMAs, m = 0..127: k-step 0 (m < 64) on wf0/xf0, k-step 1 on wf1[st]/xf1[st].  ALL of
+  // its fragments are in registers when it starts, so its stage is refilled from the top:
+  //   before m = 0        barrier: every wave holds K-tile t's fragments -> stage st is free
+  //   m = W4_DS d         DMA d (0..15) of K-tile t+2 into stage st: issued as early as possible — measured, the round trip of a
+  //                       K-tile's 64 KB under load is ~1.8 us, ~1.5 K-tile times: the lead, not the matrix pipe, sets the pace
+  //   after m = W4_BB-1   vmcnt(16) + barrier: all but this tile's own DMAs, i.e. K-tile t+1 (issued a K-tile ago), have landed
+  //   m in [W4_BB, +32)   + one fragment read of K-tile t+1 each: k-step 0 into wf0/xf0, k-step 1 into wf1[st^1]/xf1[st^1]
+  //   after m = 127       lgkmcnt(0)
+#ifndef W4P
+#define W4P 8, 88
+#endif
+  constexpr int w4p[2] = {W4P};
+  constexpr int W4_DS = w4p[0], W4_BB = w4p[1];
+  static_assert(W4_DS * 15 < 128 && W4_BB >= 64 && W4_BB + 32 <= 128, "schedule does not fit");
+  constexpr int W4_NB = (W4_BB + W4_DS - 1) / W4_DS < 16 ? (W4_BB + W4_DS - 1) / W4_DS : 16;   // this K-tile's DMAs issued before m = W4_BB
+  auto ktile = [&](auto STC) {
+    constexpr int st = decltype(STC)::value;
+    if (!(dbg & 4)) asm volatile("s_barrier" ::: "memory");
+    auto chunk = [&](auto BASEC) {   // 16 MFMAs at a time: a single 128-trip loop is beyond the full-unroll budget
+#pragma unroll
+      for (int m = decltype(BASEC)::value; m < decltype(BASEC)::value + 16; ++m) {
+        if (!(dbg & 8)) { if (m < 64) W4_MF(wf0, xf0, m); else W4_MF(wf1[st], xf1[st], m - 64); }
+        if (m % W4_DS == 0 && m / W4_DS < 16) dma1(st, m / W4_DS);
+        if (m == W4_BB - 1) {
+          if (dbg & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W4_NB) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(W4_NB) : "memory");
+        }
+        if (m >= W4_BB && m < W4_BB + 32 && !(dbg & 2)) {
+          const int r = m - W4_BB;   // W k0, X k0, W k1, X k1
+          if (r < 8) W4_RD(wf0[r & 7], wbs[st ^ 1], (r & 7) * 128);
+          else if (r < 16) W4_RD(xf0[r & 7], xbs[st ^ 1], (r & 7) * 128);
+          else if (r < 24) W4_RD(wf1[st ^ 1][r & 7], wbs[st ^ 1], (r & 7) * 128 + 64);
+          else W4_RD(xf1[st ^ 1][r & 7], xbs[st ^ 1], (r & 7) * 128 + 64);
+        }
+      }
+    };
+    chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 16>{}); chunk(std::integral_constant<int, 32>{});
+    chunk(std::integral_constant<int, 48>{}); chunk(std::integral_constant<int, 64>{}); chunk(std::integral_constant<int, 80>{});
+    chunk(std::integral_constant<int, 96>{}); chunk(std::integral_constant<int, 112>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // K-tile t+1's fragments
+    dma_advance();
+  };
+
+  for (int ti = slot; ti < x_cnt; ti += per_xcd) {
+    for (int t = 0; t < nk; t += 2) {
+      ktile(std::integral_constant<int, 0>{});
+      ktile(std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs are invisible to the hazard recogniser: let the last ones retire
+    int m0, n0;
+    tile_origin(x_first + ti, m0, n0);
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int e_l15 = tid2 & 15, e_lc = (tid2 >> 4) & 3, e_wave = tid2 >> 6;
+    const int e_wn = e_wave & 1, e_wm = e_wave >> 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = m0 + 128 * e_wm + 16 * j + e_l15;
+      float bias_m = 0.f;
+      if (EPI == K5_EPI_BIAS_M && p.bias && m < p.M) bias_m = p.bias[m];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (m < p.M) gemm_epilogue_quad<EPI>(p, v, m, n0 + 128 * e_wn + 16 * i + 4 * e_lc, bias_m);
+        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      asm volatile("" ::: "memory");   // one token row at a time: keeps the epilogue's live registers (and scratch use) small
+    }
+    // nothing may still be loading into a VGPR when the asm stream resumes (the compiler would guard the asm's outputs with
+    // vmcnt waits INSIDE the loop); the next tile's first K-tiles have had the whole epilogue to land, so this is free
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  }
+#undef W4_MF
+#undef W4_RD
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wrapped DMAs still write this workgroup's LDS
+}
+
+template <int EPI>
+int launch_w4(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)
+      return K5_ERR_HIP;
+    attr_set = true;
+  }
+  p.tiles_m = (p.M + K8_BM - 1) / K8_BM; p.tiles_n = (p.N + K8_BN - 1) / K8_BN;
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int full = tiles / num_cu * num_cu, rem = tiles - full;
+  const bool split_tail = !no_tail && full > 0 && rem > 0 && 2 * rem < num_cu;   // see launch_k8_mt
+  p.lid_limit = split_tail ? full : tiles;
+  p.tiles256_m = p.tiles_m; p.tiles256_n = p.tiles_n;
+  hipLaunchKernelGGL((gemm_bf16_w4_kernel<EPI>), dim3(min(p.lid_limit, num_cu)), dim3(256), W4_LDS, stream, p);
+  if (split_tail) {
+    p.tail_base = full;
+    p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL(gemm_bf16_glds_kernel<EPI>, dim3(4 * rem), dim3(256), 0, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
 }  // namespace
 
 // Host launcher (C++ linkage, used by the C-ABI layer in k5_api.hip and by the engine).
@@ -669,6 +920,22 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   // ... once its 256x256 tiles fill at least half of the CUs (measured crossover, tools/gemm_small.py: 91-112 tiles lose to the
   // 128x128 kernel by 5-10 %, 42 tiles by 40 %; 168 tiles win by 15 %)
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  if ((K % (2 * BK)) == 0 && K >= 4 * BK && M >= 512 && N >= 256 && force_v1 == 4) {
+    static int num_cu = 0;
+    if (!num_cu) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
+      num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    static const bool no_tail = getenv("K5_GEMM_NO_TAIL") != nullptr;
+    switch (epi) {
+      case K5_EPI_BIAS: return launch_w4<K5_EPI_BIAS>(p, stream, num_cu, no_tail);
+      case K5_EPI_BIAS_M: return launch_w4<K5_EPI_BIAS_M>(p, stream, num_cu, no_tail);
+      case K5_EPI_GELU: return launch_w4<K5_EPI_GELU>(p, stream, num_cu, no_tail);
+      case K5_EPI_GATE: return launch_w4<K5_EPI_GATE>(p, stream, num_cu, no_tail);
+      default: return K5_ERR_ARG;
+    }
+  }
   if ((K % BK) == 0 && K >= 2 * BK && M >= 512 && N >= 256 && (force_v1 == 8 || (force_v1 == 0 && tiles256 >= 128))) {
     switch (epi) {
       case K5_EPI_BIAS: return launch_k8<K5_EPI_BIAS>(p, stream);
