@@ -10,7 +10,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-vae --blocks 2 > /dev/null 2>&1
 done
-# 3. issue / wait counters of the attention kernel
+# 3. issue / wait counters of the attention kernel, launched the way the engine launches it (fixed softmax offset, pre-scaled keys)
+export BOUNDED=1 PRESCALED=1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_sq -o p -- python $R/tools/attn_only.py 2 > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_lds -o p -- python $R/tools/attn_only.py 2 > /dev/null 2>&1
 # 4. VAE decode kernel stats
