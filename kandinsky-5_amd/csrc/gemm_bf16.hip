@@ -651,13 +651,15 @@ int launch_k8(GemmP p, hipStream_t stream) {
 // global -> LDS stream costs no VALU at all: `buffer_load_dwordx4 ... lds` with a per-lane offset register that is
 // bumped once per K-tile, per-instruction SGPR row offsets, and hardware range checking (rows past M / N read as zero).
 // This is the shape the vendor library's hand-scheduled kernels use on this chip (same macro tile, same wave count);
-// the schedule below is ours.  STATUS: experimental, K5_GEMM_V1=4 only.  Measured (4096 x 4096 x 32768, steady state):
-// this kernel 1100 TFLOP/s, the 8-wave kernel 1000, hipBLASLt 1350; compile-time ablations of THIS loop: MFMA stream alone
-// 1860, DMA stream alone (no barriers) 0.63 ms = 13.6 TB/s L2->LDS = "1745", DMA + barriers without any MFMA 0.92-0.96 ms
-// = the full kernel's time.  I.e. the matrix pipe is ~50 % idle and the global->LDS stream (64 KB per K-tile and CU, whose
-// round trip under load is ~1.8 us against a 1.2 us K-tile) sets the pace; issuing the DMAs in a burst is worse (938-1046)
-// than spread over the K-tile (1100), more lead does not help, a staggered K start loses.  On the model's shapes it does
-// not beat the 8-wave kernel yet (FF2 1000 vs 1064; K = 1792 shapes lose to its unoptimised epilogue), so it is not the default.
+// the schedule below is ours.  Used for every epilogue but GELU from 512 tiles up (see the dispatch at the end of the file).
+// Measured (4096 x 4096 x 32768, steady state): this kernel 1100 TFLOP/s, the 8-wave kernel 1000, hipBLASLt 1350; compile-time
+// ablations of THIS loop: MFMA stream alone 1860, DMA stream alone (no barriers) 0.63 ms = 13.6 TB/s L2->LDS = "1745", DMA +
+// barriers without any MFMA 0.92-0.96 ms = the full kernel's time.  I.e. the matrix pipe is ~50 % idle and the global->LDS
+// stream (64 KB per K-tile and CU, whose round trip under load is ~1.8 us against a 1.2 us K-tile) sets the pace; issuing the
+// DMAs in a burst is worse (938-1046) than spread over the K-tile (1100), more lead does not help, a staggered K start loses.
+// What decides the model's short-K shapes is the tile boundary: the epilogue issues all its loads before its stores (a load
+// behind stores can only be awaited with vmcnt(0)) and the first k-step of a tile writes its accumulators (C = 0 inline), so
+// nothing is zeroed or spilled: q|k 590 -> 924, out+gate 509 -> 815, FF2+gate 961 -> 1150 TFLOP/s.
 //
 // LDS: an operand tile (256 rows x 64 k, 128 B per row) is 32 pieces; piece d = 16 h + r holds rows 128 h + 16 i + r
 // (i = 0..7) back to back, 1024 B + 16 B pad, i.e. row -> (16 h + r) * 1040 + 128 i.  One DMA instruction fills one piece
@@ -758,11 +760,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // fragment registers: k-step 0 of the current K-tile, and k-step 1 in one of two buffers (the other one receives the NEXT
   // K-tile's k-step 1 while this one is in use; k-step 0 of the next K-tile goes to wf0/xf0, dead after the first 64 MFMAs)
   bf16x8 wf0[8], xf0[8], wf1[2][8], xf1[2][8];
-  f32x4 acc[8][8];   // [n-tile][m-tile]
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[8][8];   // [n-tile][m-tile]; written (not accumulated) by the first k-step of every output tile
 
   // ds_read_b128 as asm: the compiler would otherwise guard every fragment read with s_waitcnt vmcnt(..) against the LDS-DMA
   // writes in flight (it cannot tell the stages apart) and serialise the prefetch.  All waits are explicit below.
@@ -772,6 +770,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // loads cannot cross them, so the source order below IS the instruction schedule: fragment reads and DMAs are placed
   // between the MFMAs by hand.  (An accumulator is revisited 64 MFMAs later: no dependent-issue hazard inside the stream.)
 #define W4_MF(WF, XF, Q) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(Q) & 7][(Q) >> 3]) : "v"(WF[(Q) & 7]), "v"(XF[(Q) >> 3]))
+  // first k-step of an output tile: C = 0 as an inline constant, the accumulator is only written — so the epilogue never has
+  // to create 256 zeroed registers while the old sums are still live (which made the allocator park them in scratch)
+#define W4_MF0(WF, XF, Q) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[(Q) & 7][(Q) >> 3]) : "v"(WF[(Q) & 7]), "v"(XF[(Q) >> 3]))
 #ifndef W4_DBG
 #define W4_DBG 0
 #endif
@@ -810,13 +811,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int W4_DS = w4p[0], W4_BB = w4p[1];
   static_assert(W4_DS * 15 < 128 && W4_BB >= 64 && W4_BB + 32 <= 128, "schedule does not fit");
   constexpr int W4_NB = (W4_BB + W4_DS - 1) / W4_DS < 16 ? (W4_BB + W4_DS - 1) / W4_DS : 16;   // this K-tile's DMAs issued before m = W4_BB
-  auto ktile = [&](auto STC) {
+  auto ktile = [&](auto STC, auto FIRSTC) {
     constexpr int st = decltype(STC)::value;
+    constexpr bool first = decltype(FIRSTC)::value;
     if (!(dbg & 4)) asm volatile("s_barrier" ::: "memory");
     auto chunk = [&](auto BASEC) {   // 16 MFMAs at a time: a single 128-trip loop is beyond the full-unroll budget
 #pragma unroll
       for (int m = decltype(BASEC)::value; m < decltype(BASEC)::value + 16; ++m) {
-        if (!(dbg & 8)) { if (m < 64) W4_MF(wf0, xf0, m); else W4_MF(wf1[st], xf1[st], m - 64); }
+        if (!(dbg & 8)) {
+          if (m < 64 && first) W4_MF0(wf0, xf0, m);
+          else if (m < 64) W4_MF(wf0, xf0, m);
+          else W4_MF(wf1[st], xf1[st], m - 64);
+        }
         if (m % W4_DS == 0 && m / W4_DS < 16) dma1(st, m / W4_DS);
         if (m == W4_BB - 1) {
           if (dbg & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W4_NB) : "memory");
@@ -839,9 +845,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
 
   for (int ti = slot; ti < x_cnt; ti += per_xcd) {
-    for (int t = 0; t < nk; t += 2) {
-      ktile(std::integral_constant<int, 0>{});
-      ktile(std::integral_constant<int, 1>{});
+    ktile(std::integral_constant<int, 0>{}, std::true_type{});
+    ktile(std::integral_constant<int, 1>{}, std::false_type{});
+    for (int t = 2; t < nk; t += 2) {
+      ktile(std::integral_constant<int, 0>{}, std::false_type{});
+      ktile(std::integral_constant<int, 1>{}, std::false_type{});
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs are invisible to the hazard recogniser: let the last ones retire
     int m0, n0;
@@ -850,24 +858,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("" : "+v"(tid2));
     const int e_l15 = tid2 & 15, e_lc = (tid2 >> 4) & 3, e_wave = tid2 >> 6;
     const int e_wn = e_wave & 1, e_wm = e_wave >> 1;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = m0 + 128 * e_wm + 16 * j + e_l15;
-      float bias_m = 0.f;
-      if (EPI == K5_EPI_BIAS_M && p.bias && m < p.M) bias_m = p.bias[m];
+    // straight-line quads (the launcher guarantees N % 4 == 0 and 4-element aligned ldc / ldr): the only predicate is
+    // "inside the matrix", so there is no control flow for the allocator to park accumulators around
+    // Loads first, stores after: a load that follows stores can only be awaited with vmcnt(0), i.e. after every earlier
+    // store has been acknowledged.  The per-column vectors (bias, gate) are the same for all 8 token tiles: loaded once; the
+    // residual rows of the gated epilogue are fetched two token tiles (16 loads) at a time.
+    auto epilogue = [&](auto HB) {
+      constexpr bool has_bias = decltype(HB)::value;
+      const int nb = n0 + 128 * e_wn + 4 * e_lc;          // + 16 i
+      f32x4 bvec[8], gvec[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if (m < p.M) gemm_epilogue_quad<EPI>(p, v, m, n0 + 128 * e_wn + 16 * i + 4 * e_lc, bias_m);
-        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nc = min(nb + 16 * i, p.N - 4);          // clamped: out-of-range quads are never stored
+        if (EPI != K5_EPI_BIAS_M && has_bias) bvec[i] = *reinterpret_cast<const f32x4*>(p.bias + nc);
+        if (EPI == K5_EPI_GATE) gvec[i] = *reinterpret_cast<const f32x4*>(p.gate + nc);
       }
-      asm volatile("" ::: "memory");   // one token row at a time: keeps the epilogue's live registers (and scratch use) small
-    }
+      constexpr int G = EPI == K5_EPI_GATE ? 2 : 4;        // token tiles per load / store phase (register budget)
+#pragma unroll
+      for (int jh = 0; jh < 8 / G; ++jh) {
+        u32x2 rr[G][8];
+        float bias_m[G];
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+          const int m = min(m0 + 128 * e_wm + 16 * (G * jh + jj) + e_l15, p.M - 1);
+          bias_m[jj] = (EPI == K5_EPI_BIAS_M && has_bias) ? p.bias[m] : 0.f;
+          if (EPI == K5_EPI_GATE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              rr[jj][i] = *reinterpret_cast<const u32x2*>(p.resid + (size_t)m * p.ldr + min(nb + 16 * i, p.N - 4));
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+          const int j = G * jh + jj;
+          const int m = m0 + 128 * e_wm + 16 * j + e_l15;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int n = nb + 16 * i;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (EPI == K5_EPI_BIAS_M) v[e] += bias_m[jj];
+              else if (has_bias) v[e] += bvec[i][e];
+              if (EPI == K5_EPI_GELU) v[e] = gelu_erf(bf_round(v[e]));
+            }
+            if (EPI == K5_EPI_GATE) {
+              v[0] = __uint_as_float(rr[jj][i][0] << 16) + gvec[i][0] * bf_round(v[0]);
+              v[1] = __uint_as_float(rr[jj][i][0] & 0xffff0000u) + gvec[i][1] * bf_round(v[1]);
+              v[2] = __uint_as_float(rr[jj][i][1] << 16) + gvec[i][2] * bf_round(v[2]);
+              v[3] = __uint_as_float(rr[jj][i][1] & 0xffff0000u) + gvec[i][3] * bf_round(v[3]);
+            }
+            if (m < p.M && n < p.N) {
+              u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+              *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
+            }
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+    };
+    if (p.bias) epilogue(std::true_type{}); else epilogue(std::false_type{});
     // nothing may still be loading into a VGPR when the asm stream resumes (the compiler would guard the asm's outputs with
     // vmcnt waits INSIDE the loop); the next tile's first K-tiles have had the whole epilogue to land, so this is free
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   }
 #undef W4_MF
+#undef W4_MF0
 #undef W4_RD
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wrapped DMAs still write this workgroup's LDS
 }
@@ -920,7 +976,11 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   // ... once its 256x256 tiles fill at least half of the CUs (measured crossover, tools/gemm_small.py: 91-112 tiles lose to the
   // 128x128 kernel by 5-10 %, 42 tiles by 40 %; 168 tiles win by 15 %)
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
-  if ((K % (2 * BK)) == 0 && K >= 4 * BK && M >= 512 && N >= 256 && force_v1 == 4) {
+  // the 4-wave kernel: every epilogue but GELU once there are at least two full rounds of 256x256 tiles (measured on the model's
+  // shapes, 1x MI355X: q|k 924 vs 862, out+gate 815 vs 707, FF2+gate 1150 vs 1054 TFLOP/s; FF1+GELU 811 vs 860 -> stays on
+  // the 8-wave kernel; token-shard shapes keep the 8-wave kernel's 192-row tile option).  K5_GEMM_V1=4 / 8 force one of them.
+  const bool w4_ok = (K % (2 * BK)) == 0 && K >= 4 * BK && M >= 512 && N >= 256 && !(N & 3) && !(ldc & 3) && (epi != K5_EPI_GATE || !(ldr & 3));
+  if (w4_ok && (force_v1 == 4 || (force_v1 == 0 && epi != K5_EPI_GELU && tiles256 >= 512))) {
     static int num_cu = 0;
     if (!num_cu) {
       int dev = 0; hipDeviceProp_t prop;

@@ -84,6 +84,37 @@ def test_gemm_tail_round_as_128_quadrants(E, epi):
     assert_bf16_close(got, ref, ulps=3, what=f"tail-split gemm {epi}")
 
 
+def test_gemm_four_wave_kernel_is_race_free_and_handles_edges(E):
+    """>= 512 tiles of 256x256 and a non-GELU epilogue: the 4-wave kernel (one wave per SIMD, hand-ordered MFMA / ds_read /
+    buffer_load-to-LDS stream, K-tile stream running on across output tiles).  Its LDS traffic is ordered by counted waits and
+    barriers only: repeat and demand bit-identical results; ragged M and N edges rely on the buffer range check."""
+    M, N, K = 24 * 256 - 40, 23 * 256 - 24, 384          # 552 tiles, 6 K-tiles, ragged in both directions
+    a, w = bfr(rnd(M, K, seed=71)), bfr(rnd(N, K, seed=72, scale=0.05))
+    b = bfr(rnd(N, seed=73, scale=0.1))
+    ad, wd = a.cuda().to(BF), w.cuda().to(BF)
+    first = E.gemm(ad, wd, b.cuda(), E.EPI_BIAS).clone()
+    for _ in range(10):
+        assert torch.equal(E.gemm(ad, wd, b.cuda(), E.EPI_BIAS), first)
+    acc = a @ w.t()
+    assert_bf16_close(first, bfr(acc + b), what="4-wave gemm bias")
+    assert_bf16_close(E.gemm(ad, wd, None, E.EPI_BIAS), bfr(acc), what="4-wave gemm no bias")
+    resid, gate = bfr(rnd(M, N, seed=74)), rnd(N, seed=75)
+    r = resid.cuda().to(BF)
+    got = E.gemm(ad, wd, b.cuda(), E.EPI_GATE, resid=r, gate=gate.cuda(), out=r)   # in place, as the engine calls it
+    inner = bfr(acc + b)                                                            # a 1-ulp flip of the INNER bf16 rounding (fp32
+    ref = bfr(resid + gate * inner)                                                 # summation order) is worth |gate| ulp(inner) outside
+    err = (got.float().cpu() - ref).abs()
+    tol = 1e-3 + 3 * 2.0 ** -7 * ref.abs() + gate.abs() * 2.0 ** -7 * inner.abs()
+    assert not (err > tol).any(), f"4-wave gemm gate: {int((err > tol).sum())} off, max abs err {err.max():.4g}"
+    assert (err > 3 * 2.0 ** -7 * ref.abs() + 1e-3).float().mean().item() < 1e-5   # ... and such flips are rare
+    bm = bfr(rnd(M, seed=76))
+    ld = (N + 7) // 8 * 8 + 8                                                     # padded leading dimension (the V^T layout)
+    out = torch.zeros(M, ld, dtype=BF, device="cuda")
+    E.gemm(ad, wd, bm.cuda(), E.EPI_BIAS_M, out=out)
+    assert_bf16_close(out[:, :N], bfr(acc + bm[:, None]), what="4-wave gemm bias_m")
+    assert torch.count_nonzero(out[:, N:]) == 0
+
+
 def test_gemm_is_transpose_correct(E):
     """A = I with an asymmetric W catches any row/col swap in the MFMA C/D mapping (guide rule 16)."""
     n = 256
