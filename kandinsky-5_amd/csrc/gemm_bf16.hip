@@ -651,7 +651,7 @@ int launch_k8(GemmP p, hipStream_t stream) {
 // global -> LDS stream costs no VALU at all: `buffer_load_dwordx4 ... lds` with a per-lane offset register that is
 // bumped once per K-tile, per-instruction SGPR row offsets, and hardware range checking (rows past M / N read as zero).
 // This is the shape the vendor library's hand-scheduled kernels use on this chip (same macro tile, same wave count);
-// the schedule below is ours.  Used for every epilogue but GELU from 512 tiles up (see the dispatch at the end of the file).
+// the schedule below is ours.  Used from 256 tiles (one full round of the CUs) up — see the dispatch at the end of the file.
 // Measured (4096 x 4096 x 32768, steady state): this kernel 1100 TFLOP/s, the 8-wave kernel 1000, hipBLASLt 1350; compile-time
 // ablations of THIS loop: MFMA stream alone 1860, DMA stream alone (no barriers) 0.63 ms = 13.6 TB/s L2->LDS = "1745", DMA +
 // barriers without any MFMA 0.92-0.96 ms = the full kernel's time.  I.e. the matrix pipe is ~50 % idle and the global->LDS
@@ -976,11 +976,12 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   // ... once its 256x256 tiles fill at least half of the CUs (measured crossover, tools/gemm_small.py: 91-112 tiles lose to the
   // 128x128 kernel by 5-10 %, 42 tiles by 40 %; 168 tiles win by 15 %)
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
-  // the 4-wave kernel: every epilogue but GELU once there are at least two full rounds of 256x256 tiles (measured on the model's
-  // shapes, 1x MI355X: q|k 924 vs 862, out+gate 815 vs 707, FF2+gate 1150 vs 1054 TFLOP/s; FF1+GELU 811 vs 860 -> stays on
-  // the 8-wave kernel; token-shard shapes keep the 8-wave kernel's 192-row tile option).  K5_GEMM_V1=4 / 8 force one of them.
+  // the 4-wave kernel from one full round of 256x256 tiles up (measured on one box, interleaved runs, TFLOP/s 4-wave vs 8-wave:
+  // q|k 903 vs 841, V^T 983 vs 943, out+gate 814 vs 708, FF1+GELU 1004 vs 946, FF2+gate 1163 vs 1070, 4096^3 1240 vs 1174;
+  // 4-GPU token shards (329 tiles) +6-10 %; 8-GPU shards (168 tiles) lose 3-8 % to the 8-wave kernel's 192-row tile option,
+  // which therefore keeps the range below 256 tiles).  K5_GEMM_V1=4 / 8 force one of them.
   const bool w4_ok = (K % (2 * BK)) == 0 && K >= 4 * BK && M >= 512 && N >= 256 && !(N & 3) && !(ldc & 3) && (epi != K5_EPI_GATE || !(ldr & 3));
-  if (w4_ok && (force_v1 == 4 || (force_v1 == 0 && epi != K5_EPI_GELU && tiles256 >= 512))) {
+  if (w4_ok && (force_v1 == 4 || (force_v1 == 0 && tiles256 >= 256))) {
     static int num_cu = 0;
     if (!num_cu) {
       int dev = 0; hipDeviceProp_t prop;
