@@ -919,7 +919,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     if (p.bias) epilogue(std::true_type{}); else epilogue(std::false_type{});
     // nothing may still be loading into a VGPR when the asm stream resumes (the compiler would guard the asm's outputs with
-    // vmcnt waits INSIDE the loop); the next tile's first K-tiles have had the whole epilogue to land, so this is free
+    // vmcnt waits INSIDE the loop).  Draining the stores as well measured within noise of not draining them (the next tile's
+    // first K-tiles have had the whole epilogue to land either way).
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   }
 #undef W4_MF
