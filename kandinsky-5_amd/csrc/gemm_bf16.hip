@@ -893,25 +893,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const int j = G * jh + jj;
           const int m = m0 + 128 * e_wm + 16 * j + e_l15;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int n = nb + 16 * i;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          for (int iq = 0; iq < 4; ++iq) {     // n-tiles 2 iq and 2 iq + 1 together
+            u32x2 o[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (EPI == K5_EPI_BIAS_M) v[e] += bias_m[jj];
-              else if (has_bias) v[e] += bvec[i][e];
-              if (EPI == K5_EPI_GELU) v[e] = gelu_erf(bf_round(v[e]));
+            for (int h = 0; h < 2; ++h) {
+              const int i = 2 * iq + h;
+              float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (EPI == K5_EPI_BIAS_M) v[e] += bias_m[jj];
+                else if (has_bias) v[e] += bvec[i][e];
+                if (EPI == K5_EPI_GELU) v[e] = gelu_erf(bf_round(v[e]));
+              }
+              if (EPI == K5_EPI_GATE) {
+                v[0] = __uint_as_float(rr[jj][i][0] << 16) + gvec[i][0] * bf_round(v[0]);
+                v[1] = __uint_as_float(rr[jj][i][0] & 0xffff0000u) + gvec[i][1] * bf_round(v[1]);
+                v[2] = __uint_as_float(rr[jj][i][1] << 16) + gvec[i][2] * bf_round(v[2]);
+                v[3] = __uint_as_float(rr[jj][i][1] & 0xffff0000u) + gvec[i][3] * bf_round(v[3]);
+              }
+              o[h] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
-            if (EPI == K5_EPI_GATE) {
-              v[0] = __uint_as_float(rr[jj][i][0] << 16) + gvec[i][0] * bf_round(v[0]);
-              v[1] = __uint_as_float(rr[jj][i][0] & 0xffff0000u) + gvec[i][1] * bf_round(v[1]);
-              v[2] = __uint_as_float(rr[jj][i][1] << 16) + gvec[i][2] * bf_round(v[2]);
-              v[3] = __uint_as_float(rr[jj][i][1] & 0xffff0000u) + gvec[i][3] * bf_round(v[3]);
+            // lanes l and l + 16 hold columns 4 c .. 4 c + 3 and the next four of BOTH tiles: trade (tile 2 iq + 1 of the lower
+            // row) for (tile 2 iq of the upper row) and each lane owns 8 consecutive columns of ONE tile -> 16-B stores, half
+            // as many (the epilogue is store-issue bound)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const auto sw = __builtin_amdgcn_permlane16_swap(o[0][d], o[1][d], false, false);
+              o[0][d] = sw[0]; o[1][d] = sw[1];
             }
-            if (m < p.M && n < p.N) {
-              u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-              *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
-            }
+            const int n = n0 + 128 * e_wn + 16 * (2 * iq + (e_lc & 1)) + 8 * (e_lc >> 1);
+            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(p.C + (size_t)m * p.ldc + n) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
           }
         }
         asm volatile("" ::: "memory");
@@ -981,7 +992,7 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   // q|k 903 vs 841, V^T 983 vs 943, out+gate 814 vs 708, FF1+GELU 1004 vs 946, FF2+gate 1163 vs 1070, 4096^3 1240 vs 1174;
   // 4-GPU token shards (329 tiles) +6-10 %; 8-GPU shards (168 tiles) lose 3-8 % to the 8-wave kernel's 192-row tile option,
   // which therefore keeps the range below 256 tiles).  K5_GEMM_V1=4 / 8 force one of them.
-  const bool w4_ok = (K % (2 * BK)) == 0 && K >= 4 * BK && M >= 512 && N >= 256 && !(N & 3) && !(ldc & 3) && (epi != K5_EPI_GATE || !(ldr & 3));
+  const bool w4_ok = (K % (2 * BK)) == 0 && K >= 4 * BK && M >= 512 && N >= 256 && !(N & 7) && !(ldc & 7) && (epi != K5_EPI_GATE || !(ldr & 3));
   if (w4_ok && (force_v1 == 4 || (force_v1 == 0 && tiles256 >= 256))) {
     static int num_cu = 0;
     if (!num_cu) {
