@@ -799,17 +799,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // One K-tile t (stage st = t & 1) = 128 MFMAs, m = 0..127: k-step 0 (m < 64) on wf0/xf0, k-step 1 on wf1[st]/xf1[st].  ALL of
   // its fragments are in registers when it starts, so its stage is refilled from the top:
   //   before m = 0        barrier: every wave holds K-tile t's fragments -> stage st is free
-  //   m = W4_DS d         DMA d (0..15) of K-tile t+2 into stage st: issued as early as possible — measured, the round trip of a
-  //                       K-tile's 64 KB under load is ~1.8 us, ~1.5 K-tile times: the lead, not the matrix pipe, sets the pace
-  //   after m = W4_BB-1   vmcnt(16) + barrier: all but this tile's own DMAs, i.e. K-tile t+1 (issued a K-tile ago), have landed
-  //   m in [W4_BB, +32)   + one fragment read of K-tile t+1 each: k-step 0 into wf0/xf0, k-step 1 into wf1[st^1]/xf1[st^1]
+  //   m = W4_DS d         DMA d (0..15) of K-tile t+2 into stage st, spread over the K-tile (a burst is worse: the wave stalls at a
+  //                       VMEM instruction the texture path cannot take yet, and its SIMD's matrix pipe with it)
+  //   after m = W4_BB-1   vmcnt(n) + barrier: all but this tile's own n DMAs so far, i.e. K-tile t+1 (issued a K-tile ago), have landed
+  //   from m = W4_BB      a fragment read of K-tile t+1 every W4_RS MFMAs: k-step 0 into wf0/xf0, k-step 1 into wf1[st^1]/xf1[st^1]
   //   after m = 127       lgkmcnt(0)
 #ifndef W4P
-#define W4P 8, 88
+#define W4P 8, 64, 2   // measured: read spacing 1 -> 2 is +4-6 % on every shape; barrier at 16..64 and DMA spacing 6/8: equal within noise
 #endif
-  constexpr int w4p[2] = {W4P};
-  constexpr int W4_DS = w4p[0], W4_BB = w4p[1];
-  static_assert(W4_DS * 15 < 128 && W4_BB >= 64 && W4_BB + 32 <= 128, "schedule does not fit");
+  constexpr int w4p[3] = {W4P};
+  constexpr int W4_DS = w4p[0], W4_BB = w4p[1], W4_RS = w4p[2];   // DMA spacing, barrier position, fragment-read spacing
+  static_assert(W4_DS * 15 < 128 && W4_BB >= 1, "schedule does not fit");
   constexpr int W4_NB = (W4_BB + W4_DS - 1) / W4_DS < 16 ? (W4_BB + W4_DS - 1) / W4_DS : 16;   // this K-tile's DMAs issued before m = W4_BB
   auto ktile = [&](auto STC, auto FIRSTC) {
     constexpr int st = decltype(STC)::value;
@@ -828,12 +828,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (dbg & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W4_NB) : "memory");
           else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(W4_NB) : "memory");
         }
-        if (m >= W4_BB && m < W4_BB + 32 && !(dbg & 2)) {
-          const int r = m - W4_BB;   // W k0, X k0, W k1, X k1
-          if (r < 8) W4_RD(wf0[r & 7], wbs[st ^ 1], (r & 7) * 128);
-          else if (r < 16) W4_RD(xf0[r & 7], xbs[st ^ 1], (r & 7) * 128);
-          else if (r < 24) W4_RD(wf1[st ^ 1][r & 7], wbs[st ^ 1], (r & 7) * 128 + 64);
-          else W4_RD(xf1[st ^ 1][r & 7], xbs[st ^ 1], (r & 7) * 128 + 64);
+        // fragment reads of K-tile t+1, W4_RS MFMAs apart (back to back they saturate the LDS: four waves x 1 KB per 16 cycles).
+        // k-step 1 goes to the idle buffer and may start at the barrier; k-step 0 reuses wf0/xf0, free from m = 64
+        if (!(dbg & 2)) {
+          constexpr int K1_AT = W4_BB >= 64 ? W4_BB + 16 * W4_RS : W4_BB;                       // first k-step-1 read
+          constexpr int K0_AT = W4_BB >= 64 ? W4_BB : (W4_BB + 16 * W4_RS > 64 ? W4_BB + 16 * W4_RS : 64);
+          static_assert(K0_AT + 15 * W4_RS < 128 && K1_AT + 15 * W4_RS < 128, "fragment reads do not fit");
+          if (m >= K0_AT && m < K0_AT + 16 * W4_RS && (m - K0_AT) % W4_RS == 0) {
+            const int r = (m - K0_AT) / W4_RS;
+            if (r < 8) W4_RD(wf0[r & 7], wbs[st ^ 1], (r & 7) * 128);
+            else W4_RD(xf0[r & 7], xbs[st ^ 1], (r & 7) * 128);
+          }
+          if (m >= K1_AT && m < K1_AT + 16 * W4_RS && (m - K1_AT) % W4_RS == 0) {
+            const int r = (m - K1_AT) / W4_RS;
+            if (r < 8) W4_RD(wf1[st ^ 1][r & 7], wbs[st ^ 1], (r & 7) * 128 + 64);
+            else W4_RD(xf1[st ^ 1][r & 7], xbs[st ^ 1], (r & 7) * 128 + 64);
+          }
         }
       }
     };
