@@ -1,0 +1,53 @@
+"""bench.py is the driver's measuring stick: guard its command line and the JSON line it prints."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_command_line_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """No silent CPU fallback: without a GPU the bench must fail, and loudly."""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode != 0
+    assert not any(line.startswith("{") for line in out.stdout.splitlines())
+
+
+@pytest.mark.gpu
+def test_bench_json_line_contract():
+    """One JSON line with the contract's keys; two visual blocks keep it short (the engine path is the same)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X (torch.cuda.is_available() is False)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--blocks", "2",
+                          "--no-vae"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "steps/s" and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] / 1000.0 - 1.0) < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "steps/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["value"] / c["value"] > 10.0          # sanity only: the ratio says nothing about kernel quality
