@@ -1,0 +1,47 @@
+"""Race screen: the hand-synchronised kernels must be bit-reproducible.  Repeats large GEMMs (4-wave and 8-wave ranges, all
+epilogues) and a 2-step sample of the full-size model and demands identical bits every time.  python tools/soak.py [reps]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kandinsky-5_amd"))
+import torch
+from kandinsky import _engine as E
+BF = torch.bfloat16
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+torch.manual_seed(1)
+bad = 0
+for (M, N, K, epi) in ((47616, 1792, 1792, "gate"), (47616, 3584, 1792, "bias"), (1792, 47616, 1792, "bias_m"), (47616, 7168, 1792, "gelu"),
+                       (47616, 1792, 7168, "gate"), (5952, 1792, 1792, "bias"), (11904, 7168, 1792, "gelu"), (4096, 4096, 4096, "bias")):
+    a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
+    bias = torch.randn(M if epi == "bias_m" else N, device="cuda")
+    resid0 = torch.randn(M, N, device="cuda").to(BF) if epi == "gate" else None
+    gate = torch.randn(N, device="cuda") if epi == "gate" else None
+    code = {"bias": E.EPI_BIAS, "bias_m": E.EPI_BIAS_M, "gelu": E.EPI_GELU, "gate": E.EPI_GATE}[epi]
+    def run():
+        out = resid0.clone() if epi == "gate" else torch.empty(M, N, dtype=BF, device="cuda")
+        E.gemm(a, w, bias, code, resid=out if epi == "gate" else None, gate=gate, out=out)
+        return out
+    first = run()
+    nd = sum(0 if torch.equal(run(), first) else 1 for _ in range(reps))
+    print(f"gemm {M}x{N}x{K} {epi}: {nd} of {reps} repeats differ", flush=True)
+    bad += nd
+from kandinsky.models.dit import DiffusionTransformer3D
+LITE = dict(in_visual_dim=16, in_text_dim=3584, in_text_dim2=768, time_dim=512, out_visual_dim=16, patch_size=(1, 2, 2), model_dim=1792,
+            ff_dim=7168, num_text_blocks=2, num_visual_blocks=4, axes_dims=(16, 24, 24), visual_cond=True)
+dev = torch.device("cuda", 0)
+with torch.device("meta"):
+    dit = DiffusionTransformer3D(**LITE)
+dit.init_synthetic(dev, seed=0)
+g = torch.Generator(device=dev).manual_seed(6554)
+lat0 = torch.randn(31, 64, 96, 16, device=dev, generator=g)
+te = {"text_embeds": torch.randn(256, 3584, device=dev, generator=g).bfloat16(), "pooled_embed": torch.randn(1, 768, device=dev, generator=g).bfloat16()}
+vpos = [torch.arange(31), torch.arange(32), torch.arange(48)]
+outs = []
+for i in range(max(3, reps // 20)):
+    lat = lat0.clone()
+    dit.sample(lat, [1.0, 0.9, 0.8], te, te, vpos, torch.arange(256), torch.arange(256), 1.0, scale_factor=(1.0, 2.0, 2.0), sparse_params=None)
+    outs.append(lat.clone())
+nd = sum(0 if torch.equal(o, outs[0]) else 1 for o in outs[1:])
+print(f"2-step sample, 4 visual blocks, N = 47616: {nd} of {len(outs) - 1} repeats differ; finite = {bool(torch.isfinite(outs[0]).all())}")
+bad += nd
+print("FAILED" if bad else "all reproducible")
+sys.exit(1 if bad else 0)
