@@ -11,6 +11,8 @@
 //     (to,ho,wo) --tap--> clamp (replicate pad, causal in T) --upsample map--> (ts,hs,ws) --> X + pos*C + c0.
 // Weights are pre-packed [Cout][27][Cin] (tap-major) so the W operand is a plain K-contiguous row.
 // Epilogues: bias, or bias + residual add (resnet skip, vae.py:274: bf16(bf16(acc+bias) + residual)).
+#include <stdlib.h>
+
 #include "k5_common.h"
 #include "k5_kernels.h"
 
@@ -158,6 +160,11 @@ int k5_launch_conv3d_bf16(const void* X, const void* W, const float* bias, void*
   if (Ts <= 0 || Hs <= 0 || Ws <= 0 || Cout <= 0 || !bias) return K5_ERR_ARG;
   if (Cin <= 0 || (Cin % 64)) return K5_ERR_ALIGN;
   if ((up_t != 1 && up_t != 2) || (up_s != 1 && up_s != 2)) return K5_ERR_ARG;
+  static const int force = getenv("K5_CONV_V1") ? atoi(getenv("K5_CONV_V1")) : 0;   // A/B: 1 = always the 128 x 128 kernel below
+  if (force != 1) {
+    const int r = k5_launch_conv3d_w4(X, W, bias, out, Ts, Hs, Ws, Cin, Cout, up_t, up_s, ldc, resid, ldr, stream);
+    if (r != K5_ERR_UNSUPPORTED) return r;
+  }
   ConvP p;
   p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.C = (bf16_t*)out; p.bias = bias; p.resid = (const bf16_t*)resid;
   p.Ts = Ts; p.Hs = Hs; p.Ws = Ws;

@@ -1,0 +1,293 @@
+// conv3d_w4.hip — the causal 3x3x3 convolution of conv3d.hip on the 4-wave 256-row structure of gemm_bf16.hip
+// (gemm_bf16_w4_kernel): one persistent workgroup per CU, one wave per SIMD, accumulators pinned to the AGPR file, operand
+// tiles by `buffer_load_dwordx4 ... lds`, MFMA 16x16x32 and ds_read_b128 as a hand-ordered asm stream.
+//
+// Replaces the same reference code as conv3d.hip (HunyuanVideoCausalConv3d, kandinsky/models/vae.py:125-163, with the nearest
+// upsample of HunyuanVideoUpsampleCausal3D vae.py:187-205 folded into the gather) for the layers that fill the machine:
+// Cin a multiple of 128, Cout = 128 (256 x 128 tile) or a multiple of 256 (256 x 256 tile), at least one round of tiles.
+//
+// Implicit GEMM: M = output positions, N = Cout, K = 27 taps x Cin (tap-major, as the packed weights [Cout][27][Cin]).
+// A K-tile is (tap, 64-channel slab).  The weight operand is a plain K-contiguous matrix (as in the GEMM).  The activation
+// operand is a GATHER: LDS piece d holds the 8 output positions {16 i + (d & 15)} of a 128-row half, and every lane of a DMA
+// instruction carries its own byte offset  pos(row, tap) * Cin * 2 + 16 * (lane & 7)  — recomputed per tap (replicate
+// padding, causal in T, nearest upsample map: clamps, so there is no zero fill), while the 64-channel slab rides in the
+// instruction's SGPR offset.  One lane serves 8 CONSECUTIVE output positions (one per DMA instruction), whose packed
+// (t, h, w) coordinates are derived once per output tile.
+#include <type_traits>
+
+#include "k5_common.h"
+#include "k5_kernels.h"
+
+namespace {
+
+constexpr int CBK = 64;
+constexpr int CW_PAD = 1040;   // 8 rows x 128 B + 16 B: see gemm_bf16.hip (conflict-free ds_read_b128 at immediate offsets)
+typedef __attribute__((address_space(3))) void cw_lds_t;
+
+struct ConvW4P {
+  const bf16_t* X; const bf16_t* W; bf16_t* C;
+  const float* bias; const bf16_t* resid;
+  int Ts, Hs, Ws, To, Ho, Wo, up_t, up_s;
+  int Cin, Cout, M, ldc, ldr, tiles_m, tiles_n;
+  unsigned x_bytes;
+};
+
+// NTW = 16-channel n-tiles per wave: 8 -> 256 x 256 tile (waves 2 x 2, each 128 x 128), 4 -> 256 x 128 tile (each 128 x 64)
+template <int NTW, bool RESID>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3d_w4_kernel(ConvW4P p) {
+  constexpr int BN = 32 * NTW;
+  constexpr int WP = BN / 8;                                   // weight pieces per K-tile (8 rows each)
+  constexpr int W_OP = WP * CW_PAD, X_OP = 32 * CW_PAD, STAGE = W_OP + X_OP;
+  constexpr int HALF = 8 * NTW, TOT = 16 * NTW;                // MFMAs per k-step / per K-tile and wave
+  constexpr int NDW = WP / 4, ND = NDW + 8;                    // DMA instructions per wave and K-tile: weights, then positions
+  constexpr int NR = NTW + 8;                                  // fragment reads per k-step
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;
+  const int l15 = lane & 15, lc = lane >> 4;
+
+  // persistent walk: XCD x owns a contiguous range of logical tiles (n fastest), its workgroups walk it interleaved
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7 - xcd) >> 3;
+  const int q8 = nblk >> 3, r8 = nblk & 7;
+  const int x_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, x_cnt = q8 + (xcd < r8 ? 1 : 0);
+  auto tile_origin = [&](int lid, int& m0, int& n0) __attribute__((always_inline)) { m0 = (lid / p.tiles_n) * 256; n0 = (lid % p.tiles_n) * BN; };
+  if (slot >= x_cnt) return;
+
+  const int cpt = p.Cin / CBK;                 // K-tiles per tap (even)
+  const int nk = 27 * cpt;                     // even
+  const uint32_t ldw2 = (uint32_t)(27 * p.Cin) * 2u, cin2 = (uint32_t)p.Cin * 2u;
+  const uint32_t vw0 = (uint32_t)(16 * (lane >> 3)) * ldw2 + (uint32_t)(lane & 7) * 16u;
+  const int wrow0 = NTW == 8 ? 128 * (wave >> 1) + 8 * (wave & 1) : NDW * wave;   // first weight row / LDS piece of this wave's DMAs
+  const int wslot0 = NDW * wave;
+  const int xslot0 = 8 * wave;                                                    // position pieces (h = wave >> 1, r = 8 (wave & 1) + jj)
+  uint32_t vw = vw0;
+  uint32_t vxo[8];                             // per DMA instruction: byte offset of this lane's position at the current tap
+  uint32_t pk[8];                              // its packed output coordinates  t << 24 | h << 12 | w
+  __amdgpu_buffer_rsrc_t rW;
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)p.x_bytes, 0x00020000);
+  int d_ti = slot, d_cnt = 0, d_tap = 0, d_cc = 0;   // DMA cursor: tile, K-tiles issued, tap, channel slab
+  auto set_tap = [&](int tap) __attribute__((always_inline)) {
+    const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      int tu = max((int)(pk[jj] >> 24) + dt - 2, 0);                       // causal: 2 frames of replicate pad in front
+      int hu = min(max((int)((pk[jj] >> 12) & 0xfff) + dh - 1, 0), p.Ho - 1);
+      int wu = min(max((int)(pk[jj] & 0xfff) + dw - 1, 0), p.Wo - 1);
+      if (p.up_t == 2) tu = tu == 0 ? 0 : 1 + ((tu - 1) >> 1);             // frame 0 is not repeated in time (vae.py:190-199)
+      if (p.up_s == 2) { hu >>= 1; wu >>= 1; }
+      vxo[jj] = (uint32_t)((tu * p.Hs + hu) * p.Ws + wu) * cin2 + (uint32_t)(lane & 7) * 16u;
+    }
+  };
+  auto set_dma_tile = [&](int ti) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_origin(x_first + ti, m0, n0);
+    rW = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.W) + (size_t)n0 * ldw2), 0, (int)((uint32_t)BN * ldw2), 0x00020000);
+    const int mb = m0 + 128 * (wave >> 1) + 16 * (lane >> 3) + 8 * (wave & 1);   // + jj: 8 consecutive output positions
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int m = min(mb + jj, p.M - 1);
+      const int wo = m % p.Wo, th = m / p.Wo;
+      pk[jj] = (uint32_t)(th / p.Ho) << 24 | (uint32_t)(th % p.Ho) << 12 | (uint32_t)wo;
+    }
+    d_cnt = 0; d_tap = 0; d_cc = 0; vw = vw0;
+    set_tap(0);
+  };
+  auto dma1 = [&](int stage, int d) __attribute__((always_inline)) {
+    if (d < NDW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (cw_lds_t*)(dsm + stage * STAGE + (wslot0 + d) * CW_PAD), 16, vw,
+                                                          (uint32_t)(wrow0 + d) * ldw2, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (cw_lds_t*)(dsm + stage * STAGE + W_OP + (xslot0 + d - NDW) * CW_PAD), 16, vxo[d - NDW],
+                                                  (uint32_t)d_cc * (2 * CBK), 0, 0);
+  };
+  // after a K-tile's DMAs: next channel slab / tap / output tile (past the last tile it wraps onto the same one: harmless
+  // loads that keep the vmcnt arithmetic uniform)
+  auto dma_advance = [&]() __attribute__((always_inline)) {
+    vw += 2 * CBK;
+    if (++d_cc == cpt) { d_cc = 0; if (++d_tap < 27) set_tap(d_tap); }
+    if (++d_cnt == nk) {
+      if (d_ti + per_xcd < x_cnt) d_ti += per_xcd;
+      set_dma_tile(d_ti);
+    }
+  };
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(cw_lds_t*)dsm;
+  uint32_t wbs[2], xbs[2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    wbs[st] = lds0 + st * STAGE + ((NTW == 8 ? 16 * wn : 0) + l15) * CW_PAD + lc * 16 + (NTW == 8 ? 0 : NTW * wn * 128);
+    xbs[st] = lds0 + st * STAGE + W_OP + (16 * wm + l15) * CW_PAD + lc * 16;
+    asm volatile("" : "+v"(wbs[st]), "+v"(xbs[st]));
+  }
+  bf16x8 wf0[NTW], xf0[8], wf1[2][NTW], xf1[2][8];
+  f32x4 acc[NTW][8];   // [n-tile][m-tile]; written (not accumulated) by the first k-step of every output tile
+
+#define CW_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define CW_MF(WF, XF, Q) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(Q) % NTW][(Q) / NTW]) : "v"(WF[(Q) % NTW]), "v"(XF[(Q) / NTW]))
+#define CW_MF0(WF, XF, Q) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[(Q) % NTW][(Q) / NTW]) : "v"(WF[(Q) % NTW]), "v"(XF[(Q) / NTW]))
+
+  set_dma_tile(slot);
+#pragma unroll
+  for (int d = 0; d < ND; ++d) dma1(0, d);
+  dma_advance();
+#pragma unroll
+  for (int d = 0; d < ND; ++d) dma1(1, d);
+  dma_advance();
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND) : "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) { CW_RD(wf0[i], wbs[0], i * 128); CW_RD(wf1[0][i], wbs[0], i * 128 + 64); }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { CW_RD(xf0[j], xbs[0], j * 128); CW_RD(xf1[0][j], xbs[0], j * 128 + 64); }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // One K-tile (stage st) = TOT MFMAs, m = 0..TOT-1 (schedule: see gemm_bf16_w4_kernel):
+  //   top: barrier (every wave holds this K-tile's fragments -> its stage may be refilled)
+  //   m = DS d: DMA d of K-tile t+2;  after m = HALF-1: vmcnt(NB) + barrier (K-tile t+1 landed)
+  //   second half: the 2 NR fragment reads of K-tile t+1 (k-step 0 into wf0/xf0, k-step 1 into the idle buffer), spread out
+  constexpr int DS = TOT / 16;
+  constexpr int NB = (HALF + DS - 1) / DS < ND ? (HALF + DS - 1) / DS : ND;
+  static_assert(NTW == 8 ? HALF + 2 * (2 * NR - 1) < TOT : HALF + (2 * NR - 1) + (2 * NR - 1) / 3 < TOT, "fragment reads do not fit");
+  auto ktile = [&](auto STC, auto FIRSTC) __attribute__((always_inline)) {
+    constexpr int st = decltype(STC)::value;
+    constexpr bool first = decltype(FIRSTC)::value;
+    asm volatile("s_barrier" ::: "memory");
+    auto chunk = [&](auto BASEC) __attribute__((always_inline)) {
+#pragma unroll
+      for (int m = decltype(BASEC)::value; m < decltype(BASEC)::value + 16; ++m) {
+        if (m < HALF && first) CW_MF0(wf0, xf0, m);
+        else if (m < HALF) CW_MF(wf0, xf0, m);
+        else CW_MF(wf1[st], xf1[st], m - HALF);
+        if (m % DS == 0 && m / DS < ND) dma1(st, m / DS);
+        if (m == HALF - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NB) : "memory");
+        {   // fragment read r of K-tile t+1 in this slot?  (NTW = 8: every second slot of the second half; NTW = 4: three of four)
+          const int sl = m - HALF;
+          const bool has = sl >= 0 && (NTW == 8 ? (sl & 1) == 0 : (sl & 3) != 3);
+          const int r = NTW == 8 ? sl / 2 : sl - sl / 4;
+          if (has && r < 2 * NR) {
+            const int rr = r % NR;
+            if (r < NR) { if (rr < NTW) CW_RD(wf0[rr % NTW], wbs[st ^ 1], (rr % NTW) * 128); else CW_RD(xf0[(rr - NTW) & 7], xbs[st ^ 1], ((rr - NTW) & 7) * 128); }
+            else { if (rr < NTW) CW_RD(wf1[st ^ 1][rr % NTW], wbs[st ^ 1], (rr % NTW) * 128 + 64); else CW_RD(xf1[st ^ 1][(rr - NTW) & 7], xbs[st ^ 1], ((rr - NTW) & 7) * 128 + 64); }
+          }
+        }
+      }
+    };
+    chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 16>{}); chunk(std::integral_constant<int, 32>{});
+    chunk(std::integral_constant<int, 48>{});
+    if (TOT > 64) {
+      chunk(std::integral_constant<int, (TOT > 64 ? 64 : 0)>{}); chunk(std::integral_constant<int, (TOT > 64 ? 80 : 0)>{});
+      chunk(std::integral_constant<int, (TOT > 64 ? 96 : 0)>{}); chunk(std::integral_constant<int, (TOT > 64 ? 112 : 0)>{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    dma_advance();
+  };
+
+  for (int ti = slot; ti < x_cnt; ti += per_xcd) {
+    ktile(std::integral_constant<int, 0>{}, std::true_type{});
+    ktile(std::integral_constant<int, 1>{}, std::false_type{});
+    for (int t = 2; t < nk; t += 2) {
+      ktile(std::integral_constant<int, 0>{}, std::false_type{});
+      ktile(std::integral_constant<int, 1>{}, std::false_type{});
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs are invisible to the hazard recogniser
+    int m0, n0;
+    tile_origin(x_first + ti, m0, n0);
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int e_l15 = tid2 & 15, e_lc = (tid2 >> 4) & 3, e_wave = tid2 >> 6;
+    const int e_wn = e_wave & 1, e_wm = e_wave >> 1;
+    // epilogue (vae.py:274): bf16(acc + bias), or bf16(bf16(acc + bias) + residual); loads before stores, 16-byte stores
+    const int nb = n0 + 16 * NTW * e_wn + 4 * e_lc;          // + 16 i
+    f32x4 bvec[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) bvec[i] = *reinterpret_cast<const f32x4*>(p.bias + nb + 16 * i);
+#pragma unroll
+    for (int jh = 0; jh < 4; ++jh) {
+      u32x2 rr[2][NTW];
+      if (RESID) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int m = min(m0 + 128 * e_wm + 16 * (2 * jh + jj) + e_l15, p.M - 1);
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) rr[jj][i] = *reinterpret_cast<const u32x2*>(p.resid + (size_t)m * p.ldr + nb + 16 * i);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * jh + jj;
+        const int m = m0 + 128 * e_wm + 16 * j + e_l15;
+#pragma unroll
+        for (int iq = 0; iq < NTW / 2; ++iq) {
+          u32x2 o[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int i = 2 * iq + h;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bvec[i][e];
+            if (RESID) {
+              v[0] = __uint_as_float(rr[jj][i][0] << 16) + bf_round(v[0]);
+              v[1] = __uint_as_float(rr[jj][i][0] & 0xffff0000u) + bf_round(v[1]);
+              v[2] = __uint_as_float(rr[jj][i][1] << 16) + bf_round(v[2]);
+              v[3] = __uint_as_float(rr[jj][i][1] & 0xffff0000u) + bf_round(v[3]);
+            }
+            o[h] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          }
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {   // lanes l / l + 16 trade halves: each lane owns 8 consecutive channels of one tile
+            const auto sw = __builtin_amdgcn_permlane16_swap(o[0][d], o[1][d], false, false);
+            o[0][d] = sw[0]; o[1][d] = sw[1];
+          }
+          const int n = n0 + 16 * NTW * e_wn + 16 * (2 * iq + (e_lc & 1)) + 8 * (e_lc >> 1);
+          if (m < p.M) *reinterpret_cast<u32x4*>(p.C + (size_t)m * p.ldc + n) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing may still be loading into a VGPR when the asm stream resumes
+  }
+#undef CW_MF
+#undef CW_MF0
+#undef CW_RD
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wrapped DMAs still write this workgroup's LDS
+}
+
+template <int NTW, bool RESID>
+int launch_conv_w4(const ConvW4P& p, int num_cu, hipStream_t stream) {
+  constexpr int LDS = 2 * ((32 * NTW / 8) * CW_PAD + 32 * CW_PAD);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv3d_w4_kernel<NTW, RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return K5_ERR_HIP;
+    attr_set = true;
+  }
+  const int tiles = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL((conv3d_w4_kernel<NTW, RESID>), dim3(min(tiles, num_cu)), dim3(256), LDS, stream, p);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
+}  // namespace
+
+// Same contract as k5_launch_conv3d_bf16 (conv3d.hip); returns K5_ERR_UNSUPPORTED when the shape is outside this kernel's
+// range (the caller then uses the 128 x 128 kernel).
+int k5_launch_conv3d_w4(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin, int Cout,
+                        int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream) {
+  if (Cin <= 0 || (Cin % 128) || !(Cout == 128 || (Cout % 256) == 0) || (ldc & 7) || (resid && (ldr & 3)) || !bias) return K5_ERR_UNSUPPORTED;
+  ConvW4P p;
+  p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.C = (bf16_t*)out; p.bias = bias; p.resid = (const bf16_t*)resid;
+  p.Ts = Ts; p.Hs = Hs; p.Ws = Ws;
+  p.To = up_t == 2 ? 2 * Ts - 1 : Ts; p.Ho = up_s * Hs; p.Wo = up_s * Ws;
+  p.up_t = up_t; p.up_s = up_s; p.Cin = Cin; p.Cout = Cout; p.ldc = ldc; p.ldr = ldr;
+  const long long M = (long long)p.To * p.Ho * p.Wo, xb = (long long)Ts * Hs * Ws * Cin * 2;
+  if (M > 0x7fffffffLL || xb >= 0xffffffffLL || p.Ho > 4095 || p.Wo > 4095 || p.To > 255) return K5_ERR_UNSUPPORTED;
+  p.M = (int)M; p.x_bytes = (unsigned)xb;
+  const int bn = Cout == 128 ? 128 : 256;
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = Cout / bn;
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if ((long long)p.tiles_m * p.tiles_n < num_cu) return K5_ERR_UNSUPPORTED;   // less than one round: the small tiles fill the chip better
+  if (Cout == 128) return resid ? launch_conv_w4<4, true>(p, num_cu, stream) : launch_conv_w4<4, false>(p, num_cu, stream);
+  return resid ? launch_conv_w4<8, true>(p, num_cu, stream) : launch_conv_w4<8, false>(p, num_cu, stream);
+}

@@ -94,6 +94,9 @@ int k5_launch_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, in
                                float alpha, hipStream_t stream);
 
 // ---- VAE decoder kernels (channels-last bf16 activations) ----
+// 4-wave 256-row variant (conv3d_w4.hip); K5_ERR_UNSUPPORTED outside its range (Cin % 128, Cout = 128 or % 256, >= one round of tiles)
+int k5_launch_conv3d_w4(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin, int Cout,
+                        int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream);
 int k5_launch_conv3d_bf16(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin,
                           int Cout, int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream);
 size_t k5_groupnorm_workspace_bytes(int M, int G);

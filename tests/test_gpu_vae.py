@@ -74,6 +74,46 @@ def test_conv3d_kernel_with_upsample_and_residual(vae):
             assert err <= 2.0 ** -6 * max(1.0, want.abs().max().item()), (up_t, up_s, use_res, err)
 
 
+@pytest.mark.parametrize("Cin,Cout,up,dims", [(128, 128, (1, 1), (5, 112, 128)), (128, 256, (2, 2), (3, 60, 64)), (256, 128, (1, 2), (4, 64, 72))])
+def test_conv3d_four_wave_kernel(vae, Cin, Cout, up, dims):
+    """Shapes in the range of the 4-wave 256-row kernel (conv3d_w4.hip: Cin % 128 == 0, Cout = 128 or % 256, >= 256 tiles):
+    gather offsets per tap (replicate pad, causal T, folded nearest upsample), both tile shapes, residual epilogue, ragged M."""
+    from kandinsky import _engine as E
+    torch.manual_seed(1)
+    Ts, Hs, Ws = dims
+    up_t, up_s = up
+    x = bfr(torch.randn(1, Cin, Ts, Hs, Ws))
+    w = bfr(torch.randn(Cout, Cin, 3, 3, 3) * 0.03)
+    b = bfr(torch.randn(Cout) * 0.1)
+    xin = x
+    if up_t > 1 or up_s > 1:
+        first = torch.nn.functional.interpolate(x[:, :, 0], scale_factor=(up_s, up_s), mode="nearest").unsqueeze(2)
+        rest = torch.nn.functional.interpolate(x[:, :, 1:], scale_factor=(up_t, up_s, up_s), mode="nearest")
+        xin = torch.cat([first, rest], 2)
+    ref = V.causal_conv3d({"c.conv.weight": w, "c.conv.bias": b}, "c", xin, "bf16")
+    To, Ho, Wo = ref.shape[2:]
+    assert (To * Ho * Wo + 255) // 256 * max(1, Cout // 256) >= 256        # really in the 4-wave kernel's range
+    want = ref[0].permute(1, 2, 3, 0).reshape(-1, Cout)
+    resid = bfr(torch.randn(To * Ho * Wo, Cout))
+    xd = x[0].permute(1, 2, 3, 0).contiguous().cuda().bfloat16()
+    wd = w.permute(0, 2, 3, 4, 1).reshape(Cout, 27 * Cin).contiguous().cuda().bfloat16()
+    out = torch.empty(To * Ho * Wo, Cout, dtype=torch.bfloat16, device="cuda")
+    rd, bd = resid.cuda().bfloat16(), b.cuda()
+    for use_res in (False, True):
+        out.zero_()
+        E.check(E.lib().k5_conv3d_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), Ts, Hs, Ws, Cin, Cout, up_t, up_s,
+                                       Cout, rd.data_ptr() if use_res else None, Cout, E.stream_ptr()))
+        torch.cuda.synchronize()
+        tgt = bfr(want + resid) if use_res else want
+        err = (out.float().cpu() - tgt).abs()
+        tol = 2.0 ** -6 * tgt.abs().clamp(min=1.0) + (2.0 ** -7 * want.abs() if use_res else 0)   # + a 1-ulp flip of the inner rounding
+        assert not (err > tol).any(), (Cin, Cout, up, use_res, float(err.max()), int((err > tol).sum()))
+        again = out.clone()
+        E.check(E.lib().k5_conv3d_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), Ts, Hs, Ws, Cin, Cout, up_t, up_s,
+                                       Cout, rd.data_ptr() if use_res else None, Cout, E.stream_ptr()))
+        assert torch.equal(out, again)                                         # hand-counted waits: bit-reproducible
+
+
 @pytest.mark.parametrize("M,C,G", [(90, 64, 16), (1000, 128, 16), (3000, 512, 32), (77, 256, 32)])
 def test_groupnorm_silu_kernel(M, C, G):
     from kandinsky import _engine as E
