@@ -122,6 +122,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   const int tiles_per_chunk = p.vt_chunk_keys > 0 ? p.vt_chunk_keys / KB : 0x7fffffff;
   typedef __attribute__((address_space(3))) void lds_void_t;
   typedef const __attribute__((address_space(1))) void gbl_void_t;
+  const uint32_t kvoff = (uint32_t)lrow * kstride + klane;
+  const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)p.K, 0, -1, 0x00020000);   // 4 GB window from the base
+  const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)p.Vt, 0, -1, 0x00020000);
   auto load_tile = [&](int e, int buf) {   // e = position in the tile sequence; tile t = tile_of(e) -> LDS buffer `buf`
     const int t = tile_of(e);
     const int kv0 = t * KB;
@@ -129,6 +132,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     if (p.vt_chunk_keys > 0) {   // sequence-parallel V^T layout only (uniform branch): per-rank chunks
       const int chunk = t / tiles_per_chunk;
       vsrc = Vb + 2 * ((long long)chunk * p.vt_chunk_stride + (kv0 - chunk * tiles_per_chunk * KB));
+    }
+    if (PRE) {   // whole tiles only (launcher): constant per-lane offsets, the tile rides in the instruction's SGPR offset: no address VALU
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_void_t*)(sK + buf * TILE + wave_u * 1024), 16, kvoff, (uint32_t)kv0 * kstride, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_void_t*)(sV + buf * TILE + wave_u * 1024), 16, vlane, (uint32_t)(vsrc - Vb), 0, 0);
+      return;
     }
     __builtin_amdgcn_global_load_lds((gbl_void_t*)(Kb + ((uint32_t)min(kv0 + lrow, p.kv_len - 1) * kstride + klane)),
                                      (lds_void_t*)(sK + buf * TILE + wave_u * 1024), 16, 0, 0);
