@@ -25,17 +25,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   const int rows_par = 256 / nch > 0 ? 256 / nch : 1;
   const int ch = tid % nch, rsub = tid / nch;
   float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
-  const int g0 = (8 * ch) / cg;
   if (rsub < rows_par) {
-    for (int r = r0 + rsub; r < r1; r += rows_par) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)r * ldx + 8 * ch);
+    // a chunk's 8 channels lie in ONE group (cg >= 8) or are the two 4-channel groups of cg == 4: sum the halves separately
+    float slo = 0.f, shi = 0.f, qlo = 0.f, qhi = 0.f;
+    for (int rb = r0 + rsub; rb < r1; rb += 4 * rows_par) {   // four independent loads in flight; summation order unchanged
+      u32x4 raw[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = (j & 1) ? __uint_as_float(raw[j >> 1] & 0xffff0000u) : __uint_as_float(raw[j >> 1] << 16);
-        const int gi = ((8 * ch + j) / cg) - g0;  // 0 or 1 (cg >= 4)
-        s[gi] += v; q[gi] += v * v;
+      for (int u = 0; u < 4; ++u) {
+        const int r = rb + u * rows_par;
+        raw[u] = r < r1 ? *reinterpret_cast<const u32x4*>(x + (size_t)r * ldx + 8 * ch) : u32x4{0u, 0u, 0u, 0u};
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = (j & 1) ? __uint_as_float(raw[u][j >> 1] & 0xffff0000u) : __uint_as_float(raw[u][j >> 1] << 16);
+          if (j < 4) { slo += v; qlo += v * v; } else { shi += v; qhi += v * v; }
+        }
     }
+    if (cg == 4) { s[0] = slo; q[0] = qlo; s[1] = shi; q[1] = qhi; }
+    else { s[0] = slo + shi; q[0] = qlo + qhi; }
   }
   ps[tid][0] = s[0]; ps[tid][1] = q[0]; ps[tid][2] = s[1]; ps[tid][3] = q[1];
   __syncthreads();
@@ -74,25 +83,45 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// thread -> fixed 16-B chunk column (tid % nch; nch a power of two <= 256), rows strided: the eight channels' affine
+// y = v * (rstd gamma) + (beta - mean rstd gamma) is folded once per thread, SiLU = y * rcp(1 + exp2(-y log2 e)) on the
+// hardware exp2 / rcp (the result is rounded to bf16).  One 16-B load, ~50 VALU, one 16-B store per chunk: HBM-bound.
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       bf16_t* __restrict__ out, int64_t nchunks, int nch, int cg, int ldx, int ldo) {
-  for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < nchunks; gidx += (int64_t)gridDim.x * 256) {
-    const int ch = (int)(gidx % nch);
-    const int64_t row = gidx / nch;
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(x + row * ldx + 8 * ch);
-    float o[8];
+                                                       bf16_t* __restrict__ out, int M, int nch_sh, int cg_sh, int ldx, int ldo,
+                                                       int rows_per_block) {
+  const int nch = 1 << nch_sh, ch = threadIdx.x & (nch - 1), rsub = threadIdx.x >> nch_sh, rows_par = 256 >> nch_sh;
+  float sc[8], sh[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = 8 * ch + j, g = c / cg;
-      const float v = (j & 1) ? __uint_as_float(raw[j >> 1] & 0xffff0000u) : __uint_as_float(raw[j >> 1] << 16);
-      float y = (v - stats[2 * g]) * stats[2 * g + 1] * gamma[c] + beta[c];
-      if (SILU) y = y / (1.0f + expf(-y));
-      o[j] = y;
+  for (int j = 0; j < 8; ++j) {
+    const int c = 8 * ch + j, g = c >> cg_sh;
+    sc[j] = stats[2 * g + 1] * gamma[c];
+    sh[j] = beta[c] - stats[2 * g] * sc[j];
+  }
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+  for (int rb = r0 + rsub; rb < r1; rb += 4 * rows_par) {   // four independent 16-B loads in flight per thread
+    u32x4 raw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = rb + u * rows_par;
+      if (r < r1) raw[u] = *reinterpret_cast<const u32x4*>(x + (size_t)r * ldx + 8 * ch);
     }
-    u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-    *reinterpret_cast<u32x4*>(out + row * ldo + 8 * ch) = pk;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = rb + u * rows_par;
+      if (r >= r1) break;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = (j & 1) ? __uint_as_float(raw[u][j >> 1] & 0xffff0000u) : __uint_as_float(raw[u][j >> 1] << 16);
+        float y = fmaf(v, sc[j], sh[j]);
+        if (SILU) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * y));
+        o[j] = y;
+      }
+      u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+      *reinterpret_cast<u32x4*>(out + (size_t)r * ldo + 8 * ch) = pk;
+    }
   }
 }
 
@@ -167,17 +196,22 @@ int k5_launch_groupnorm_bf16(const void* x, const float* gamma, const float* bet
                              int silu, int ldx, int ldo, void* workspace, hipStream_t s) {
   if (M <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G)) return K5_ERR_ARG;
   const int cg = C / G;
-  if ((C & 7) || (ldx & 7) || (ldo & 7) || cg < 4 || (cg & (cg - 1)) || (C >> 3) > 256) return K5_ERR_UNSUPPORTED;
+  if ((C & 7) || (ldx & 7) || (ldo & 7) || cg < 4 || (cg & (cg - 1)) || (C >> 3) > 256 || ((C >> 3) & ((C >> 3) - 1))) return K5_ERR_UNSUPPORTED;
   const int nblk = (M + GN_ROWS - 1) / GN_ROWS;
   float* partial = (float*)workspace;
   float* stats = partial + (size_t)nblk * G * 2;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, partial, M, C, ldx, G);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(G), dim3(256), 0, s, partial, stats, nblk, G, (double)M * cg, eps);
-  const int64_t nchunks = (int64_t)M * (C >> 3);
-  if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid_for(nchunks)), dim3(256), 0, s, (const bf16_t*)x, stats, gamma, beta,
-                               (bf16_t*)out, nchunks, C >> 3, cg, ldx, ldo);
-  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid_for(nchunks)), dim3(256), 0, s, (const bf16_t*)x, stats, gamma, beta,
-                          (bf16_t*)out, nchunks, C >> 3, cg, ldx, ldo);
+  const int nch = C >> 3;   // chunk columns per row: a power of two (checked above; C = 128 / 256 / 512 and the tiny test widths)
+  int nch_sh = 0, cg_sh = 0;
+  while ((1 << nch_sh) < nch) ++nch_sh;
+  while ((1 << cg_sh) < cg) ++cg_sh;
+  const int rows_par = 256 >> nch_sh, rows_per_block = 32 * rows_par;   // 32 chunks per thread
+  const int nb = (M + rows_per_block - 1) / rows_per_block;
+  if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)out, M,
+                               nch_sh, cg_sh, ldx, ldo, rows_per_block);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)out, M,
+                          nch_sh, cg_sh, ldx, ldo, rows_per_block);
   return done();
 }
 
