@@ -551,7 +551,7 @@ size_t k5_attention_state_bytes(int H, int q_len) { return (size_t)q_len * H * (
 
 // Workspace of the balanced launcher below: up to K5_ATTN_MAX_SPLITS - 1 extra states + (when the caller passes no state
 // of its own) one base state.
-constexpr int K5_ATTN_MAX_SPLITS = 4;
+constexpr int K5_ATTN_MAX_SPLITS = 6;
 size_t k5_attention_balance_bytes(int H, int q_len) { return (size_t)K5_ATTN_MAX_SPLITS * k5_attention_state_bytes(H, q_len); }
 
 namespace {
