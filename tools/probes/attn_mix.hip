@@ -1,0 +1,75 @@
+// What would a hand-ordered one-wave-per-SIMD attention stream buy?  The attention tile loop's instruction mix per 64 queries x
+// 64 keys is 72 MFMA 16x16x32 + 64 v_exp_f32 + 32 v_cvt_pk_bf16_f32 (no memory traffic here).
+//   V=0: ONE wave per SIMD, hand order: after MFMA i (i < 64) one exp, after every second one also a cvt
+//   V=1: FOUR waves per SIMD, each running half of that work in the blocked order a compiler produces
+//        (16 MFMA | 24 VALU | 10 MFMA | 24 VALU | 10 MFMA), the hardware interleaves the waves
+//   V=2: one wave per SIMD, blocked order (no hand interleave)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MF(ACC) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(a), "v"(b))
+#define EX(X) asm volatile("v_exp_f32 %0, %0" : "+v"(X))
+#define CV(O, X, Y) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(O) : "v"(X), "v"(Y))
+template <int V>
+__global__ __launch_bounds__(V == 1 ? 1024 : 256) void k(float* out, const bf16x8* in, int iters) {
+  bf16x8 a = in[threadIdx.x & 63], b = in[64 + (threadIdx.x & 63)];
+  constexpr int NACC = V == 1 ? 18 : 36;
+  f32x4 acc[NACC];
+  for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0, 0, 0, 0};
+  float fx[16];
+  for (int i = 0; i < 16; ++i) fx[i] = -(float)(threadIdx.x & 7) - i;
+  unsigned fp = 0;
+  for (int it = 0; it < iters; ++it) {
+    if (V == 0) {
+#pragma unroll
+      for (int i = 0; i < 72; ++i) {
+        MF(acc[i % NACC]);
+        if (i < 64) { EX(fx[i & 15]); if (i & 1) CV(fp, fx[(i - 1) & 15], fx[i & 15]); }
+      }
+    } else {
+      const int reps = V == 1 ? 1 : 2;
+#pragma unroll
+      for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) MF(acc[i % NACC]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { EX(fx[i]); if (i & 1) CV(fp, fx[i - 1], fx[i]); }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) MF(acc[(16 + i) % NACC]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { EX(fx[i]); if (i & 1) CV(fp, fx[i - 1], fx[i]); }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) MF(acc[(26 + i) % NACC]);
+      }
+    }
+  }
+  float s = fp;
+  for (int i = 0; i < 16; ++i) s += fx[i];
+  for (int i = 0; i < NACC; ++i) s += acc[i][0];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int V> void run(const char* name, float* out, bf16x8* in) {
+  const int iters = 3000, threads = V == 1 ? 1024 : 256;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  k<V><<<256, threads>>>(out, in, 10);
+  hipEventRecord(e0);
+  k<V><<<256, threads>>>(out, in, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  // work per SIMD and iteration: V=0/2: one wave x 72 MFMA; V=1: four waves x 36 MFMA = 144 MFMA
+  const double mf_per_simd = (double)iters * (V == 1 ? 144 : 72);
+  printf("%-58s %.3f ms   %.2f ns per MFMA slot  (%.0f TFLOP/s of MFMA work)\n", name, ms, ms * 1e6 / mf_per_simd,
+         256.0 * 4 * mf_per_simd * 16384 / ms / 1e9);
+}
+int main() {
+  float* out; bf16x8* in; hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&in, 128 * 16);
+  unsigned short h[128 * 8];
+  for (int i = 0; i < 128 * 8; ++i) h[i] = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));
+  hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
+  run<0>("one wave/SIMD, hand-interleaved (72 MFMA + 64 exp + 32 cvt)", out, in);
+  run<1>("four waves/SIMD, blocked order per wave", out, in);
+  run<2>("one wave/SIMD, blocked order", out, in);
+  return 0;
+}
