@@ -13,16 +13,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define EX(X) asm volatile("v_exp_f32 %0, %0" : "+v"(X))
 #define CV(O, X, Y) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(O) : "v"(X), "v"(Y))
 template <int V>
-__global__ __launch_bounds__(V == 1 ? 1024 : 256) void k(float* out, const bf16x8* in, int iters) {
+__global__ __launch_bounds__((V == 1 || V >= 3) ? 1024 : 256) void k(float* out, const bf16x8* in, int iters) {
   bf16x8 a = in[threadIdx.x & 63], b = in[64 + (threadIdx.x & 63)];
-  constexpr int NACC = V == 1 ? 18 : 36;
+  constexpr int NACC = (V == 1 || V >= 3) ? 18 : 36;
   f32x4 acc[NACC];
   for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0, 0, 0, 0};
   float fx[16];
   for (int i = 0; i < 16; ++i) fx[i] = -(float)(threadIdx.x & 7) - i;
   unsigned fp = 0;
   for (int it = 0; it < iters; ++it) {
-    if (V == 0) {
+    if (V == 3) {   // four waves/SIMD, each wave hand-interleaved (36 MFMA + 32 exp + 16 cvt)
+#pragma unroll
+      for (int i = 0; i < 36; ++i) {
+        MF(acc[i % NACC]);
+        if (i < 32) { EX(fx[i & 15]); if (i & 1) CV(fp, fx[(i - 1) & 15], fx[i & 15]); }
+      }
+    } else if (V == 4) {   // four waves/SIMD, the dependency-limited order: S (16 MFMA) | exp(ks0) | PV(ks0) interleaved with exp(ks1) | PV(ks1)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) MF(acc[i % NACC]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { EX(fx[i]); if (i & 1) CV(fp, fx[i - 1], fx[i]); }
+#pragma unroll
+      for (int i = 0; i < 10; ++i) { MF(acc[(16 + i) % NACC]); EX(fx[i]); if (i < 6) EX(fx[10 + i]); if (i < 8) CV(fp, fx[i], fx[i + 1]); }
+#pragma unroll
+      for (int i = 0; i < 10; ++i) MF(acc[(26 + i) % NACC]);
+    } else if (V == 0) {
 #pragma unroll
       for (int i = 0; i < 72; ++i) {
         MF(acc[i % NACC]);
@@ -51,7 +66,7 @@ __global__ __launch_bounds__(V == 1 ? 1024 : 256) void k(float* out, const bf16x
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 template <int V> void run(const char* name, float* out, bf16x8* in) {
-  const int iters = 3000, threads = V == 1 ? 1024 : 256;
+  const int iters = 3000, threads = (V == 1 || V >= 3) ? 1024 : 256;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   k<V><<<256, threads>>>(out, in, 10);
   hipEventRecord(e0);
@@ -59,7 +74,7 @@ template <int V> void run(const char* name, float* out, bf16x8* in) {
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   // work per SIMD and iteration: V=0/2: one wave x 72 MFMA; V=1: four waves x 36 MFMA = 144 MFMA
-  const double mf_per_simd = (double)iters * (V == 1 ? 144 : 72);
+  const double mf_per_simd = (double)iters * ((V == 1 || V >= 3) ? 144 : 72);
   printf("%-58s %.3f ms   %.2f ns per MFMA slot  (%.0f TFLOP/s of MFMA work)\n", name, ms, ms * 1e6 / mf_per_simd,
          256.0 * 4 * mf_per_simd * 16384 / ms / 1e9);
 }
@@ -71,5 +86,7 @@ int main() {
   run<0>("one wave/SIMD, hand-interleaved (72 MFMA + 64 exp + 32 cvt)", out, in);
   run<1>("four waves/SIMD, blocked order per wave", out, in);
   run<2>("one wave/SIMD, blocked order", out, in);
+  run<3>("four waves/SIMD, each hand-interleaved", out, in);
+  run<4>("four waves/SIMD, PV(ks0) interleaved with exp(ks1) only", out, in);
   return 0;
 }
