@@ -75,7 +75,7 @@ def test_conv3d_kernel_with_upsample_and_residual(vae):
 
 
 @pytest.mark.parametrize("Cin,Cout,up,dims", [(128, 128, (1, 1), (5, 112, 128)), (128, 256, (2, 2), (3, 60, 64)), (256, 128, (1, 2), (4, 64, 72)),
-                                              (512, 512, (2, 2), (3, 36, 48))])
+                                              (512, 512, (2, 2), (3, 36, 48)), (128, 128, (1, 1), (5, 113, 127))])   # the last one: M not a multiple of 256, odd width
 def test_conv3d_four_wave_kernel(vae, Cin, Cout, up, dims):
     """Shapes in the range of the 4-wave 256-row kernel (conv3d_w4.hip: Cin % 128 == 0, Cout = 128 or % 256, >= 256 tiles):
     gather offsets per tap (replicate pad, causal T, folded nearest upsample), both tile shapes, residual epilogue, ragged M."""
