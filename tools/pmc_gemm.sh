@@ -8,7 +8,7 @@ cd $R
 python - <<PY
 import csv, collections
 for suf in ("", "b"):
-    acc = collections.defaultdict(dict)
+    acc = collections.defaultdict(dict); names = {}
     try:
         rows = csv.DictReader(open("gpurun_out/pmcg_${TAG}%s/p_counter_collection.csv" % suf))
     except FileNotFoundError:
@@ -16,8 +16,9 @@ for suf in ("", "b"):
     name = ""
     for r in rows:
         if "gemm_bf16" in r["Kernel_Name"]:
-            name = r["Kernel_Name"][:60]
+            names[r["Dispatch_Id"]] = r["Kernel_Name"].replace("(anonymous namespace)::", "")[:48]
             acc[r["Dispatch_Id"]][r["Counter_Name"]] = acc[r["Dispatch_Id"]].get(r["Counter_Name"], 0) + float(r["Counter_Value"])
-    d = list(acc.values())[-1]
-    print("$TAG", name, {k: round(v, 0) for k, v in sorted(d.items())})
+    big = max(acc, key=lambda i: max(acc[i].values()))   # the main launch (a tail-split GEMM also has a small 128x128 launch)
+    d = acc[big]
+    print("$TAG", names[big], {k: round(v, 0) for k, v in sorted(d.items())})
 PY
