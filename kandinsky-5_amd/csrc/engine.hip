@@ -463,18 +463,27 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     // ... while the main stream attends the local query rows to the LOCAL key chunk (pass 1, leaves the fp32 state),
     // then, once every chunk has arrived, to all the other chunks (pass 2, resumes the state and normalises).
     const int tpc = rows / 64, total = N / 64;
+    // Pass 1 exists to cover the gather, and it cannot be load-balanced (only a pass that normalises can split its tail jobs
+    // and merge them): it takes only as many LOCAL key tiles as the gather is expected to last — gather time grows with
+    // (P-1)/P N, attention with N^2 / P; calibrated on 0.9 ms of gather against 1.6 ms of attention at P = 8, N = 47 616 —
+    // and never more than the local chunk.  At P = 2 that is 8 % of the keys instead of 50 %: the other local keys move to the
+    // balanced pass 2 (5.1 rounds of jobs instead of 6).  K5_SP_PASS1_TILES overrides.
+    static const int force_k1 = getenv("K5_SP_PASS1_TILES") ? atoi(getenv("K5_SP_PASS1_TILES")) : 0;
+    int k1 = (int)(0.08 * (P - 1) * (47616.0 / N) * total + 0.5);
+    if (force_k1 > 0) k1 = force_k1;
+    k1 = k1 < 1 ? 1 : (k1 > tpc ? tpc : k1);
     K5CHK(d->ws_attn_state.ensure(k5_attention_state_bytes(H, rows)));
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     {
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
-                                           r * tpc, tpc, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s, nullptr, use_prescale(a)));
+                                           r * tpc, k1, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s, nullptr, use_prescale(a)));
     }
     HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
     {
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
-                                           0, total - tpc, r * tpc, tpc, d->ws_attn_state.as<float>(), 1, s, d->ws_attn_bal.as<float>(),
+                                           0, total - k1, r * tpc, k1, d->ws_attn_state.as<float>(), 1, s, d->ws_attn_bal.as<float>(),
                                          use_prescale(a)));
     }
   }
