@@ -464,14 +464,14 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     // then, once every chunk has arrived, to all the other chunks (pass 2, resumes the state and normalises).
     const int tpc = rows / 64, total = N / 64;
     // Pass 1 exists to cover the gather, and it cannot be load-balanced (only a pass that normalises can split its tail jobs
-    // and merge them): it takes only as many LOCAL key tiles as the gather is expected to last — gather time grows with
-    // (P-1)/P N, attention with N^2 / P; calibrated on 0.9 ms of gather against 1.6 ms of attention at P = 8, N = 47 616 —
-    // and never more than the local chunk.  At P = 2 that is 8 % of the keys instead of 50 %: the other local keys move to the
-    // balanced pass 2 (5.1 rounds of jobs instead of 6).  K5_SP_PASS1_TILES overrides.
+    // and merge them), so it should be no longer than the gather.  How long the gather takes is a property of the node (one
+    // xGMI link per GPU pair: ~341 MB / (P x link rate) per block, i.e. about 0.4 of a rank's attention time at any P if a link
+    // gives ~70 GB/s each way, much less if RCCL drives several paths) and cannot be measured here, so the default is the
+    // safe one — all local key tiles — and K5_SP_PASS1_TILES sets it on a real node (emulated, P = 2: 41 tiles instead of 372
+    // take the step from 282 to 259 ms).
     static const int force_k1 = getenv("K5_SP_PASS1_TILES") ? atoi(getenv("K5_SP_PASS1_TILES")) : 0;
-    int k1 = (int)(0.08 * (P - 1) * (47616.0 / N) * total + 0.5);
-    if (force_k1 > 0) k1 = force_k1;
-    k1 = k1 < 1 ? 1 : (k1 > tpc ? tpc : k1);
+    int k1 = force_k1 > 0 ? force_k1 : tpc;
+    k1 = k1 > tpc ? tpc : k1;
     K5CHK(d->ws_attn_state.ensure(k5_attention_state_bytes(H, rows)));
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     {
