@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // "inside the matrix", so there is no control flow for the allocator to park accumulators around
     // Loads first, stores after: a load that follows stores can only be awaited with vmcnt(0), i.e. after every earlier
     // store has been acknowledged.  The per-column vectors (bias, gate) are the same for all 8 token tiles: loaded once; the
-    // residual rows of the gated epilogue are fetched two token tiles (16 loads) at a time.
+    // residual rows of the gated epilogue are fetched one token tile (8 loads) at a time.
     auto epilogue = [&](auto HB) {
       constexpr bool has_bias = decltype(HB)::value;
       const int nb = n0 + 128 * e_wn + 4 * e_lc;          // + 16 i
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (EPI != K5_EPI_BIAS_M && has_bias) bvec[i] = *reinterpret_cast<const f32x4*>(p.bias + nc);
         if (EPI == K5_EPI_GATE) gvec[i] = *reinterpret_cast<const f32x4*>(p.gate + nc);
       }
-      constexpr int G = EPI == K5_EPI_GATE ? 2 : 4;        // token tiles per load / store phase (register budget)
+      constexpr int G = EPI == K5_EPI_GATE ? 1 : 4;        // token tiles per load / store phase (register budget: 2 spills 37 VGPRs, 1 is +1.5-2 %)
 #pragma unroll
       for (int jh = 0; jh < 8 / G; ++jh) {
         u32x2 rr[G][8];
