@@ -120,6 +120,14 @@ def main():
     ap.add_argument("--emulate-shard", type=int, default=0, metavar="P",
                     help="debug only (INVALID as a bench): per-rank compute of a P-GPU run on one GPU, collectives move nothing")
     ap.add_argument("--blocks", type=int, default=32, help="debug only: fewer visual blocks => INVALID as a bench")
+    ap.add_argument("--attn-online", action="store_true",
+                    help="run every self-attention head on the online-max softmax kernel (what heads whose |q||k| bound exceeds "
+                         "the fixed-offset window get); reported as roofline.variant")
+    ap.add_argument("--qk-gain", type=float, default=1.0,
+                    help="multiply the synthetic QK-norm weights (query_norm / key_norm) by this factor: > ~2.9 pushes the "
+                         "data-derived softmax bound past the fixed-offset window")
+    ap.add_argument("--nabla-p", type=float, default=0.9, help="NABLA cumulative-mass threshold P (config: 0.9); with random weights the "
+                    "block softmax is near uniform, so kept density ~ P: 0.0 = STA window only, 0.15 ~ 20 %% density")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,7 +150,7 @@ def main():
     cfgd = dict(LITE, num_visual_blocks=args.blocks)
     with torch.device("meta"):
         dit = DiffusionTransformer3D(**cfgd)
-    dit.init_synthetic(dev, seed=0)
+    dit.init_synthetic(dev, seed=0, qk_gain=args.qk_gain)
     if args.magcache:
         from kandinsky.config import default_configs
         from kandinsky.magcache_utils import set_magcache_params
@@ -153,10 +161,12 @@ def main():
         set_magcache_params(dit, default_configs()[cname]["magcache"]["mag_ratios"], 50, abs(wl["w"] - 1.0) <= 1e-6)
     if args.fp8:
         dit.set_fp8(True)
-    if args.emulate_shard > 1:
-        os.environ["K5_SP_EMULATE_WORLD"] = str(args.emulate_shard)
     if world > 1 or args.force_sp or args.emulate_shard > 1:
         dit.enable_sequence_parallel(rank, world)
+    if args.emulate_shard > 1:
+        dit.set_option("emulate_world", args.emulate_shard)
+    if args.attn_online:
+        dit.set_option("attn_mode", 1)
 
     g = torch.Generator(device=dev).manual_seed(6554)
     latent = torch.randn(T, H, W, 16, device=dev, generator=g)
@@ -172,7 +182,7 @@ def main():
 
     sparse = None
     if wl["attn"] == "nabla":
-        sparse = {"P": 0.9, "wT": 11, "wH": 3, "wW": 3, "to_fractal": True}
+        sparse = {"P": args.nabla_p, "wT": 11, "wH": 3, "wW": 3, "to_fractal": True}
 
     def run(k0, k):  # k consecutive Euler steps of the 50-step schedule starting at step k0
         dit.sample(latent, sig[k0:k0 + k + 1], te, ne, vpos, tpos, ntpos, wl["w"], scale_factor=(1.0, 2.0, 2.0),
@@ -188,6 +198,7 @@ def main():
     barrier()
     dit.set_profiling(True)
     dit.reset_profile()
+    dit.attn_variant_counts(reset=True)
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     barrier()
@@ -217,19 +228,41 @@ def main():
         del vae, img, u8
     attn_ms, attn_n = fam["attn_self"]
     fwd_per_step = 2 if abs(wl["w"] - 1.0) > 1e-6 else 1
-    # algorithmic FLOPs of the dense self-attention on THIS rank per block (queries sharded over ranks); under sequence
-    # parallelism the block's attention is two launches (local chunk, then the gathered chunks) -> rate over their sum
-    attn_flop = 4.0 * N * N * 64 * 28 / world
-    n_blocks_run = args.blocks * fwd_per_step * args.steps
-    achieved = attn_flop * n_blocks_run / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0
+    sp_on = world > 1 or args.force_sp or args.emulate_shard > 1
+    shard = world if world > 1 else max(args.emulate_shard, 1)
+    # algorithmic FLOPs of the self-attention on THIS rank, from the launches actually MADE (MagCache skips whole block
+    # stacks; under sequence parallelism a block's attention is two timed launches: local chunk, then the gathered chunks):
+    #   dense: 4 * N^2 * 64 * 28 / shard per block;  NABLA: that times the kept fraction of 64x64 blocks, counted on the device
+    blocks_run = attn_n / (2 if (sp_on and wl["attn"] == "flash") else 1)
+    density = None
+    if wl["attn"] == "nabla":
+        kept, possible = dit.nabla_block_counts()
+        density = kept / possible if possible else None
+    attn_flop = 4.0 * N * N * 64 * 28 / shard * (density if density is not None else 1.0)
+    achieved = attn_flop * blocks_run / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0
+    n_fixed, n_online = dit.attn_variant_counts()
+    if args.attn_online:
+        variant = "online-max softmax on every head (forced: --attn-online)"
+    elif n_fixed + n_online == 0:
+        variant = "n/a (no data-derived flags on this path)"
+    else:
+        variant = (f"fixed-offset softmax on {n_fixed} and online-max on {n_online} of {n_fixed + n_online} (block, head) "
+                   f"launches, chosen per head on the device from max|q|*max|k'| <= 90")
     traffic = None   # HBM-side bytes per attention launch from the committed PMC profile (separate --pmc passes; cannot be
     try:             # collected inside a timed run) — only quoted for the exact workload it was measured on
-        with open(os.path.join(ROOT, "profiles", "r01_attention_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_attention_traffic.json")) as f:
             tj = json.load(f)
-        if tj.get("tokens") == N and world == 1 and wl["attn"] == "flash":
+        if tj.get("tokens") == N and world == 1 and wl["attn"] == "flash" and not args.attn_online and n_online == 0:
             traffic = tj["bytes_per_launch"]
     except Exception:
         pass
+    invalid = []
+    if args.emulate_shard > 1 or dit.get_option("emulated"):
+        invalid.append("emulated shard layout (timing only, results garbage)")
+    if args.blocks != 32:
+        invalid.append("fewer visual blocks than the model")
+    if args.fp8:
+        invalid.append("reduced precision (fp8 feed-forward)")
     step_flop = fwd_per_step * flops_forward(N, L, blocks=args.blocks)
     assert torch.isfinite(latent).all(), "latent diverged"
 
@@ -244,16 +277,19 @@ def main():
             "nfe_per_s": fwd_per_step * args.steps / dt,
             "step_tflop": step_flop / 1e12,
             "model_tflops_per_gpu": step_flop * args.steps / dt / 1e12 / world,
-            "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (dense self-attention, 32 launches per forward)",
-                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": traffic, "flop_per_launch": attn_flop * n_blocks_run / max(attn_n, 1), "avg_launch_ms": attn_ms / max(attn_n, 1),
-                         "launches": attn_n},
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (visual self-attention, one balanced launch group per block)",
+                         "variant": variant, "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "flop_per_launch": attn_flop * blocks_run / max(attn_n, 1), "avg_launch_ms": attn_ms / max(attn_n, 1),
+                         "launches": attn_n, "blocks_run": blocks_run, "kept_block_density": density},
             "kernel_time_ms_per_step": {k: v[0] / args.steps for k, v in fam.items() if v[1]},
             "e2e_clip_s": {"denoise_50_steps_s": 50 * dt / args.steps, "vae_decode_s": vae_s,
                            "total_s": None if vae_s is None else 50 * dt / args.steps + vae_s,
                            "note": "50 x measured ms_per_step + measured HunyuanVideo VAE decode (14 temporal tiles, uint8 out); "
                                    "text encoding excluded (no weights offline); reference README: 77 s on 1xH100 incl. text encoder"},
         }
+        if invalid:
+            out["INVALID_AS_BENCH"] = invalid
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N)
         elif not args.no_cpu_baseline:

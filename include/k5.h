@@ -60,12 +60,23 @@ int k5_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* 
                             int ldq, int ldk, int ldvt, int ldo, float score_bound, int tile_off0, int tile_cnt,
                             int tile_skip_at, int tile_skip_n, void* state, int flags, void* stream);
 /* The same attention with the keys ALREADY multiplied by the softmax scale in the exp2 domain: Kc = bf16(log2(e)/8 * k)
- * (one rounding, done by the producer: the engine's rmsnorm/RoPE kernel).  The scores are then the exp2 arguments up to the
- * fixed offset score_bound * log2(e)/8, which rides in the MFMA accumulator's initial value: no per-score multiply-add.
- * Needs the fixed-offset softmax (score_bound > 0 with 2 * score_bound * log2(e)/8 <= 96) and whole key tiles
- * (kv_len % 64 == 0: this entry carries no ragged-tile masking); K5_ERR_ARG otherwise. */
+ * (one rounding, done by the producer: the engine's rmsnorm/RoPE kernel).  The scores are then the exp2 arguments: no
+ * per-score multiply-add.  Whole key tiles only (kv_len % 64 == 0: no ragged-tile masking; K5_ERR_ARG otherwise).
+ * Softmax form: with score_bound > 0 and score_bound * log2(e)/8 <= 90 (score_bound bounds |q.k| in RAW units) the
+ * constant offset 0 (exp2 can neither overflow nor flush a row); otherwise the lazy online max (the running offset rides
+ * in the MFMA accumulator's initial value and is only revised when a tile's maximum leaves a 2^60 window). */
 int k5_attention_bf16_prescaled(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len,
                                 int ldq, int ldk, int ldvt, int ldo, float score_bound, void* stream);
+/* What the engine runs for FA(q,k,v) of the visual self-attention (nn.py:254): the form is chosen PER HEAD on the device.
+ * k5_rmsnorm_rope_stats_bf16 (below) leaves max |q_h|^2 / max |k'_h|^2 over the rows; k5_attention_flags turns them into
+ * head_flags[h] = 1 (|q|max |k'|max <= 90: fixed offset) or 0 (online max) and resets the statistics (kstat: nk partial
+ * maxima at stride kstride floats — one per sequence-parallel rank).  k5_attention_bf16_prescaled_auto launches both forms
+ * over the same grid; a workgroup exits at once unless its head is its form's.  head_flags NULL: variant 1 = online max
+ * everywhere.  workspace: NULL or k5_attention_balance_size bytes (balanced launch). */
+int k5_attention_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* head_flags, void* stream);
+int k5_attention_bf16_prescaled_auto(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len,
+                                     int ldq, int ldk, int ldvt, int ldo, const int* head_flags, int variant, void* workspace,
+                                     void* stream);
 /* k5_attention_bf16[_bounded] with load balancing: the (head, 256-query) jobs that do not fill a whole round of the
  * device's resident workgroups are split 2-4 ways along the keys and merged (same result up to fp32 summation order).
  * workspace: k5_attention_balance_size(H, q_len) bytes.  The engine uses this for every large self-attention. */
@@ -97,9 +108,9 @@ int k5_attention_nabla_rect_bf16(const void* Q, const void* K, const void* Vt, v
 int k5_nabla_mask_rect_u8(const void* workspace, int H, int q_blocks, int num_blocks, void* out_u8, void* stream);
 
 /* Dense k5_attention_bf16 with a caller-proved bound |q.k| <= score_bound for every (query, key) pair
- * (after norm_qk nn.py:193-197 every head vector has |x| <= 8*max|weight|).  When 2*bound*log2(e)/8 <= 96
- * the bound replaces the online running max (same softmax, fewer VALU ops); otherwise, or with
- * score_bound <= 0, the online-max kernel runs. */
+ * (after norm_qk nn.py:193-197 every head vector has |x| <= 8*max|weight|).  When bound*log2(e)/8 <= 90 the
+ * softmax runs with the constant offset 0 instead of the online running max (same softmax, fewer VALU ops);
+ * otherwise, or with score_bound <= 0, the online-max kernel runs. */
 int k5_attention_bf16_bounded(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                               int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound, void* stream);
 
@@ -111,6 +122,12 @@ int k5_ln_modulate_bf16(const void* x, const float* scale, const float* shift, v
  * cos/sin[rows][32] (heads < rope_heads; cos==NULL: no rotation) -> bf16. */
 int k5_rmsnorm_rope_bf16(void* x, const float* weight, const float* cos_tab, const float* sin_tab, int rows,
                          int H, int ld, int heads_per_weight, int rope_heads, void* stream);
+/* The engine's form of the same op: heads >= scale_from_head are multiplied by out_scale before their (single) bf16
+ * rounding (keys for the pre-scaled attention), and stats[h] (device fp32 [H], zero before the first use) receives
+ * max(stats[h], |x_row,h|^2) over the rows, of the bf16 values written. */
+int k5_rmsnorm_rope_stats_bf16(void* x, const float* weight, const float* cos_tab, const float* sin_tab, int rows, int H,
+                               int ld, int heads_per_weight, int rope_heads, float out_scale, int scale_from_head,
+                               float* stats, void* stream);
 /* apply_gate_sum nn.py:30-33 (standalone form). */
 int k5_gate_sum_bf16(const void* x, const void* y, const float* gate, void* out, int rows, int D, void* stream);
 /* fp32-island GEMV (Modulation nn.py:161-164, TimeEmbeddings nn.py:56-61): y = W.act(x) + b (+add). */
@@ -204,6 +221,26 @@ int k5_sample(k5_dit* dit, const k5_sample_args* args, void* stream);
  * 128-byte ncclUniqueId with k5_comm_unique_id, the host broadcasts it, every rank calls k5_dit_comm_init. */
 int k5_comm_unique_id(const char* rccl_lib_path, void* out_unique_id_128);
 int k5_dit_comm_init(k5_dit* dit, const char* rccl_lib_path, int rank, int world, const void* unique_id_128);
+/* Token counts that do not divide: whole 64-token blocks, ceil(blocks / world) per rank, the last rank takes the rest
+ * (3660 blocks over 8 ranks = 7 x 458 + 454); K5_ERR_UNSUPPORTED if a rank would be left without a block.
+ *
+ * Loopback group (tests): `world` handles of ONE process on ONE GPU act as the ranks of a sequence-parallel run.  Every rank
+ * must be driven by its own host thread (a collective is a rendezvous of the threads around device-to-device copies), and
+ * every rank runs exactly the code path / offsets / launch sequence of a real multi-GPU run.  Not with k5_dit_set_graph. */
+typedef struct k5_loopback k5_loopback;
+int k5_loopback_create(int world, k5_loopback** out);
+void k5_loopback_destroy(k5_loopback* group);
+int k5_dit_comm_init_loopback(k5_dit* dit, k5_loopback* group, int rank);
+/* Engine options by name (all default 0): "attn_mode" 0 = softmax form per head from the data, 1 = online max everywhere;
+ * "sp_pass1_tiles" local key tiles attended before the K / V^T gather has landed (0 = all); "emulate_world" P = TIMING
+ * ONLY: rank 0's share of a P-rank run on a world = 1 communicator — collectives move nothing, results are garbage and
+ * k5_dit_get_option("emulated") reads 1 so that a bench can refuse the number. */
+int k5_dit_set_option(k5_dit* dit, const char* name, int value);
+int k5_dit_get_option(k5_dit* dit, const char* name, int* value);
+/* (block, head) self-attention launches that took the fixed-offset / the online-max softmax since the last reset. */
+int k5_dit_attn_variant_counts(k5_dit* dit, long long* fixed_heads, long long* online_heads, int reset);
+/* kept / possible 64x64 blocks of the NABLA maps computed while profiling was on, since that reset (realised density). */
+int k5_dit_nabla_block_counts(k5_dit* dit, long long* kept, long long* possible);
 
 /* ------------------------------------------------------------------------------------------
  * HunyuanVideo 3D-VAE decoder (kandinsky/models/vae.py): post_quant_conv + HunyuanVideoDecoder3D.forward

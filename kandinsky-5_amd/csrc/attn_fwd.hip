@@ -42,7 +42,10 @@ struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
   int H, q_len, kv_len, ldq, ldk, ldvt, ldo, nqb;
   float c;        // softmax scale * log2(e)
-  float m_fixed;  // BOUNDED: raw-score upper bound used instead of the running max
+  // per-head variant selection (engine: decided on the device from the data, attn_flags_kernel): a workgroup whose head's
+  // flag differs from my_flag exits at once, so a fixed-offset launch and an online-max launch over the same grid
+  // partition the heads between them.  null = every head.
+  const int* head_flags; int my_flag;
   // sequence-parallel layout of V^T: keys are split in chunks of vt_chunk_keys (multiple of 64) and chunk c
   // starts at Vt + c * vt_chunk_stride ([rank][H*64][ldvt] after an in-place all-gather); 0 = one chunk
   int vt_chunk_keys; long long vt_chunk_stride;
@@ -69,12 +72,28 @@ K5_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_
 // 16-B chunk: XOR the chunk with row bits (4,3,1) so that those 16 rows (x row&1) hit 16 distinct 16-B bank slots.
 K5_DEV int lds_swz_k(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 4); }
 
+K5_DEV float max3(float a, float b, float c) {   // one instruction, no canonicalising v_max in front of MFMA results
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // RANGE: key-tile sub-range + resumable fp32 state (sequence-parallel two-pass schedule); kept out of the plain dense
 // instantiation, whose loop is sensitive to every extra live value (128-VGPR budget for 2 workgroups per CU).
 // PRE: K arrives pre-multiplied by log2(e)/8 (rounded to bf16 once, by the rmsnorm/RoPE kernel): the scores ARE the exp2
-// arguments up to the fixed offset, which rides in the MFMA accumulator's initial value -> no per-score fma at all.
+// arguments -> no per-score fma at all.
+// BOUNDED: the caller proved |score| * log2(e)/8 <= 90 for every pair, so exp2 of the raw argument can neither overflow nor
+// flush a whole row: the softmax offset is the constant 0 (any offset gives the same softmax; a CENTRED one needs only
+// |s| <= 90 where an upper-bound offset needs 2|s| <= 90).  !BOUNDED (PRE only): lazy online max — the offset of a query
+// rides in the accumulator's initial value, the tile maximum of (score - offset) is folded with v_max3 (16 ops per tile)
+// and only when some lane sees it exceed ONLINE_THR does the wave take the rescale branch.
+constexpr float ONLINE_THR = 60.f;
+#ifndef K5_ONLINE_WPS
+#define K5_ONLINE_WPS 4   // waves per SIMD the online-max instantiations are compiled for (A/B: 2 = 256 VGPRs, one workgroup per CU)
+#endif
 template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false>
-__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_kernel(AttnP p) {
+  static_assert(BOUNDED || PRE, "the online-max form of this kernel takes pre-scaled keys (attn_fwd32_kernel serves the rest)");
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
   char* sK = smem;
   char* sV = smem + 2 * TILE;
@@ -83,6 +102,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
   const int part = RANGE ? gid % p.splits : 0;
   const int lid = p.job0 + (RANGE ? gid / p.splits : gid);
   const int h = lid / p.nqb, qb = lid % p.nqb;
+  if (p.head_flags && p.head_flags[h] != p.my_flag) return;   // workgroup-uniform: the other variant's launch owns this head
   const int q0 = qb * QB + wave * 32;   // this wave: queries q0 .. q0+31 = two 16-query MFMA tiles (qt = 0, 1)
 
   // Q^T fragments (MFMA 16x16x32 B operand): lane (l15, g) holds Q[q0 + 16 qt + l15][32 ks + 8 g .. +8]
@@ -163,8 +183,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) ot[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float c = p.c;
-  float m_run[2] = {BOUNDED ? p.m_fixed : -1e30f, BOUNDED ? p.m_fixed : -1e30f};
-  const float mc_fixed = p.m_fixed * c;
+  // !BOUNDED: nm[qt] = MINUS the softmax offset of the lane's query (exp2 domain), four copies = the S^T accumulators' start
+  f32x4 nm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  bool fresh = true;             // !BOUNDED, wave-uniform: no tile processed yet -> the first one SETS the offset
   f32x4 lt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   const bf16x8 onesf = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
   // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
@@ -178,9 +199,13 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
         const float* st_o = state_o(qt); const float* st_ml = state_ml(qt);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) ot[dt][qt] = *reinterpret_cast<const f32x4*>(st_o + 16 * dt);
-        if (!BOUNDED) m_run[qt] = st_ml[0];
+        if (!BOUNDED) { const float m = st_ml[0]; nm[qt] = f32x4{-m, -m, -m, -m}; }
         { const float* b4 = st_ml - 2 * g; const float L = (b4[1] + b4[3]) + (b4[5] + b4[7]); lt[qt] = f32x4{L, L, L, L}; }   // the four slots' row sums
       }
+    if (!BOUNDED) {   // a state left by a launch that saw no tile carries m = -1e30: still fresh (wave-uniform by construction:
+      fresh = __all(nm[0][0] > 1e29f && nm[1][0] > 1e29f);   // every query of a wave sees the same tiles; rows >= q_len keep 0)
+      if (fresh) { nm[0] = f32x4{0.f, 0.f, 0.f, 0.f}; nm[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
   }
 
   if (T > E0) load_tile(E0, 0);
@@ -194,16 +219,15 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
     const char* cK = sK + buf * TILE;
     const char* cV = sV + buf * TILE;
     if (!SPARSE || (sp_list[e] & my_bit)) {   // wave-uniform: skip kv blocks this query block did not select
-    static_assert(BOUNDED, "the 16x16x32 formulation is instantiated for the fixed softmax offset only (attn_fwd32_kernel has the online max)");
     {
     // ---- S^T = K Q^T : four 16-key x two 16-query MFMA tiles, two k-steps over d; K fragments streamed from LDS ----
     f32x4 st[4][2];
-    const f32x4 zero4 = PRE ? f32x4{-mc_fixed, -mc_fixed, -mc_fixed, -mc_fixed} : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {   // first k-step starts from a constant (0, or the softmax offset when PRE)
+    for (int kt = 0; kt < 4; ++kt) {   // first k-step starts from the constant 0, or from minus the query's softmax offset
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), g));
-      st[kt][0] = mfma16(kf, qf[0][0], zero4);
-      st[kt][1] = mfma16(kf, qf[1][0], zero4);
+      st[kt][0] = mfma16(kf, qf[0][0], BOUNDED ? zero4 : nm[0]);
+      st[kt][1] = mfma16(kf, qf[1][0], BOUNDED ? zero4 : nm[1]);
     }
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -221,7 +245,44 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
           if (key >= p.kv_len) { st[kt][0][r] = -1e30f; st[kt][1][r] = -1e30f; }
         }
     }
-    const float mc[2] = {mc_fixed, mc_fixed};
+    if (!BOUNDED) {
+      // lazy online max: st = score - offset.  Fold the lane's 16 values per query tile; nothing else happens unless some
+      // lane's maximum left the safe window (or this is the wave's first tile, which sets the offset).
+      float mx[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        mx[qt] = max3(st[0][qt][0], st[0][qt][1], st[0][qt][2]);
+        mx[qt] = max3(mx[qt], st[0][qt][3], st[1][qt][0]);
+        mx[qt] = max3(mx[qt], st[1][qt][1], st[1][qt][2]);
+        mx[qt] = max3(mx[qt], st[1][qt][3], st[2][qt][0]);
+        mx[qt] = max3(mx[qt], st[2][qt][1], st[2][qt][2]);
+        mx[qt] = max3(mx[qt], st[2][qt][3], st[3][qt][0]);
+        mx[qt] = max3(mx[qt], st[3][qt][1], st[3][qt][2]);
+        mx[qt] = fmaxf(mx[qt], st[3][qt][3]);
+      }
+      if (fresh || __any(fmaxf(mx[0], mx[1]) > ONLINE_THR)) {   // wave-uniform, rare
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          float mf = mx[qt];   // the query's four lanes (l15 + 16 g) combine -> identical offsets in all of them
+          mf = fmaxf(mf, __shfl_xor(mf, 16, 64));
+          mf = fmaxf(mf, __shfl_xor(mf, 32, 64));
+          const float dlt = fresh ? mf : fmaxf(mf, 0.f);   // an established offset is never lowered
+          const float alpha = fresh ? 1.f : __builtin_amdgcn_exp2f(-dlt);
+          { const float n = nm[qt][0] - dlt; nm[qt] = f32x4{n, n, n, n}; }
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[kt][qt][r] -= dlt;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[dt][qt][r] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lt[qt][r] *= alpha;
+        }
+        fresh = false;
+      }
+    }
     // ---- P = exp2(S c - m c) -> bf16 fragments; O^T += V^T P^T (two k-steps of 32 keys), V^T fragments streamed ----
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {   // both query tiles' probabilities first (8 live registers), V^T fragments streamed
@@ -232,7 +293,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             e[j] = PRE ? __builtin_amdgcn_exp2f(st[2 * ks2 + (j >> 2)][qt][j & 3])
-                       : __builtin_amdgcn_exp2f(fmaf(st[2 * ks2 + (j >> 2)][qt][j & 3], c, -mc[qt]));
+                       : __builtin_amdgcn_exp2f(st[2 * ks2 + (j >> 2)][qt][j & 3] * c);
           }
           u32x4 pk = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
           pf[qt] = __builtin_bit_cast(bf16x8, pk);
@@ -261,7 +322,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnP p) {
         float* st_o = state_o(qt); float* st_ml = state_ml(qt);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(st_o + 16 * dt) = ot[dt][qt];
-        st_ml[0] = m_run[qt]; st_ml[1] = g == 0 ? lt[qt][0] : 0.f;   // slot 0 carries the whole row sum
+        st_ml[0] = BOUNDED ? 0.f : (fresh ? -1e30f : -nm[qt][0]);   // no tile seen: weight 0 in a merge, "still fresh" on resume
+        st_ml[1] = g == 0 ? lt[qt][0] : 0.f;                    // slot 0 carries the whole row sum
       }
     return;
   }
@@ -364,8 +426,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd32_kernel(AttnP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
   const float c = p.c;
-  float m_run = BOUNDED ? p.m_fixed : -1e30f, l_run = 0.f;
-  const float mc_fixed = p.m_fixed * c;
+  float m_run = BOUNDED ? 0.f : -1e30f, l_run = 0.f;
+  const float mc_fixed = 0.f;
   // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
   auto state_base = [&]() { return part == 0 ? p.state : p.split_state + (size_t)(part - 1) * p.split_stride; };
   auto state_o = [&]() { return state_base() + (size_t)(q0 + l31) * (p.H * 64) + h * 64 + 4 * hi; };
@@ -507,10 +569,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd32_kernel(AttnP p) {
 // One workgroup per job, one thread per query: O = sum_s w_s O_s / sum_s w_s l_s,  w_s = exp2((m_s - max m) c)  (w_s = 1 when
 // the softmax offset is fixed).  State layout as written by attn_fwd_kernel: O^T accumulators [q][H*64] fp32 in natural d
 // order, then (m, l) per (q, h, lane group g = 0..3) — l is that lane's partial sum, m is common to the four.
-template <bool BOUNDED>
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, const float* split_state, long long split_stride,
-                                                         int splits, int job0, int H, int q_len, int nqb, float c, bf16_t* O, int ldo) {
+                                                         int splits, int job0, int H, int q_len, int nqb, float c, bf16_t* O, int ldo,
+                                                         int bounded_all, const int* head_flags) {
   const int job = job0 + blockIdx.x, h = job / nqb, qb = job % nqb;
+  const bool bounded = head_flags ? head_flags[h] == 1 : bounded_all != 0;   // fixed offset: every part's weight is 1
   const int q = qb * QB + threadIdx.x;
   if (q >= q_len) return;
   const size_t o_off = (size_t)q * (H * 64) + h * 64;
@@ -519,11 +582,11 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
   for (int s = 0; s < splits; ++s) {
     const float* st = s == 0 ? state0 : split_state + (size_t)(s - 1) * split_stride;
     w[s] = st[ml_off];                       // m_s for now
-    if (!BOUNDED) m = fmaxf(m, w[s]);
+    if (!bounded) m = fmaxf(m, w[s]);
   }
   for (int s = 0; s < splits; ++s) {
     const float* st = s == 0 ? state0 : split_state + (size_t)(s - 1) * split_stride;
-    w[s] = BOUNDED ? 1.f : __builtin_amdgcn_exp2f((w[s] - m) * c);
+    w[s] = bounded ? 1.f : __builtin_amdgcn_exp2f((w[s] - m) * c);
     l += w[s] * ((st[ml_off + 1] + st[ml_off + 3]) + (st[ml_off + 5] + st[ml_off + 7]));
   }
   const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -542,11 +605,36 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
   }
 }
 
+// Per-head choice between the fixed-offset and the online-max softmax, decided on the device from the data: qstat / kstat
+// hold max |q_h|^2 and max |k'_h|^2 (k' = log2(e)/8 * k, the pre-scaled keys) over all rows, left by rmsnorm_rope_kernel
+// (kstat: nk partial maxima at stride kstride — one per sequence-parallel rank after the gather).  Cauchy-Schwarz:
+// every exp2 argument of head h lies in [-B, B], B = |q|max |k'|max; B <= limit -> flag 1 (fixed offset 0), else 0.
+// The statistics are consumed: reset to 0 for the next producer.  counters[0 / 1] count heads sent each way.
+__global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstride, int H, float limit, int force_online,
+                                  int* flags, unsigned long long* counters) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  const float q2 = qstat[h];
+  float k2 = 0.f;
+  for (int i = 0; i < nk; ++i) { const float v = kstat[(size_t)i * kstride + h]; k2 = v == v ? fmaxf(k2, v) : __uint_as_float(0x7f800000u); }
+  const float b = sqrtf(q2) * sqrtf(k2) * 1.002f;   // margin: fp32 rounding of the norms and of the MFMA accumulation
+  const int fast = (!force_online && b <= limit) ? 1 : 0;   // NaN / inf compare false -> online
+  flags[h] = fast;
+  if (counters) atomicAdd(counters + (fast ? 0 : 1), 1ull);
+  qstat[h] = 0.f;
+  for (int i = 0; i < nk; ++i) kstat[(size_t)i * kstride + h] = 0.f;
+}
+
 }  // namespace
 
-// score_bound > 0: caller guarantees |q.k| <= score_bound for every pair (e.g. RMS-normalised q, k:
-// 64 * max|w_q| * max|w_k|).  If the bound is small enough that exp2 can neither overflow nor flush a
-// whole row to zero, the kernel uses it as a fixed softmax offset and skips the online running max.
+// Softmax offset policy.  score_bound > 0: the caller guarantees |q.k| <= score_bound for every pair (e.g. RMS-normalised
+// q, k: 64 * max|w_q| * max|w_k|).  If score_bound * log2(e)/8 <= K5_ATTN_EXP_LIMIT, exp2 of the raw argument can neither
+// overflow nor flush a whole row, so the kernels run with the constant offset 0 and skip the online running max.
+// head_flags (device, [H], pre-scaled keys only): the same decision per head, taken on the device from the data
+// (k5_launch_attn_flags) — flag 1: fixed offset, flag 0: lazy online max; both variants are launched over the same grid and
+// each workgroup exits at once unless its head is its variant's.
+constexpr float K5_ATTN_EXP_LIMIT = 90.f;   // |exp2 argument| bound of the fixed-offset form: p <= 2^90, l <= 2^107, O <= 2^114
+
 size_t k5_attention_state_bytes(int H, int q_len) { return (size_t)q_len * H * (64 + 8) * sizeof(float); }
 
 // Workspace of the balanced launcher below: up to K5_ATTN_MAX_SPLITS - 1 extra states + (when the caller passes no state
@@ -566,15 +654,25 @@ int attn_slots() {
 }
 }  // namespace
 
+int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
+                         unsigned long long* counters, hipStream_t stream) {
+  if (!qstat || !kstat || !flags || H <= 0 || nk <= 0) return K5_ERR_ARG;
+  hipLaunchKernelGGL(attn_flags_kernel, dim3((H + 63) / 64), dim3(64), 0, stream, qstat, kstat, nk, kstride, H, K5_ATTN_EXP_LIMIT,
+                     force_online, flags, counters);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
 // Dense attention over a key-tile range (see AttnP).  With a workspace `ws` (k5_attention_balance_bytes) and final output
 // requested (flags & 2 == 0), the launch is BALANCED: the jobs that fill whole rounds of the device's resident-workgroup
 // slots run as usual; the jobs of the last, partially filled round are split 2-4 ways along the key sequence into short
 // workgroups that fill the slots, and a merge kernel combines their states.  5208 jobs on 512 slots: 10.25 rounds instead
 // of 11; an 8-GPU shard's 672 jobs: 1.33 instead of 2.
+// variant (pre-scaled keys only): K5_ATTN_AUTO = by score_bound / head_flags, K5_ATTN_ONLINE = force the lazy online max.
 int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
-                                   int tile_skip_n, float* state, int flags, hipStream_t stream, float* ws, bool k_prescaled) {
+                                   int tile_skip_n, float* state, int flags, hipStream_t stream, float* ws, bool k_prescaled,
+                                   const int* head_flags, int variant) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -583,11 +681,10 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.H = H; p.q_len = q_len; p.kv_len = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
   p.nqb = (q_len + QB - 1) / QB;
   p.c = 0.125f * 1.44269504088896340736f;
-  p.m_fixed = 0.f;
+  p.head_flags = nullptr; p.my_flag = 0;
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   const dim3 block(512);
-  // exponent range used: [-2*bound*c, 0]; fp32 exp2 flushes below -126 -> require 2*bound*c <= 96
-  const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
+  const bool bounded = score_bound > 0.f && score_bound * p.c <= K5_ATTN_EXP_LIMIT;
   p.sp_list = nullptr; p.sp_cnt = nullptr; p.sp_stride = 0;
   const int total_tiles = (kv_len + KB - 1) / KB;
   if (tile_cnt < 0) tile_cnt = total_tiles - tile_off0;
@@ -597,12 +694,18 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.state = state; p.flags = flags;
   p.job0 = 0; p.splits = 1; p.split_state = nullptr; p.split_stride = 0;
   const bool range = tile_off0 != 0 || tile_cnt != total_tiles || (flags & 3);
-  if (k_prescaled && (!bounded || (kv_len % KB))) return K5_ERR_ARG;   // pre-scaled keys: fixed-offset softmax, whole key tiles only
-  if (bounded) p.m_fixed = score_bound;
+  if (k_prescaled && (kv_len % KB)) return K5_ERR_ARG;      // pre-scaled keys: whole key tiles only (no ragged-tile code)
+  if ((head_flags || variant != K5_ATTN_AUTO) && !k_prescaled) return K5_ERR_ARG;
+  // which softmax form(s) run: 1 = fixed offset, 0 = online max; per head when head_flags is given
+  const bool run_fixed = head_flags ? variant == K5_ATTN_AUTO : (variant == K5_ATTN_AUTO && bounded);
+  const bool run_online = head_flags ? true : !run_fixed;
   auto launch = [&](int njobs, bool use_range) {
     const dim3 grid(njobs);
-    // fixed-offset softmax: always the RANGE instantiation (a superset; with the plain one the register allocator spills)
-    if (bounded && k_prescaled) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true>), grid, block, 0, stream, p);
+    if (k_prescaled) {   // always the RANGE instantiation (a superset; with the plain one the register allocator spills)
+      p.head_flags = (run_fixed && run_online) ? head_flags : nullptr;
+      if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true>), grid, block, 0, stream, p); }
+      if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, false, true, true>), grid, block, 0, stream, p); }
+    }
     else if (bounded) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), grid, block, 0, stream, p);
     else if (use_range) hipLaunchKernelGGL((attn_fwd32_kernel<false, false, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((attn_fwd32_kernel<false, false, false>), grid, block, 0, stream, p);
@@ -624,8 +727,10 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.job0 = full; p.splits = S; p.state = base; p.split_state = ws + stride; p.split_stride = stride;
   p.flags = (flags & 1) | 2;
   launch(rem * S, true);
-  if (bounded) hipLaunchKernelGGL(attn_merge_kernel<true>, dim3(rem), dim3(256), 0, stream, base, ws + stride, stride, S, full, H, q_len, p.nqb, p.c, (bf16_t*)O, ldo);
-  else hipLaunchKernelGGL(attn_merge_kernel<false>, dim3(rem), dim3(256), 0, stream, base, ws + stride, stride, S, full, H, q_len, p.nqb, p.c, (bf16_t*)O, ldo);
+  // merge weights: 1 for the fixed-offset heads, exp2(m_s - max m) for the online ones (exp2 domain when the keys are pre-scaled)
+  hipLaunchKernelGGL(attn_merge_kernel, dim3(rem), dim3(256), 0, stream, base, ws + stride, stride, S, full, H, q_len, p.nqb,
+                     k_prescaled ? 1.f : p.c, (bf16_t*)O, ldo, (k_prescaled ? (run_fixed && !run_online) : bounded) ? 1 : 0,
+                     (k_prescaled && run_fixed && run_online) ? head_flags : nullptr);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -641,27 +746,31 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
 // V^T optionally in per-rank chunks (sequence parallel).
 int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
-                                    int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled) {
+                                    int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled,
+                                    const int* head_flags, int variant) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0 || (q_len % KB) || (kv_len % KB) || !list || !cnt) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
+  if ((head_flags || variant != K5_ATTN_AUTO) && !k_prescaled) return K5_ERR_ARG;
   AttnP p;
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
   p.H = H; p.q_len = q_len; p.kv_len = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
   p.nqb = (q_len + QB - 1) / QB;
   p.c = 0.125f * 1.44269504088896340736f;
-  p.m_fixed = 0.f; p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
+  p.head_flags = nullptr; p.my_flag = 0;
+  p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride;
   p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;
   p.job0 = 0; p.splits = 1; p.split_state = nullptr; p.split_stride = 0;
   const dim3 grid(H * p.nqb), block(512);
-  const bool bounded = score_bound > 0.f && 2.f * score_bound * p.c <= 96.f;
-  if (k_prescaled && !bounded) return K5_ERR_ARG;
-  if (bounded && k_prescaled) {
-    p.m_fixed = score_bound;
-    hipLaunchKernelGGL((attn_fwd_kernel<true, true, false, true>), grid, block, 0, stream, p);
+  const bool bounded = score_bound > 0.f && score_bound * p.c <= K5_ATTN_EXP_LIMIT;
+  if (k_prescaled) {
+    const bool run_fixed = head_flags ? variant == K5_ATTN_AUTO : (variant == K5_ATTN_AUTO && bounded);
+    const bool run_online = head_flags ? true : !run_fixed;
+    p.head_flags = (run_fixed && run_online) ? head_flags : nullptr;
+    if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, true, false, true>), grid, block, 0, stream, p); }
+    if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, true, false, true>), grid, block, 0, stream, p); }
   } else if (bounded) {
-    p.m_fixed = score_bound;
     hipLaunchKernelGGL((attn_fwd_kernel<true, true, false>), grid, block, 0, stream, p);
   } else {
     hipLaunchKernelGGL((attn_fwd32_kernel<false, true, false>), grid, block, 0, stream, p);

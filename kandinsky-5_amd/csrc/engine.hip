@@ -14,6 +14,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <pthread.h>
 #include <rccl/rccl.h>  // types / enums only: the library is dlopen()ed (see Comm)
 
 #include "k5_common.h"
@@ -110,9 +111,23 @@ struct Prof { double ms = 0; int64_t n = 0; };
 // RCCL over xGMI, one process per GPU.  The library is dlopen()ed (RTLD_LOCAL) from a path given by the
 // host — normally the librccl.so that torch already mapped — so libk5 has no link-time RCCL dependency
 // and never ends up with a second, conflicting copy of the nccl* symbols in the global namespace.
+// Loopback group: P handles of ONE process on ONE GPU act as the P ranks of a sequence-parallel run (k5_loopback_create /
+// k5_dit_comm_init_loopback).  Each rank is driven by its own host thread; a collective is a rendezvous of those threads
+// (two pthread barriers) around device-to-device copies ordered by events, so every rank executes exactly the code path,
+// offsets and launch sequence of a real multi-GPU run — what moves the bytes is hipMemcpyAsync instead of RCCL.
+struct LoopGroup {
+  int world = 0;
+  pthread_barrier_t bar;
+  std::vector<void*> ptr;
+  std::vector<hipEvent_t> ready, pulled;
+  std::vector<int> joined;
+};
+
 struct Comm {
   void* lib = nullptr;
   ncclComm_t comm = nullptr;
+  LoopGroup* loop = nullptr;
+  bool active() const { return comm != nullptr || loop != nullptr; }
   int rank = 0, world = 1;
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
@@ -141,6 +156,24 @@ struct Comm {
   // in-place all-gather: every rank's chunk already sits at buf + rank*count*elem
   int all_gather_inplace(void* buf, size_t count_per_rank, size_t elem_bytes, hipStream_t s) {
     char* b = (char*)buf;
+    if (loop) {
+      // pull every peer's chunk out of the peer's copy of the buffer; the call completes (stream-wise) only when every peer
+      // has pulled mine, as an RCCL all-gather does — the caller may overwrite its own slot afterwards
+      const size_t chunk = count_per_rank * elem_bytes;
+      loop->ptr[rank] = buf;
+      HIPCHK(hipEventRecord(loop->ready[rank], s));
+      pthread_barrier_wait(&loop->bar);
+      for (int p = 0; p < world; ++p) {
+        if (p == rank) continue;
+        HIPCHK(hipStreamWaitEvent(s, loop->ready[p], 0));
+        HIPCHK(hipMemcpyAsync(b + (size_t)p * chunk, (const char*)loop->ptr[p] + (size_t)p * chunk, chunk, hipMemcpyDeviceToDevice, s));
+      }
+      HIPCHK(hipEventRecord(loop->pulled[rank], s));
+      pthread_barrier_wait(&loop->bar);
+      for (int p = 0; p < world; ++p)
+        if (p != rank) HIPCHK(hipStreamWaitEvent(s, loop->pulled[p], 0));
+      return K5_OK;
+    }
     const ncclResult_t r = AllGather(b + (size_t)rank * count_per_rank * elem_bytes, b, count_per_rank * elem_bytes,
                                      ncclUint8, comm, s);
     if (r != ncclSuccess) { k5_set_error("ncclAllGather: %s", GetErrorString(r)); return K5_ERR_HIP; }
@@ -185,8 +218,16 @@ struct k5_dit {
   hipEvent_t ev_graph = nullptr;
   DevBuf ws_kc;                                    // NABLA: keys pre-multiplied by the softmax scale (separate from the map's keys)
   DevBuf ws_attn_bal;                              // states of the split tail jobs (k5_launch_attention_bf16_range, balanced)
+  // data-derived softmax bound of the visual self-attention (pre-scaled keys): per-head max |q|^2 [Hh] | max |k'|^2 [P][Hh]
+  // (fp32, filled by the rmsnorm/RoPE kernel, consumed by k5_launch_attn_flags), the per-head variant flags [Hh] (int) and
+  // two u64 counters: heads that ran the fixed-offset / the online-max kernel since the last reset
+  DevBuf ws_attn_stats, ws_attn_flags, ws_attn_cnt;
+  long long nabla_possible = 0;                    // profiling: 64x64 blocks the NABLA maps could have kept (kept: ws_attn_cnt[2])
+  int attn_mode = 0;                               // K5_ATTN_AUTO / K5_ATTN_ONLINE (k5_dit_set_option "attn_mode")
+  int sp_pass1_tiles = 0;                          // k5_dit_set_option "sp_pass1_tiles" (0 = all local key tiles)
+  bool emulated = false;                           // "emulate_world": timing-only layout, results are garbage
   hipStream_t comm_stream = nullptr;              // all-gathers run here, overlapped with pass 1 of the attention
-  hipEvent_t ev_k = nullptr, ev_v = nullptr, ev_gathered = nullptr;
+  hipEvent_t ev_k = nullptr, ev_v = nullptr, ev_gathered = nullptr, ev_stats = nullptr;
   // NABLA: fractal token permutation (cached per shape) and the selection workspace
   DevBuf ws_perm, ws_nabla; int perm_shape[3] = {0, 0, 0}; bool key_fractal = false;
   // rope cache keys
@@ -303,8 +344,21 @@ const HostTensor* find(k5_dit* d, const std::string& k) {
   return it == d->staged.end() ? nullptr : &it->second;
 }
 
+// shape check of one staged tensor: [r][c], or [r] when c == 0 (a mismatched tensor handed through the C ABI must come back as
+// K5_ERR_ARG, not as an out-of-bounds host read while packing)
+bool shape_ok(k5_dit* d, const std::string& k, size_t r, size_t c) {
+  const HostTensor* t = find(d, k);
+  const bool ok = t && ((c == 0 && t->shape.size() == 1 && (size_t)t->shape[0] == r) ||
+                        (c && t->shape.size() == 2 && (size_t)t->shape[0] == r && (size_t)t->shape[1] == c));
+  if (!ok) k5_set_error("shape mismatch for %s", k.c_str());
+  return ok;
+}
+
 int pack_attn(k5_dit* d, const std::string& p, AttnW& a, bool fuse_qk) {
   const size_t D = d->D;
+  for (const char* nm : {".to_query", ".to_key", ".to_value", ".out_layer"})
+    if (!shape_ok(d, p + nm + ".weight", D, D) || !shape_ok(d, p + nm + ".bias", D, 0)) return K5_ERR_ARG;
+  if (!shape_ok(d, p + ".query_norm.weight", 64, 0) || !shape_ok(d, p + ".key_norm.weight", 64, 0)) return K5_ERR_ARG;
   const HostTensor *wq = find(d, p + ".to_query.weight"), *wk = find(d, p + ".to_key.weight"),
                    *wv = find(d, p + ".to_value.weight"), *wo = find(d, p + ".out_layer.weight"),
                    *bq = find(d, p + ".to_query.bias"), *bk = find(d, p + ".to_key.bias"),
@@ -333,15 +387,27 @@ int pack_attn(k5_dit* d, const std::string& p, AttnW& a, bool fuse_qk) {
 
 inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Dense visual self-attention runs with the keys pre-multiplied by log2(e)/8 (attn_fwd_kernel<.., PRE>) whenever the fixed
-// softmax offset is usable (2 * bound * c <= 96, the same condition the attention launcher applies); NABLA keeps unscaled
-// keys (its block map is computed from them).  K5_NO_PRESCALE=1: A/B switch.
+// The visual self-attention runs with the keys pre-multiplied by log2(e)/8 (attn_fwd_kernel<.., PRE>: the scores are the exp2
+// arguments) whenever the rows come in whole 64-key tiles.  Which softmax form a head takes — constant offset 0, or the lazy
+// online max — is decided ON THE DEVICE from the data: the rmsnorm/RoPE kernel leaves max |q_h|^2 and max |k'_h|^2, and
+// k5_launch_attn_flags turns |q|max |k'|max <= 90 into the per-head flag both attention launches read.  (Round 1 derived
+// the bound from the QK-norm weights, 64 max|w_q| max|w_k|, which no trained checkpoint is known to satisfy.)
+// Text and cross attention (tiny) keep the weight-derived bound + the 32x32 online kernel as their fallback.
 constexpr float K5_SOFTMAX_C = 0.125f * 1.44269504088896340736f;
-inline bool use_prescale(const AttnW& a) {
-  static const bool off = getenv("K5_NO_PRESCALE") != nullptr;
-  return !off && a.score_bound > 0.f && 2.f * a.score_bound * K5_SOFTMAX_C <= 96.f;
+
+int ensure_zeroed(DevBuf& b, size_t n, hipStream_t s) {
+  if (n <= b.bytes) return K5_OK;
+  K5CHK(b.ensure(n));
+  HIPCHK(hipMemsetAsync(b.p, 0, b.bytes, s));
+  return K5_OK;
 }
-// (the pre-scaled instantiations have no ragged-tile code: callers add `keys % 64 == 0`)
+// statistics / flags / counters of the data-derived softmax bound; layout of ws_attn_stats: [q: Hh][k: sp_world x Hh]
+int ensure_attn_flags(k5_dit* d, hipStream_t s) {
+  K5CHK(ensure_zeroed(d->ws_attn_stats, (size_t)d->Hh * (1 + d->sp_world) * 4, s));
+  K5CHK(d->ws_attn_flags.ensure((size_t)d->Hh * 4));
+  K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
+  return K5_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // one attention module on `rows` tokens:  x_resid += gate * out_l(attn(...)) fused in the out GEMM
@@ -358,14 +424,23 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     K5CHK(k5_launch_gemm_bf16(h, a.wqk.p, a.bqk.as<float>(), qk, rows, 2 * D, D, D, D, 2 * D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
     K5CHK(k5_launch_gemm_bf16(a.wv.p, h, a.bv.as<float>(), vt, D, rows, D, D, D, ldvt, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
   }
+  const bool pre = !strcmp(fam_attn, "attn_self") && rows % 64 == 0;   // visual blocks only (not the text blocks)
+  const bool by_data = pre && d->attn_mode == K5_ATTN_AUTO;            // per-head flags from the data
+  const int* hflags = nullptr;
   {
     Scope sc(d, s, "elementwise");
     const int32_t hc[2] = {H, 2 * H};
-    const bool pre = !strcmp(fam_attn, "attn_self") && use_prescale(a) && rows % 64 == 0;   // visual blocks only (not the text blocks)
     void* kc = nullptr;   // NABLA: the block map needs the unscaled keys -> the scaled copy goes to its own buffer
     if (pre && nabla) { K5CHK(d->ws_kc.ensure((size_t)rows * D * 2)); kc = d->ws_kc.p; }
-    K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D));
+    float* stats = nullptr;
+    if (by_data) { K5CHK(ensure_attn_flags(d, s)); stats = d->ws_attn_stats.as<float>(); }   // [q heads | k' heads] = the call's 2H heads
+    K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D, stats));
+    if (by_data) {
+      hflags = d->ws_attn_flags.as<int>();
+      K5CHK(k5_launch_attn_flags(stats, stats + H, 1, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s));
+    }
   }
+  const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
   if (nabla) {  // nablaT_v2 map (utils.py:136-163) + block-sparse attention (nn.py:257-280)
     const int nb = rows / 64;
     K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
@@ -374,18 +449,21 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
       K5CHK(k5_launch_nabla_select(qk, (const bf16_t*)qk + D, 2 * D, 2 * D, H, rows, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
                                    nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s));
     }
+    if (d->profiling) {   // realised density of the map (bench.py: attention FLOPs actually done)
+      K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
+      K5CHK(k5_launch_nabla_count(d->ws_nabla.p, H, nb, nb, d->ws_attn_cnt.as<unsigned long long>() + 2, s));
+      d->nabla_possible += (long long)H * nb * nb;
+    }
     const int *list, *cnt;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
     Scope sc(d, s, fam_attn);
-    const bool pre = !strcmp(fam_attn, "attn_self") && use_prescale(a) && rows % 64 == 0;
     K5CHK(k5_launch_attention_bf16_sparse(qk, pre ? d->ws_kc.as<bf16_t>() : (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, pre ? D : 2 * D,
-                                          ldvt, D, a.score_bound, list, cnt, nb, 0, 0, s, pre));
+                                          ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant));
   } else {
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     Scope sc(d, s, fam_attn);
-    K5CHK(k5_launch_attention_bf16_range(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, a.score_bound, 0, 0, 0, -1,
-                                         0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(),
-                                         !strcmp(fam_attn, "attn_self") && use_prescale(a) && rows % 64 == 0));
+    K5CHK(k5_launch_attention_bf16_range(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, pre ? 0.f : a.score_bound, 0, 0, 0, -1,
+                                         0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), pre, hflags, variant));
   }
   {
     Scope sc(d, s, "gemm");
@@ -398,25 +476,34 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
 // q / k / v^T are projected for the local rows only; k and v^T land directly in this rank's slot of the
 // gather buffers, one in-place all-gather each makes every rank hold all keys, then attention runs for the
 // local query rows.  No head-count constraint (28 heads do not divide by 8), no activation all-reduce.
-int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, void* o, const float* cosT,
-                          const float* sinT, void* resid, const float* gate, const NablaArgs* nabla = nullptr) {
+// Uneven shards: every rank's slot in the gather buffers holds rows_pad = ceil(blocks / P) * 64 rows; only the LAST rank may
+// own fewer (rows < rows_pad), so the padded row index of every real key equals its global index and the unused tail of the
+// last slot is never read (the key-tile ranges stop at N).
+int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, int rows_pad, int N, void* o,
+                          const float* cosT, const float* sinT, void* resid, const float* gate, const NablaArgs* nabla = nullptr) {
   const int D = d->D, H = d->Hh, P = d->sp_world, r = d->sp_rank;
-  const int N = rows * P, ldv = rows;  // rows is a multiple of 64 (checked by the caller)
+  const int ldv = rows_pad;  // rows, rows_pad, N are multiples of 64 (checked by the caller)
   bf16_t* q = d->ws_q.as<bf16_t>();
   bf16_t* kfull = d->ws_kfull.as<bf16_t>();
   bf16_t* vtfull = d->ws_vtfull.as<bf16_t>();
-  bf16_t* kloc = kfull + (size_t)r * rows * D;
+  bf16_t* kloc = kfull + (size_t)r * rows_pad * D;
   bf16_t* vtloc = vtfull + (size_t)r * D * ldv;
   const bf16_t* wq = a.wqk.as<bf16_t>();
   const bf16_t* wk = wq + (size_t)D * D;
+  // dense: pre-scaled keys, softmax form per head from the data (the |k'|^2 maxima of all ranks are gathered with the keys);
+  // NABLA under SP keeps unscaled keys (the map is computed from them) and the weight-derived bound
+  const bool pre = !nabla;
+  const bool by_data = pre && d->attn_mode == K5_ATTN_AUTO;
+  float *qstat = nullptr, *kstat = nullptr;
+  if (by_data) { K5CHK(ensure_attn_flags(d, s)); qstat = d->ws_attn_stats.as<float>(); kstat = qstat + H; }
   {
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(h, wk, a.bqk.as<float>() + D, kloc, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   }
   {
     Scope sc(d, s, "elementwise");
-    const bool pre = !nabla && use_prescale(a);
-    K5CHK(k5_launch_rmsnorm_rope(kloc, a.norm.as<float>() + 64, cosT, sinT, rows, H, D, nullptr, s, K5_SOFTMAX_C, pre ? 0 : 0x7fffffff));
+    K5CHK(k5_launch_rmsnorm_rope(kloc, a.norm.as<float>() + 64, cosT, sinT, rows, H, D, nullptr, s, K5_SOFTMAX_C, pre ? 0 : 0x7fffffff,
+                                 nullptr, 0, by_data ? kstat + (size_t)r * H : nullptr));
   }
   HIPCHK(hipEventRecord(d->ev_k, s));
   {
@@ -430,18 +517,29 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   }
   {
     Scope sc(d, s, "elementwise");
-    K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), cosT, sinT, rows, H, D, nullptr, s));
+    K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), cosT, sinT, rows, H, D, nullptr, s, 1.f, 0x7fffffff, nullptr, 0, qstat));
   }
   // all-gathers on the side stream (they only need k / v^T, which are complete at ev_k / ev_v) ...
   hipStream_t cs = d->comm_stream;
   HIPCHK(hipStreamWaitEvent(cs, d->ev_k, 0));
   {
     Scope sc(d, cs, "comm");
-    K5CHK(d->comm.all_gather_inplace(kfull, (size_t)rows * D, 2, cs));
+    if (by_data) {   // H floats per rank, first: the flags must exist before pass 1 (both passes take the same form per head)
+      K5CHK(d->comm.all_gather_inplace(kstat, (size_t)H, 4, cs));
+      HIPCHK(hipEventRecord(d->ev_stats, cs));
+    }
+    K5CHK(d->comm.all_gather_inplace(kfull, (size_t)rows_pad * D, 2, cs));
     HIPCHK(hipStreamWaitEvent(cs, d->ev_v, 0));
     K5CHK(d->comm.all_gather_inplace(vtfull, (size_t)D * ldv, 2, cs));
   }
   HIPCHK(hipEventRecord(d->ev_gathered, cs));
+  const int* hflags = nullptr;
+  if (by_data) {
+    HIPCHK(hipStreamWaitEvent(s, d->ev_stats, 0));
+    hflags = d->ws_attn_flags.as<int>();
+    K5CHK(k5_launch_attn_flags(qstat, kstat, P, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s));
+  }
+  const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
   if (nabla) {
     // NABLA under sequence parallelism: the map rows of this rank's query blocks need the block means of
     // ALL keys -> wait for the gathered K, then select (local query blocks x all key blocks) and run the list-driven
@@ -451,40 +549,44 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
     {
       Scope sc(d, s, "nabla_map");
-      K5CHK(k5_launch_nabla_select_rect(q, kfull, D, D, H, rows, r * (rows / 64), N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
+      K5CHK(k5_launch_nabla_select_rect(q, kfull, D, D, H, rows, r * (rows_pad / 64), N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
                                         nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s));
+    }
+    if (d->profiling) {
+      K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
+      K5CHK(k5_launch_nabla_count(d->ws_nabla.p, H, rows / 64, nb, d->ws_attn_cnt.as<unsigned long long>() + 2, s));
+      d->nabla_possible += (long long)H * (rows / 64) * nb;
     }
     const int *list, *cnt;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
     Scope sc(d, s, "attn_self");
-    K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, list, cnt, nb, rows,
+    K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, list, cnt, nb, rows_pad,
                                           (long long)D * ldv, s));
   } else {
     // ... while the main stream attends the local query rows to the LOCAL key chunk (pass 1, leaves the fp32 state),
     // then, once every chunk has arrived, to all the other chunks (pass 2, resumes the state and normalises).
-    const int tpc = rows / 64, total = N / 64;
+    const int tpc = rows / 64, tpc_pad = rows_pad / 64, total = N / 64;
     // Pass 1 exists to cover the gather, and it cannot be load-balanced (only a pass that normalises can split its tail jobs
     // and merge them), so it should be no longer than the gather.  How long the gather takes is a property of the node (one
     // xGMI link per GPU pair: ~341 MB / (P x link rate) per block, i.e. about 0.4 of a rank's attention time at any P if a link
     // gives ~70 GB/s each way, much less if RCCL drives several paths) and cannot be measured here, so the default is the
-    // safe one — all local key tiles — and K5_SP_PASS1_TILES sets it on a real node (emulated, P = 2: 41 tiles instead of 372
-    // take the step from 282 to 259 ms).
-    static const int force_k1 = getenv("K5_SP_PASS1_TILES") ? atoi(getenv("K5_SP_PASS1_TILES")) : 0;
-    int k1 = force_k1 > 0 ? force_k1 : tpc;
+    // safe one — all local key tiles — and k5_dit_set_option("sp_pass1_tiles") sets it on a real node (emulated, P = 2: 41
+    // tiles instead of 372 take the step from 282 to 259 ms).
+    int k1 = d->sp_pass1_tiles > 0 ? d->sp_pass1_tiles : tpc;
     k1 = k1 > tpc ? tpc : k1;
     K5CHK(d->ws_attn_state.ensure(k5_attention_state_bytes(H, rows)));
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     {
       Scope sc(d, s, "attn_self");
-      K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
-                                           r * tpc, k1, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s, nullptr, use_prescale(a)));
+      K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, rows_pad, (long long)D * ldv,
+                                           r * tpc_pad, k1, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s, nullptr, true, hflags, variant));
     }
     HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
     {
       Scope sc(d, s, "attn_self");
-      K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, rows, (long long)D * ldv,
-                                           0, total - k1, r * tpc, k1, d->ws_attn_state.as<float>(), 1, s, d->ws_attn_bal.as<float>(),
-                                         use_prescale(a)));
+      K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, rows_pad, (long long)D * ldv,
+                                           0, total - k1, r * tpc_pad, k1, d->ws_attn_state.as<float>(), 1, s, d->ws_attn_bal.as<float>(),
+                                           true, hflags, variant));
     }
   }
   {
@@ -633,16 +735,21 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
   if (N <= 0 || L <= 0 || (a->H & 1) || (a->W & 1)) { k5_set_error("bad shapes"); return K5_ERR_ARG; }
   if (x_channels != Cin && x_channels != c.in_visual_dim) { k5_set_error("x_channels must be %d or %d", Cin, c.in_visual_dim); return K5_ERR_ARG; }
   const int P = d->sp_world;
-  if (d->comm.comm && (N % (64 * P))) {
-    k5_set_error("sequence parallel x%d needs the token count (%d) to be a multiple of %d", P, N, 64 * P);
-    return K5_ERR_UNSUPPORTED;
-  }
-  const int n = N / P, tok0 = d->sp_rank * n;  // this rank's token rows [tok0, tok0 + n)
-  const bool sp = d->comm.comm != nullptr;  // a communicator (even of size 1) selects the sharded code path
-  K5CHK(ensure_workspaces(d, N, L));
+  const bool sp = d->comm.active();  // a communicator (even of size 1) selects the sharded code path
+  // token shards: whole 64-token blocks, ceil(blocks / P) per rank; the last rank takes what is left (3660 blocks over 8
+  // ranks: 7 x 458 + 454).  n_pad = slot size in the gather buffers, n = rows this rank really owns.
+  int n = N, n_pad = N, tok0 = 0;
   if (sp) {
-    K5CHK(d->ws_q.ensure((size_t)n * D * 2)); K5CHK(d->ws_kfull.ensure((size_t)N * D * 2));
-    K5CHK(d->ws_vtfull.ensure((size_t)N * D * 2));
+    if (N % 64) { k5_set_error("sequence parallelism needs whole 64-token blocks (token count %d)", N); return K5_ERR_UNSUPPORTED; }
+    n_pad = ((N / 64 + P - 1) / P) * 64;
+    tok0 = d->sp_rank * n_pad;
+    n = N - tok0 < n_pad ? N - tok0 : n_pad;
+    if ((long long)(P - 1) * n_pad >= N) { k5_set_error("sequence parallel x%d: %d token blocks leave a rank without work", P, N / 64); return K5_ERR_UNSUPPORTED; }
+  }
+  K5CHK(ensure_workspaces(d, sp ? P * n_pad : N, L));
+  if (sp) {
+    K5CHK(d->ws_q.ensure((size_t)n_pad * D * 2)); K5CHK(d->ws_kfull.ensure((size_t)P * n_pad * D * 2));
+    K5CHK(d->ws_vtfull.ensure((size_t)P * n_pad * D * 2));
   }
   // NABLA: tokens are processed in fractal order (8x8 spatial tiles contiguous), utils.py:31-41,54-78
   const bool nabla = a->attention_type == 1;
@@ -735,7 +842,7 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     const float* vsin = d->ws_vsin.as<float>() + (size_t)tok0 * 32;
     K5CHK(ln_mod(d, s, d->ws_vis.p, m, d->ws_h.p, n));
     if (sp) {
-      K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D, nabla ? &na : nullptr));
+      K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, n_pad, N, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D, nabla ? &na : nullptr));
     } else {
       K5CHK(run_self_attention(d, s, b.self_attn, d->ws_h.p, n, d->ws_qk.p, d->ws_vt.p, d->ws_o.p, vcos, vsin, d->ws_vis.p,
                                m + 2 * D, "attn_self", nabla ? &na : nullptr));
@@ -766,7 +873,7 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     K5CHK(k5_launch_gemm_bf16(d->ws_h.p, d->out_w.p, d->out_b.as<float>(), d->ws_y.as<bf16_t>() + (size_t)tok0 * d->Fout, n,
                               d->Fout, D, D, D, d->Fout, K5_EPI_BIAS, nullptr, 0, nullptr, s));
     // every rank needs the whole velocity: the (replicated) latent is advanced identically on all ranks
-    if (sp) K5CHK(d->comm.all_gather_inplace(d->ws_y.p, (size_t)n * d->Fout, 2, s));
+    if (sp) K5CHK(d->comm.all_gather_inplace(d->ws_y.p, (size_t)n_pad * d->Fout, 2, s));
     K5CHK(k5_launch_unpatchify(d->ws_y.p, out_velocity, Tp, Hp, Wp, c.out_visual_dim, d->Fout, perm, s));
   }
   return K5_OK;
@@ -811,10 +918,12 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
   d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_kc.release(); d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
+  d->ws_attn_stats.release(); d->ws_attn_flags.release(); d->ws_attn_cnt.release();
+  d->mag.residual[0].release(); d->mag.residual[1].release(); d->mag.pm_one.release();
   for (auto& b : d->vblocks) { b.w1_f8.release(); b.w2_f8.release(); b.s1_f8.release(); b.s2_f8.release(); }
   if (d->graph_stream) { (void)hipStreamSynchronize(d->graph_stream); (void)hipStreamDestroy(d->graph_stream); (void)hipEventDestroy(d->ev_graph); }
   if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
-  for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
+  for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered, d->ev_stats}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
   auto rel_attn = [](AttnW& a) {
     DevBuf* bs[] = {&a.wqk, &a.wq, &a.wk, &a.wv, &a.wo, &a.bqk, &a.bq, &a.bk, &a.bv, &a.bo, &a.norm};
@@ -877,7 +986,12 @@ extern "C" int k5_dit_finalize(k5_dit* d) {
       !shape_is("text_embeddings.in_layer.weight", D, c.in_text_dim) ||
       !shape_is("pooled_text_embeddings.in_layer.weight", TD, c.in_text_dim2) ||
       !shape_is("visual_embeddings.in_layer.weight", D, d->Kvis) || !shape_is("out_layer.out_layer.weight", d->Fout, D) ||
-      !shape_is("out_layer.modulation.out_layer.weight", 2 * D, TD))
+      !shape_is("out_layer.modulation.out_layer.weight", 2 * D, TD) ||
+      !shape_is("time_embeddings.in_layer.bias", TD, 0) || !shape_is("time_embeddings.out_layer.bias", TD, 0) ||
+      !shape_is("text_embeddings.in_layer.bias", D, 0) || !shape_is("text_embeddings.norm.weight", D, 0) ||
+      !shape_is("text_embeddings.norm.bias", D, 0) || !shape_is("pooled_text_embeddings.in_layer.bias", TD, 0) ||
+      !shape_is("pooled_text_embeddings.norm.weight", TD, 0) || !shape_is("pooled_text_embeddings.norm.bias", TD, 0) ||
+      !shape_is("visual_embeddings.in_layer.bias", D, 0) || !shape_is("out_layer.out_layer.bias", d->Fout, 0))
     return K5_ERR_ARG;
   K5CHK(upload_f32(d->time_w1, find(d, "time_embeddings.in_layer.weight")->data.data(), TD * D));
   K5CHK(upload_f32(d->time_b1, find(d, "time_embeddings.in_layer.bias")->data.data(), TD));
@@ -902,7 +1016,7 @@ extern "C" int k5_dit_finalize(k5_dit* d) {
   size_t off = 0;
   auto put_mod = [&](const std::string& p, size_t rows) -> bool {
     const HostTensor *w = find(d, p + ".weight"), *b = find(d, p + ".bias");
-    if (!w || w->data.size() != rows * TD || b->data.size() != rows) { k5_set_error("shape mismatch for %s", p.c_str()); return false; }
+    if (!w || !b || w->data.size() != rows * TD || b->data.size() != rows) { k5_set_error("shape mismatch for %s", p.c_str()); return false; }
     memcpy(mw.data() + off * TD, w->data.data(), rows * TD * 4);
     memcpy(mb.data() + off, b->data.data(), rows * 4);
     off += rows;
@@ -914,6 +1028,7 @@ extern "C" int k5_dit_finalize(k5_dit* d) {
     d->tblocks[i].mod_off = off;
     if (!put_mod(p + ".text_modulation.out_layer", 6 * D)) return K5_ERR_ARG;
     K5CHK(pack_attn(d, p + ".self_attention", d->tblocks[i].self_attn, true));
+    if (!shape_ok(d, p + ".feed_forward.in_layer.weight", FF, D) || !shape_ok(d, p + ".feed_forward.out_layer.weight", D, FF)) return K5_ERR_ARG;
     K5CHK(upload_bf16(d->tblocks[i].w1, find(d, p + ".feed_forward.in_layer.weight")->data.data(), FF, D, D));
     K5CHK(upload_bf16(d->tblocks[i].w2, find(d, p + ".feed_forward.out_layer.weight")->data.data(), D, FF, FF));
   }
@@ -923,6 +1038,7 @@ extern "C" int k5_dit_finalize(k5_dit* d) {
     if (!put_mod(p + ".visual_modulation.out_layer", 9 * D)) return K5_ERR_ARG;
     K5CHK(pack_attn(d, p + ".self_attention", d->vblocks[i].self_attn, true));
     K5CHK(pack_attn(d, p + ".cross_attention", d->vblocks[i].cross_attn, false));
+    if (!shape_ok(d, p + ".feed_forward.in_layer.weight", FF, D) || !shape_ok(d, p + ".feed_forward.out_layer.weight", D, FF)) return K5_ERR_ARG;
     K5CHK(upload_bf16(d->vblocks[i].w1, find(d, p + ".feed_forward.in_layer.weight")->data.data(), FF, D, D));
     K5CHK(upload_bf16(d->vblocks[i].w2, find(d, p + ".feed_forward.out_layer.weight")->data.data(), D, FF, FF));
   }
@@ -1087,25 +1203,121 @@ extern "C" int k5_comm_unique_id(const char* rccl_lib_path, void* out128) {
   return K5_OK;
 }
 
+static int comm_common_init(k5_dit* d, int rank, int world) {
+  d->comm.rank = rank; d->comm.world = world;
+  d->sp_rank = rank; d->sp_world = world;
+  HIPCHK(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&d->ev_k, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&d->ev_v, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&d->ev_gathered, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&d->ev_stats, hipEventDisableTiming));
+  return K5_OK;
+}
+
 extern "C" int k5_dit_comm_init(k5_dit* d, const char* rccl_lib_path, int rank, int world, const void* unique_id128) {
   g_err[0] = 0;
   if (!d || !unique_id128 || world < 1 || rank < 0 || rank >= world) return K5_ERR_ARG;
-  if (d->comm.comm) { k5_set_error("communicator already initialised"); return K5_ERR_STATE; }
+  if (d->comm.active()) { k5_set_error("communicator already initialised"); return K5_ERR_STATE; }
   K5CHK(d->comm.open(rccl_lib_path));
   ncclUniqueId id;
   memcpy(&id, unique_id128, 128);
   const ncclResult_t r = d->comm.CommInitRank(&d->comm.comm, world, id, rank);
   if (r != ncclSuccess) { k5_set_error("ncclCommInitRank: %s", d->comm.GetErrorString(r)); return K5_ERR_HIP; }
-  d->comm.rank = rank; d->comm.world = world;
-  d->sp_rank = rank; d->sp_world = world;
-  // timing aid (bench.py --emulate-shard P, one GPU): lay the work out as rank 0 of a P-rank group while the communicator has
-  // one rank, i.e. the collectives move nothing and the other ranks' key chunks are never filled -> per-rank COMPUTE time of a
-  // P-GPU run; the numbers it produces are garbage
-  if (world == 1 && getenv("K5_SP_EMULATE_WORLD")) { const int e = atoi(getenv("K5_SP_EMULATE_WORLD")); if (e > 1) d->sp_world = e; }
-  HIPCHK(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&d->ev_k, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&d->ev_v, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&d->ev_gathered, hipEventDisableTiming));
+  return comm_common_init(d, rank, world);
+}
+
+// ---- loopback group: P handles of one process on one GPU as the P ranks of a sequence-parallel run (tests) ----
+struct k5_loopback { LoopGroup g; };
+extern "C" int k5_loopback_create(int world, k5_loopback** out) {
+  g_err[0] = 0;
+  if (!out || world < 1 || world > 64) return K5_ERR_ARG;
+  k5_loopback* lb = new k5_loopback();
+  lb->g.world = world;
+  if (pthread_barrier_init(&lb->g.bar, nullptr, (unsigned)world)) { delete lb; k5_set_error("pthread_barrier_init failed"); return K5_ERR_STATE; }
+  lb->g.ptr.assign(world, nullptr); lb->g.joined.assign(world, 0);
+  lb->g.ready.resize(world); lb->g.pulled.resize(world);
+  for (int i = 0; i < world; ++i) {
+    HIPCHK(hipEventCreateWithFlags(&lb->g.ready[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&lb->g.pulled[i], hipEventDisableTiming));
+  }
+  *out = lb;
+  return K5_OK;
+}
+extern "C" void k5_loopback_destroy(k5_loopback* lb) {
+  if (!lb) return;
+  for (auto e : lb->g.ready) (void)hipEventDestroy(e);
+  for (auto e : lb->g.pulled) (void)hipEventDestroy(e);
+  pthread_barrier_destroy(&lb->g.bar);
+  delete lb;
+}
+extern "C" int k5_dit_comm_init_loopback(k5_dit* d, k5_loopback* lb, int rank) {
+  g_err[0] = 0;
+  if (!d || !lb || rank < 0 || rank >= lb->g.world) return K5_ERR_ARG;
+  if (d->comm.active()) { k5_set_error("communicator already initialised"); return K5_ERR_STATE; }
+  if (lb->g.joined[rank]) { k5_set_error("loopback rank %d is already taken", rank); return K5_ERR_STATE; }
+  lb->g.joined[rank] = 1;
+  d->comm.loop = &lb->g;
+  return comm_common_init(d, rank, lb->g.world);
+}
+
+// Engine options (all default 0).
+//   "attn_mode"       0 = softmax form per head from the data (fixed offset where |q||k'| <= 90, online max elsewhere),
+//                     1 = online max everywhere (what a checkpoint with large QK-norm gains gets; bench.py --attn-online)
+//   "sp_pass1_tiles"  local key tiles attended before the K/V^T gather has landed (0 = all of the rank's own tiles)
+//   "emulate_world"   TIMING ONLY, one GPU: lay the work out as rank 0 of a P-rank group while the communicator has one rank —
+//                     collectives move nothing, the other ranks' keys are never filled, RESULTS ARE GARBAGE; the handle is
+//                     marked (k5_dit_get_option "emulated" = 1) so that a bench can refuse to report it as a measurement
+extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
+  g_err[0] = 0;
+  if (!d || !name) return K5_ERR_ARG;
+  if (!strcmp(name, "attn_mode")) {
+    if (value != K5_ATTN_AUTO && value != K5_ATTN_ONLINE) { k5_set_error("attn_mode must be 0 or 1"); return K5_ERR_ARG; }
+    d->attn_mode = value; return K5_OK;
+  }
+  if (!strcmp(name, "sp_pass1_tiles")) { if (value < 0) return K5_ERR_ARG; d->sp_pass1_tiles = value; return K5_OK; }
+  if (!strcmp(name, "emulate_world")) {
+    if (!d->comm.active() || d->comm.world != 1 || value < 1) { k5_set_error("emulate_world needs a world = 1 communicator"); return K5_ERR_STATE; }
+    d->sp_world = value; d->emulated = value > 1;
+    if (d->emulated) fprintf(stderr, "libk5: emulate_world=%d — timing-only layout, the results of this handle are garbage\n", value);
+    return K5_OK;
+  }
+  k5_set_error("unknown option %s", name);
+  return K5_ERR_ARG;
+}
+extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
+  if (!d || !name || !value) return K5_ERR_ARG;
+  if (!strcmp(name, "attn_mode")) *value = d->attn_mode;
+  else if (!strcmp(name, "sp_pass1_tiles")) *value = d->sp_pass1_tiles;
+  else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
+  else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
+  else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }
+  return K5_OK;
+}
+
+// How many (block, head) self-attention launches took the fixed-offset / the online-max softmax since the last reset
+// (synchronises the device; bench.py reports it as roofline.variant).  reset != 0 clears the counters.
+extern "C" int k5_dit_attn_variant_counts(k5_dit* d, long long* fixed_heads, long long* online_heads, int reset) {
+  if (!d) return K5_ERR_ARG;
+  unsigned long long c[4] = {0, 0, 0, 0};
+  if (d->ws_attn_cnt.p) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(c, d->ws_attn_cnt.p, 32, hipMemcpyDeviceToHost));
+    if (reset) { HIPCHK(hipMemset(d->ws_attn_cnt.p, 0, 32)); d->nabla_possible = 0; }
+  }
+  if (fixed_heads) *fixed_heads = (long long)c[0];
+  if (online_heads) *online_heads = (long long)c[1];
+  return K5_OK;
+}
+// NABLA maps computed while profiling was on: kept / possible 64x64 blocks since the last k5_dit_attn_variant_counts reset
+extern "C" int k5_dit_nabla_block_counts(k5_dit* d, long long* kept, long long* possible) {
+  if (!d) return K5_ERR_ARG;
+  unsigned long long c[4] = {0, 0, 0, 0};
+  if (d->ws_attn_cnt.p) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(c, d->ws_attn_cnt.p, 32, hipMemcpyDeviceToHost));
+  }
+  if (kept) *kept = (long long)c[2];
+  if (possible) *possible = d->nabla_possible;
   return K5_OK;
 }
 

@@ -51,6 +51,17 @@ int k5_attention_bf16_prescaled(const void* Q, const void* Kc, const void* Vt, v
                                             nullptr, 0, (hipStream_t)stream, nullptr, true), "k5_attention_bf16_prescaled");
 }
 
+int k5_attention_bf16_prescaled_auto(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                     int ldk, int ldvt, int ldo, const int* head_flags, int variant, void* workspace, void* stream) {
+  return ret(k5_launch_attention_bf16_range(Q, Kc, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, 0.f, 0, 0, 0, -1, 0x7fffffff, 0,
+                                            nullptr, 0, (hipStream_t)stream, (float*)workspace, true, head_flags, variant),
+             "k5_attention_bf16_prescaled_auto");
+}
+
+int k5_attention_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags, void* stream) {
+  return ret(k5_launch_attn_flags(qstat, kstat, nk, kstride, H, force_online, flags, nullptr, (hipStream_t)stream), "k5_attention_flags");
+}
+
 int64_t k5_attention_balance_size(int H, int q_len) { return (int64_t)k5_attention_balance_bytes(H, q_len); }
 
 int k5_attention_bf16_balanced(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
@@ -118,6 +129,13 @@ int k5_rmsnorm_rope_bf16(void* x, const float* weight, const float* cos_tab, con
   const int32_t hc[2] = {heads_per_weight, rope_heads};
   return ret(k5_launch_rmsnorm_rope(x, weight, cos_tab, sin_tab, rows, H, ld, hc, (hipStream_t)stream),
              "k5_rmsnorm_rope_bf16");
+}
+
+int k5_rmsnorm_rope_stats_bf16(void* x, const float* weight, const float* cos_tab, const float* sin_tab, int rows, int H, int ld,
+                               int heads_per_weight, int rope_heads, float out_scale, int scale_from_head, float* stats, void* stream) {
+  const int32_t hc[2] = {heads_per_weight, rope_heads};
+  return ret(k5_launch_rmsnorm_rope(x, weight, cos_tab, sin_tab, rows, H, ld, hc, (hipStream_t)stream, out_scale, scale_from_head,
+                                    nullptr, 0, stats), "k5_rmsnorm_rope_stats_bf16");
 }
 
 int k5_gate_sum_bf16(const void* x, const void* y, const float* gate, void* out, int rows, int D, void* stream) {

@@ -28,8 +28,16 @@ size_t k5_attention_state_bytes(int H, int q_len);
 int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
-                                   int tile_skip_n, float* state, int flags, hipStream_t stream, float* balance_ws = nullptr, bool k_prescaled = false);
+                                   int tile_skip_n, float* state, int flags, hipStream_t stream, float* balance_ws = nullptr, bool k_prescaled = false,
+                                   const int* head_flags = nullptr, int variant = 0);
 size_t k5_attention_balance_bytes(int H, int q_len);
+// softmax form of the pre-scaled-key launches: AUTO = fixed offset where the bound (score_bound, or the per-head device
+// flags) allows it and the lazy online max elsewhere; ONLINE = the online max everywhere
+enum { K5_ATTN_AUTO = 0, K5_ATTN_ONLINE = 1 };
+// per-head flags from the |q|^2 / |k'|^2 maxima that k5_launch_rmsnorm_rope(stats) left (consumed: reset to 0); kstat holds
+// nk partial maxima at stride kstride floats; counters (optional, device u64[2]) += heads sent to {fixed, online}
+int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
+                         unsigned long long* counters, hipStream_t stream);
 
 // ---- fp8 (e4m3) feed-forward path, opt-in (gemm_fp8.hip) ----
 int k5_launch_gemm_fp8(const void* A8, const void* W8, const float* w_scale, void* C, int M, int N, int K, int lda, int ldw, int ldc,
@@ -45,9 +53,12 @@ void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned lon
 int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
                                 int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s);
 int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void* out, hipStream_t s);
+// *acc += number of kept (query block, key block) pairs of the map in `workspace` (H x nqb rows)
+int k5_launch_nabla_count(const void* workspace, int H, int nqb, int nb, unsigned long long* acc, hipStream_t s);
 int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
-                                    int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled = false);
+                                    int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled = false,
+                                    const int* head_flags = nullptr, int variant = 0);
 
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,
@@ -57,9 +68,12 @@ int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift,
 //   < rope_heads.  heads_cfg = host pointer to {heads_per_weight, rope_heads} or null (= {H, H}).
 int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cos, const float* sin, int rows,
                            int H, int ld, const int32_t* heads_cfg, hipStream_t stream,
-                           float out_scale = 1.f, int scale_from_head = 0x7fffffff, void* scaled_out = nullptr, int ld_scaled = 0);
+                           float out_scale = 1.f, int scale_from_head = 0x7fffffff, void* scaled_out = nullptr, int ld_scaled = 0,
+                           float* stats = nullptr);
 // heads >= scale_from_head are multiplied by out_scale before the bf16 rounding — in place, or (scaled_out != null) into
-// scaled_out[row][(head - scale_from_head) * 64 ...] while the unscaled values stay in place
+// scaled_out[row][(head - scale_from_head) * 64 ...] while the unscaled values stay in place.
+// stats (device, [H] floats, zeroed by the consumer): stats[h] = max(stats[h], |x_row,h|^2) over the rows of the call, of the
+// values the softmax reads (the scaled ones for heads >= scale_from_head) -> data-derived softmax bound (k5_launch_attn_flags)
 // K15: cos/sin tables [T*H*W][n0+n1+n2] for RoPE3D (RoPE1D: H=W=1, n1=n2=0), optional token permutation
 int k5_launch_rope_table(float* cosT, float* sinT, const int32_t* p0, const int32_t* p1, const int32_t* p2, int T,
                          int H, int W, int n0, int n1, int n2, float s0, float s1, float s2, const int32_t* tok_perm,

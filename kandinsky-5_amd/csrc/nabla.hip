@@ -167,7 +167,28 @@ __global__ __launch_bounds__(256) void nabla_expand_kernel(const unsigned long l
   }
 }
 
+// sum of the per-row kept-block counts -> one atomic per workgroup (profiling only: realised map density)
+__global__ __launch_bounds__(256) void nabla_count_kernel(const int* __restrict__ kv_nb, int rows, unsigned long long* acc) {
+  unsigned long long v = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) v += (unsigned long long)kv_nb[i];
+  __shared__ unsigned long long part[4];
+  float dummy = 0.f; (void)dummy;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
 }  // namespace
+
+int k5_launch_nabla_count(const void* workspace, int H, int nqb, int nb, unsigned long long* acc, hipStream_t s) {
+  if (!workspace || !acc || H <= 0 || nqb <= 0) return K5_ERR_ARG;
+  const int* kv_nb;
+  k5_nabla_workspace_views(const_cast<void*>(workspace), H, nb, nullptr, &kv_nb, nullptr, nullptr);
+  const int rows = H * nqb;
+  hipLaunchKernelGGL(nabla_count_kernel, dim3((rows + 4095) / 4096), dim3(256), 0, s, kv_nb, rows, acc);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
 
 int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void* out, hipStream_t s) {
   if (H <= 0 || nqb <= 0 || nqb > nb) return K5_ERR_ARG;

@@ -80,62 +80,89 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// K5 + K3: one thread per 16-B chunk (8 of the 64 head elements); 8-lane groups own one head.
+// K5 + K3: one thread per 16-B chunk (8 of the 64 head elements); 8-lane groups own one head.  Grid-stride over rows with a
+// stride that is a multiple of H*8 threads, so a thread keeps its (head, chunk) and can carry the head's running
+// max |x|^2 in a register: one atomic per 8-lane group per launch instead of one per head vector.
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                            const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                            int rows, int H, int heads_per_weight, int ld, int rope_heads,
                                                            float out_scale, int scale_from_head, bf16_t* __restrict__ scaled_out,
-                                                           int ld_scaled) {
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                           int ld_scaled, float* __restrict__ stats) {
   const int64_t total = (int64_t)rows * H * 8;
-  const bool valid = gid < total;
-  const int64_t g = valid ? gid : total - 1;
-  const int c = (int)(g & 7);
-  const int head = (int)((g >> 3) % H);
-  const int row = (int)((g >> 3) / H);
-  bf16_t* px = x + (size_t)row * ld + head * 64 + 8 * c;
-  const u32x4 raw = *reinterpret_cast<const u32x4*>(px);
-  float v[8];
-  float sq = 0.f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    v[2 * j] = __uint_as_float(raw[j] << 16);
-    v[2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u);
-    sq += v[2 * j] * v[2 * j] + v[2 * j + 1] * v[2 * j + 1];
-  }
-  sq += __shfl_xor(sq, 1, 64);
-  sq += __shfl_xor(sq, 2, 64);
-  sq += __shfl_xor(sq, 4, 64);
-  const float rs = rsqrtf(sq * (1.0f / 64.0f) + 1.1920928955078125e-07f);  // eps = finfo(fp32).eps
+  const int64_t stride = (int64_t)gridDim.x * 256;        // multiple of H * 8 (launcher)
+  const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)(g0 & 7);
+  const int head = (int)((g0 >> 3) % H);
+  const int row_step = (int)(stride / (H * 8));
   const float* w = weight + (head / heads_per_weight) * 64 + 8 * c;
-  float y[8];
+  float wv[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) y[j] = bf_round(__fmul_rn(__fmul_rn(v[j], rs), w[j]));  // .type_as(q)
-  if (cosT && head < rope_heads) {
-    const f32x4 cs = *reinterpret_cast<const f32x4*>(cosT + (size_t)row * 32 + 4 * c);
-    const f32x4 sn = *reinterpret_cast<const f32x4*>(sinT + (size_t)row * 32 + 4 * c);
+  for (int j = 0; j < 8; ++j) wv[j] = w[j];
+  const bool rope = cosT && head < rope_heads;
+  const bool scaled = head >= scale_from_head;
+  float n2max = 0.f;
+  // every lane of a wave runs the same number of iterations except in the last one (shuffles need the whole 8-lane group:
+  // groups never straddle the end because total is a multiple of 8)
+  for (int64_t g = g0; g < total; g += stride) {
+    const int row = (int)((g >> 3) / H);
+    bf16_t* px = x + (size_t)row * ld + head * 64 + 8 * c;
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(px);
+    float v[8];
+    float sq = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float x0 = y[2 * j], x1 = y[2 * j + 1];
-      y[2 * j] = __fadd_rn(__fmul_rn(cs[j], x0), __fmul_rn(-sn[j], x1));
-      y[2 * j + 1] = __fadd_rn(__fmul_rn(sn[j], x0), __fmul_rn(cs[j], x1));
+      v[2 * j] = __uint_as_float(raw[j] << 16);
+      v[2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u);
+      sq += v[2 * j] * v[2 * j] + v[2 * j + 1] * v[2 * j + 1];
     }
-  }
-  if (head >= scale_from_head) {   // keys handed to the pre-scaled softmax: k' = bf16(log2(e)/8 * k), one rounding
-    if (scaled_out) {              // NABLA: the unscaled keys stay in place (block map), the scaled copy goes to its own buffer
-      if (valid) {
-        u32x4 pks = {pack_bf16x2(__fmul_rn(y[0], out_scale), __fmul_rn(y[1], out_scale)), pack_bf16x2(__fmul_rn(y[2], out_scale), __fmul_rn(y[3], out_scale)),
-                     pack_bf16x2(__fmul_rn(y[4], out_scale), __fmul_rn(y[5], out_scale)), pack_bf16x2(__fmul_rn(y[6], out_scale), __fmul_rn(y[7], out_scale))};
-        *reinterpret_cast<u32x4*>(scaled_out + (size_t)row * ld_scaled + (head - scale_from_head) * 64 + 8 * c) = pks;
-      }
-    } else {
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    sq += __shfl_xor(sq, 4, 64);
+    const float rs = rsqrtf(sq * (1.0f / 64.0f) + 1.1920928955078125e-07f);  // eps = finfo(fp32).eps
+    float y[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = __fmul_rn(y[j], out_scale);
+    for (int j = 0; j < 8; ++j) y[j] = bf_round(__fmul_rn(__fmul_rn(v[j], rs), wv[j]));  // .type_as(q)
+    if (rope) {
+      const f32x4 cs = *reinterpret_cast<const f32x4*>(cosT + (size_t)row * 32 + 4 * c);
+      const f32x4 sn = *reinterpret_cast<const f32x4*>(sinT + (size_t)row * 32 + 4 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x0 = y[2 * j], x1 = y[2 * j + 1];
+        y[2 * j] = __fadd_rn(__fmul_rn(cs[j], x0), __fmul_rn(-sn[j], x1));
+        y[2 * j + 1] = __fadd_rn(__fmul_rn(sn[j], x0), __fmul_rn(cs[j], x1));
+      }
+    }
+    u32x4 pks = {0u, 0u, 0u, 0u};
+    if (scaled) {   // keys handed to the pre-scaled softmax: k' = bf16(log2(e)/8 * k), one rounding
+      if (scaled_out) {   // NABLA: the unscaled keys stay in place (block map), the scaled copy goes to its own buffer
+        pks = u32x4{pack_bf16x2(__fmul_rn(y[0], out_scale), __fmul_rn(y[1], out_scale)), pack_bf16x2(__fmul_rn(y[2], out_scale), __fmul_rn(y[3], out_scale)),
+                    pack_bf16x2(__fmul_rn(y[4], out_scale), __fmul_rn(y[5], out_scale)), pack_bf16x2(__fmul_rn(y[6], out_scale), __fmul_rn(y[7], out_scale))};
+        *reinterpret_cast<u32x4*>(scaled_out + (size_t)row * ld_scaled + (head - scale_from_head) * 64 + 8 * c) = pks;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = __fmul_rn(y[j], out_scale);
+      }
+    }
+    const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+    *reinterpret_cast<u32x4*>(px) = pk;
+    if (stats) {   // |x|^2 of the bf16 values the softmax will consume (the scaled copy where there is one)
+      const u32x4 src = (scaled && scaled_out) ? pks : pk;
+      float n2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = __uint_as_float(src[j] << 16), hi = __uint_as_float(src[j] & 0xffff0000u);
+        n2 += lo * lo + hi * hi;
+      }
+      n2max = n2 == n2 ? fmaxf(n2max, n2) : __uint_as_float(0x7f800000u);   // NaN -> +inf: forces the online-max path
     }
   }
-  if (valid) {
-    u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
-    *reinterpret_cast<u32x4*>(px) = pk;
+  if (stats) {
+    // per-head max over the rows of this call: |q.k'| <= |q| |k'| then bounds every exp2 argument of the head
+    // (attn_flags_kernel).  Non-negative floats order like their bit patterns.
+    n2max = fmaxf(n2max, __shfl_xor(n2max, 1, 64));
+    n2max = fmaxf(n2max, __shfl_xor(n2max, 2, 64));
+    n2max = fmaxf(n2max, __shfl_xor(n2max, 4, 64));
+    if (c == 0 && g0 < total) atomicMax(reinterpret_cast<unsigned int*>(stats) + head, __float_as_uint(n2max));
   }
 }
 
@@ -307,15 +334,23 @@ int k5_launch_ln_affine(const void* x, const float* w, const float* b, void* out
 
 int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, const float* sinT, int rows, int H,
                            int ld, const int32_t* heads_cfg, hipStream_t s, float out_scale, int scale_from_head, void* scaled_out,
-                           int ld_scaled) {
+                           int ld_scaled, float* stats) {
   // heads_cfg (host pointer, optional): {heads_per_weight, rope_heads}; default: one weight, rope on all heads
   if (rows <= 0 || H <= 0) return K5_ERR_ARG;
   if (ld & 7) return K5_ERR_ALIGN;
   const int hpw = heads_cfg ? heads_cfg[0] : H;
   const int rope_heads = heads_cfg ? heads_cfg[1] : H;
   const int64_t total = (int64_t)rows * H * 8;
-  hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (bf16_t*)x, weight,
-                     cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled);
+  // grid: a multiple of `unit` blocks so that the grid stride (grid * 256 threads) is a multiple of H * 8 threads per row
+  int gcd = 256, b8 = H * 8;
+  for (int a = gcd, b = b8; b;) { const int t = a % b; a = b; b = t; gcd = a; }
+  const int unit = b8 / gcd;
+  int64_t blocks = (total + 255) / 256;
+  const int64_t cap = 4096 > unit ? 4096 : unit;
+  if (blocks > cap) blocks = cap;
+  blocks = (blocks + unit - 1) / unit * unit;
+  hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)x, weight,
+                     cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled, stats);
   return done();
 }
 

@@ -66,6 +66,16 @@ SYMBOLS = {
     "k5_gemm_fp8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "k5_quant_rows_fp8": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "k5_attention_bf16_prescaled": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "k5_attention_bf16_prescaled_auto": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "k5_attention_flags": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "k5_rmsnorm_rope_stats_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "k5_loopback_create": (_I, [_I, C.POINTER(_P)]),
+    "k5_loopback_destroy": (None, [_P]),
+    "k5_dit_comm_init_loopback": (_I, [_P, _P, _I]),
+    "k5_dit_set_option": (_I, [_P, C.c_char_p, _I]),
+    "k5_dit_get_option": (_I, [_P, C.c_char_p, C.POINTER(_I)]),
+    "k5_dit_attn_variant_counts": (_I, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _I]),
+    "k5_dit_nabla_block_counts": (_I, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "k5_attention_balance_size": (_I64, [_I, _I]),
     "k5_attention_bf16_balanced": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "k5_nabla_workspace_size": (_I64, [_I, _I]),
@@ -134,6 +144,24 @@ def lib() -> C.CDLL:
         fn.argtypes = args
     _lib = L
     return L
+
+
+class LoopbackGroup:
+    """k5_loopback: `world` engine handles of this process act as the ranks of one sequence-parallel group on one GPU
+    (each rank driven by its own host thread).  Test infrastructure for the multi-GPU code path."""
+
+    def __init__(self, world: int):
+        h = C.c_void_p()
+        check(lib().k5_loopback_create(int(world), C.byref(h)), "k5_loopback_create")
+        self.handle, self.world = h, int(world)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().k5_loopback_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 def last_error() -> str:

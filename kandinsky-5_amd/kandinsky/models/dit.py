@@ -79,16 +79,22 @@ class DiffusionTransformer3D(nn.Module):
         self._handle = None          # k5_dit*
         self._handle_device = None
         self._keepalive = []
+        self._sp = None              # (rank, world) once a communicator lives on the handle
+        self._settings = {"fp8": False, "graph": False, "options": {}}   # re-applied when the engine is rebuilt
 
     # ---------------------------------------------------------------- engine lifetime
-    def _destroy_engine(self):
+    def _destroy_engine(self, force=False):
         if self._handle is not None:
+            if getattr(self, "_sp", None) is not None and not force:
+                # a rank that silently rebuilt its engine would run the unsharded forward while its peers wait in a collective
+                raise RuntimeError("this DiffusionTransformer3D holds a live sequence-parallel communicator: replacing its "
+                                   "weights or moving it to another device would desynchronise the ranks")
             E.lib().k5_dit_destroy(self._handle)
-        self._handle, self._handle_device = None, None
+        self._handle, self._handle_device, self._sp = None, None, None
 
     def __del__(self):
         try:
-            self._destroy_engine()
+            self._destroy_engine(force=True)
         except Exception:
             pass
 
@@ -127,11 +133,23 @@ class DiffusionTransformer3D(nn.Module):
                 self._load_one(h, name, t)
             E.check(E.lib().k5_dit_finalize(h), "k5_dit_finalize")
         self._handle, self._handle_device = h, device
+        self._reapply_settings()
+
+    def _reapply_settings(self):
+        """Engine state that lives on the handle (not in the parameters) survives a rebuild."""
+        st = self._settings
+        if st["fp8"]:
+            E.check(E.lib().k5_dit_set_fp8(self._handle, 1), "k5_dit_set_fp8")
+        if st["graph"]:
+            E.check(E.lib().k5_dit_set_graph(self._handle, 1), "k5_dit_set_graph")
+        for k, v in st["options"].items():
+            if k != "emulate_world":
+                E.check(E.lib().k5_dit_set_option(self._handle, k.encode(), int(v)), f"k5_dit_set_option({k})")
         if getattr(self, "mag_ratios", None) is not None:   # set_magcache_params() before the weights were loaded
             from ..magcache_utils import _apply
             _apply(self)
 
-    def init_synthetic(self, device, seed=0, std=0.02):
+    def init_synthetic(self, device, seed=0, std=0.02, qk_gain=1.0):
         """Random-init weights of this architecture generated ON DEVICE tensor by tensor and handed straight
         to the engine (no 8 GB host copy).  Linear ~ N(0,std^2) incl. Modulation (reference zero-inits it,
         nn.py:158-159, which would make every block an identity), norm weights 1, biases N(0,std^2)."""
@@ -144,6 +162,8 @@ class DiffusionTransformer3D(nn.Module):
                 g.manual_seed(seed * 1000003 + idx)
                 if name.endswith("norm.weight"):
                     t = torch.ones(p.shape, device=device)
+                    if name.endswith(("query_norm.weight", "key_norm.weight")):
+                        t = t * float(qk_gain)   # QK-norm gains of a trained checkpoint are not 1: bench.py --qk-gain
                 else:
                     s = std * (2.5 if "modulation" in name else 1.0)
                     t = torch.randn(p.shape, device=device, generator=g) * s
@@ -151,6 +171,7 @@ class DiffusionTransformer3D(nn.Module):
             torch.cuda.synchronize(device)
             E.check(E.lib().k5_dit_finalize(h), "k5_dit_finalize")
         self._handle, self._handle_device = h, device
+        self._reapply_settings()
         return self
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
@@ -162,7 +183,9 @@ class DiffusionTransformer3D(nn.Module):
         out = super()._apply(fn, *a, **k)
         if self._handle is not None:
             p = next(self.parameters(), None)
-            if p is not None and p.device != self._handle_device and not p.is_meta:
+            # the engine owns packed copies of the weights: `.to("cpu")` (the pipeline's offload, t2v_pipeline.py) keeps the
+            # handle — the next forward on the same GPU costs nothing; only a move to ANOTHER GPU rebuilds
+            if p is not None and p.device.type == "cuda" and p.device != self._handle_device:
                 self._destroy_engine()
         return out
 
@@ -278,14 +301,51 @@ class DiffusionTransformer3D(nn.Module):
         self._sp = (rank, world)
         return self
 
+    def enable_loopback(self, group, rank):
+        """Tests: this handle becomes rank `rank` of a loopback group (`kandinsky._engine.LoopbackGroup`) — several handles of
+        one process on one GPU run the sequence-parallel code path of a multi-GPU job, one host thread per rank."""
+        if self._handle is None:
+            raise RuntimeError("build the engine first")
+        with torch.cuda.device(self._handle_device):
+            E.check(E.lib().k5_dit_comm_init_loopback(self._handle, group.handle, int(rank)), "k5_dit_comm_init_loopback")
+        self._sp = (rank, group.world)
+        self._keepalive.append(group)
+        return self
+
+    def set_option(self, name, value):
+        """k5_dit_set_option: "attn_mode" (0 = softmax form per head from the data, 1 = online max everywhere),
+        "sp_pass1_tiles", "emulate_world" (timing only)."""
+        E.check(E.lib().k5_dit_set_option(self._handle, name.encode(), int(value)), f"k5_dit_set_option({name})")
+        self._settings["options"][name] = int(value)
+        return self
+
+    def get_option(self, name):
+        v = C.c_int()
+        E.check(E.lib().k5_dit_get_option(self._handle, name.encode(), C.byref(v)), f"k5_dit_get_option({name})")
+        return v.value
+
+    def attn_variant_counts(self, reset=False):
+        """(fixed-offset, online-max) head launches of the visual self-attention since the last reset."""
+        a, b = C.c_longlong(), C.c_longlong()
+        E.check(E.lib().k5_dit_attn_variant_counts(self._handle, C.byref(a), C.byref(b), int(reset)))
+        return a.value, b.value
+
+    def nabla_block_counts(self):
+        """(kept, possible) 64x64 blocks of the NABLA maps computed while profiling was on (bench.py: realised density)."""
+        a, b = C.c_longlong(), C.c_longlong()
+        E.check(E.lib().k5_dit_nabla_block_counts(self._handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_fp8(self, on=True):
         """opt-in, lossy: visual feed-forward GEMMs in W8A8 e4m3 (k5_dit_set_fp8; BASELINE config 5)"""
         E.check(E.lib().k5_dit_set_fp8(self._handle, int(on)), "k5_dit_set_fp8")
+        self._settings["fp8"] = bool(on)
         return self
 
     def set_graph(self, on=True):
         """sample() replays one hipGraph-captured step (k5_dit_set_graph); bit-identical results"""
         E.check(E.lib().k5_dit_set_graph(self._handle, int(on)))
+        self._settings["graph"] = bool(on)
         return self
 
     # ---------------------------------------------------------------- profiling (bench.py roofline)

@@ -149,6 +149,72 @@ def test_full_width_two_blocks_vs_oracle():
     assert rel(got, G["sample_val"]) <= 3e-2, rel(got, G["sample_val"])
 
 
+# ------------------------------------------------------------------------------------------ QK-norm gains != 1
+def _qk_gain_sd(cfg, case):
+    """seed-3 synthetic weights with the QK-norm gains (query_norm / key_norm, 64 each) of every attention replaced"""
+    sd = O.synthetic_state_dict(cfg, seed=3)
+    g = torch.Generator().manual_seed(77)
+    for k in sorted(sd):
+        if k.endswith(("query_norm.weight", "key_norm.weight")):
+            if case == "n05":
+                sd[k] = 1.0 + 0.5 * torch.randn(64, generator=g)
+            elif case == "x3":
+                sd[k] = torch.full((64,), 3.0)
+            elif case == "ch8":
+                w = torch.ones(64); w[int(torch.randint(0, 64, (1,), generator=g))] = 8.0
+                sd[k] = w
+            elif case == "x2":
+                sd[k] = torch.full((64,), 2.0)
+            else:
+                raise ValueError(case)
+    return sd
+
+
+@pytest.mark.parametrize("case,expect", [("n05", "fixed"), ("x2", "fixed"), ("ch8", "any"), ("x3", "online")])
+def test_full_width_qk_norm_gains_vs_oracle(case, expect):
+    """The engine on QK-norm gains a trained checkpoint could have: N(1, 0.5), every gain 2 (|q||k'| = 64 * 4 * 0.18 = 46),
+    every gain 3 (104: just outside the fixed-offset window), one channel at 8 (the bound depends on how much of a row's
+    energy sits in that channel: heads fall on either side).  The softmax form is chosen per head ON THE
+    DEVICE from the data; the test states which one must have run and demands oracle parity either way (round 1 derived the
+    bound from max|w| and never left the fixed-offset branch in any engine-level test)."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
+    cfg = O.DitConfig(**c)
+    sd = _qk_gain_sd(cfg, case)
+    dit = DiffusionTransformer3D(**c)
+    dit.load_state_dict(sd, assign=True)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(5, 16, 16, 16, generator=g)
+    text, pooled = torch.randn(37, 3584, generator=g), torch.randn(1, 768, generator=g)
+    pos = [torch.arange(5), torch.arange(8), torch.arange(8)]
+    t = torch.tensor([875.0])
+    dit = dit.to("cuda:0")
+    args = (x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(37))
+    out = dit(*args, scale_factor=(1.0, 2.0, 2.0))
+    n_fixed, n_online = dit.attn_variant_counts(reset=True)
+    assert n_fixed + n_online == 2 * 28                                  # 2 visual blocks x 28 heads were flagged
+    if expect == "fixed":
+        assert n_online == 0, (n_fixed, n_online)
+    elif expect == "online":
+        assert n_fixed == 0, (n_fixed, n_online)
+    xin = torch.cat([x, torch.zeros(5, 16, 16, 17)], dim=-1)
+    O.PRESCALE_K = True
+    try:
+        refp = O.dit_forward(sd, cfg, xin, text, pooled, t, pos, torch.arange(37), (1.0, 2.0, 2.0), None, "bf16")
+    finally:
+        O.PRESCALE_K = False
+    ref32 = O.dit_forward(sd, cfg, xin, text, pooled, t, pos, torch.arange(37), (1.0, 2.0, 2.0), None, "fp32")
+    print(f"qk gains {case}: fixed/online heads {n_fixed}/{n_online}; engine vs bf16 oracle {rel(out, refp):.3e}, vs fp32 {rel(out, ref32):.3e}")
+    assert rel(out, refp) <= 1.5e-2, rel(out, refp)
+    assert rel(out, ref32) <= 3e-2, rel(out, ref32)
+    # the other form on the same weights: online max everywhere — same velocity up to the softmax's bf16 noise
+    dit.set_option("attn_mode", 1)
+    out_on = dit(*args, scale_factor=(1.0, 2.0, 2.0))
+    dit.set_option("attn_mode", 0)
+    assert rel(out_on, refp) <= 1.5e-2, rel(out_on, refp)
+    assert rel(out_on, out) <= 5e-3, rel(out_on, out)
+
+
 # ------------------------------------------------------------------------------------------ MagCache (SURVEY §8f-1)
 @pytest.mark.parametrize("tag", ["sft_12", "nocfg_9", "hand_10"])
 def test_magcache_generate(tiny_dit, tiny_sd, cfg, golden, tag):
