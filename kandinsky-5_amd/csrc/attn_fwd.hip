@@ -72,11 +72,9 @@ K5_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_
 // 16-B chunk: XOR the chunk with row bits (4,3,1) so that those 16 rows (x row&1) hit 16 distinct 16-B bank slots.
 K5_DEV int lds_swz_k(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 4); }
 
-K5_DEV float max3(float a, float b, float c) {   // one instruction, no canonicalising v_max in front of MFMA results
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// v_max3_f32.  Compiler-visible on purpose: the operands are MFMA results, and only the compiler's hazard recogniser
+// knows how many wait states an XDL write needs before a VALU read (an inline-asm v_max3 read stale accumulators).
+K5_DEV float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 // RANGE: key-tile sub-range + resumable fp32 state (sequence-parallel two-pass schedule); kept out of the plain dense
 // instantiation, whose loop is sensitive to every extra live value (128-VGPR budget for 2 workgroups per CU).
@@ -251,14 +249,14 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
       float mx[2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        mx[qt] = max3(st[0][qt][0], st[0][qt][1], st[0][qt][2]);
-        mx[qt] = max3(mx[qt], st[0][qt][3], st[1][qt][0]);
-        mx[qt] = max3(mx[qt], st[1][qt][1], st[1][qt][2]);
-        mx[qt] = max3(mx[qt], st[1][qt][3], st[2][qt][0]);
-        mx[qt] = max3(mx[qt], st[2][qt][1], st[2][qt][2]);
-        mx[qt] = max3(mx[qt], st[2][qt][3], st[3][qt][0]);
-        mx[qt] = max3(mx[qt], st[3][qt][1], st[3][qt][2]);
-        mx[qt] = fmaxf(mx[qt], st[3][qt][3]);
+        mx[qt] = max3(-3.0e38f, st[0][qt][0], st[0][qt][1]);   // a constant first operand: no canonicalising v_max
+        mx[qt] = max3(mx[qt], st[0][qt][2], st[0][qt][3]);
+        mx[qt] = max3(mx[qt], st[1][qt][0], st[1][qt][1]);
+        mx[qt] = max3(mx[qt], st[1][qt][2], st[1][qt][3]);
+        mx[qt] = max3(mx[qt], st[2][qt][0], st[2][qt][1]);
+        mx[qt] = max3(mx[qt], st[2][qt][2], st[2][qt][3]);
+        mx[qt] = max3(mx[qt], st[3][qt][0], st[3][qt][1]);
+        mx[qt] = max3(mx[qt], st[3][qt][2], st[3][qt][3]);
       }
       if (fresh || __any(fmaxf(mx[0], mx[1]) > ONLINE_THR)) {   // wave-uniform, rare
 #pragma unroll

@@ -153,17 +153,15 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
         const float lo = __uint_as_float(src[j] << 16), hi = __uint_as_float(src[j] & 0xffff0000u);
         n2 += lo * lo + hi * hi;
       }
+      n2 += __shfl_xor(n2, 1, 64);   // the head vector's 8 lanes
+      n2 += __shfl_xor(n2, 2, 64);
+      n2 += __shfl_xor(n2, 4, 64);
       n2max = n2 == n2 ? fmaxf(n2max, n2) : __uint_as_float(0x7f800000u);   // NaN -> +inf: forces the online-max path
     }
   }
-  if (stats) {
-    // per-head max over the rows of this call: |q.k'| <= |q| |k'| then bounds every exp2 argument of the head
-    // (attn_flags_kernel).  Non-negative floats order like their bit patterns.
-    n2max = fmaxf(n2max, __shfl_xor(n2max, 1, 64));
-    n2max = fmaxf(n2max, __shfl_xor(n2max, 2, 64));
-    n2max = fmaxf(n2max, __shfl_xor(n2max, 4, 64));
-    if (c == 0 && g0 < total) atomicMax(reinterpret_cast<unsigned int*>(stats) + head, __float_as_uint(n2max));
-  }
+  // per-head max over the rows of this call: |q.k'| <= |q| |k'| then bounds every exp2 argument of the head
+  // (attn_flags_kernel).  Non-negative floats order like their bit patterns.
+  if (stats && c == 0 && g0 < total) atomicMax(reinterpret_cast<unsigned int*>(stats) + head, __float_as_uint(n2max));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -62,12 +62,13 @@ def test_rmsnorm_rope_statistics_are_the_max_row_norms(E, rows, H):
     """k5_rmsnorm_rope_stats_bf16: stats[h] = max over rows of |x_h|^2 of the bf16 values it wrote (scaled heads included),
     accumulated on top of what the buffer held."""
     x = bfr(rnd(rows, H * 64, seed=1, scale=3.0))
-    w = rnd(H // 2 * 0 + 64, seed=2).abs() + 0.5
+    w = rnd(64, seed=2).abs() + 0.5
     cos, sin = torch.cos(rnd(rows, 32, seed=3)), torch.sin(rnd(rows, 32, seed=3))
     xd = x.cuda().to(BF)
+    wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()      # named: a temporary's memory may be reused before the kernel runs
     stats = torch.zeros(H, device="cuda")
     stats[0] = 1e9                                     # an existing larger value must survive (max, not overwrite)
-    E.check(E.lib().k5_rmsnorm_rope_stats_bf16(xd.data_ptr(), w.cuda().data_ptr(), cos.cuda().data_ptr(), sin.cuda().data_ptr(), rows, H,
+    E.check(E.lib().k5_rmsnorm_rope_stats_bf16(xd.data_ptr(), wd.data_ptr(), cd.data_ptr(), sd.data_ptr(), rows, H,
                                                xd.stride(0), H, H, float(O.SOFTMAX_C), H // 2, stats.data_ptr(), E.stream_ptr()))
     torch.cuda.synchronize()
     y = xd.float().reshape(rows, H, 64)
@@ -76,7 +77,7 @@ def test_rmsnorm_rope_statistics_are_the_max_row_norms(E, rows, H):
     assert torch.allclose(stats, n2, rtol=1e-5), (stats, n2)
     # the op itself: same values as the stats-less entry (oracle parity of that entry: test_gpu_kernels.py), scaled heads scaled
     x2 = x.cuda().to(BF)
-    E.rmsnorm_rope_(x2, w.cuda(), cos.cuda(), sin.cuda(), heads=H)
+    E.rmsnorm_rope_(x2, wd, cd, sd, heads=H)
     ref = x2.float().reshape(rows, H, 64).clone()
     assert torch.equal(xd.float().reshape(rows, H, 64)[:, :H // 2], ref[:, :H // 2])
     assert (xd.float().reshape(rows, H, 64)[:, H // 2:] - bfr(ref[:, H // 2:].cpu() * C).cuda()).abs().max() <= 2 ** -7 * ref.abs().max() * O.SOFTMAX_C
@@ -122,7 +123,8 @@ def test_prescaled_online_two_pass_and_balanced_merge(E):
     vt = torch.randn(H * 64, Sk, device="cuda", generator=g).to(BF)
     one = run_auto(E, q, kc, vt, H, None, 1)
     bal = run_auto(E, q, kc, vt, H, None, 1, balanced=True)
-    close(bal, one.cpu(), ulps=2, atol=2e-3, what="balanced online")
+    # split parts exponentiate against their own offsets: the bf16 roundings of P differ from the single launch's
+    close(bal, one.cpu(), ulps=4, atol=1e-2, what="balanced online")
     rows = torch.tensor([0, 77, 255, 256, 3000, Sq - 1])
     ref = O.sdpa(q[rows].float().cpu().reshape(-1, H, 64), kc.float().cpu().reshape(Sk, H, 64), vt.t().float().cpu().reshape(Sk, H, 64),
                  "bf16", None, base2=True)

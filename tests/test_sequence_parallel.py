@@ -130,7 +130,7 @@ def test_engine_sharded_path_world1_rccl_matches_fused(golden, golden_meta, tiny
     dit = DiffusionTransformer3D(**c)
     dit.load_state_dict(tiny_sd, assign=True)
     dit = dit.to("cuda:0").enable_sequence_parallel(0, 1, device="cuda:0")
-    with pytest.raises(RuntimeError, match="multiple of 64"):
+    with pytest.raises(RuntimeError, match="whole 64-token blocks"):
         dit(golden["fwd.x"].cuda(), text, pooled, torch.tensor([432.0]), [torch.arange(3), torch.arange(4), torch.arange(6)],
             torch.arange(9), scale_factor=(1.0, 2.0, 2.0))
 
