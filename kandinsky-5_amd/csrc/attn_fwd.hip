@@ -87,7 +87,7 @@ K5_DEV float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_
 // and only when some lane sees it exceed ONLINE_THR does the wave take the rescale branch.
 constexpr float ONLINE_THR = 60.f;
 #ifndef K5_ONLINE_WPS
-#define K5_ONLINE_WPS 4   // waves per SIMD the online-max instantiations are compiled for (A/B: 2 = 256 VGPRs, one workgroup per CU)
+#define K5_ONLINE_WPS 2   // waves per SIMD the online-max instantiations are compiled for: 2 = up to 256 VGPRs, one workgroup per CU (at 4 = 128 VGPRs the allocator spills the cold path into the tile loop: 4x slower, measured)
 #endif
 template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false>
 __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_kernel(AttnP p) {
@@ -262,8 +262,12 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           float mf = mx[qt];   // the query's four lanes (l15 + 16 g) combine -> identical offsets in all of them
-          mf = fmaxf(mf, __shfl_xor(mf, 16, 64));
-          mf = fmaxf(mf, __shfl_xor(mf, 32, 64));
+          {
+            const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mf), __float_as_uint(mf), false, false);
+            mf = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));   // max with lane ^ 16
+            const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mf), __float_as_uint(mf), false, false);
+            mf = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));   // max with lane ^ 32
+          }
           const float dlt = fresh ? mf : fmaxf(mf, 0.f);   // an established offset is never lowered
           const float alpha = fresh ? 1.f : __builtin_amdgcn_exp2f(-dlt);
           { const float n = nm[qt][0] - dlt; nm[qt] = f32x4{n, n, n, n}; }

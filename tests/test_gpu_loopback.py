@@ -1,0 +1,178 @@
+"""The engine as P > 1 ranks on ONE GPU: a loopback group makes P handles of this process the ranks
+of a sequence-parallel run — one host thread per rank, collectives = rendezvous + device-to-device copies — so every
+rank executes exactly the offsets, slot layout and launch sequence of a real multi-GPU job (ranks r > 0 had never run).
+
+Checked: every rank returns the SAME velocity bit for bit (each holds the whole gathered result), and it matches the
+unsharded single-handle path — not bit for bit: the sharded schedule attends the local key chunk first and the
+gathered chunks second, another fp32 summation order (and the shard-size GEMMs may pick another tile shape); a bf16
+rounding that flips in one block's attention output travels through the rest of the network, so two VALID schedules sit
+3-4e-3 apart at full width (measured) while each is ~7e-3 from the oracle — hence: sharded vs fused <= 6e-3, and
+sharded vs the bf16 oracle within the suite's 1.5e-2.  Even and uneven shards, dense and NABLA, tiny and full width."""
+import threading
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import k5_oracle as O  # noqa: E402
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def run_ranks(P, make_dit, call):
+    """P handles, rank r driven by thread r on its own stream; returns the per-rank results (raises the first error)."""
+    from kandinsky import _engine as E
+    group = E.LoopbackGroup(P)
+    dits = []
+    for r in range(P):
+        d = make_dit()
+        d.engine("cuda:0")
+        d.enable_loopback(group, r)
+        dits.append(d)
+    torch.cuda.synchronize()
+    out, err = [None] * P, [None] * P
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.default_stream())
+            with torch.cuda.stream(st):
+                out[r] = call(dits[r], r)
+            st.synchronize()
+        except Exception as e:   # a failed rank would leave its peers in the rendezvous: report, the timeout reaps
+            err[r] = e
+
+    ths = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(P)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(180)
+    assert not any(t.is_alive() for t in ths), f"ranks stuck in a collective (errors so far: {err})"
+    for e in err:
+        if e is not None:
+            raise e
+    for d in dits:
+        d._destroy_engine(force=True)
+    return out
+
+
+def tiny_cfg(golden_meta):
+    c = dict(golden_meta["tiny_config"])
+    c["patch_size"], c["axes_dims"] = tuple(c["patch_size"]), tuple(c["axes_dims"])
+    return c
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("P,T,sparse", [(2, 8, False), (4, 8, False), (8, 8, False), (2, 7, False), (4, 7, False),
+                                        (2, 8, True), (4, 8, True), (8, 8, True), (4, 7, True)])
+def test_tiny_forward_P_ranks_on_one_gpu(golden_meta, tiny_sd, P, T, sparse):
+    """latent (T,16,16): T blocks of 64 tokens (8x8 spatial tile per frame) -> T = 7 gives uneven shards (P=2: 4+3,
+    P=4: 2+2+2+1)."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = tiny_cfg(golden_meta)
+    g = torch.Generator().manual_seed(100 + T)
+    x = torch.randn(T, 16, 16, 33, generator=g)
+    text, pooled = torch.randn(9, 96, generator=g), torch.randn(1, 48, generator=g)
+    pos = [torch.arange(T), torch.arange(8), torch.arange(8)]
+    t = torch.tensor([432.0])
+    sp = {"P": 0.6, "wT": 3, "wH": 3, "wW": 3, "to_fractal": True} if sparse else None
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(tiny_sd, assign=True)
+        return d.to("cuda:0")
+
+    def call(d, r):
+        return d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(9), scale_factor=(1.0, 2.0, 2.0), sparse_params=sp)
+
+    fused = call(make(), 0)
+    outs = run_ranks(P, make, call)
+    for r in range(1, P):
+        assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
+    assert torch.isfinite(outs[0].float()).all()
+    assert rel(outs[0], fused) <= 3e-3, rel(outs[0], fused)
+    if not sparse:
+        ref = O.dit_forward(tiny_sd, O.DitConfig(**c), x, text, pooled, t, pos, torch.arange(9), (1.0, 2.0, 2.0), None, "bf16")
+        assert rel(outs[0], ref) <= 1.5e-2, rel(outs[0], ref)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("P,W,gain", [(2, 32, 1.0), (4, 32, 1.0), (8, 48, 1.0), (4, 32, 3.0)])
+def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain):
+    """2B-Lite width (28 heads, D = 1792), 2 visual blocks, latent (5,16,W): 10 blocks (P=2: 5+5, P=4: 3+3+3+1) or 15 blocks
+    (P=8: 7 x 2 + 1).  gain 3 on the QK-norm weights sends every head to the online-max softmax: the per-head flags come from
+    the gathered |k'|^2 maxima of ALL ranks, and both attention passes must take the same form."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
+    cfg = O.DitConfig(**c)
+    sd = O.synthetic_state_dict(cfg, seed=3)
+    if gain != 1.0:
+        for k in sd:
+            if k.endswith(("query_norm.weight", "key_norm.weight")):
+                sd[k] = sd[k] * gain
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(5, 16, W, 16, generator=g)
+    text, pooled = torch.randn(37, 3584, generator=g), torch.randn(1, 768, generator=g)
+    pos = [torch.arange(5), torch.arange(8), torch.arange(W // 2)]
+    t = torch.tensor([875.0])
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(sd, assign=True)
+        return d.to("cuda:0")
+
+    def call(d, r):
+        return d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(37), scale_factor=(1.0, 2.0, 2.0))
+
+    one = make()
+    fused = call(one, 0)
+    n_fixed, n_online = one.attn_variant_counts()
+    assert (n_online == 0) if gain == 1.0 else (n_fixed == 0), (n_fixed, n_online)
+    outs = run_ranks(P, make, call)
+    for r in range(1, P):
+        assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
+    xin = torch.cat([x, torch.zeros(5, 16, W, 17)], dim=-1)
+    O.PRESCALE_K = True
+    try:
+        ref = O.dit_forward(sd, cfg, xin, text, pooled, t, pos, torch.arange(37), (1.0, 2.0, 2.0), None, "bf16")
+    finally:
+        O.PRESCALE_K = False
+    print(f"P={P} gain={gain}: sharded vs fused rel-L2 {rel(outs[0], fused):.3e}; sharded vs oracle {rel(outs[0], ref):.3e}, fused vs oracle {rel(fused, ref):.3e}")
+    assert rel(outs[0], fused) <= (6e-3 if gain == 1.0 else 1.5e-2), rel(outs[0], fused)
+    assert rel(outs[0], ref) <= (1.5e-2 if gain == 1.0 else 3e-2), rel(outs[0], ref)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("P,w", [(2, 1.0), (4, 5.0)])
+def test_tiny_sampler_P_ranks_on_one_gpu(golden_meta, tiny_sd, P, w):
+    """k5_sample (whole Euler / CFG loop in one C call per rank): 4 steps, every rank ends with the same latent."""
+    from types import SimpleNamespace as NS
+    from kandinsky.generation_utils import generate
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = tiny_cfg(golden_meta)
+    g = torch.Generator().manual_seed(5)
+    shape = (8, 16, 16, 16)
+    noise = torch.randn(*shape, generator=g)
+    te = {"text_embeds": torch.randn(9, 96, generator=g).cuda(), "pooled_embed": torch.randn(1, 48, generator=g).cuda()}
+    ne = {"text_embeds": torch.randn(4, 96, generator=g).cuda(), "pooled_embed": torch.randn(1, 48, generator=g).cuda()}
+    pos = [torch.arange(8), torch.arange(8), torch.arange(8)]
+    conf = NS(model=NS(dit_params=NS(patch_size=(1, 2, 2)), attention=NS(type="flash")), metrics=NS(scale_factor=(1.0, 2.0, 2.0)))
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(tiny_sd, assign=True)
+        return d.to("cuda:0")
+
+    def call(d, r):
+        return generate(d, "cuda:0", shape, 4, te, ne, pos, torch.arange(9), torch.arange(4), w, 5.0, conf, noise=noise)
+
+    fused = call(make(), 0)
+    outs = run_ranks(P, make, call)
+    for r in range(1, P):
+        assert torch.equal(outs[r], outs[0])
+    assert rel(outs[0], fused) <= 1e-2, rel(outs[0], fused)     # the suite's tolerance on a final latent

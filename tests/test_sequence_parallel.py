@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _sp_forward(sd, cfg, x, text, pooled, time, vpos, tpos, rank, world):
     """Sequence-parallel restatement of O.dit_forward: mirrors csrc/engine.hip forward_impl + run_self_attention_sp."""
-    from kandinsky.models.parallelize import token_shard
+    from kandinsky.models.parallelize import shard_slot, token_shard
     mode = "fp32"
     txt = O.text_embeddings(sd, "text_embeddings", text, mode)
     temb = O.time_embeddings(sd, time, cfg) + O.text_embeddings(sd, "pooled_text_embeddings", pooled, mode)
@@ -29,6 +29,7 @@ def _sp_forward(sd, cfg, x, text, pooled, time, vpos, tpos, rank, world):
     va = O.rope_3d_args((Tp, Hp, Wp), vpos, cfg.axes_dims, (1.0, 2.0, 2.0)).reshape(-1, 32)
     N = Tp * Hp * Wp
     t0, n = token_shard(N, world, rank)
+    slot = shard_slot(N, world)
     vis = vis.reshape(N, D)[t0:t0 + n]
     cos, sin = torch.cos(va)[t0:t0 + n], torch.sin(va)[t0:t0 + n]
     H = cfg.num_heads
@@ -40,12 +41,15 @@ def _sp_forward(sd, cfg, x, text, pooled, time, vpos, tpos, rank, world):
         h = O.scale_shift_norm(vis, scale, shift, mode)
         q, k, v = O._attn_qkv(sd, f"{p}.self_attention", h, h, mode, H)
         q, k = O.apply_rotary(q, cos, sin, mode), O.apply_rotary(k, cos, sin, mode)
-        kfull = [torch.empty_like(k) for _ in range(world)]
-        vtfull = [torch.empty(D, n) for _ in range(world)]
-        dist.all_gather(kfull, k.contiguous())
-        dist.all_gather(vtfull, v.reshape(n, D).t().contiguous())
-        kall = torch.cat(kfull, 0)
-        vall = torch.cat(vtfull, 1).t().reshape(N, H, 64)
+        # every rank's slot holds `slot` rows; only the last rank's may be partly unused (its tail is never read)
+        kpad, vtpad = torch.zeros(slot, H, 64), torch.zeros(D, slot)
+        kpad[:n], vtpad[:, :n] = k, v.reshape(n, D).t()
+        kfull = [torch.empty_like(kpad) for _ in range(world)]
+        vtfull = [torch.empty_like(vtpad) for _ in range(world)]
+        dist.all_gather(kfull, kpad)
+        dist.all_gather(vtfull, vtpad)
+        kall = torch.cat(kfull, 0)[:N]
+        vall = torch.cat(vtfull, 1)[:, :N].t().reshape(N, H, 64)
         o = O.sdpa(q, kall, vall, mode)
         o = O._linear(o, sd[f"{p}.self_attention.out_layer.weight"], sd[f"{p}.self_attention.out_layer.bias"], mode)
         vis = O.gate_sum(vis, o, gate, mode)
@@ -56,12 +60,14 @@ def _sp_forward(sd, cfg, x, text, pooled, time, vpos, tpos, rank, world):
         vis = O.gate_sum(vis, O.feed_forward(sd, f"{p}.feed_forward", O.scale_shift_norm(vis, scale, shift, mode), mode),
                          gate, mode)
     y = O.out_layer(sd, vis, temb, cfg, mode)
-    yall = [torch.empty_like(y) for _ in range(world)]
-    dist.all_gather(yall, y.contiguous())
-    return O.unpatchify(torch.cat(yall, 0).reshape(Tp, Hp, Wp, -1), cfg.patch_size)
+    ypad = torch.zeros(slot, y.shape[1])
+    ypad[:n] = y
+    yall = [torch.empty_like(ypad) for _ in range(world)]
+    dist.all_gather(yall, ypad)
+    return O.unpatchify(torch.cat(yall, 0)[:N].reshape(Tp, Hp, Wp, -1), cfg.patch_size)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, T=2):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "kandinsky-5_amd"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -72,21 +78,22 @@ def _worker(rank, world, port, q):
                       axes_dims=(16, 24, 24), visual_cond=True)
     sd = O.synthetic_state_dict(cfg, seed=5, std=0.05)
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(2, 16, 16, 33, generator=g)  # 2*8*8 = 128 tokens = 2 ranks x 64
+    x = torch.randn(T, 16, 16, 33, generator=g)  # T*8*8 tokens: T = 2 -> 2 ranks x 64; T = 3 -> 128 + 64 (uneven shards)
     text, pooled = torch.randn(9, 96, generator=g), torch.randn(1, 48, generator=g)
     t = torch.tensor([432.0])
-    vpos = [torch.arange(2), torch.arange(8), torch.arange(8)]
+    vpos = [torch.arange(T), torch.arange(8), torch.arange(8)]
     out = _sp_forward(sd, cfg, x, text, pooled, t, vpos, torch.arange(9), rank, world)
     ref = O.dit_forward(sd, cfg, x, text, pooled, t, vpos, torch.arange(9), (1.0, 2.0, 2.0), None, "fp32")
     q.put((rank, float((out - ref).abs().max()), float(ref.abs().max())))
     dist.destroy_process_group()
 
 
-def test_sequence_parallel_algorithm_two_ranks_gloo():
+@pytest.mark.parametrize("T", [2, 3])
+def test_sequence_parallel_algorithm_two_ranks_gloo(T):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + T
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, T)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(2)]
@@ -102,10 +109,17 @@ def test_token_shard_contract():
     assert token_shard(47616, 8, 3) == (3 * 5952, 5952)
     assert token_shard(47616, 1, 0) == (0, 47616)
     assert token_shard(93696, 4, 3) == (3 * 23424, 23424)
-    with pytest.raises(ValueError):
-        token_shard(234240, 8, 0)  # 3660 blocks do not split over 8 ranks
+    # 3660 blocks (BASELINE config 5, 1280x768 10 s) over 8 ranks: 7 x 458 blocks + 454
+    assert token_shard(234240, 8, 0) == (0, 458 * 64) and token_shard(234240, 8, 6) == (6 * 458 * 64, 458 * 64)
+    assert token_shard(234240, 8, 7) == (7 * 458 * 64, 454 * 64)
+    assert sum(token_shard(234240, 8, r)[1] for r in range(8)) == 234240
+    assert token_shard(192, 2, 0) == (0, 128) and token_shard(192, 2, 1) == (128, 64)
     with pytest.raises(ValueError):
         token_shard(128, 2, 2)
+    with pytest.raises(ValueError):
+        token_shard(640, 8, 0)     # 10 blocks, ceil = 2 per rank: ranks 5..7 would idle
+    with pytest.raises(ValueError):
+        token_shard(100, 2, 0)     # not whole blocks
 
 
 @pytest.mark.gpu
