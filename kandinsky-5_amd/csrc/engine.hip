@@ -235,6 +235,12 @@ struct k5_dit {
   struct TextRope { std::vector<int32_t> key; DevBuf cosT, sinT, pos; };
   std::vector<TextRope> text_rope;  // small cache: cond / null-cond position vectors
 
+  // Step-invariant text prologue: TextEmbeddings(text) and the pooled projection (dit.py:132,134) depend on the
+  // prompt only, so k5_sample computes them once per call and branch (slot 0 = cond, 1 = uncond) and every later step copies
+  // 0.9 MB instead of re-running two GEMMs + two LayerNorms.  k5_dit_forward (one call per step, caller-owned buffers that
+  // may change between calls) does not cache.
+  struct TextCache { DevBuf text, pool; bool valid = false; int L = 0; } text_cache[2];
+
   // MagCache (reference kandinsky/magcache_utils.py:16-101): skip the visual blocks on some calls and re-apply the
   // cached bf16 residual of the same cond / uncond slot.  Decisions depend on the ratio table and the call counter only.
   struct MagCache {
@@ -724,7 +730,8 @@ int to_bf16(k5_dit* d, hipStream_t s, const void* src, int dtype, size_t n, DevB
 }
 
 int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, float time, const float* x,
-                 int x_channels, void* out_velocity, hipStream_t s, const float* tvec = nullptr, const int* step = nullptr) {
+                 int x_channels, void* out_velocity, hipStream_t s, const float* tvec = nullptr, const int* step = nullptr,
+                 int text_slot = -1) {
   const k5_dit_config& c = d->cfg;
   if (!d->finalized) { k5_set_error("k5_dit_forward before k5_dit_finalize"); return K5_ERR_STATE; }
   if (a->attention_type != 0 && a->attention_type != 1) { k5_set_error("attention_type must be 0 (flash) or 1 (nabla)"); return K5_ERR_ARG; }
@@ -779,16 +786,28 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
   // ---- before_text_transformer_blocks (dit.py:129-137) ----
   {
     Scope sc(d, s, "prologue");
-    const void* text_bf; const void* pool_bf;
-    K5CHK(to_bf16(d, s, cond.text_embed, cond.text_dtype, (size_t)L * c.in_text_dim, d->ws_text_in, &text_bf));
-    K5CHK(to_bf16(d, s, cond.pooled_embed, cond.text_dtype, (size_t)c.in_text_dim2, d->ws_pool_in, &pool_bf));
-    K5CHK(k5_launch_gemm_bf16(text_bf, d->text_w.p, d->text_b.as<float>(), d->ws_th.p, L, D, c.in_text_dim, c.in_text_dim,
-                              c.in_text_dim, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
-    K5CHK(k5_launch_ln_affine(d->ws_th.p, d->text_lnw.as<float>(), d->text_lnb.as<float>(), d->ws_text.p, nullptr, L, D, s));
-    K5CHK(k5_launch_gemm_bf16(pool_bf, d->pool_w.p, d->pool_b.as<float>(), d->ws_pool_lin.p, 1, d->TD, c.in_text_dim2,
-                              c.in_text_dim2, c.in_text_dim2, d->TD, K5_EPI_BIAS, nullptr, 0, nullptr, s));
-    K5CHK(k5_launch_ln_affine(d->ws_pool_lin.p, d->pool_lnw.as<float>(), d->pool_lnb.as<float>(), nullptr,
-                              d->ws_pool_f32.as<float>(), 1, d->TD, s));
+    k5_dit::TextCache* tc = text_slot >= 0 ? &d->text_cache[text_slot] : nullptr;
+    if (tc && tc->valid && tc->L == L) {   // the text blocks update ws_text in place: restore their input
+      HIPCHK(hipMemcpyAsync(d->ws_text.p, tc->text.p, (size_t)L * D * 2, hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(d->ws_pool_f32.p, tc->pool.p, (size_t)d->TD * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+      const void* text_bf; const void* pool_bf;
+      K5CHK(to_bf16(d, s, cond.text_embed, cond.text_dtype, (size_t)L * c.in_text_dim, d->ws_text_in, &text_bf));
+      K5CHK(to_bf16(d, s, cond.pooled_embed, cond.text_dtype, (size_t)c.in_text_dim2, d->ws_pool_in, &pool_bf));
+      K5CHK(k5_launch_gemm_bf16(text_bf, d->text_w.p, d->text_b.as<float>(), d->ws_th.p, L, D, c.in_text_dim, c.in_text_dim,
+                                c.in_text_dim, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+      K5CHK(k5_launch_ln_affine(d->ws_th.p, d->text_lnw.as<float>(), d->text_lnb.as<float>(), d->ws_text.p, nullptr, L, D, s));
+      K5CHK(k5_launch_gemm_bf16(pool_bf, d->pool_w.p, d->pool_b.as<float>(), d->ws_pool_lin.p, 1, d->TD, c.in_text_dim2,
+                                c.in_text_dim2, c.in_text_dim2, d->TD, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+      K5CHK(k5_launch_ln_affine(d->ws_pool_lin.p, d->pool_lnw.as<float>(), d->pool_lnb.as<float>(), nullptr,
+                                d->ws_pool_f32.as<float>(), 1, d->TD, s));
+      if (tc) {
+        K5CHK(tc->text.ensure((size_t)L * D * 2)); K5CHK(tc->pool.ensure((size_t)d->TD * 4));
+        HIPCHK(hipMemcpyAsync(tc->text.p, d->ws_text.p, (size_t)L * D * 2, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(tc->pool.p, d->ws_pool_f32.p, (size_t)d->TD * 4, hipMemcpyDeviceToDevice, s));
+        tc->valid = true; tc->L = L;
+      }
+    }
     K5CHK(k5_launch_time_features(time, d->ws_tfeat.as<float>(), D, s, tvec, step));
     K5CHK(k5_launch_gemv_f32(d->ws_tfeat.as<float>(), d->time_w1.as<float>(), d->time_b1.as<float>(), d->ws_th1.as<float>(),
                              d->TD, D, 0, nullptr, s));
@@ -919,6 +938,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
   d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_kc.release(); d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
   d->ws_attn_stats.release(); d->ws_attn_flags.release(); d->ws_attn_cnt.release();
+  for (auto& t : d->text_cache) { t.text.release(); t.pool.release(); }
   d->mag.residual[0].release(); d->mag.residual[1].release(); d->mag.pm_one.release();
   for (auto& b : d->vblocks) { b.w1_f8.release(); b.w2_f8.release(); b.s1_f8.release(); b.s2_f8.release(); }
   if (d->graph_stream) { (void)hipStreamSynchronize(d->graph_stream); (void)hipStreamDestroy(d->graph_stream); (void)hipEventDestroy(d->ev_graph); }
@@ -1130,10 +1150,11 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
     HIPCHK(hipStreamSynchronize(s));   // host_tab is a local
     tvec = d->ws_sched.as<float>(); dtvec = tvec + a->num_steps;
   }
+  d->text_cache[0].valid = d->text_cache[1].valid = false;   // the prompt tensors are constant for THIS call only
   auto one_step = [&](int i) -> int {
     const float t1000 = host_tab[i], dt = host_tab[a->num_steps + i];
-    K5CHK(forward_impl(d, &a->fwd, a->fwd.cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_c.p, s, tvec, step));
-    if (cfg_on) K5CHK(forward_impl(d, &a->fwd, a->null_cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_u.p, s, tvec, step));
+    K5CHK(forward_impl(d, &a->fwd, a->fwd.cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_c.p, s, tvec, step, 0));
+    if (cfg_on) K5CHK(forward_impl(d, &a->fwd, a->null_cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_u.p, s, tvec, step, 1));
     {
       Scope sc(d, s, "elementwise");
       K5CHK(k5_launch_cfg_euler(a->latent, d->ws_vel_c.p, cfg_on ? d->ws_vel_u.p : nullptr, a->guidance_weight, dt, n, s, dtvec, step));

@@ -192,7 +192,12 @@ def test_generate_sample_postprocess_matches_reference_uint8(vae):
     u8 = ((dec.clamp(-1.0, 1.0) + 1.0) * 127.5).to(torch.uint8)           # generation_utils.py:222
     ref = V.postprocess_uint8(_r16(V.decoder_forward(sd, z, CFG, "bf16")))
     diff = (u8.int().cpu() - ref.int()).abs()
-    assert diff.float().mean().item() < 1.0 and (diff <= 8).float().mean().item() > 0.99
+    hist = [round((diff == i).float().mean().item(), 5) for i in range(int(diff.max()) + 1)]
+    print("uint8 |engine - oracle| histogram (fraction of pixels per grey-level difference):", hist)
+    # Two bf16 evaluations of the same ~30-layer decoder (different fp32 summation orders) sit ~1e-2 apart in relative L2,
+    # i.e. ~1 grey level of the 255 on this random-weight decoder — DESIGN.md §2 states exactly what is asserted here:
+    assert diff.float().mean().item() < 1.0
+    assert (diff <= 1).float().mean().item() >= 0.75 and (diff <= 3).float().mean().item() >= 0.99 and int(diff.max()) <= 8, hist
 
 
 def _r16(x):

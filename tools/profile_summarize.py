@@ -56,23 +56,26 @@ def attention_block_md():
             groups[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     lines = ["", "## Attention launches by grid (kernel trace of the same run)", "",
              "| kernel | workgroups | launches | avg us | role |", "|---|---:|---:|---:|---|"]
-    block_us = 0.0
+    self_total_us, n_merge = 0.0, 0
     for (name, wgs), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         avg = sum(v) / len(v)
+        pre = "true>(" in name.replace(" ", "") or name.rstrip().endswith("true>") or ", true>" in name   # <.., PRE = true>: visual self-attention
         role = ""
-        if wgs == 5120:
-            role = "self-attention, 5120 whole-round jobs"; block_us += avg
-        elif "merge" in name:
-            role = "merge of the split tail jobs"; block_us += avg
-        elif wgs in (352, 264, 176):
-            role = "self-attention, 88 tail jobs x parts"; block_us += avg
-        elif wgs == 5208:
-            role = "cross-attention (N queries x 256 text keys) / unbalanced launch"
+        if "merge" in name:
+            role = "merge of the split tail jobs (1 per block)"; self_total_us += sum(v); n_merge += len(v)
+        elif pre and "<true" in name:
+            role = "self-attention, fixed-offset form" + (" (whole-round jobs)" if wgs >= 5000 else " (tail jobs x parts)"); self_total_us += sum(v)
+        elif pre:
+            role = "self-attention, online-max form: same grid, exits at once unless the head is flagged"; self_total_us += sum(v)
+        else:
+            role = "cross / text attention"
         lines.append(f"| `{name}` | {wgs} | {len(v)} | {avg:.1f} | {role} |")
     lines.append("")
-    lines.append(f"Self-attention of one block = {block_us / 1e3:.2f} ms (sum of the three rows above) -> "
-                 f"{4.0 * 47616 * 47616 * 64 * 28 / (block_us * 1e-6) / 1e12:.0f} TFLOP/s; bench.py's `roofline.avg_launch_ms` is the HIP-event "
-                 "time of the same three launches.")
+    if n_merge:
+        block_us = self_total_us / n_merge
+        lines.append(f"Self-attention of one block = {block_us / 1e3:.2f} ms (all self-attention rows above: {self_total_us / 1e3:.1f} ms over {n_merge} blocks) -> "
+                     f"{4.0 * 47616 * 47616 * 64 * 28 / (block_us * 1e-6) / 1e12:.0f} TFLOP/s; bench.py's `roofline.avg_launch_ms` is the HIP-event "
+                     "time of the same launch group (events also see the gaps between its launches).")
     open(f"{OUT}/{tag}_bench_kernel_stats.md", "a").write("\n".join(lines) + "\n")
 
 
@@ -95,7 +98,7 @@ for k, d in sorted(per_kernel.items(), key=lambda kv: -max(kv[1]["FETCH_SIZE"] o
     w = max(d["WRITE_SIZE"]) if d["WRITE_SIZE"] else 0.0
     short = k.replace("(anonymous namespace)::", "")[:80]
     md.append(f"| `{short}` | {len(d['FETCH_SIZE'])} | {2 * f / 1024:.1f} | {w / 1024:.1f} |")
-    if "attn_fwd_kernel<true, false, false>" in k or (attn_main is None and "attn_fwd" in k):
+    if "attn_fwd_kernel<true, false, true, true>" in k.replace("(anonymous namespace)::", "") or (attn_main is None and "attn_fwd" in k):
         attn_main = (k, f, w)
 open(f"{OUT}/{tag}_hbm_traffic.md", "w").write("\n".join(md) + "\n")
 if attn_main:
