@@ -795,6 +795,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int j = 0; j < 8; ++j) { W4_RD(xf0[j], xbs[0], j * 128); W4_RD(xf1[0][j], xbs[0], j * 128 + 64); }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // (schedule 2 re-reads the k-step-1 fragments at the start of the K-tile; the extra 16 reads here happen once per workgroup)
 
   // One K-tile t (stage st = t & 1) = 128 MFMAs, m = 0..127: k-step 0 (m < 64) on wf0/xf0, k-step 1 on wf1[st]/xf1[st].  ALL of
   // its fragments are in registers when it starts, so its stage is refilled from the top:
@@ -854,12 +855,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     dma_advance();
   };
 
+#ifndef W4_SCHED
+#define W4_SCHED 1
+#endif
+  // Schedule 2 (W4_SCHED=2): ONE fragment set.  K-tile t (stage st): its k-step-0 fragments are in registers (read at the end
+  // of K-tile t-1), its k-step-1 fragments are read at the START of the tile — W's first, then barrier -> the W half of the
+  // stage is free and W(t+2) streams in while X's k-step-1 fragments are read, barrier -> X(t+2) — and the k-step-0 fragments of
+  // K-tile t+1 are read in the LAST quarter, after the one vmcnt + barrier that says "K-tile t+1 has landed".  Against
+  // schedule 1 the landing deadline of a K-tile moves from m = 63 to m = S2_WAIT of the tile before it is used (the last DMA of a
+  // tile gets ~50 % more time), for one more barrier per K-tile and 64 fewer live registers.
+  constexpr int S2_R1 = 0, S2_RS1 = 2;          // W k-step-1 reads at m = 0, 2, .., 14
+  constexpr int S2_B1 = 17;                     // lgkmcnt(0) + barrier after m = 17: W half of the stage is free
+  constexpr int S2_DW = 18, S2_DS = 3;          // W DMAs at m = 18, 21, .., 39   (8)
+  constexpr int S2_R2 = 19;                     // X k-step-1 reads at m = 19, 21, .., 33
+  constexpr int S2_B2 = 41;                     // lgkmcnt(0) + barrier after m = 41: X half free
+  constexpr int S2_DX = 42, S2_DXS = 7;         // X DMAs at m = 42, 49, .., 91    (8)
+  constexpr int S2_WAIT = 97;                   // vmcnt(16) + barrier after m = 97: K-tile t+1 (issued a K-tile ago) landed
+  constexpr int S2_R0 = 98, S2_R0S = 2;         // k-step-0 reads of K-tile t+1: W at m = 98, 100, .. 112 and X at m = 99, 101, .. 113
+  static_assert(S2_DX + 7 * S2_DXS < S2_WAIT, "all 16 DMAs of the K-tile are issued before the wait (vmcnt(16) = the tile before)");
+  auto ktile2 = [&](auto STC, auto FIRSTC) {
+    constexpr int st = decltype(STC)::value;
+    constexpr bool first = decltype(FIRSTC)::value;
+    auto chunk = [&](auto BASEC) {
+#pragma unroll
+      for (int m = decltype(BASEC)::value; m < decltype(BASEC)::value + 16; ++m) {
+        if (!(dbg & 8)) {
+          if (m < 64 && first) W4_MF0(wf0, xf0, m);
+          else if (m < 64) W4_MF(wf0, xf0, m);
+          else W4_MF(wf1[0], xf1[0], m - 64);
+        }
+        if (!(dbg & 2)) {
+          if (m >= S2_R1 && m < S2_R1 + 8 * S2_RS1 && (m - S2_R1) % S2_RS1 == 0) W4_RD(wf1[0][(m - S2_R1) / S2_RS1], wbs[st], ((m - S2_R1) / S2_RS1) * 128 + 64);
+          if (m >= S2_R2 && m < S2_R2 + 8 * S2_RS1 && (m - S2_R2) % S2_RS1 == 0) W4_RD(xf1[0][(m - S2_R2) / S2_RS1], xbs[st], ((m - S2_R2) / S2_RS1) * 128 + 64);
+          if (m >= S2_R0 && m < S2_R0 + 8 * S2_R0S && (m - S2_R0) % S2_R0S == 0) W4_RD(wf0[(m - S2_R0) / S2_R0S], wbs[st ^ 1], ((m - S2_R0) / S2_R0S) * 128);
+          if (m >= S2_R0 + 1 && m < S2_R0 + 1 + 8 * S2_R0S && (m - S2_R0 - 1) % S2_R0S == 0) W4_RD(xf0[(m - S2_R0 - 1) / S2_R0S], xbs[st ^ 1], ((m - S2_R0 - 1) / S2_R0S) * 128);
+        }
+        if (m == S2_B1 || m == S2_B2) {
+          if (dbg & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (m >= S2_DW && m < S2_DW + 8 * S2_DS && (m - S2_DW) % S2_DS == 0) dma1(st, (m - S2_DW) / S2_DS);
+        if (m >= S2_DX && m < S2_DX + 8 * S2_DXS && (m - S2_DX) % S2_DXS == 0) dma1(st, 8 + (m - S2_DX) / S2_DXS);
+        if (m == S2_WAIT) {
+          if (dbg & 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        }
+      }
+    };
+    chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 16>{}); chunk(std::integral_constant<int, 32>{});
+    chunk(std::integral_constant<int, 48>{}); chunk(std::integral_constant<int, 64>{}); chunk(std::integral_constant<int, 80>{});
+    chunk(std::integral_constant<int, 96>{}); chunk(std::integral_constant<int, 112>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // K-tile t+1's k-step-0 fragments
+    dma_advance();
+  };
+  auto kt = [&](auto STC, auto FIRSTC) { if constexpr (W4_SCHED == 2) ktile2(STC, FIRSTC); else ktile(STC, FIRSTC); };
+
   for (int ti = slot; ti < x_cnt; ti += per_xcd) {
-    ktile(std::integral_constant<int, 0>{}, std::true_type{});
-    ktile(std::integral_constant<int, 1>{}, std::false_type{});
+    kt(std::integral_constant<int, 0>{}, std::true_type{});
+    kt(std::integral_constant<int, 1>{}, std::false_type{});
     for (int t = 2; t < nk; t += 2) {
-      ktile(std::integral_constant<int, 0>{}, std::false_type{});
-      ktile(std::integral_constant<int, 1>{}, std::false_type{});
+      kt(std::integral_constant<int, 0>{}, std::false_type{});
+      kt(std::integral_constant<int, 1>{}, std::false_type{});
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs are invisible to the hazard recogniser: let the last ones retire
     int m0, n0;

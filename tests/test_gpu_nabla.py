@@ -88,9 +88,13 @@ def test_nabla_map_matches_oracle(E, grid, window, P, H, data):
         # exact ties: which of several EQUAL probabilities straddling the cut are kept depends on the sort's order among
         # them (the reference's torch.sort is not stable; the kernel ranks ties by index) -> a differing entry may also be
         # one that ties with an entry at the threshold
+        # -> a differing entry may also belong to a tie group whose cumulative span [below the group, top of the group]
+        # contains the threshold
         for h, i, j in diff.nonzero().tolist():
             tied = p[h, i] == p[h, i, j]
-            assert near[h, i][tied].any(), (h, i, j, float(cdf[h, i, j]), thr)
+            lo = float((cdf[h, i][tied] - p[h, i][tied]).min()) - tol
+            hi = float(cdf[h, i][tied].max()) + tol
+            assert near[h, i, j] or (int(tied.sum()) > 1 and lo <= thr <= hi), (h, i, j, float(cdf[h, i, j]), thr, int(tied.sum()))
     assert diff.float().mean().item() <= (1e-3 if data == "exact" else 5e-3), (int(diff.sum()), diff.numel())
     assert (got & sta[None]).sum() == sta.sum() * H                     # the STA window is always kept
     assert got.any(-1).all()                                            # every row keeps at least one block
