@@ -908,14 +908,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // K-tile t+1's k-step-0 fragments
     dma_advance();
   };
-  auto kt = [&](auto STC, auto FIRSTC) { if constexpr (W4_SCHED == 2) ktile2(STC, FIRSTC); else ktile(STC, FIRSTC); };
+#if W4_SCHED == 2
+#define W4_KT ktile2
+#else
+#define W4_KT ktile
+#endif
 
   for (int ti = slot; ti < x_cnt; ti += per_xcd) {
-    kt(std::integral_constant<int, 0>{}, std::true_type{});
-    kt(std::integral_constant<int, 1>{}, std::false_type{});
+    W4_KT(std::integral_constant<int, 0>{}, std::true_type{});
+    W4_KT(std::integral_constant<int, 1>{}, std::false_type{});
     for (int t = 2; t < nk; t += 2) {
-      kt(std::integral_constant<int, 0>{}, std::false_type{});
-      kt(std::integral_constant<int, 1>{}, std::false_type{});
+      W4_KT(std::integral_constant<int, 0>{}, std::false_type{});
+      W4_KT(std::integral_constant<int, 1>{}, std::false_type{});
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs are invisible to the hazard recogniser: let the last ones retire
     int m0, n0;
@@ -1000,6 +1004,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // first K-tiles have had the whole epilogue to land either way).
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   }
+#undef W4_KT
 #undef W4_MF
 #undef W4_MF0
 #undef W4_RD

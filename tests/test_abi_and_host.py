@@ -208,3 +208,32 @@ def test_default_configs_equal_the_reference_configs_and_materialise(tmp_path):
     assert conf.model.attention.type == "nabla" and conf.model.num_steps == 50 and len(conf.magcache.mag_ratios) == 98
     assert conf.to_dict() == ref["config_10s_sft.yaml"]
     assert sorted(os.listdir(tmp_path / "configs")) == sorted(DEFAULT_CONFIG_NAMES)
+
+
+def test_hot_kernels_keep_their_register_budget():
+    """The hand-scheduled kernels live or die by their register allocation: an innocent source edit once sent the 256
+    accumulators of the 4-wave GEMM to scratch (2416 B/lane, 40x slower, every parity test still green).  build.py records
+    the compiler's per-kernel resource report; this pins the budgets the performance numbers in DESIGN.md rest on."""
+    import json
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("k5_build", os.path.join(PKG, "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    if not os.path.exists(b.RESOURCES):
+        b.build(force=True, verbose=False)
+    res = json.load(open(b.RESOURCES))
+
+    def kernels(tag):
+        ks = {k: v for k, v in res.items() if tag in k}
+        assert ks, tag
+        return ks
+    for k, v in kernels("gemm_bf16_w4_kernel").items():       # 256 accumulators in AGPRs, one wave per SIMD
+        assert v["AGPRs"] == 256 and v["ScratchSize [bytes/lane]"] <= 64 and v["VGPRs Spill"] <= 8, (k, v)
+    for k, v in kernels("conv3d_w4_kernel").items():
+        assert v["ScratchSize [bytes/lane]"] <= 128, (k, v)
+    for k, v in kernels("attn_fwd_kernelILb1E").items():        # fixed-offset forms: two workgroups per CU
+        assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
+    for k, v in kernels("attn_fwd_kernelILb0E").items():        # online-max forms: no spills at their (larger) budget
+        assert v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
+    for k, v in kernels("attn_fwd32_kernel").items():
+        assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0, (k, v)
