@@ -266,12 +266,20 @@ typedef struct k5_vae_config {   /* AutoencoderKLHunyuanVideo.__init__ kwargs, v
 } k5_vae_config;
 int k5_vae_create(const k5_vae_config* cfg, k5_vae** out);
 void k5_vae_destroy(k5_vae* vae);
-/* checkpoint tensors by state_dict key (decoder.* and post_quant_conv.*; other keys are ignored), host or device ptr */
+/* checkpoint tensors by state_dict key (decoder.*, post_quant_conv.*; encoder.*, quant_conv.* enable k5_vae_encode_tile;
+ * other keys are ignored), host or device ptr */
 int k5_vae_load_tensor(k5_vae* vae, const char* key, const void* ptr, int dtype, const int64_t* shape, int rank);
 int k5_vae_finalize(k5_vae* vae);
 /* z: device fp32 (latent_channels,T,H,W) (already divided by scaling_factor, generation_utils.py:220) ->
  * out: device bf16 (out_channels, 4(T-1)+1, 8H, 8W) = self.decoder(self.post_quant_conv(z)) */
 int k5_vae_decode_tile(k5_vae* vae, const float* z, int T, int H, int W, void* out, void* stream);
+/* Encoder half (SURVEY.md §8 f4 — image / video conditioning): quant_conv(HunyuanVideoEncoder3D.forward(x)) on ONE tile
+ * (vae.py:574-586, 808-809); the tiling policy (tiled_encode :938-1010, _temporal_tiled_encode :1096-1142) stays on the
+ * host mirror.  Needs the encoder.* / quant_conv.* tensors (k5_vae_has_encoder = 1; a decode-only load leaves them out).
+ * x: device fp32 (3, T, H, W), T = 4k+1 frames, H, W multiples of 8 -> out: device bf16 (2*latent_channels, k+1, H/8, W/8)
+ * = the moments [mean | logvar] the reference hands to DiagonalGaussianDistribution. */
+int k5_vae_encode_tile(k5_vae* vae, const float* x, int T, int H, int W, void* out, void* stream);
+int k5_vae_has_encoder(k5_vae* vae);
 /* blend_t / blend_v / blend_h (vae.py:908-936) on contiguous bf16 tensors viewed as [outer][len][inner]:
  * b[:, y, :] = a[:, len_a-extent+y, :]*(1-y/extent) + b[:, y, :]*(y/extent), y < extent (eager bf16 rounding) */
 int k5_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, void* stream);

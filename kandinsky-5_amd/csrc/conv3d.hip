@@ -27,8 +27,10 @@ struct ConvP {
   const bf16_t* X; const bf16_t* W; bf16_t* C;
   const float* bias; const bf16_t* resid;
   int Ts, Hs, Ws;     // source grid
-  int To, Ho, Wo;     // output grid (= source, or its upsampled size)
+  int To, Ho, Wo;     // output grid (= source, its upsampled size, or its strided size)
+  int Hu, Wu;         // clamp extent of the gather = up_s * (Hs, Ws)
   int up_t, up_s;     // nearest-upsample factors folded into the gather (1 or 2)
+  int st_t, st_s;     // output stride (encoder downsample, vae.py:208-227): source = out * stride + tap - pad; 1 with an upsample
   int Cin, Cout, M, ldc, ldr;
   int tiles_m, tiles_n;
 };
@@ -65,9 +67,9 @@ __global__ __launch_bounds__(256) void conv3d_kernel(ConvP p) {
     const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int tu = max(ro_t[i] + dt - 2, 0);                       // causal: 2 frames of replicate pad in front
-      int hu = min(max(ro_h[i] + dh - 1, 0), p.Ho - 1);
-      int wu = min(max(ro_w[i] + dw - 1, 0), p.Wo - 1);
+      int tu = max(ro_t[i] * p.st_t + dt - 2, 0);              // causal: 2 frames of replicate pad in front
+      int hu = min(max(ro_h[i] * p.st_s + dh - 1, 0), p.Hu - 1);   // Hu, Wu: extent of the (virtually upsampled) source grid
+      int wu = min(max(ro_w[i] * p.st_s + dw - 1, 0), p.Wu - 1);
       if (p.up_t == 2) tu = tu == 0 ? 0 : 1 + ((tu - 1) >> 1); // frame 0 is not repeated in time (vae.py:190-199)
       if (p.up_s == 2) { hu >>= 1; wu >>= 1; }
       ga[i] = p.X + ((size_t)(tu * p.Hs + hu) * p.Ws + wu) * p.Cin + rc[i];
@@ -157,11 +159,20 @@ __global__ __launch_bounds__(256) void conv3d_kernel(ConvP p) {
 // (To,Ho,Wo) = (Ts,Hs,Ws) scaled by the folded nearest upsample: Ho = up_s*Hs, Wo = up_s*Ws, To = up_t==2 ? 2*Ts-1 : Ts.
 int k5_launch_conv3d_bf16(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin,
                           int Cout, int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream) {
+  return k5_launch_conv3d_bf16_strided(X, W, bias, out, Ts, Hs, Ws, Cin, Cout, up_t, up_s, 1, 1, ldc, resid, ldr, stream);
+}
+
+// The same with an output stride (st_t, st_s in {1, 2}; only without upsample): HunyuanVideoDownsampleCausal3D (vae.py:208-227,
+// encoder).  Output grid: To = (Ts - 1) / st_t + 1, Ho = (Hs - 1) / st_s + 1, Wo likewise (pad (1,1),(1,1),(2,0), kernel 3, padding 0).
+int k5_launch_conv3d_bf16_strided(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin,
+                                  int Cout, int up_t, int up_s, int st_t, int st_s, int ldc, const void* resid, int ldr, hipStream_t stream) {
   if (Ts <= 0 || Hs <= 0 || Ws <= 0 || Cout <= 0 || !bias) return K5_ERR_ARG;
   if (Cin <= 0 || (Cin % 64)) return K5_ERR_ALIGN;
   if ((up_t != 1 && up_t != 2) || (up_s != 1 && up_s != 2)) return K5_ERR_ARG;
+  if ((st_t != 1 && st_t != 2) || (st_s != 1 && st_s != 2) || ((st_t > 1 || st_s > 1) && (up_t > 1 || up_s > 1))) return K5_ERR_ARG;
+  const bool strided = st_t > 1 || st_s > 1;
   static const int force = getenv("K5_CONV_V1") ? atoi(getenv("K5_CONV_V1")) : 0;   // A/B: 1 = always the 128 x 128 kernel below
-  if (force != 1) {
+  if (force != 1 && !strided) {
     const int r = k5_launch_conv3d_w4(X, W, bias, out, Ts, Hs, Ws, Cin, Cout, up_t, up_s, ldc, resid, ldr, stream);
     if (r != K5_ERR_UNSUPPORTED) return r;
   }
@@ -169,6 +180,8 @@ int k5_launch_conv3d_bf16(const void* X, const void* W, const float* bias, void*
   p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.C = (bf16_t*)out; p.bias = bias; p.resid = (const bf16_t*)resid;
   p.Ts = Ts; p.Hs = Hs; p.Ws = Ws;
   p.To = up_t == 2 ? 2 * Ts - 1 : Ts; p.Ho = up_s * Hs; p.Wo = up_s * Ws;
+  p.Hu = p.Ho; p.Wu = p.Wo; p.st_t = st_t; p.st_s = st_s;
+  if (strided) { p.To = (Ts - 1) / st_t + 1; p.Ho = (Hs - 1) / st_s + 1; p.Wo = (Ws - 1) / st_s + 1; }
   p.up_t = up_t; p.up_s = up_s; p.Cin = Cin; p.Cout = Cout; p.ldc = ldc; p.ldr = ldr;
   const long long M = (long long)p.To * p.Ho * p.Wo;
   if (M > 0x7fffffffLL) return K5_ERR_UNSUPPORTED;

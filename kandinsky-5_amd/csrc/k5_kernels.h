@@ -113,6 +113,8 @@ int k5_launch_conv3d_w4(const void* X, const void* W, const float* bias, void* o
                         int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream);
 int k5_launch_conv3d_bf16(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin,
                           int Cout, int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream);
+int k5_launch_conv3d_bf16_strided(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin,
+                                  int Cout, int up_t, int up_s, int st_t, int st_s, int ldc, const void* resid, int ldr, hipStream_t stream);
 size_t k5_groupnorm_workspace_bytes(int M, int G);
 int k5_launch_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
                              int silu, int ldx, int ldo, void* workspace, hipStream_t s);

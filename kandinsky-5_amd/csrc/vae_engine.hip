@@ -71,6 +71,8 @@ struct Conv { Buf w, b; int cin = 0, cin_pad = 0, cout = 0, k = 3; };   // k=3: 
 struct GN { Buf g, b; int c = 0; };
 struct Resnet { GN n1, n2; Conv c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; };
 struct Up { Conv conv; int up_t = 1, up_s = 1; bool present = false; };
+struct Down { Conv conv; int st_t = 1, st_s = 1; bool present = false; };
+struct MidAttn { GN gn; Buf wqk, bqk, wv, bv, wo, bo, ones; };   // diffusers Attention of the mid block: 1 head of dim C
 
 inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -83,10 +85,20 @@ struct k5_vae {
   std::vector<std::string> expected;
   Conv pq, conv_in, conv_out;
   Resnet mid0, mid1;
-  GN attn_gn; Buf attn_wqk, attn_bqk, attn_wv, attn_bv, attn_wo, attn_bo, ones;
+  MidAttn attn;
   std::vector<std::vector<Resnet>> up_res;
   std::vector<Up> ups;
   GN norm_out;
+  // encoder half (vae.py:478-586 + quant_conv :747): optional — a T2V checkpoint load may leave it out
+  std::vector<std::string> expected_enc;
+  bool has_encoder = false;
+  Conv e_conv_in, e_conv_out, e_quant;
+  std::vector<std::vector<Resnet>> down_res;
+  std::vector<Down> downs;
+  Resnet e_mid0, e_mid1;
+  MidAttn e_attn;
+  GN e_norm_out;
+  Buf xin, mom;
   int G = 32;
   // workspaces
   Buf zin, x0, bx, balt, bt1, bt2, bres, gnws, qk, vt, scores, P, o, yout;
@@ -143,6 +155,40 @@ int pack_linear(k5_vae* v, const std::string& n, std::vector<uint16_t>& w, std::
   return K5_OK;
 }
 
+int pack_mid_attn(k5_vae* v, const std::string& ap, MidAttn& a) {
+  K5CHK(pack_gn(v, ap + "group_norm", a.gn));
+  std::vector<uint16_t> w; std::vector<float> b;
+  K5CHK(pack_linear(v, ap + "to_q", w, b)); K5CHK(pack_linear(v, ap + "to_k", w, b));
+  K5CHK(upload_bf16(a.wqk, w)); K5CHK(upload_f32(a.bqk, b.data(), b.size()));
+  w.clear(); b.clear(); K5CHK(pack_linear(v, ap + "to_v", w, b));
+  K5CHK(upload_bf16(a.wv, w)); K5CHK(upload_f32(a.bv, b.data(), b.size()));
+  w.clear(); b.clear(); K5CHK(pack_linear(v, ap + "to_out.0", w, b));
+  K5CHK(upload_bf16(a.wo, w)); K5CHK(upload_f32(a.bo, b.data(), b.size()));
+  std::vector<float> one(a.gn.c, 1.0f);
+  return upload_f32(a.ones, one.data(), one.size());
+}
+
+// encoder.* / quant_conv.* keys (HunyuanVideoEncoder3D.__init__ vae.py:504-572)
+void expected_enc_keys(const k5_vae_config& c, std::vector<std::string>& out) {
+  auto wb = [&](const std::string& n) { out.push_back(n + ".weight"); out.push_back(n + ".bias"); };
+  auto resnet = [&](const std::string& p, bool sc) {
+    wb(p + ".norm1"); wb(p + ".conv1.conv"); wb(p + ".norm2"); wb(p + ".conv2.conv");
+    if (sc) wb(p + ".conv_shortcut.conv");
+  };
+  wb("quant_conv"); wb("encoder.conv_in.conv");
+  int prev = c.block_out_channels[0];
+  for (int i = 0; i < 4; ++i) {
+    const int outc = c.block_out_channels[i];
+    for (int j = 0; j < c.layers_per_block; ++j)
+      resnet("encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), (j == 0 ? prev : outc) != outc);
+    if (i < 3) wb("encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv.conv");
+    prev = outc;
+  }
+  resnet("encoder.mid_block.resnets.0", false); resnet("encoder.mid_block.resnets.1", false);
+  for (const char* n : {"group_norm", "to_q", "to_k", "to_v", "to_out.0"}) wb(std::string("encoder.mid_block.attentions.0.") + n);
+  wb("encoder.conv_norm_out"); wb("encoder.conv_out.conv");
+}
+
 void expected_keys(const k5_vae_config& c, std::vector<std::string>& out) {
   auto wb = [&](const std::string& n) { out.push_back(n + ".weight"); out.push_back(n + ".bias"); };
   auto resnet = [&](const std::string& p, bool sc) {
@@ -186,20 +232,20 @@ int resnet(k5_vae* v, hipStream_t s, const Resnet& r, const void* x, void* out, 
   return conv(s, r.c2, v->bt1.p, out, T, H, W, 1, 1, res);
 }
 
-int mid_attention(k5_vae* v, hipStream_t s, void* h, int T, int H, int W) {
-  const int C = v->attn_gn.c, S = T * H * W, Sp = (int)rup(S, 8);
+int mid_attention(k5_vae* v, hipStream_t s, const MidAttn& a, void* h, int T, int H, int W) {
+  const int C = a.gn.c, S = T * H * W, Sp = (int)rup(S, 8);
   K5CHK(v->qk.ensure((size_t)S * 2 * C * 2)); K5CHK(v->vt.ensure((size_t)C * Sp * 2));
   K5CHK(v->scores.ensure((size_t)S * Sp * 4)); K5CHK(v->P.ensure((size_t)S * Sp * 2)); K5CHK(v->o.ensure((size_t)S * C * 2));
-  K5CHK(gn(v, s, v->attn_gn, h, v->bt1.p, S, false));
-  K5CHK(k5_launch_gemm_bf16(v->bt1.p, v->attn_wqk.p, v->attn_bqk.as<float>(), v->qk.p, S, 2 * C, C, C, C, 2 * C, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+  K5CHK(gn(v, s, a.gn, h, v->bt1.p, S, false));
+  K5CHK(k5_launch_gemm_bf16(v->bt1.p, a.wqk.p, a.bqk.as<float>(), v->qk.p, S, 2 * C, C, C, C, 2 * C, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   HIPCHK(hipMemsetAsync(v->vt.p, 0, (size_t)C * Sp * 2, s));
-  K5CHK(k5_launch_gemm_bf16(v->attn_wv.p, v->bt1.p, v->attn_bv.as<float>(), v->vt.p, C, S, C, C, C, Sp, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+  K5CHK(k5_launch_gemm_bf16(a.wv.p, v->bt1.p, a.bv.as<float>(), v->vt.p, C, S, C, C, C, Sp, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
   K5CHK(k5_launch_gemm_bf16_f32out(v->qk.p, v->qk.as<bf16_t>() + C, v->scores.as<float>(), S, S, C, 2 * C, 2 * C, Sp,
                                     1.0f / sqrtf((float)C), s));
   K5CHK(k5_launch_causal_softmax(v->scores.as<float>(), v->P.p, S, H * W, Sp, Sp, s));
   K5CHK(k5_launch_gemm_bf16(v->P.p, v->vt.p, nullptr, v->o.p, S, C, Sp, Sp, Sp, C, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   // to_out[0] + residual (diffusers Attention residual_connection=True): bf16(h + 1 * bf16(o Wo^T + bo)), in place
-  return k5_launch_gemm_bf16(v->o.p, v->attn_wo.p, v->attn_bo.as<float>(), h, S, C, C, C, C, C, K5_EPI_GATE, h, C, v->ones.as<float>(), s);
+  return k5_launch_gemm_bf16(v->o.p, a.wo.p, a.bo.as<float>(), h, S, C, C, C, C, C, K5_EPI_GATE, h, C, a.ones.as<float>(), s);
 }
 
 }  // namespace
@@ -217,6 +263,7 @@ extern "C" int k5_vae_create(const k5_vae_config* cfg, k5_vae** out) {
   k5_vae* v = new k5_vae();
   v->cfg = *cfg; v->G = G;
   expected_keys(*cfg, v->expected);
+  expected_enc_keys(*cfg, v->expected_enc);
   *out = v;
   return K5_OK;
 }
@@ -228,7 +275,8 @@ extern "C" int k5_vae_load_tensor(k5_vae* v, const char* key, const void* ptr, i
   if (v->finalized) return K5_ERR_STATE;
   bool known = false;
   for (auto& e : v->expected) if (e == key) { known = true; break; }
-  if (!known) return K5_OK;  // encoder / quant_conv tensors of the checkpoint are not needed by decode (T2V never encodes)
+  if (!known) for (auto& e : v->expected_enc) if (e == key) { known = true; break; }
+  if (!known) return K5_OK;  // anything else in the checkpoint is ignored
   HostT t; size_t n = 1;
   for (int i = 0; i < rank; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
   t.d.resize(n);
@@ -255,19 +303,7 @@ extern "C" int k5_vae_finalize(k5_vae* v) {
   K5CHK(pack_conv(v, "decoder.conv_in.conv", v->conv_in));
   K5CHK(pack_resnet(v, "decoder.mid_block.resnets.0", v->mid0));
   K5CHK(pack_resnet(v, "decoder.mid_block.resnets.1", v->mid1));
-  const std::string ap = "decoder.mid_block.attentions.0.";
-  K5CHK(pack_gn(v, ap + "group_norm", v->attn_gn));
-  {
-    std::vector<uint16_t> w; std::vector<float> b;
-    K5CHK(pack_linear(v, ap + "to_q", w, b)); K5CHK(pack_linear(v, ap + "to_k", w, b));
-    K5CHK(upload_bf16(v->attn_wqk, w)); K5CHK(upload_f32(v->attn_bqk, b.data(), b.size()));
-    w.clear(); b.clear(); K5CHK(pack_linear(v, ap + "to_v", w, b));
-    K5CHK(upload_bf16(v->attn_wv, w)); K5CHK(upload_f32(v->attn_bv, b.data(), b.size()));
-    w.clear(); b.clear(); K5CHK(pack_linear(v, ap + "to_out.0", w, b));
-    K5CHK(upload_bf16(v->attn_wo, w)); K5CHK(upload_f32(v->attn_bo, b.data(), b.size()));
-    std::vector<float> one(v->attn_gn.c, 1.0f);
-    K5CHK(upload_f32(v->ones, one.data(), one.size()));
-  }
+  K5CHK(pack_mid_attn(v, "decoder.mid_block.attentions.0.", v->attn));
   v->up_res.resize(4); v->ups.resize(4);
   for (int i = 0; i < 4; ++i) {  // up-block schedule vae.py:644-659 (time_compression 4, spatial 8)
     v->up_res[i].resize(c.layers_per_block + 1);
@@ -281,6 +317,38 @@ extern "C" int k5_vae_finalize(k5_vae* v) {
   }
   K5CHK(pack_gn(v, "decoder.conv_norm_out", v->norm_out));
   K5CHK(pack_conv(v, "decoder.conv_out.conv", v->conv_out));
+  // encoder: all of its keys or none (decode-only checkpoints)
+  {
+    int have = 0;
+    for (auto& e : v->expected_enc) have += v->staged.count(e) ? 1 : 0;
+    if (have && have != (int)v->expected_enc.size()) {
+      std::string names; int miss = 0;
+      for (auto& e : v->expected_enc) if (!v->staged.count(e)) { if (miss++ < 6) names += e + " "; }
+      k5_set_error("VAE encoder: %d of its keys are missing: %s", miss, names.c_str());
+      return K5_ERR_KEY;
+    }
+    if (have) {
+      K5CHK(pack_conv(v, "quant_conv", v->e_quant));
+      K5CHK(pack_conv(v, "encoder.conv_in.conv", v->e_conv_in));
+      v->down_res.resize(4); v->downs.resize(4);
+      for (int i = 0; i < 4; ++i) {   // down-block schedule vae.py:522-566 (temporal_compression_ratio 4, spatial 8)
+        v->down_res[i].resize(c.layers_per_block);
+        for (int j = 0; j < c.layers_per_block; ++j)
+          K5CHK(pack_resnet(v, "encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), v->down_res[i][j]));
+        const bool sp = i < 3, tm = (i >= 1) && (i != 3);
+        if (sp || tm) {
+          K5CHK(pack_conv(v, "encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv.conv", v->downs[i].conv));
+          v->downs[i].present = true; v->downs[i].st_t = tm ? 2 : 1; v->downs[i].st_s = sp ? 2 : 1;
+        }
+      }
+      K5CHK(pack_resnet(v, "encoder.mid_block.resnets.0", v->e_mid0));
+      K5CHK(pack_resnet(v, "encoder.mid_block.resnets.1", v->e_mid1));
+      K5CHK(pack_mid_attn(v, "encoder.mid_block.attentions.0.", v->e_attn));
+      K5CHK(pack_gn(v, "encoder.conv_norm_out", v->e_norm_out));
+      K5CHK(pack_conv(v, "encoder.conv_out.conv", v->e_conv_out));
+      v->has_encoder = true;
+    }
+  }
   v->staged.clear();
   v->finalized = true;
   return K5_OK;
@@ -320,7 +388,7 @@ extern "C" int k5_vae_decode_tile(k5_vae* v, const float* z, int T, int H, int W
   void* nxt = v->balt.p;
   auto swap = [&]() { void* t_ = cur; cur = nxt; nxt = t_; };
   K5CHK(resnet(v, s, v->mid0, cur, nxt, T, H, W)); swap();
-  K5CHK(mid_attention(v, s, cur, T, H, W));
+  K5CHK(mid_attention(v, s, v->attn, cur, T, H, W));
   K5CHK(resnet(v, s, v->mid1, cur, nxt, T, H, W)); swap();
   int t = T, h = H, w = W;
   for (int i = 0; i < 4; ++i) {
@@ -338,6 +406,59 @@ extern "C" int k5_vae_decode_tile(k5_vae* v, const float* z, int T, int H, int W
   K5CHK(k5_launch_mc_to_nchw(v->yout.p, out, c.out_channels, M, c.out_channels, s));
   return K5_OK;
 }
+
+// x: device fp32 (in_channels = 3, T, H, W), T = 4k + 1 frames (or 1), H, W multiples of 8 ->
+// out: device bf16 (2 * latent_channels, (T-1)/4+1, H/8, W/8) = quant_conv(encoder(x)) = [mean | logvar]   (vae.py:808-809)
+extern "C" int k5_vae_encode_tile(k5_vae* v, const float* x, int T, int H, int W, void* out, void* stream) {
+  if (!v || !x || !out || T <= 0 || H <= 0 || W <= 0) return K5_ERR_ARG;
+  if (!v->finalized) { k5_set_error("k5_vae_encode_tile before k5_vae_finalize"); return K5_ERR_STATE; }
+  if (!v->has_encoder) { k5_set_error("this VAE handle was loaded without encoder.* / quant_conv.* tensors"); return K5_ERR_STATE; }
+  if ((H & 7) || (W & 7) || ((T - 1) & 3)) { k5_set_error("encode: need H, W multiples of 8 and T = 4k + 1 frames (got %d x %d x %d)", T, H, W); return K5_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const k5_vae_config& c = v->cfg;
+  const int Cin = 3;
+  // activation high-water mark: the full-resolution stage
+  size_t maxel = (size_t)T * H * W * (size_t)std::max(64, c.block_out_channels[0]);
+  {
+    int t = T, h = H, w = W;
+    for (int i = 0; i < 4; ++i) {
+      maxel = std::max(maxel, (size_t)t * h * w * (size_t)std::max(c.block_out_channels[i], i ? c.block_out_channels[i - 1] : 0));
+      if (v->downs[i].present) { t = (t - 1) / v->downs[i].st_t + 1; h = (h - 1) / v->downs[i].st_s + 1; w = (w - 1) / v->downs[i].st_s + 1; }
+    }
+  }
+  const int M0 = T * H * W;
+  K5CHK(v->xin.ensure((size_t)M0 * 64 * 2));
+  for (Buf* b : {&v->bx, &v->balt, &v->bt1, &v->bt2, &v->bres}) K5CHK(b->ensure(maxel * 2));
+  K5CHK(k5_launch_nchw_to_mc(x, v->xin.p, Cin, M0, 64, s));     // channels 3..63 zero: conv_in's weight is packed to 64 input channels
+  K5CHK(conv(s, v->e_conv_in, v->xin.p, v->bx.p, T, H, W, 1, 1, nullptr));
+  void* cur = v->bx.p;
+  void* nxt = v->balt.p;
+  auto swap = [&]() { void* t_ = cur; cur = nxt; nxt = t_; };
+  int t = T, h = H, w = W;
+  for (int i = 0; i < 4; ++i) {
+    for (auto& r : v->down_res[i]) { K5CHK(resnet(v, s, r, cur, nxt, t, h, w)); swap(); }
+    if (v->downs[i].present) {
+      const Conv& dc = v->downs[i].conv;
+      K5CHK(k5_launch_conv3d_bf16_strided(cur, dc.w.p, dc.b.as<float>(), nxt, t, h, w, dc.cin_pad, dc.cout, 1, 1, v->downs[i].st_t,
+                                          v->downs[i].st_s, dc.cout, nullptr, dc.cout, s));
+      swap();
+      t = (t - 1) / v->downs[i].st_t + 1; h = (h - 1) / v->downs[i].st_s + 1; w = (w - 1) / v->downs[i].st_s + 1;
+    }
+  }
+  K5CHK(resnet(v, s, v->e_mid0, cur, nxt, t, h, w)); swap();
+  K5CHK(mid_attention(v, s, v->e_attn, cur, t, h, w));
+  K5CHK(resnet(v, s, v->e_mid1, cur, nxt, t, h, w)); swap();
+  const int M = t * h * w, C2 = 2 * c.latent_channels;
+  K5CHK(gn(v, s, v->e_norm_out, cur, v->bt1.p, M, true));
+  K5CHK(conv(s, v->e_conv_out, v->bt1.p, v->bt2.p, t, h, w, 1, 1, nullptr));      // [M][2 Cz]
+  K5CHK(v->mom.ensure((size_t)M * C2 * 2));
+  K5CHK(k5_launch_gemm_bf16(v->bt2.p, v->e_quant.w.p, v->e_quant.b.as<float>(), v->mom.p, M, C2, v->e_quant.cin_pad, C2, v->e_quant.cin_pad,
+                            C2, K5_EPI_BIAS, nullptr, 0, nullptr, s));             // quant_conv 1x1x1
+  K5CHK(k5_launch_mc_to_nchw(v->mom.p, out, C2, M, C2, s));
+  return K5_OK;
+}
+
+extern "C" int k5_vae_has_encoder(k5_vae* v) { return v && v->has_encoder ? 1 : 0; }
 
 extern "C" int k5_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, void* stream) {
   return k5_launch_blend_bf16(a, b, outer, len_a, len_b, inner, extent, (hipStream_t)stream);

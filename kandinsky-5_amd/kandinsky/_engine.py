@@ -113,6 +113,8 @@ SYMBOLS = {
     "k5_vae_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
     "k5_vae_finalize": (_I, [_P]),
     "k5_vae_decode_tile": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "k5_vae_encode_tile": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "k5_vae_has_encoder": (_I, [_P]),
     "k5_blend_bf16": (_I, [_P, _P, _I64, _I, _I, _I64, _I, _P]),
     "k5_dit_set_graph": (_I, [_P, _I]),
     "k5_dit_set_fp8": (_I, [_P, _I]),

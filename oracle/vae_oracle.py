@@ -196,3 +196,100 @@ def tiled_decode(sd, z, cfg, tile, stride, mode="fp32", decode_tile=None):
 def postprocess_uint8(images: Tensor) -> Tensor:
     """generation_utils.py:222."""
     return ((images.clamp(-1.0, 1.0) + 1.0) * 127.5).to(torch.uint8)
+
+
+# ------------------------------------------------------------------------------------------ encode path (SURVEY §8 f4)
+def causal_conv3d_strided(sd, name: str, x: Tensor, stride: Sequence[int], mode: str) -> Tensor:
+    """HunyuanVideoDownsampleCausal3D vae.py:208-227 = HunyuanVideoCausalConv3d with a stride and padding 0 (the encoder
+    passes downsample_padding=0, vae.py:560): the same replicate pad (W 1,1 ; H 1,1 ; T 2,0), then Conv3d(stride)."""
+    w, b = sd[name + ".conv.weight"].float(), sd[name + ".conv.bias"].float()
+    x = F.pad(x, (1, 1, 1, 1, 2, 0), mode="replicate")
+    return _r(F.conv3d(_r(x, mode), _r(w, mode), _r(b, mode), stride=tuple(stride)), mode)
+
+
+def down_schedule(n_blocks: int, n_sp: int = 3, n_t: int = 2):
+    """per down block: stride (t, h, w) of its downsampler or None — HunyuanVideoEncoder3D.__init__ vae.py:522-566
+    (temporal_compression_ratio 4: time is halved by the blocks i >= n-1-n_t that are not the last one)."""
+    out = []
+    for i in range(n_blocks):
+        sp = i < n_sp
+        tm = (i >= n_blocks - 1 - n_t) and (i != n_blocks - 1)
+        out.append((2 if tm else 1, 2 if sp else 1, 2 if sp else 1) if (sp or tm) else None)
+    return out
+
+
+def encoder_forward(sd, x: Tensor, cfg: dict, mode: str = "fp32") -> Tensor:
+    """HunyuanVideoEncoder3D.forward vae.py:574-586 + quant_conv (vae.py:808-809): x (B,3,T,H,W) -> moments
+    (B, 2*latent_channels, (T-1)/4+1, H/8, W/8) = [mean | logvar]."""
+    G = cfg["norm_num_groups"]
+    boc = list(cfg["block_out_channels"])
+    h = causal_conv3d(sd, "encoder.conv_in", x.float(), mode)
+    for i, st in enumerate(down_schedule(len(boc))):
+        for j in range(cfg["layers_per_block"]):
+            h = resnet_block(sd, f"encoder.down_blocks.{i}.resnets.{j}", h, G, mode)
+        if st is not None:
+            h = causal_conv3d_strided(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", h, st, mode)
+    h = resnet_block(sd, "encoder.mid_block.resnets.0", h, G, mode)
+    h = mid_attention(sd, "encoder.mid_block.attentions.0", h, G, mode)
+    h = resnet_block(sd, "encoder.mid_block.resnets.1", h, G, mode)
+    h = F.silu(group_norm(sd, "encoder.conv_norm_out", h, G))
+    h = causal_conv3d(sd, "encoder.conv_out", h, mode)
+    return _r(F.conv3d(_r(h, mode), _r(sd["quant_conv.weight"].float(), mode), _r(sd["quant_conv.bias"].float(), mode)), mode)
+
+
+def gaussian_moments(h: Tensor):
+    """diffusers DiagonalGaussianDistribution (NOT in the reference tree; restated from its definition — parity unpinned):
+    mean, logvar = chunk(h, 2, dim=1); logvar clamped to [-30, 20]; std = exp(logvar / 2); mode() = mean;
+    sample() = mean + std * N(0, 1)."""
+    mean, logvar = torch.chunk(h, 2, dim=1)
+    logvar = logvar.clamp(-30.0, 20.0)
+    return mean, logvar, torch.exp(0.5 * logvar)
+
+
+def tiled_encode(sd, x, cfg, tile, stride, mode="fp32", encode_tile=None):
+    """AutoencoderKLHunyuanVideo._encode with apply_tiling(tile, stride): vae.py:795-810 (dispatch), 938-1010 (spatial
+    tiles, blends on the LATENT grid), 1096-1142 (temporal tiles of min_frames + 1 frames, first latent frame of every
+    later tile dropped, blend_t)."""
+    _, ft, ht, wt = tile
+    fs, hs, ws = stride
+    min_f, str_f = ft - 1, fs
+    enc = encode_tile or (lambda t: encoder_forward(sd, t, cfg, mode))
+    lat_min_h, lat_min_w, lat_str_h, lat_str_w = ht // 8, wt // 8, hs // 8, ws // 8
+
+    def spatial(xx):
+        _, _, _, H, W = xx.shape
+        rows = []
+        for i in range(0, H - ht + 1, hs):
+            rows.append([enc(xx[:, :, :, i:i + ht, j:j + wt]).clone() for j in range(0, W - wt + 1, ws)])
+        out_rows = []
+        for i, row in enumerate(rows):
+            out = []
+            for j, t in enumerate(row):
+                if i > 0:
+                    t = blend(rows[i - 1][j], t, lat_min_h - lat_str_h, 3, mode)
+                if j > 0:
+                    t = blend(row[j - 1], t, lat_min_w - lat_str_w, 4, mode)
+                out.append(t[:, :, :, :(lat_min_h if i == len(rows) - 1 else lat_str_h), :(lat_min_w if j == len(row) - 1 else lat_str_w)])
+            out_rows.append(torch.cat(out, dim=4))
+        return torch.cat(out_rows, dim=3)[:, :, :, :H // 8, :W // 8]
+
+    _, _, nf, H, W = x.shape
+    if nf > min_f + 1:   # _temporal_tiled_encode
+        lat_nf = (nf - 1) // 4 + 1
+        lat_min_f, lat_str_f = min_f // 4, str_f // 4
+        row = []
+        for i in range(0, nf - min_f + 1, str_f):
+            t = x[:, :, i:i + min_f + 1]
+            t = spatial(t) if (H > ht or W > wt) else enc(t).clone()
+            row.append(t[:, :, 1:] if i > 0 else t)
+        out = []
+        for i, t in enumerate(row):
+            if i > 0:
+                t = blend(row[i - 1], t, lat_min_f - lat_str_f, 2, mode)
+                out.append(t[:, :, :(lat_min_f if i == len(row) - 1 else lat_str_f)])
+            else:
+                out.append(t[:, :, :lat_str_f + 1])
+        return torch.cat(out, dim=2)[:, :, :lat_nf]
+    if W > wt or H > ht:
+        return spatial(x)
+    return enc(x)
