@@ -252,6 +252,10 @@ int k5_dit_nabla_block_counts(k5_dit* dit, long long* kept, long long* possible)
  * resid (optional) [To*Ho*Wo][ldr]: out = bf16(bf16(conv+bias) + resid) (resnet skip, vae.py:274). */
 int k5_conv3d_bf16(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin, int Cout,
                    int up_t, int up_s, int ldc, const void* resid, int ldr, void* stream);
+/* HunyuanVideoDownsampleCausal3D (vae.py:208-227; encoder): the same causal conv with an output stride st_t, st_s in {1, 2}
+ * and padding 0: out [To*Ho*Wo][ldc], To = (Ts-1)/st_t + 1, Ho = (Hs-1)/st_s + 1, Wo = (Ws-1)/st_s + 1. */
+int k5_conv3d_strided_bf16(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin, int Cout,
+                           int st_t, int st_s, int ldc, void* stream);
 /* nn.GroupNorm(G, C, eps) (+SiLU) on channels-last bf16 rows [M][C] (vae.py:246-263,672-673): fp32 statistics,
  * bf16 out.  workspace: device scratch of k5_groupnorm_workspace_size(M, G) bytes. */
 int64_t k5_groupnorm_workspace_size(int M, int G);

@@ -184,6 +184,12 @@ int k5_conv3d_bf16(const void* X, const void* W, const float* bias, void* out, i
              "k5_conv3d_bf16");
 }
 
+int k5_conv3d_strided_bf16(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin, int Cout,
+                           int st_t, int st_s, int ldc, void* stream) {
+  return ret(k5_launch_conv3d_bf16_strided(X, W, bias, out, Ts, Hs, Ws, Cin, Cout, 1, 1, st_t, st_s, ldc, nullptr, 0, (hipStream_t)stream),
+             "k5_conv3d_strided_bf16");
+}
+
 int64_t k5_groupnorm_workspace_size(int M, int G) { return (int64_t)k5_groupnorm_workspace_bytes(M, G); }
 
 int k5_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,

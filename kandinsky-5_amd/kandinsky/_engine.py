@@ -106,6 +106,7 @@ SYMBOLS = {
     "k5_comm_unique_id": (_I, [C.c_char_p, _P]),
     "k5_dit_comm_init": (_I, [_P, C.c_char_p, _I, _I, _P]),
     "k5_conv3d_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "k5_conv3d_strided_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k5_groupnorm_workspace_size": (_I64, [_I, _I]),
     "k5_groupnorm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P]),
     "k5_vae_create": (_I, [C.POINTER(VaeConfig), C.POINTER(_P)]),

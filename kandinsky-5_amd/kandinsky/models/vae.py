@@ -1,11 +1,14 @@
-"""AutoencoderKLHunyuanVideo (decode only) — host mirror of kandinsky/models/vae.py (reference).
+"""AutoencoderKLHunyuanVideo — host mirror of kandinsky/models/vae.py (reference): decode (the T2V hot path) and encode
+(image / video conditioning).
 
 Keeps what callers touch: `build_vae(conf)` (vae.py:1276-1282), `.decode(z).sample`, `.config.scaling_factor`, `.eval()`,
 `.to()`, the checkpoint key names of `decoder.*` / `post_quant_conv.*`, and the reference's tiling
 policy — `get_dec_optimal_tiling` tables (data in vae_tiling.json), temporal tiles with a dropped first frame, optional
 spatial tiles, linear cross-fades, including the quirk that `_decode` compares the width with the STRIDE-derived tile
 width (vae.py:854-856).  The arithmetic runs in libk5.so: `k5_vae_decode_tile` per tile, `k5_blend_bf16` for the
-cross-fades; torch only slices / concatenates.  T2V never encodes, so the encoder half is not mirrored.
+cross-fades; torch only slices / concatenates.  The encoder half (`encode`, `tiled_encode`, `_temporal_tiled_encode`,
+vae.py:795-845, 938-1010, 1096-1142) works the same way through `k5_vae_encode_tile`; its tensors (`encoder.*`,
+`quant_conv.*`) are optional in a checkpoint load — T2V itself never encodes.
 """
 from __future__ import annotations
 
@@ -30,6 +33,68 @@ OPT_SPATIAL_TILING = {int(k): tuple(v) for k, v in _T["spatial"].items()}
 class DecoderOutput:
     def __init__(self, sample):
         self.sample = sample
+
+
+class DiagonalGaussianDistribution:
+    """diffusers' class of that name (third-party, not in the reference tree; restated from its definition): the encoder's
+    moments tensor = [mean | logvar] along the channel axis, logvar clamped to [-30, 20]."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, logvar = torch.chunk(parameters.float(), 2, dim=1)
+        self.logvar = logvar.clamp(-30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def sample(self, generator=None):
+        eps = torch.randn(self.mean.shape, generator=generator, device=self.mean.device if generator is None else generator.device,
+                          dtype=self.mean.dtype).to(self.mean.device)
+        return self.mean + self.std * eps
+
+    def mode(self):
+        return self.mean
+
+
+class AutoencoderKLOutput:
+    def __init__(self, latent_dist):
+        self.latent_dist = latent_dist
+
+
+def encoder_manifest(in_channels, latent_channels, block_out_channels, layers_per_block):
+    """state_dict names / shapes of encoder + quant_conv (vae.py:478-572, 747)."""
+    m = {}
+    boc = list(block_out_channels)
+
+    def conv(n, o, i, k):
+        m[n + ".weight"], m[n + ".bias"] = (o, i, k, k, k), (o,)
+
+    def norm(n, c):
+        m[n + ".weight"], m[n + ".bias"] = (c,), (c,)
+
+    def resnet(p, i, o):
+        norm(p + ".norm1", i); conv(p + ".conv1.conv", o, i, 3); norm(p + ".norm2", o); conv(p + ".conv2.conv", o, o, 3)
+        if i != o:
+            conv(p + ".conv_shortcut.conv", o, i, 1)
+
+    conv("encoder.conv_in.conv", boc[0], in_channels, 3)
+    prev = boc[0]
+    for i, outc in enumerate(boc):
+        for j in range(layers_per_block):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else outc, outc)
+        if i < len(boc) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv.conv", outc, outc, 3)
+        prev = outc
+    top = boc[-1]
+    resnet("encoder.mid_block.resnets.0", top, top)
+    a = "encoder.mid_block.attentions.0."
+    norm(a + "group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        m[a + n + ".weight"], m[a + n + ".bias"] = (top, top), (top,)
+    resnet("encoder.mid_block.resnets.1", top, top)
+    norm("encoder.conv_norm_out", top)
+    conv("encoder.conv_out.conv", 2 * latent_channels, top, 3)
+    conv("quant_conv", 2 * latent_channels, 2 * latent_channels, 1)
+    return m
 
 
 def decoder_manifest(latent_channels, out_channels, block_out_channels, layers_per_block):
@@ -86,7 +151,11 @@ class AutoencoderKLHunyuanVideo(nn.Module):
                                       block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
                                       norm_num_groups=norm_num_groups, scaling_factor=scaling_factor,
                                       spatial_compression_ratio=8, temporal_compression_ratio=4)
-        for name, shape in decoder_manifest(latent_channels, out_channels, block_out_channels, layers_per_block).items():
+        names = dict(decoder_manifest(latent_channels, out_channels, block_out_channels, layers_per_block))
+        self._encoder_keys = list(encoder_manifest(in_channels, latent_channels, block_out_channels, layers_per_block))
+        names.update(encoder_manifest(in_channels, latent_channels, block_out_channels, layers_per_block))
+        self._encoder_loaded = False
+        for name, shape in names.items():
             node = self
             parts = name.split(".")
             for p in parts[:-1]:
@@ -125,8 +194,21 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         return model
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
-        state_dict = {k: v for k, v in state_dict.items() if k in self.state_dict()}  # encoder.* / quant_conv.* unused
-        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        """decoder.* / post_quant_conv.* are required; encoder.* / quant_conv.* are optional as a group (a decode-only load
+        leaves `encode` unavailable, loudly)."""
+        state_dict = {k: v for k, v in state_dict.items() if k in self.state_dict()}
+        enc = set(self._encoder_keys)
+        have = [k for k in state_dict if k in enc]
+        if have and len(have) != len(enc):
+            raise RuntimeError(f"VAE checkpoint has only {len(have)} of the {len(enc)} encoder tensors")
+        self._encoder_loaded = bool(have)
+        if not have:   # strict load of the decoder half only
+            missing = [k for k in self.state_dict() if k not in enc and k not in state_dict]
+            if strict and missing:
+                raise RuntimeError(f"missing VAE decoder keys: {missing[:6]}")
+            out = super().load_state_dict(state_dict, strict=False, assign=assign)
+        else:
+            out = super().load_state_dict(state_dict, strict=strict, assign=assign)
         self._drop_engine()
         return out
 
@@ -149,6 +231,8 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         with torch.cuda.device(device):
             E.check(E.lib().k5_vae_create(C.byref(cc), C.byref(h)), "k5_vae_create")
             for name, t in self.state_dict().items():
+                if not self._encoder_loaded and name in self._encoder_keys:
+                    continue      # placeholders of a decode-only load
                 t = t.detach()
                 if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
                     t = t.float()
@@ -169,6 +253,18 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         with torch.cuda.device(z.device):
             E.check(E.lib().k5_vae_decode_tile(h, zz.data_ptr(), t, hh, ww, out.data_ptr(), E.stream_ptr(z.device)),
                     "k5_vae_decode_tile")
+        return out
+
+    def _encode_tile(self, x):
+        """x (1,3,T,H,W) -> moments (1, 2*latent, (T-1)/4+1, H/8, W/8) bf16 = quant_conv(encoder(x))."""
+        h = self._engine(x.device)
+        if not self._encoder_loaded or not E.lib().k5_vae_has_encoder(h):
+            raise RuntimeError("this VAE was loaded without its encoder.* / quant_conv.* tensors: encode() is unavailable")
+        xx = x[0].float().contiguous()
+        _, t, hh, ww = xx.shape
+        out = torch.empty(1, 2 * self.config.latent_channels, (t - 1) // 4 + 1, hh // 8, ww // 8, dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            E.check(E.lib().k5_vae_encode_tile(h, xx.data_ptr(), t, hh, ww, out.data_ptr(), E.stream_ptr(x.device)), "k5_vae_encode_tile")
         return out
 
     @staticmethod
@@ -315,8 +411,81 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         dec = self._decode(z).sample
         return DecoderOutput(dec) if return_dict else (dec,)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("T2V only decodes; the VAE encoder is outside the hot path (SURVEY.md §2 #5)")
+    # ------------------------------------------------------------------ encode (vae.py:795-845, 938-1010, 1096-1142)
+    def tiled_encode(self, x):
+        _, _, _, H, W = x.shape
+        mh, mw = self.tile_sample_min_height, self.tile_sample_min_width
+        sh, sw = self.tile_sample_stride_height, self.tile_sample_stride_width
+        lmh, lmw, lsh, lsw = mh // 8, mw // 8, sh // 8, sw // 8
+        rows = [[self._encode_tile(x[:, :, :, i:i + mh, j:j + mw]) for j in range(0, W - mw + 1, sw)]
+                for i in range(0, H - mh + 1, sh)]
+        out_rows = []
+        for i, row in enumerate(rows):
+            out = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = self._blend(rows[i - 1][j], tile, lmh - lsh, 3)
+                if j > 0:
+                    tile = self._blend(row[j - 1], tile, lmw - lsw, 4)
+                rows[i][j] = tile
+                out.append(tile[:, :, :, :(lmh if i == len(rows) - 1 else lsh), :(lmw if j == len(row) - 1 else lsw)])
+            out_rows.append(torch.cat(out, dim=4))
+        return torch.cat(out_rows, dim=3)[:, :, :, :H // 8, :W // 8]
+
+    def _temporal_tiled_encode(self, x):
+        _, _, nf, H, W = x.shape
+        lat_nf = (nf - 1) // 4 + 1
+        mf, sf = self.tile_sample_min_num_frames, self.tile_sample_stride_num_frames
+        lmf, lsf = mf // 4, sf // 4
+        row = []
+        for i in range(0, nf - mf + 1, sf):
+            tile = x[:, :, i:i + mf + 1]
+            if self.use_tiling and (H > self.tile_sample_min_height or W > self.tile_sample_min_width):
+                tile = self.tiled_encode(tile)
+            else:
+                tile = self._encode_tile(tile)
+            row.append(tile[:, :, 1:] if i > 0 else tile)
+        out = []
+        for i, tile in enumerate(row):
+            if i > 0:
+                tile = self._blend(row[i - 1], tile, lmf - lsf, 2)
+                row[i] = tile
+                out.append(tile[:, :, :(lmf if i == len(row) - 1 else lsf)])
+            else:
+                out.append(tile[:, :, :lsf + 1])
+        return torch.cat(out, dim=2)[:, :, :lat_nf]
+
+    def _encode(self, x):
+        _, _, nf, H, W = x.shape
+        if self.use_framewise_decoding and nf > self.tile_sample_min_num_frames + 1:
+            return self._temporal_tiled_encode(x)
+        if self.use_tiling and (W > self.tile_sample_min_width or H > self.tile_sample_min_height):
+            return self.tiled_encode(x)
+        return self._encode_tile(x)
+
+    @torch.no_grad()
+    def encode(self, x, opt_tiling=True, return_dict=True):
+        """vae.py:813-845: x (B,3,F,H,W) in [-1,1] -> AutoencoderKLOutput(latent_dist=DiagonalGaussianDistribution)."""
+        if x.shape[0] != 1:
+            h = torch.cat([self.encode(x[i:i + 1]).latent_dist.parameters for i in range(x.shape[0])], 0)
+        else:
+            if opt_tiling:
+                tile_size, tile_stride = self.get_enc_optimal_tiling(x.shape)
+            else:
+                b, _, f, hh, ww = x.shape
+                tile_size, tile_stride = (b, f, hh, ww), (f, hh, ww)
+            if tile_size != self.tile_size:
+                self.tile_size = tile_size
+                self.apply_tiling(tile_size, tile_stride)
+            h = self._encode(x)
+        posterior = DiagonalGaussianDistribution(h)
+        return AutoencoderKLOutput(posterior) if return_dict else (posterior,)
+
+    def forward(self, sample, sample_posterior=False, return_dict=True, generator=None):
+        """vae.py:1206-1228: encode -> mode / sample -> decode."""
+        posterior = self.encode(sample).latent_dist
+        z = posterior.sample(generator=generator) if sample_posterior else posterior.mode()
+        return self.decode(z, return_dict=return_dict)
 
 
 def build_vae(conf):
