@@ -221,7 +221,7 @@ struct k5_dit {
   // data-derived softmax bound of the visual self-attention (pre-scaled keys): per-head max |q|^2 [Hh] | max |k'|^2 [P][Hh]
   // (fp32, filled by the rmsnorm/RoPE kernel, consumed by k5_launch_attn_flags), the per-head variant flags [Hh] (int) and
   // two u64 counters: heads that ran the fixed-offset / the online-max kernel since the last reset
-  DevBuf ws_attn_stats, ws_attn_flags, ws_attn_cnt;
+  DevBuf ws_attn_stats, ws_attn_flags, ws_attn_cnt, ws_attn_part;   // ws_attn_part: per-block partial maxima of the norm kernel
   long long nabla_possible = 0;                    // profiling: 64x64 blocks the NABLA maps could have kept (kept: ws_attn_cnt[2])
   int attn_mode = 0;                               // K5_ATTN_AUTO / K5_ATTN_ONLINE (k5_dit_set_option "attn_mode")
   int sp_pass1_tiles = 0;                          // k5_dit_set_option "sp_pass1_tiles" (0 = all local key tiles)
@@ -411,6 +411,7 @@ int ensure_zeroed(DevBuf& b, size_t n, hipStream_t s) {
 int ensure_attn_flags(k5_dit* d, hipStream_t s) {
   K5CHK(ensure_zeroed(d->ws_attn_stats, (size_t)d->Hh * (1 + d->sp_world) * 4, s));
   K5CHK(d->ws_attn_flags.ensure((size_t)d->Hh * 4));
+  K5CHK(d->ws_attn_part.ensure(k5_rmsnorm_stats_workspace_bytes(2 * d->Hh)));
   K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
   return K5_OK;
 }
@@ -440,7 +441,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     if (pre && nabla) { K5CHK(d->ws_kc.ensure((size_t)rows * D * 2)); kc = d->ws_kc.p; }
     float* stats = nullptr;
     if (by_data) { K5CHK(ensure_attn_flags(d, s)); stats = d->ws_attn_stats.as<float>(); }   // [q heads | k' heads] = the call's 2H heads
-    K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D, stats));
+    K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D, stats, d->ws_attn_part.as<float>()));
     if (by_data) {
       hflags = d->ws_attn_flags.as<int>();
       K5CHK(k5_launch_attn_flags(stats, stats + H, 1, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s));
@@ -509,7 +510,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   {
     Scope sc(d, s, "elementwise");
     K5CHK(k5_launch_rmsnorm_rope(kloc, a.norm.as<float>() + 64, cosT, sinT, rows, H, D, nullptr, s, K5_SOFTMAX_C, pre ? 0 : 0x7fffffff,
-                                 nullptr, 0, by_data ? kstat + (size_t)r * H : nullptr));
+                                 nullptr, 0, by_data ? kstat + (size_t)r * H : nullptr, d->ws_attn_part.as<float>()));
   }
   HIPCHK(hipEventRecord(d->ev_k, s));
   {
@@ -523,7 +524,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   }
   {
     Scope sc(d, s, "elementwise");
-    K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), cosT, sinT, rows, H, D, nullptr, s, 1.f, 0x7fffffff, nullptr, 0, qstat));
+    K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), cosT, sinT, rows, H, D, nullptr, s, 1.f, 0x7fffffff, nullptr, 0, qstat, d->ws_attn_part.as<float>()));
   }
   // all-gathers on the side stream (they only need k / v^T, which are complete at ev_k / ev_v) ...
   hipStream_t cs = d->comm_stream;
@@ -937,7 +938,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
   d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_kc.release(); d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
-  d->ws_attn_stats.release(); d->ws_attn_flags.release(); d->ws_attn_cnt.release();
+  d->ws_attn_stats.release(); d->ws_attn_flags.release(); d->ws_attn_cnt.release(); d->ws_attn_part.release();
   for (auto& t : d->text_cache) { t.text.release(); t.pool.release(); }
   d->mag.residual[0].release(); d->mag.residual[1].release(); d->mag.pm_one.release();
   for (auto& b : d->vblocks) { b.w1_f8.release(); b.w2_f8.release(); b.s1_f8.release(); b.s2_f8.release(); }

@@ -134,8 +134,16 @@ int k5_rmsnorm_rope_bf16(void* x, const float* weight, const float* cos_tab, con
 int k5_rmsnorm_rope_stats_bf16(void* x, const float* weight, const float* cos_tab, const float* sin_tab, int rows, int H, int ld,
                                int heads_per_weight, int rope_heads, float out_scale, int scale_from_head, float* stats, void* stream) {
   const int32_t hc[2] = {heads_per_weight, rope_heads};
+  static float* ws = nullptr; static size_t ws_bytes = 0;   // scratch of the kernel-level entry (the engine owns its own)
+  const size_t need = k5_rmsnorm_stats_workspace_bytes(H);
+  if (stats && need > ws_bytes) {
+    if (ws) (void)hipFree(ws);
+    ws = nullptr; ws_bytes = 0;
+    if (hipMalloc((void**)&ws, need) != hipSuccess) return ret(K5_ERR_HIP, "k5_rmsnorm_rope_stats_bf16");
+    ws_bytes = need;
+  }
   return ret(k5_launch_rmsnorm_rope(x, weight, cos_tab, sin_tab, rows, H, ld, hc, (hipStream_t)stream, out_scale, scale_from_head,
-                                    nullptr, 0, stats), "k5_rmsnorm_rope_stats_bf16");
+                                    nullptr, 0, stats, ws), "k5_rmsnorm_rope_stats_bf16");
 }
 
 int k5_gate_sum_bf16(const void* x, const void* y, const float* gate, void* out, int rows, int D, void* stream) {

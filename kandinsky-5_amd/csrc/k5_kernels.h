@@ -69,7 +69,8 @@ int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift,
 int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cos, const float* sin, int rows,
                            int H, int ld, const int32_t* heads_cfg, hipStream_t stream,
                            float out_scale = 1.f, int scale_from_head = 0x7fffffff, void* scaled_out = nullptr, int ld_scaled = 0,
-                           float* stats = nullptr);
+                           float* stats = nullptr, float* stats_ws = nullptr);
+size_t k5_rmsnorm_stats_workspace_bytes(int H);   // stats_ws: scratch of this size whenever stats is given
 // heads >= scale_from_head are multiplied by out_scale before the bf16 rounding — in place, or (scaled_out != null) into
 // scaled_out[row][(head - scale_from_head) * 64 ...] while the unscaled values stay in place.
 // stats (device, [H] floats, zeroed by the consumer): stats[h] = max(stats[h], |x_row,h|^2) over the rows of the call, of the

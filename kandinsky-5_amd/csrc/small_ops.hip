@@ -88,6 +88,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
                                                            int rows, int H, int heads_per_weight, int ld, int rope_heads,
                                                            float out_scale, int scale_from_head, bf16_t* __restrict__ scaled_out,
                                                            int ld_scaled, float* __restrict__ stats) {
+  __shared__ unsigned int smax[256];   // stats: per-head maxima of this block (H <= 256 heads per row)
+  if (stats) { smax[threadIdx.x] = 0u; __syncthreads(); }
   const int64_t total = (int64_t)rows * H * 8;
   const int64_t stride = (int64_t)gridDim.x * 256;        // multiple of H * 8 (launcher)
   const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -160,8 +162,32 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
     }
   }
   // per-head max over the rows of this call: |q.k'| <= |q| |k'| then bounds every exp2 argument of the head
-  // (attn_flags_kernel).  Non-negative floats order like their bit patterns.
-  if (stats && c == 0 && g0 < total) atomicMax(reinterpret_cast<unsigned int*>(stats) + head, __float_as_uint(n2max));
+  // (attn_flags_kernel).  Non-negative floats order like their bit patterns.  No global atomics (a hundred thousand of them on
+  // 28 addresses cost more than the kernel): LDS max per block, one partial row per block, reduced by stats_reduce_kernel.
+  if (stats) {
+    if (c == 0 && g0 < total) atomicMax(&smax[head], __float_as_uint(n2max));
+    __syncthreads();
+    if ((int)threadIdx.x < H) stats[(size_t)blockIdx.x * H + threadIdx.x] = __uint_as_float(smax[threadIdx.x]);
+  }
+}
+
+// out[h] = max(out[h], max over the nblk partial rows): a few blocks, each over a slice of the rows (thread t: head t % H, row
+// lane t / H), then one atomic per head and block — a handful, not one per head vector
+__global__ __launch_bounds__(256) void stats_reduce_kernel(const float* __restrict__ part, int nblk, int H, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int per = 256 / H;                  // row lanes per head
+  const int h = threadIdx.x % H, lane = threadIdx.x / H;
+  const int b0 = (int)((long long)nblk * blockIdx.x / gridDim.x), b1 = (int)((long long)nblk * (blockIdx.x + 1) / gridDim.x);
+  float m = 0.f;
+  if (lane < per)
+    for (int b = b0 + lane; b < b1; b += per) { const float v = part[(size_t)b * H + h]; m = v == v ? fmaxf(m, v) : __uint_as_float(0x7f800000u); }
+  red[threadIdx.x] = lane < per ? m : 0.f;
+  __syncthreads();
+  if ((int)threadIdx.x < H) {
+    float r = 0.f;
+    for (int l = 0; l < per; ++l) r = fmaxf(r, red[l * H + threadIdx.x]);   // NaNs were mapped to +inf above
+    atomicMax(reinterpret_cast<unsigned int*>(out) + threadIdx.x, __float_as_uint(r));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -330,9 +356,11 @@ int k5_launch_ln_affine(const void* x, const float* w, const float* b, void* out
   return done();
 }
 
+size_t k5_rmsnorm_stats_workspace_bytes(int H) { return (size_t)4096 * H * sizeof(float); }
+
 int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, const float* sinT, int rows, int H,
                            int ld, const int32_t* heads_cfg, hipStream_t s, float out_scale, int scale_from_head, void* scaled_out,
-                           int ld_scaled, float* stats) {
+                           int ld_scaled, float* stats, float* stats_ws) {
   // heads_cfg (host pointer, optional): {heads_per_weight, rope_heads}; default: one weight, rope on all heads
   if (rows <= 0 || H <= 0) return K5_ERR_ARG;
   if (ld & 7) return K5_ERR_ALIGN;
@@ -343,12 +371,15 @@ int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, cons
   int gcd = 256, b8 = H * 8;
   for (int a = gcd, b = b8; b;) { const int t = a % b; a = b; b = t; gcd = a; }
   const int unit = b8 / gcd;
+  if (stats && (!stats_ws || H > 256)) return K5_ERR_ARG;
+  int64_t cap = 4096 / unit * unit;   // with statistics: one partial row per block (k5_rmsnorm_stats_workspace_bytes)
+  if (cap < unit) { if (stats) return K5_ERR_UNSUPPORTED; cap = unit; }
   int64_t blocks = (total + 255) / 256;
-  const int64_t cap = 4096 > unit ? 4096 : unit;
   if (blocks > cap) blocks = cap;
-  blocks = (blocks + unit - 1) / unit * unit;
+  blocks = (blocks + unit - 1) / unit * unit;           // <= cap: cap is a multiple of unit
   hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)x, weight,
-                     cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled, stats);
+                     cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled, stats ? stats_ws : nullptr);
+  if (stats) hipLaunchKernelGGL(stats_reduce_kernel, dim3(blocks >= 512 ? 16 : 1), dim3(256), 0, s, stats_ws, (int)blocks, H, stats);
   return done();
 }
 
