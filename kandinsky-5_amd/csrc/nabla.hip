@@ -12,6 +12,8 @@
 //   3. nabla_union_kernel  the attention workgroup covers 4 query blocks: OR their rows, compact the kv-block ids and
 //                          attach a 4-bit membership mask (which of the 4 query blocks wants that kv block).
 // The sparse attention kernel itself is attn_fwd.hip (SPARSE variant).
+#include <type_traits>
+
 #include "k5_common.h"
 #include "k5_kernels.h"
 
@@ -44,91 +46,168 @@ struct SelP {
   float target;                         // 1 - P
 };
 
-constexpr int SEL_WAVES = 4;
 constexpr int SEL_MAXNB = 4096;
 
+// sum over the 64 lanes, the same value returned in every lane.  DPP inside the 16-lane rows (quad swaps, half-mirror,
+// mirror), then two readlanes across the rows — no LDS round trips (the bisection below does 30 of these per row).
+K5_DEV float wave_sum_dpp(float v) {
+#ifdef K5_NABLA_SHFL
+  return wave_sum(v);
+#endif
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+  // every lane of a 16-lane row now holds the row's sum
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+K5_DEV float wave_max_dpp(float v) {
+#ifdef K5_NABLA_SHFL
+  return wave_max(v);
+#endif
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)));
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// One wave = R query-block rows of ONE head; lane l owns the key blocks l, l + 64, ... (NV per lane) of each of its rows, all
+// in registers.  Round 1 gave every row its own wave and re-read the head's whole key-mean matrix (187 KB at nb = 1464) from
+// L2 per row — 7.7 GB per layer, the kernel's time; here a key mean is loaded once per R rows, the dot products run on
+// v_dot2c_f32_bf16 (both operands ARE bf16), and the bisection works on registers with DPP reductions, the R rows in
+// lockstep (R independent reduction chains in flight).  1.02 -> see DESIGN §4.3 ms per layer at nb = 1464.
+template <int NV, int R>
 __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
-  extern __shared__ float srow[];   // SEL_WAVES rows of nb floats
+  __shared__ __attribute__((aligned(16))) bf16_t sq[4 * R * 64];   // the block's 4 R query-block means
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * SEL_WAVES + wave;      // (h, i)
-  if (row >= p.H * p.nqb) return;
-  const int h = row / p.nqb, il = row % p.nqb, i = p.qb0 + il;   // il: local query block, i: its global block index
-  float* pr = srow + wave * p.nb;
-  // query block mean (broadcast loads)
-  float qa[64];
-  {
-    const bf16_t* q = p.qa + ((size_t)h * p.nqb + il) * 64;
+  const int rows_per_block = 4 * R;
+  const int blocks_per_head = (p.nqb + rows_per_block - 1) / rows_per_block;
+  const int h = blockIdx.x / blocks_per_head, il0 = (blockIdx.x % blocks_per_head) * rows_per_block + wave * R;
+  // stage the query means (rows past nqb: clamped, their results are dropped)
+  for (int c = threadIdx.x; c < rows_per_block * 8; c += 256) {
+    const int r = c >> 3, il = min((blockIdx.x % blocks_per_head) * rows_per_block + r, p.nqb - 1);
+    *reinterpret_cast<u32x4*>(sq + r * 64 + 8 * (c & 7)) = *reinterpret_cast<const u32x4*>(p.qa + ((size_t)h * p.nqb + il) * 64 + 8 * (c & 7));
+  }
+  __syncthreads();
+  if (il0 >= p.nqb) return;   // wave-uniform; no barrier follows
+  float pv[R][NV];
+  float mx[R];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(q + 8 * c);
+  for (int r = 0; r < R; ++r) mx[r] = -3.0e38f;
+  // logits: bf16(qa . ka_j) / sqrt(64)   (bf16 matmul output, then an exact /8)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { qa[8 * c + 2 * j] = __uint_as_float(raw[j] << 16); qa[8 * c + 2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u); }
+  for (int v = 0; v < NV; ++v) {
+    const int j = v * 64 + lane;
+    const bf16_t* kp = p.ka + ((size_t)h * p.nb + min(j, p.nb - 1)) * 64;
+    u32x4 kk[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) kk[c] = *reinterpret_cast<const u32x4*>(kp + 8 * c);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const u32x4 qq = *reinterpret_cast<const u32x4*>(sq + (wave * R + r) * 64 + 8 * c);   // same address in every lane: broadcast
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#ifdef K5_NABLA_FMA
+          d = fmaf(__uint_as_float(qq[e] << 16), __uint_as_float(kk[c][e] << 16), d);
+          d = fmaf(__uint_as_float(qq[e] & 0xffff0000u), __uint_as_float(kk[c][e] & 0xffff0000u), d);
+#else
+          // inline asm on purpose: the builtin fed through bit_cast(vector element) was compiled with the element index collapsed
+          // to 0 (four identical v_dot2c per 16-byte chunk, ROCm 7.2 clang) — the map then selects from wrong logits
+          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(qq[e]), "v"(kk[c][e]));
+#endif
+        }
+      }
+      const float lg = j < p.nb ? bf_round(d) * 0.125f : -3.0e38f;
+      pv[r][v] = lg;
+      mx[r] = fmaxf(mx[r], lg);
     }
   }
-  // logits: bf16(qa . ka_j) / sqrt(64)   (bf16 matmul output, then an exact /8)
-  float mx = -3.0e38f;
-  for (int j = lane; j < p.nb; j += 64) {
-    const bf16_t* k = p.ka + ((size_t)h * p.nb + j) * 64;
-    float d = 0.f;
+  float target_base[R];
+  unsigned lo[R], hi[R];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(k + 8 * c);
+  for (int r = 0; r < R; ++r) {
+    mx[r] = wave_max_dpp(mx[r]);
+    float sum = 0.f;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        d = fmaf(qa[8 * c + 2 * jj], __uint_as_float(raw[jj] << 16), d);
-        d = fmaf(qa[8 * c + 2 * jj + 1], __uint_as_float(raw[jj] & 0xffff0000u), d);
+    for (int v = 0; v < NV; ++v) { const float e = v * 64 + lane < p.nb ? expf(pv[r][v] - mx[r]) : 0.f; pv[r][v] = e; sum += e; }
+    sum = wave_sum_dpp(sum);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) pv[r][v] = pv[r][v] / sum;   // padding lanes: 0 / sum = 0, below every cut, excluded at emission
+    lo[r] = 0u; hi[r] = 0x7f800000u;                          // invariant: g(lo-1) < target <= g(hi)
+    target_base[r] = 0.f;
+  }
+  // smallest value v* with  sum_{p <= v*} p  >= target  (bisection over the bit pattern of non-negative floats), R rows in lockstep
+  bool more = true;
+  while (more) {
+    more = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (lo[r] < hi[r]) {   // wave-uniform
+        const unsigned mid = lo[r] + ((hi[r] - lo[r]) >> 1);
+        float g = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) g += (__float_as_uint(pv[r][v]) <= mid && v * 64 + lane < p.nb) ? pv[r][v] : 0.f;
+        g = wave_sum_dpp(g);
+        if (g >= p.target) hi[r] = mid; else lo[r] = mid + 1;
+        more = more || lo[r] < hi[r];
       }
     }
-    const float lg = bf_round(d) * 0.125f;
-    pr[j] = lg;
-    mx = fmaxf(mx, lg);
   }
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int j = lane; j < p.nb; j += 64) { const float e = expf(pr[j] - mx); pr[j] = e; sum += e; }
-  sum = wave_sum(sum);
-  for (int j = lane; j < p.nb; j += 64) pr[j] = pr[j] / sum;
-  // smallest value v* with  sum_{p <= v*} p  >= target  (bisection over the bit pattern of non-negative floats)
-  unsigned lo = 0u, hi = 0x7f800000u;   // invariant: g(lo-1) < target <= g(hi)
-  while (lo < hi) {
-    const unsigned mid = lo + ((hi - lo) >> 1);
-    float g = 0.f;
-    for (int j = lane; j < p.nb; j += 64) { const float v = pr[j]; g += (__float_as_uint(v) <= mid) ? v : 0.f; }
-    g = wave_sum(g);
-    if (g >= p.target) hi = mid; else lo = mid + 1;
-  }
-  const unsigned vbits = lo;
-  const float vstar = __uint_as_float(vbits);
-  float base = 0.f;
-  for (int j = lane; j < p.nb; j += 64) { const float v = pr[j]; base += (__float_as_uint(v) < vbits) ? v : 0.f; }
-  base = wave_sum(base);
-  // ties at v*: a stable ascending sort orders them by index; the m-th tie has cumsum base + m*v*
-  int m0 = 1;
-  if (vstar > 0.f) { const float need = (p.target - base) / vstar; m0 = (int)ceilf(need); if (m0 < 1) m0 = 1; }
-  // emit bits, 64 kv blocks per word
-  const int ti = i / (p.Hb * p.Wb), hi_ = (i / p.Wb) % p.Hb, wi = i % p.Wb;
-  int tie_seen = 0, kept = 0;
-  for (int c = 0; c < p.nw; ++c) {
-    const int j = c * 64 + lane;
-    bool keep = false, tie = false;
-    if (j < p.nb) {
-      const unsigned vb = __float_as_uint(pr[j]);
-      tie = vb == vbits;
-      keep = vb > vbits;
-      const int tj = j / (p.Hb * p.Wb), hj = (j / p.Wb) % p.Hb, wj = j % p.Wb;
-      keep = keep || (abs(ti - tj) <= p.wT / 2 && abs(hi_ - hj) <= p.wH / 2 && abs(wi - wj) <= p.wW / 2);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int il = il0 + r;
+    if (il < p.nqb) {         // wave-uniform (a guard, not a break: the loop must unroll fully or pv[][] goes to scratch)
+    const int i = p.qb0 + il;
+    const unsigned vbits = lo[r];
+    const float vstar = __uint_as_float(vbits);
+    float base = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) base += (__float_as_uint(pv[r][v]) < vbits && v * 64 + lane < p.nb) ? pv[r][v] : 0.f;
+    base = wave_sum_dpp(base);
+    // ties at v*: a stable ascending sort orders them by index; the m-th tie has cumsum base + m*v*
+    int m0 = 1;
+    if (vstar > 0.f) { const float need = (p.target - base) / vstar; m0 = (int)ceilf(need); if (m0 < 1) m0 = 1; }
+    // emit bits, 64 kv blocks per word (word c = this lane's value v = c)
+    const int ti = i / (p.Hb * p.Wb), hi_ = (i / p.Wb) % p.Hb, wi = i % p.Wb;
+    int tie_seen = 0, kept = 0;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      if (c < p.nw) {
+      const int j = c * 64 + lane;
+      bool keep = false, tie = false;
+      if (j < p.nb) {
+        const unsigned vb = __float_as_uint(pv[r][c]);
+        tie = vb == vbits;
+        keep = vb > vbits;
+        const int tj = j / (p.Hb * p.Wb), hj = (j / p.Wb) % p.Hb, wj = j % p.Wb;
+        keep = keep || (abs(ti - tj) <= p.wT / 2 && abs(hi_ - hj) <= p.wH / 2 && abs(wi - wj) <= p.wW / 2);
+      }
+      const unsigned long long tmask = __ballot(tie);
+      if (tie) {
+        const int rank = tie_seen + __popcll(tmask & ((1ull << lane) - 1ull)) + 1;
+        keep = keep || rank >= m0;
+      }
+      tie_seen += __popcll(tmask);
+      const unsigned long long w = __ballot(keep);
+      kept += __popcll(w);
+      if (lane == 0) p.bits[((size_t)h * p.nqb + il) * p.nw + c] = w;
+      }
     }
-    const unsigned long long tmask = __ballot(tie);
-    if (tie) {
-      const int rank = tie_seen + __popcll(tmask & ((1ull << lane) - 1ull)) + 1;
-      keep = keep || rank >= m0;
+    if (lane == 0 && p.kv_nb) p.kv_nb[h * p.nqb + il] = kept;
     }
-    tie_seen += __popcll(tmask);
-    const unsigned long long w = __ballot(keep);
-    kept += __popcll(w);
-    if (lane == 0) p.bits[((size_t)h * p.nqb + il) * p.nw + c] = w;
   }
-  if (lane == 0 && p.kv_nb) p.kv_nb[row] = kept;
 }
 
 // per (h, group of 4 query blocks): list[(h*ng+g)*nb + e] = kv_block | membership << 24 ; cnt[h*ng+g]
@@ -233,8 +312,19 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   p.qa = qa; p.ka = ka; p.bits = bits; p.kv_nb = kv_nb; p.H = H; p.nb = nb; p.nw = nw; p.T = T; p.Hb = Hb; p.Wb = Wb;
   p.wT = wT; p.wH = wH; p.wW = wW; p.target = (float)(1.0 - (double)P);
   p.nqb = nqb; p.qb0 = q_block0;
-  const int rows = H * nqb;
-  hipLaunchKernelGGL(nabla_select_kernel, dim3((rows + SEL_WAVES - 1) / SEL_WAVES), dim3(256), (size_t)SEL_WAVES * nb * 4, s, p);
+  // values per lane NV = ceil(nb / 64) rounded up to an instantiated size; rows per wave R = 4 (2, then 1, for the largest maps: registers)
+  const int nv = nw;
+  auto launch = [&](auto NVC, auto RC) {
+    constexpr int NV = decltype(NVC)::value, R = decltype(RC)::value;
+    const int bph = (nqb + 4 * R - 1) / (4 * R);
+    hipLaunchKernelGGL((nabla_select_kernel<NV, R>), dim3(H * bph), dim3(256), 0, s, p);
+  };
+  if (nv <= 4) launch(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+  else if (nv <= 8) launch(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
+  else if (nv <= 16) launch(std::integral_constant<int, 16>{}, std::integral_constant<int, 4>{});
+  else if (nv <= 24) launch(std::integral_constant<int, 24>{}, std::integral_constant<int, 4>{});
+  else if (nv <= 32) launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 2>{});
+  else launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 1>{});
   hipLaunchKernelGGL(nabla_union_kernel, dim3((H * ng + 3) / 4), dim3(256), 0, s, bits, list, cnt, H, nqb, nb, nw, ng);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }

@@ -95,7 +95,9 @@ def test_nabla_map_matches_oracle(E, grid, window, P, H, data):
             lo = float((cdf[h, i][tied] - p[h, i][tied]).min()) - tol
             hi = float(cdf[h, i][tied].max()) + tol
             assert near[h, i, j] or (int(tied.sum()) > 1 and lo <= thr <= hi), (h, i, j, float(cdf[h, i, j]), thr, int(tied.sum()))
-    assert diff.float().mean().item() <= (1e-3 if data == "exact" else 5e-3), (int(diff.sum()), diff.numel())
+    # how MANY entries may differ: integer logits make large tie groups (every member of a group straddling the cut may flip,
+    # checked one by one above), random logits at most a few entries next to the cut per row
+    assert diff.float().mean().item() <= (3e-2 if data == "exact" else 5e-3), (int(diff.sum()), diff.numel())
     assert (got & sta[None]).sum() == sta.sum() * H                     # the STA window is always kept
     assert got.any(-1).all()                                            # every row keeps at least one block
 
