@@ -3,7 +3,8 @@
 
 Outside the accelerated hot path: it runs once per clip and its output — `(L,3584)` bf16 token
 embeddings + `(1,768)` pooled — is what the engine consumes.  Differences from the reference: no hard requirement on
-flash-attn (`attn_implementation="sdpa"`) or torch.compile.  The system-prompt templates and crop offsets are data the
+flash-attn (`attn_implementation="sdpa"`) or torch.compile, and a text-only processor when the VL image / video processors cannot
+be built (no torchvision).  The system-prompt templates and crop offsets are data the
 encoder was used with (reference text_embedders.py:36-53), kept in text_prompts.json.
 """
 import json
@@ -19,6 +20,24 @@ def _freeze(model):
     for p in model.parameters():
         p.requires_grad = False
     return model
+
+
+class _TextOnlyProcessor:
+    """Qwen2_5_VLProcessor restricted to text: same call signature, tokenizer underneath."""
+
+    def __init__(self, tokenizer):
+        self.tokenizer = tokenizer
+
+    def __call__(self, text=None, images=None, videos=None, **kw):
+        if images is not None or videos is not None:
+            raise ValueError("text-only processor: the image / video processors could not be loaded")
+        return self.tokenizer(text, **kw)
+
+    def apply_chat_template(self, *a, **k):
+        return self.tokenizer.apply_chat_template(*a, **k)
+
+    def batch_decode(self, *a, **k):
+        return self.tokenizer.batch_decode(*a, **k)
 
 
 class ClipTextEmbedder:
@@ -42,7 +61,13 @@ class Qwen2_5_VLTextEmbedder:
         from transformers import AutoProcessor, Qwen2_5_VLForConditionalGeneration
         self.model = _freeze(Qwen2_5_VLForConditionalGeneration.from_pretrained(
             conf.checkpoint_path, dtype=torch.bfloat16, attn_implementation="sdpa", device_map=device))
-        self.processor = AutoProcessor.from_pretrained(conf.checkpoint_path, use_fast=True)
+        try:
+            self.processor = AutoProcessor.from_pretrained(conf.checkpoint_path, use_fast=True)
+        except (ImportError, OSError):
+            # the VL processor also builds the image / video processors (torchvision, preprocessor_config.json); this class only
+            # ever passes images=None, videos=None, for which the processor hands its keyword arguments to the tokenizer
+            from transformers import AutoTokenizer
+            self.processor = _TextOnlyProcessor(AutoTokenizer.from_pretrained(conf.checkpoint_path))
         self.max_length = conf.max_length
 
     @torch.no_grad()
