@@ -208,3 +208,29 @@ def test_config2_size_both_forms_sampled_rows_vs_oracle(E):
     close(out[rows], ref, ulps=4, atol=5e-3, what="config-2 sampled rows")
     oc = run_auto(E, q, kc, torch.full_like(vt, 0.75), H, flags, 0, balanced=True)
     assert (oc.float() - 0.75).abs().max().item() <= 2 ** -8
+
+
+def test_config5_size_both_forms_sampled_rows_vs_oracle(E):
+    """BASELINE config-5 sequence length (1280x768, 10 s: 234 240 tokens = 3660 blocks), two heads — head 0 on the fixed offset,
+    head 1 (gain 3) on the online max — through the balanced launch: sampled query rows against the oracle, and V = const ->
+    O = const on every one of the 234 240 rows (every workgroup's softmax sums to one over all 3660 key blocks)."""
+    N, H = 234240, 2
+    g = torch.Generator(device="cuda").manual_seed(5)
+    gains = torch.tensor([1.0, 3.0]).cuda()
+    def rmsn(x):
+        return gains[None, :, None] * x / x.pow(2).mean(-1, keepdim=True).sqrt()
+    q = rmsn(torch.randn(N, H, 64, device="cuda", generator=g)).reshape(N, -1).to(BF)
+    kc = (rmsn(torch.randn(N, H, 64, device="cuda", generator=g)) * O.SOFTMAX_C).reshape(N, -1).to(BF)
+    v = torch.randn(N, H * 64, device="cuda", generator=g).to(BF)
+    vt = v.t().contiguous()
+    qf, kf = q.float().reshape(N, H, 64), kc.float().reshape(N, H, 64)
+    qstat, kstat = (qf * qf).sum(-1).amax(0).contiguous(), (kf * kf).sum(-1).amax(0).contiguous()
+    flags = torch.zeros(H, dtype=torch.int32, device="cuda")
+    E.check(E.lib().k5_attention_flags(qstat.data_ptr(), kstat.data_ptr(), 1, H, H, 0, flags.data_ptr(), E.stream_ptr()))
+    assert flags.tolist() == [1, 0], flags
+    out = run_auto(E, q, kc, vt, H, flags, 0, balanced=True)
+    rows = torch.tensor([0, 63, 64, 4097, 117120, 200000, N - 65, N - 1])
+    ref = O.sdpa(qf[rows].cpu(), kf.cpu(), v.float().cpu().reshape(N, H, 64), "bf16", None, base2=True)
+    close(out[rows], ref, ulps=4, atol=5e-3, what="config-5 sampled rows")
+    oc = run_auto(E, q, kc, torch.full_like(vt, 0.75), H, flags, 0, balanced=True)
+    assert (oc.float() - 0.75).abs().max().item() <= 2 ** -8

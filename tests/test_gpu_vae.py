@@ -202,3 +202,43 @@ def test_generate_sample_postprocess_matches_reference_uint8(vae):
 
 def _r16(x):
     return x.bfloat16()
+
+
+def test_config5_spatial_tiling_at_real_size():
+    """BASELINE config 5 (1280x768, 10 s) is the one shape whose decode tiles SPATIALLY at real size: the reference's policy for
+    the (61, 96, 160) latent is 17-frame x 416 x 672 tiles at stride 8 x 352 x 608 (golden dec_tiling table, pinned to the reference).
+    Full-width synthetic decoder, 9 latent frames of that 96 x 160 plane -> 3 temporal x 2 x 2 spatial tiles with all three blends.
+    Expected = the ORACLE's tiling / blending policy driven by the engine's own tile decode, so the comparison isolates the host
+    mirror's tile origins, crops, blend extents and order at real size: identical tile kernels, bit-exact blends -> equality."""
+    from kandinsky.models.vae import AutoencoderKLHunyuanVideo
+    meta = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vae_meta.json")))
+    tile, stride = meta["dec_tiling"]["1x16x61x96x160"]
+    dev = "cuda:0"
+    with torch.device("meta"):
+        m = AutoencoderKLHunyuanVideo()
+    g = torch.Generator(device=dev).manual_seed(0)
+    sd = {}
+    for k, p in m.state_dict().items():
+        if "norm" in k and k.endswith("weight"):
+            sd[k] = torch.ones(p.shape, device=dev)
+        elif k.endswith("bias"):
+            sd[k] = torch.zeros(p.shape, device=dev)
+        else:
+            sd[k] = (torch.randn(p.shape, device=dev, generator=g) / p[0].numel() ** 0.5).half()
+    m.load_state_dict(sd, assign=True)
+    a, b = m.get_dec_optimal_tiling([1, 16, 61, 96, 160])
+    assert [list(a), list(b)] == [tile, stride]
+    z = torch.randn(1, 16, 9, 96, 160, device=dev, generator=g)
+    m.apply_tiling(tuple(tile), tuple(stride))
+    calls = []
+
+    def decode_tile(t):
+        calls.append(tuple(t.shape[2:]))
+        return m._decode_tile(t.contiguous()).float()
+
+    out = m._decode(z).sample
+    ref = V.tiled_decode(None, z, None, tile, stride, "bf16", decode_tile=decode_tile)
+    assert calls == [(5, 52, 84)] * 12, calls                       # 3 temporal x 2 x 2 spatial tiles of 5 x 52 x 84 latents
+    assert tuple(out.shape) == tuple(ref.shape) == (1, 3, 33, 768, 1280)
+    assert torch.isfinite(out.float()).all() and out.float().std().item() > 1e-3
+    assert torch.equal(out.float(), ref.float()), rel(out, ref)
