@@ -176,3 +176,47 @@ def test_tiny_sampler_P_ranks_on_one_gpu(golden_meta, tiny_sd, P, w):
     for r in range(1, P):
         assert torch.equal(outs[r], outs[0])
     assert rel(outs[0], fused) <= 1e-2, rel(outs[0], fused)     # the suite's tolerance on a final latent
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("P,sparse,fp8", [(8, False, False), (4, True, True), (4, True, False), (4, False, True)])
+def test_config5_sequence_length_P_ranks_on_one_gpu(P, sparse, fp8):
+    """BASELINE's last configuration at its real sequence length: 1280x768, 10 s -> latent (61, 96, 160) -> 234 240 tokens = 3660
+    blocks, 2B-Lite width, one visual block.  (8, dense, bf16): 3660 blocks over 8 ranks = 7 x 458 + 454, the uneven layout.
+    (4, NABLA, fp8): one CFG branch of the SP x 4 + CFG x 2 plan, with the 10 s config's NABLA map (P = 0.9, 11 x 3 x 3 window,
+    3660-block rows: the 64-values-per-lane select kernel) and the W8A8 feed-forward.  Every rank must hold the same velocity and
+    it must agree with the single-handle run of the same settings — bf16: the 6e-3 of two valid summation orders; fp8: e4m3
+    re-quantises the feed-forward input (3 mantissa bits), which turns the 2.5e-3 between the two schedules into roundings that
+    flip on a few per cent of the elements by 6 % each: measured 1.0e-2 (dense) / 1.6e-2 (NABLA), against the mode's own 5.2e-2
+    distance from bf16 -> 2.5e-2."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=1, num_text_blocks=1)
+    sd = O.synthetic_state_dict(O.DitConfig(**c), seed=4)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(61, 96, 160, 16, generator=g)
+    text, pooled = torch.randn(48, 3584, generator=g), torch.randn(1, 768, generator=g)
+    pos = [torch.arange(61), torch.arange(48), torch.arange(80)]
+    t = torch.tensor([600.0])
+    sp = {"P": 0.9, "wT": 11, "wH": 3, "wW": 3, "to_fractal": True} if sparse else None
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(sd, assign=True)
+        d = d.to("cuda:0")
+        if fp8:
+            d.engine("cuda:0")
+            d.set_fp8(True)
+        return d
+
+    def call(d, r):
+        return d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(48), scale_factor=(1.0, 2.0, 2.0), sparse_params=sp)
+
+    one = make()
+    fused = call(one, 0)
+    one._destroy_engine(force=True)
+    assert tuple(fused.shape) == (61, 96, 160, 16) and torch.isfinite(fused.float()).all()
+    outs = run_ranks(P, make, call)
+    for r in range(1, P):
+        assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
+    print(f"config-5 length, P={P} sparse={sparse} fp8={fp8}: sharded vs fused rel-L2 {rel(outs[0], fused):.3e}")
+    assert rel(outs[0], fused) <= (2.5e-2 if fp8 else 6e-3), rel(outs[0], fused)
