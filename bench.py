@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--force-sp", action="store_true", help="debug: drive the sharded code path through a world=1 RCCL communicator")
     ap.add_argument("--magcache", action="store_true", help="MagCache with the config's ratio table (changes the work per step: not the headline metric)")
     ap.add_argument("--fp8", action="store_true", help="opt-in lossy mode (feed-forward GEMMs in W8A8 e4m3): NOT the headline number, reported as dtype bf16+fp8ff")
+    ap.add_argument("--profile-level", type=int, default=2, choices=(0, 1, 2),
+                    help="HIP events inside the timed region: 2 = around the roofline kernel only (default), 1 = every kernel family, 0 = none")
+    ap.add_argument("--no-breakdown", action="store_true", help="skip the separate per-family timing pass")
     ap.add_argument("--emulate-shard", type=int, default=0, metavar="P",
                     help="debug only (INVALID as a bench): per-rank compute of a P-GPU run on one GPU, collectives move nothing")
     ap.add_argument("--blocks", type=int, default=32, help="debug only: fewer visual blocks => INVALID as a bench")
@@ -196,7 +199,7 @@ def main():
     if args.warmup > 0:
         run(0, args.warmup)
     barrier()
-    dit.set_profiling(True)
+    dit.set_profiling(args.profile_level)   # 2: HIP events around the roofline kernel only (one pair per block) inside the timed region
     dit.reset_profile()
     dit.attn_variant_counts(reset=True)
     t0 = time.perf_counter()
@@ -207,10 +210,27 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = tt.item()
-    dit.set_profiling(False)
+    dit.set_profiling(0)
 
-    fam = {f: dit.get_profile(f) for f in ("attn_self", "attn_cross", "attn_text", "gemm", "elementwise", "prologue",
-                                           "epilogue", "comm", "nabla_map")}
+    FAMS = ("attn_self", "attn_cross", "attn_text", "gemm", "elementwise", "prologue", "epilogue", "comm", "nabla_map")
+    fam = {f: dit.get_profile(f) for f in FAMS}
+    fam_steps = args.steps
+    n_fixed, n_online = dit.attn_variant_counts()
+    nabla_counts = dit.nabla_block_counts() if wl["attn"] == "nabla" else None
+    if args.profile_level == 2 and not args.no_breakdown:
+        # per-family breakdown from a SEPARATE short pass: an event pair at every family switch (~15 per block) drains the stream
+        # each time, which costs the step 1-2 % at one GPU and ~8 % at 8-GPU shard sizes — not something to leave inside `value`
+        fam_steps = min(args.steps, 2)
+        dit.set_profiling(1)
+        dit.reset_profile()
+        run(args.warmup, fam_steps)
+        barrier()
+        dit.set_profiling(0)
+        fam_b = {f: dit.get_profile(f) for f in FAMS}
+        fam_b["attn_self"] = (fam["attn_self"][0] / args.steps * fam_steps, fam_b["attn_self"][1])   # keep the timed region's figure
+        fam_break = fam_b
+    else:
+        fam_break = fam
     # end-to-end leg (not part of `value`): HunyuanVideo VAE decode of the final latent on the same GPU
     vae_s = None
     if rank == 0 and not args.no_vae:
@@ -236,11 +256,10 @@ def main():
     blocks_run = attn_n / (2 if (sp_on and wl["attn"] == "flash") else 1)
     density = None
     if wl["attn"] == "nabla":
-        kept, possible = dit.nabla_block_counts()
+        kept, possible = nabla_counts
         density = kept / possible if possible else None
     attn_flop = 4.0 * N * N * 64 * 28 / shard * (density if density is not None else 1.0)
     achieved = attn_flop * blocks_run / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0
-    n_fixed, n_online = dit.attn_variant_counts()
     if args.attn_online:
         variant = "online-max softmax on every head (forced: --attn-online)"
     elif n_fixed + n_online == 0:
@@ -282,7 +301,10 @@ def main():
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "flop_per_launch": attn_flop * blocks_run / max(attn_n, 1), "avg_launch_ms": attn_ms / max(attn_n, 1),
                          "launches": attn_n, "blocks_run": blocks_run, "kept_block_density": density},
-            "kernel_time_ms_per_step": {k: v[0] / args.steps for k, v in fam.items() if v[1]},
+            "kernel_time_ms_per_step": {k: v[0] / fam_steps for k, v in fam_break.items() if v[1]},
+            "kernel_time_source": ("HIP events inside the timed region" if fam_break is fam else
+                                   f"attn_self: HIP events inside the timed region; other families: separate {fam_steps}-step pass with an "
+                                   "event pair at every family switch (not part of `value`)"),
             "e2e_clip_s": {"denoise_50_steps_s": 50 * dt / args.steps, "vae_decode_s": vae_s,
                            "total_s": None if vae_s is None else 50 * dt / args.steps + vae_s,
                            "note": "50 x measured ms_per_step + measured HunyuanVideo VAE decode (14 temporal tiles, uint8 out); "

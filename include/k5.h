@@ -326,8 +326,10 @@ int k5_dit_magcache_calls(k5_dit* dit, int first_call, int stride);
 int k5_dit_magcache_state(k5_dit* dit, int* cnt, long long* n_ran, long long* n_skipped);
 
 /* per-kernel-family accumulated GPU time of the last forward(s), measured with hipEvents on the
- * engine's stream when profiling is enabled.  names: "attn_self","attn_cross","gemm","elementwise",...  */
-int k5_dit_set_profiling(k5_dit* dit, int enabled);
+ * engine's stream when profiling is enabled.  names: "attn_self","attn_cross","gemm","elementwise",...
+ * level 0 = off, 1 = every family (an event pair per family switch: ~15 per block, the stream drains at each one),
+ * 2 = only "attn_self", the roofline kernel (one pair per block) — what bench.py keeps on inside its timed region. */
+int k5_dit_set_profiling(k5_dit* dit, int level);
 int k5_dit_get_profile(k5_dit* dit, const char* family, double* total_ms, int64_t* launches);
 int k5_dit_reset_profile(k5_dit* dit);
 

@@ -257,7 +257,7 @@ struct k5_dit {
   } mag;
 
   // profiling
-  bool profiling = false;
+  int profiling = 0;                               // 0 off, 1 every kernel family, 2 only the visual self-attention (the roofline kernel)
   std::map<std::string, Prof> prof;
   struct Pending { std::string fam; hipEvent_t a, b; };
   std::vector<Pending> pending;
@@ -280,7 +280,7 @@ hipEvent_t get_event(k5_dit* d) {
 }
 struct Scope {
   k5_dit* d; hipStream_t s; const char* fam; hipEvent_t a{}, b{}; bool on;
-  Scope(k5_dit* d_, hipStream_t s_, const char* f) : d(d_), s(s_), fam(f), on(d_->profiling) {
+  Scope(k5_dit* d_, hipStream_t s_, const char* f) : d(d_), s(s_), fam(f), on(d_->profiling == 1 || (d_->profiling == 2 && !strcmp(f, "attn_self"))) {
     if (on) { a = get_event(d); b = get_event(d); (void)hipEventRecord(a, s); }
   }
   ~Scope() { if (on) { (void)hipEventRecord(b, s); d->pending.push_back({fam, a, b}); } }
@@ -1343,7 +1343,7 @@ extern "C" int k5_dit_nabla_block_counts(k5_dit* d, long long* kept, long long* 
   return K5_OK;
 }
 
-extern "C" int k5_dit_set_profiling(k5_dit* d, int enabled) { if (!d) return K5_ERR_ARG; d->profiling = enabled != 0; return K5_OK; }
+extern "C" int k5_dit_set_profiling(k5_dit* d, int level) { if (!d || level < 0 || level > 2) return K5_ERR_ARG; d->profiling = level; return K5_OK; }
 extern "C" int k5_dit_reset_profile(k5_dit* d) { if (!d) return K5_ERR_ARG; drain_profile(d); d->prof.clear(); return K5_OK; }
 extern "C" int k5_dit_get_profile(k5_dit* d, const char* family, double* total_ms, int64_t* launches) {
   if (!d || !family) return K5_ERR_ARG;
