@@ -44,6 +44,13 @@ const char* k5_last_error(void);
 int k5_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda,
                  int ldw, int ldc, int epilogue, const void* resid, int ldr, const float* gate, void* stream);
 
+/* S_f32[M][N] = alpha * A[M][K] . W[N][K]^T — the fp32 attention scores of the VAE mid block (diffusers Attention called from
+ * HunyuanVideoMidBlock3D, kandinsky/models/vae.py:341-362, with prepare_causal_attention_mask vae.py:110-122).  causal_hw > 0:
+ * row i is only ever read at columns < (i / causal_hw + 1) * causal_hw (its own and earlier frames); output tiles wholly beyond
+ * that limit are not computed and left unwritten.  C is fp32 [M][ldc]. */
+int k5_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc,
+                        float alpha, int causal_hw, void* stream);
+
 /* O[q][h*64+d] = softmax(Q K^T / 8) V per head (head_dim 64, non-causal, fp32 softmax).
  * Replaces FA(q,k,v): nn.py:201 (text self-attn), :254 (visual self-attn), :336 (cross-attn).
  * Q [q_len][ldq], K [kv_len][ldk] with head h at columns h*64..; Vt [H*64][ldvt] is V transposed

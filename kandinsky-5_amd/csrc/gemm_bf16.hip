@@ -33,6 +33,8 @@ struct GemmP {
   int M, N, K, lda, ldw, ldc, ldr;
   int tiles_m, tiles_n;
   float alpha;            // EPI_F32: C_f32 = alpha * acc
+  int causal_hw;          // EPI_F32, 4-wave kernel: > 0 = frame-causal scores, row i only needs columns < (i / hw + 1) * hw; output
+                          // tiles wholly beyond that are not computed (nor written).  0 = all tiles
   int dbg;                // benchmarking experiments only (K5_GEMM_DBG); 0 in production
   // 256x256 kernel: logical tiles [0, lid_limit) only.  128x128 kernel in tail mode (tail_base >= 0): workgroup b computes
   // quadrant b & 3 of the 256x256 logical tile tail_base + b / 4 (tiles256_m/n = that grid's extent).
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   const int tm = first_m + (lid % per_group) % gsz;
   const int tn = (lid % per_group) / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
+  if (EPI == K5_EPI_F32 && p.causal_hw > 0 && n0 >= ((min(m0 + BM, p.M) - 1) / p.causal_hw + 1) * p.causal_hw) return;
 
   // loader mapping: 1024 16-B chunks per operand tile, 4 per thread
   int ld_row[4], ld_c[4];
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmP p) {
     n0 = ((plid % (4 * p.tiles256_n)) / pgsz) * 256 + 128 * (q & 1);
     if (m0 >= p.M || n0 >= p.N) return;
   }
+  if (EPI == K5_EPI_F32 && p.causal_hw > 0 && n0 >= ((min(m0 + BM, p.M) - 1) / p.causal_hw + 1) * p.causal_hw) return;   // beyond the frame-causal limit
 
   // this wave stages pieces wave*4 .. wave*4+3 (8 rows x 128 B each) of both operand tiles
   const bf16_t* ga[4]; const bf16_t* gw[4];
@@ -692,6 +696,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int GM = 4;
   const int per_group = GM * p.tiles_n;
   auto tile_origin = [&](int lid, int& m0, int& n0) {
+    if (EPI == K5_EPI_F32 && p.causal_hw > 0) {
+      // frame-causal scores: m-tile i keeps its first c(i) = ceil(limit(last row of the tile) / 256) n-tiles; lid indexes the kept
+      // tiles row by row (a scalar walk over <= tiles_m rows, twice per 256x256 tile: noise)
+      int i = 0;
+      for (;; ++i) {
+        const int last = min((i + 1) * K8_BM, p.M) - 1;
+        const int c = min(p.tiles_n, (min(p.N, (last / p.causal_hw + 1) * p.causal_hw) + K8_BN - 1) / K8_BN);
+        if (lid < c || i + 1 >= p.tiles_m) break;
+        lid -= c;
+      }
+      m0 = i * K8_BM; n0 = lid * K8_BN;
+      return;
+    }
     const int g = lid / per_group, first_m = g * GM;
     const int gsz = min(p.tiles_m - first_m, GM);
     m0 = (first_m + (lid % per_group) % gsz) * K8_BM;
@@ -936,6 +953,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto epilogue = [&](auto HB) {
       constexpr bool has_bias = decltype(HB)::value;
       const int nb = n0 + 128 * e_wn + 4 * e_lc;          // + 16 i
+      if constexpr (EPI == K5_EPI_F32) {                  // raw fp32 scores: C is float*, one 16-B store per quad
+        float* cf = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int m = m0 + 128 * e_wm + 16 * j + e_l15;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int n = nb + 16 * i;
+            if (m < p.M && n < p.N)
+              *reinterpret_cast<f32x4*>(cf + (size_t)m * p.ldc + n) =
+                  f32x4{acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
+          }
+        }
+        return;
+      }
       f32x4 bvec[8], gvec[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -1048,7 +1080,7 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   p.resid = (const bf16_t*)resid; p.gate = gate;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
-  p.alpha = 1.f; p.trace = nullptr; p.lid_limit = 0; p.tail_base = -1; p.tiles256_m = p.tiles256_n = 0;
+  p.alpha = 1.f; p.causal_hw = 0; p.trace = nullptr; p.lid_limit = 0; p.tail_base = -1; p.tiles256_m = p.tiles256_n = 0;
   static const int dbg = getenv("K5_GEMM_DBG") ? atoi(getenv("K5_GEMM_DBG")) : 0;
   p.dbg = dbg;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
@@ -1119,13 +1151,42 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
 }
 
 // C_f32[M][N] = alpha * A[M][K] . W[N][K]^T   (fp32 output; attention scores of the VAE mid block)
+// causal_hw > 0: frame-causal scores — row i is only read at columns < (i / causal_hw + 1) * causal_hw (k5_launch_causal_softmax
+// with the same hw), so output tiles wholly beyond that limit are neither computed nor written (15 of 25 frame pairs at T = 5).
 int k5_launch_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc,
-                               float alpha, hipStream_t stream) {
-  if (M <= 0 || N <= 0 || K <= 0) return K5_ERR_ARG;
+                               float alpha, int causal_hw, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || causal_hw < 0) return K5_ERR_ARG;
   if ((K & 7) || (lda & 7) || (ldw & 7)) return K5_ERR_ALIGN;
   GemmP p;
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = (bf16_t*)C; p.bias = nullptr; p.resid = nullptr; p.gate = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.alpha = alpha; p.dbg = 0; p.trace = nullptr; p.lid_limit = 0; p.tail_base = -1; p.tiles256_m = p.tiles256_n = 0;
+  p.causal_hw = causal_hw;
+  // the 4-wave persistent kernel from one round of kept 256x256 tiles up (same conditions as k5_launch_gemm_bf16)
+  const int tm = (M + K8_BM - 1) / K8_BM, tn = (N + K8_BN - 1) / K8_BN;
+  long long kept = 0;
+  for (int i = 0; i < tm; ++i) {
+    const int last = std::min((i + 1) * K8_BM, M) - 1;
+    kept += causal_hw > 0 ? std::min(tn, (int)((std::min((long long)N, ((long long)last / causal_hw + 1) * causal_hw) + K8_BN - 1) / K8_BN)) : tn;
+  }
+  static const int force_v1 = getenv("K5_GEMM_V1") ? atoi(getenv("K5_GEMM_V1")) : 0;
+  if ((K % (2 * BK)) == 0 && K >= 4 * BK && M >= 512 && N >= 256 && !(N & 3) && !(ldc & 3) && kept >= 256 && kept < (1ll << 30) &&
+      (force_v1 == 0 || force_v1 == 4)) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<K5_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)
+        return K5_ERR_HIP;
+      attr_set = true;
+    }
+    static int num_cu = 0;
+    if (!num_cu) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
+      num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    p.tiles_m = tm; p.tiles_n = tn; p.lid_limit = (int)kept; p.tiles256_m = tm; p.tiles256_n = tn;
+    hipLaunchKernelGGL((gemm_bf16_w4_kernel<K5_EPI_F32>), dim3(std::min((int)kept, num_cu)), dim3(256), W4_LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+  }
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
   if ((K % BK) == 0) hipLaunchKernelGGL(gemm_bf16_glds_kernel<K5_EPI_F32>, grid, block, 0, stream, p);

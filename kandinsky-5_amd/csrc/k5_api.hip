@@ -20,6 +20,11 @@ int k5_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M
              "k5_gemm_bf16");
 }
 
+int k5_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc, float alpha,
+                        int causal_hw, void* stream) {
+  return ret(k5_launch_gemm_bf16_f32out(A, W, C, M, N, K, lda, ldw, ldc, alpha, causal_hw, (hipStream_t)stream), "k5_gemm_bf16_f32out");
+}
+
 int k5_attention_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                       int ldk, int ldvt, int ldo, void* stream) {
   return ret(k5_launch_attention_bf16_bounded(Q, K, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, 0.f, (hipStream_t)stream),

@@ -105,8 +105,9 @@ int k5_launch_cfg_euler(float* img, const void* v_cond, const void* v_uncond, fl
 // fp32 -> bf16 cast, bf16 -> fp32
 int k5_launch_cast_f32_bf16(const float* x, void* out, int64_t n, hipStream_t stream);
 
+// causal_hw > 0: frame-causal scores, tiles wholly at columns >= (row / causal_hw + 1) * causal_hw are skipped (left unwritten)
 int k5_launch_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc,
-                               float alpha, hipStream_t stream);
+                               float alpha, int causal_hw, hipStream_t stream);
 
 // ---- VAE decoder kernels (channels-last bf16 activations) ----
 // 4-wave 256-row variant (conv3d_w4.hip); K5_ERR_UNSUPPORTED outside its range (Cin % 128, Cout = 128 or % 256, >= one round of tiles)

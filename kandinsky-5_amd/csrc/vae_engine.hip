@@ -241,7 +241,7 @@ int mid_attention(k5_vae* v, hipStream_t s, const MidAttn& a, void* h, int T, in
   HIPCHK(hipMemsetAsync(v->vt.p, 0, (size_t)C * Sp * 2, s));
   K5CHK(k5_launch_gemm_bf16(a.wv.p, v->bt1.p, a.bv.as<float>(), v->vt.p, C, S, C, C, C, Sp, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
   K5CHK(k5_launch_gemm_bf16_f32out(v->qk.p, v->qk.as<bf16_t>() + C, v->scores.as<float>(), S, S, C, 2 * C, 2 * C, Sp,
-                                    1.0f / sqrtf((float)C), s));
+                                    1.0f / sqrtf((float)C), H * W, s));   // frame-causal: key frames after the query's are never read
   K5CHK(k5_launch_causal_softmax(v->scores.as<float>(), v->P.p, S, H * W, Sp, Sp, s));
   K5CHK(k5_launch_gemm_bf16(v->P.p, v->vt.p, nullptr, v->o.p, S, C, Sp, Sp, Sp, C, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   // to_out[0] + residual (diffusers Attention residual_connection=True): bf16(h + 1 * bf16(o Wo^T + bo)), in place

@@ -158,6 +158,34 @@ def test_gemm_gelu_epilogue_persistent_kernel(E):
     assert_bf16_close(got, ref, what="gelu epilogue (k8)")
 
 
+@pytest.mark.parametrize("S,K,hw", [(6144, 512, 2048), (5000, 512, 1000), (4608, 512, 1536), (700, 192, 100), (6144, 512, 0)])
+def test_gemm_f32out_frame_causal_scores(E, S, K, hw):
+    """k5_gemm_bf16_f32out (fp32 attention scores of the VAE mid block, vae.py:341-362 + causal mask vae.py:110-122): every
+    entry a causal softmax of frame size hw reads — column < (row // hw + 1) * hw — against an fp32 matmul of the same bf16
+    operands; 256x256 (128x128 on the small shapes) tiles wholly beyond the limit must have been skipped: the NaN the buffer was
+    filled with is still there.  (6144, 2048) and (5000, 1000) take the 4-wave persistent kernel (>= 256 kept tiles), the others
+    the 128x128 one; hw = 1000 puts frame boundaries inside tiles; hw = 0 = no mask."""
+    q = rnd(S, K, seed=1).cuda().to(BF)
+    k = rnd(S, K, seed=2).cuda().to(BF)
+    ld = (S + 7) // 8 * 8
+    out = torch.full((S, ld), float("nan"), device="cuda")
+    alpha = 1.0 / math.sqrt(K)
+    E.check(E.lib().k5_gemm_bf16_f32out(q.data_ptr(), k.data_ptr(), out.data_ptr(), S, S, K, K, K, ld, alpha, hw, E.stream_ptr()),
+            "k5_gemm_bf16_f32out")
+    torch.cuda.synchronize()
+    ref = (q.float() @ k.float().t()) * alpha
+    rows = torch.arange(S, device="cuda")[:, None]
+    cols = torch.arange(S, device="cuda")[None, :]
+    need = (cols < ((rows // hw + 1) * hw if hw else S)).expand(S, S)
+    got = out[:, :S]
+    assert torch.isfinite(got[need]).all()
+    assert (got[need] - ref[need]).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    if hw:
+        tile = 256 if S >= 5000 else 128
+        skipped = cols // tile * tile >= ((torch.clamp((rows // tile + 1) * tile, max=S) - 1) // hw + 1) * hw
+        assert skipped.any() and torch.isnan(got[skipped]).all()      # those tiles were never computed
+
+
 def test_gemm_alignment_error_is_loud(E):
     a, w = torch.zeros(8, 12, dtype=BF, device="cuda"), torch.zeros(8, 12, dtype=BF, device="cuda")
     with pytest.raises(RuntimeError, match="status 2"):
