@@ -51,6 +51,10 @@ int k5_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M
 int k5_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc,
                         float alpha, int causal_hw, void* stream);
 
+/* P_bf16[i][j] = softmax_j(scores[i][j]) over the frame-causal columns j < (i / hw + 1) * hw, 0 elsewhere (j < ldp) — the masked
+ * softmax of the same mid-block attention (mask: prepare_causal_attention_mask, vae.py:110-122).  scores fp32 [S][lds]. */
+int k5_causal_softmax_bf16(const float* scores, void* P, int S, int hw, int lds, int ldp, void* stream);
+
 /* O[q][h*64+d] = softmax(Q K^T / 8) V per head (head_dim 64, non-causal, fp32 softmax).
  * Replaces FA(q,k,v): nn.py:201 (text self-attn), :254 (visual self-attn), :336 (cross-attn).
  * Q [q_len][ldq], K [kv_len][ldk] with head h at columns h*64..; Vt [H*64][ldvt] is V transposed

@@ -173,7 +173,7 @@ int k5_launch_conv3d_bf16_strided(const void* X, const void* W, const float* bia
   const bool strided = st_t > 1 || st_s > 1;
   static const int force = getenv("K5_CONV_V1") ? atoi(getenv("K5_CONV_V1")) : 0;   // A/B: 1 = always the 128 x 128 kernel below
   if (force != 1 && !strided) {
-    const int r = k5_launch_conv3d_w4(X, W, bias, out, Ts, Hs, Ws, Cin, Cout, up_t, up_s, ldc, resid, ldr, stream);
+    const int r = k5_launch_conv3d_w4(X, W, bias, out, Ts, Hs, Ws, Cin, Cout, up_t, up_s, ldc, resid, ldr, nullptr, stream);
     if (r != K5_ERR_UNSUPPORTED) return r;
   }
   ConvP p;

@@ -30,10 +30,12 @@ struct ConvW4P {
   int Ts, Hs, Ws, To, Ho, Wo, up_t, up_s;
   int Cin, Cout, M, ldc, ldr, tiles_m, tiles_n;
   unsigned x_bytes;
+  float* quad_stats;   // STATS: [2 tiles_m][Cout / 4][2] fp32 = (sum, sum of squares) of the STORED bf16 outputs over the 128 rows of
+                       // half an m-tile, per 4 consecutive channels — the GroupNorm that consumes this tensor sums them per group
 };
 
 // NTW = 16-channel n-tiles per wave: 8 -> 256 x 256 tile (waves 2 x 2, each 128 x 128), 4 -> 256 x 128 tile (each 128 x 64)
-template <int NTW, bool RESID>
+template <int NTW, bool RESID, bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3d_w4_kernel(ConvW4P p) {
   constexpr int BN = 32 * NTW;
   constexpr int WP = BN / 8;                                   // weight pieces per K-tile (8 rows each)
@@ -208,6 +210,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x4 bvec[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) bvec[i] = *reinterpret_cast<const f32x4*>(p.bias + nb + 16 * i);
+    float gs[NTW], gq[NTW];   // STATS: this lane's sums over its 8 rows, per n-tile (its 4 channels of that tile)
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
 #pragma unroll
     for (int jh = 0; jh < 4; ++jh) {
       u32x2 rr[2][NTW];
@@ -239,6 +244,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               v[3] = __uint_as_float(rr[jj][i][1] & 0xffff0000u) + bf_round(v[3]);
             }
             o[h] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            if (STATS && m < p.M) {        // of the values as stored (bf16), which is what the next GroupNorm reads
+              const float r0 = __uint_as_float(o[h][0] << 16), r1 = __uint_as_float(o[h][0] & 0xffff0000u);
+              const float r2 = __uint_as_float(o[h][1] << 16), r3 = __uint_as_float(o[h][1] & 0xffff0000u);
+              gs[i] += (r0 + r1) + (r2 + r3);
+              gq[i] = fmaf(r3, r3, fmaf(r2, r2, fmaf(r1, r1, fmaf(r0, r0, gq[i]))));
+            }
           }
 #pragma unroll
           for (int d = 0; d < 2; ++d) {   // lanes l / l + 16 trade halves: each lane owns 8 consecutive channels of one tile
@@ -251,6 +262,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       asm volatile("" ::: "memory");
     }
+    if (STATS) {
+      // the 16 lanes of a DPP row are the 16 rows of a token tile for one channel quad: four row-local steps leave the row sum
+      // in every lane; lanes 0 / 16 / 32 / 48 store their quad's pair.  Fixed order: deterministic.
+      auto row_sum = [](float x) __attribute__((always_inline)) {
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4e, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));   // row_half_mirror
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));   // row_mirror
+        return x;
+      };
+      float* qs = p.quad_stats + ((size_t)(2 * (m0 >> 8) + e_wm) * (p.Cout >> 2) + ((n0 + 16 * NTW * e_wn) >> 2) + e_lc) * 2;
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const float a = row_sum(gs[i]), b = row_sum(gq[i]);
+        if (e_l15 == 0) *reinterpret_cast<f32x2*>(qs + 8 * i) = f32x2{a, b};
+      }
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing may still be loading into a VGPR when the asm stream resumes
   }
 #undef CW_MF
@@ -259,16 +287,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wrapped DMAs still write this workgroup's LDS
 }
 
-template <int NTW, bool RESID>
+template <int NTW, bool RESID, bool STATS>
 int launch_conv_w4(const ConvW4P& p, int num_cu, hipStream_t stream) {
   constexpr int LDS = 2 * ((32 * NTW / 8) * CW_PAD + 32 * CW_PAD);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3d_w4_kernel<NTW, RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return K5_ERR_HIP;
+    if (hipFuncSetAttribute((const void*)conv3d_w4_kernel<NTW, RESID, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return K5_ERR_HIP;
     attr_set = true;
   }
   const int tiles = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((conv3d_w4_kernel<NTW, RESID>), dim3(min(tiles, num_cu)), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((conv3d_w4_kernel<NTW, RESID, STATS>), dim3(min(tiles, num_cu)), dim3(256), LDS, stream, p);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -276,8 +304,10 @@ int launch_conv_w4(const ConvW4P& p, int num_cu, hipStream_t stream) {
 
 // Same contract as k5_launch_conv3d_bf16 (conv3d.hip); returns K5_ERR_UNSUPPORTED when the shape is outside this kernel's
 // range (the caller then uses the 128 x 128 kernel).
+// quad_stats (may be null): [2 ceil(M / 256)][Cout / 4][2] fp32, filled with the per-128-row (sum, sum of squares) of the stored
+// outputs per channel quad — GroupNorm statistics without another pass over the tensor (k5_launch_groupnorm_bf16_quads).
 int k5_launch_conv3d_w4(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin, int Cout,
-                        int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream) {
+                        int up_t, int up_s, int ldc, const void* resid, int ldr, float* quad_stats, hipStream_t stream) {
   if (Cin <= 0 || (Cin % 128) || !(Cout == 128 || (Cout % 256) == 0) || (ldc & 7) || (resid && (ldr & 3)) || !bias) return K5_ERR_UNSUPPORTED;
   ConvW4P p;
   p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.C = (bf16_t*)out; p.bias = bias; p.resid = (const bf16_t*)resid;
@@ -296,6 +326,11 @@ int k5_launch_conv3d_w4(const void* X, const void* W, const float* bias, void* o
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   if ((long long)p.tiles_m * p.tiles_n < num_cu) return K5_ERR_UNSUPPORTED;   // less than one round: the small tiles fill the chip better
-  if (Cout == 128) return resid ? launch_conv_w4<4, true>(p, num_cu, stream) : launch_conv_w4<4, false>(p, num_cu, stream);
-  return resid ? launch_conv_w4<8, true>(p, num_cu, stream) : launch_conv_w4<8, false>(p, num_cu, stream);
+  p.quad_stats = quad_stats;
+  if (quad_stats) {
+    if (Cout == 128) return resid ? launch_conv_w4<4, true, true>(p, num_cu, stream) : launch_conv_w4<4, false, true>(p, num_cu, stream);
+    return resid ? launch_conv_w4<8, true, true>(p, num_cu, stream) : launch_conv_w4<8, false, true>(p, num_cu, stream);
+  }
+  if (Cout == 128) return resid ? launch_conv_w4<4, true, false>(p, num_cu, stream) : launch_conv_w4<4, false, false>(p, num_cu, stream);
+  return resid ? launch_conv_w4<8, true, false>(p, num_cu, stream) : launch_conv_w4<8, false, false>(p, num_cu, stream);
 }

@@ -20,6 +20,11 @@ int k5_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M
              "k5_gemm_bf16");
 }
 
+int k5_causal_softmax_bf16(const float* scores, void* P, int S, int hw, int lds, int ldp, void* stream) {
+  if (!scores || !P || lds < S) return K5_ERR_ARG;
+  return ret(k5_launch_causal_softmax(scores, P, S, hw, lds, ldp, (hipStream_t)stream), "k5_causal_softmax_bf16");
+}
+
 int k5_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc, float alpha,
                         int causal_hw, void* stream) {
   return ret(k5_launch_gemm_bf16_f32out(A, W, C, M, N, K, lda, ldw, ldc, alpha, causal_hw, (hipStream_t)stream), "k5_gemm_bf16_f32out");

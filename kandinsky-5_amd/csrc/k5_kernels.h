@@ -111,8 +111,9 @@ int k5_launch_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, in
 
 // ---- VAE decoder kernels (channels-last bf16 activations) ----
 // 4-wave 256-row variant (conv3d_w4.hip); K5_ERR_UNSUPPORTED outside its range (Cin % 128, Cout = 128 or % 256, >= one round of tiles)
+// quad_stats (nullable): [2 ceil(M / 256)][Cout / 4][2] fp32 partial GroupNorm sums of the stored outputs (see conv3d_w4.hip)
 int k5_launch_conv3d_w4(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin, int Cout,
-                        int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream);
+                        int up_t, int up_s, int ldc, const void* resid, int ldr, float* quad_stats, hipStream_t stream);
 int k5_launch_conv3d_bf16(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin,
                           int Cout, int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream);
 int k5_launch_conv3d_bf16_strided(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin,
@@ -120,6 +121,9 @@ int k5_launch_conv3d_bf16_strided(const void* X, const void* W, const float* bia
 size_t k5_groupnorm_workspace_bytes(int M, int G);
 int k5_launch_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
                              int silu, int ldx, int ldo, void* workspace, hipStream_t s);
+// GroupNorm whose statistics were emitted by the producing conv: quad_stats [nblk][C / 4][2] (k5_launch_conv3d_w4); stats_ws: 2 G floats
+int k5_launch_groupnorm_bf16_quads(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
+                                   int silu, int ldx, int ldo, const float* quad_stats, int nblk, float* stats_ws, hipStream_t s);
 int k5_launch_causal_softmax(const float* scores, void* P, int S, int hw, int lds, int ldp, hipStream_t s);
 int k5_launch_nchw_to_mc(const float* z, void* out, int C, int64_t M, int Cpad, hipStream_t s);
 int k5_launch_mc_to_nchw(const void* x, void* out, int C, int64_t M, int ldx, hipStream_t s);

@@ -33,8 +33,14 @@ void k5_set_error(const char* fmt, ...);
 
 namespace {
 
-struct Buf {
+struct Buf {   // owning device buffer: freed with the handle (k5_vae_destroy)
   void* p = nullptr; size_t bytes = 0;
+  Buf() = default;
+  Buf(const Buf&) = delete;
+  Buf& operator=(const Buf&) = delete;
+  Buf(Buf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  Buf& operator=(Buf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
+  ~Buf() { release(); }
   int ensure(size_t n) {
     if (n <= bytes) return K5_OK;
     if (p) (void)hipFree(p);
@@ -101,7 +107,8 @@ struct k5_vae {
   Buf xin, mom;
   int G = 32;
   // workspaces
-  Buf zin, x0, bx, balt, bt1, bt2, bres, gnws, qk, vt, scores, P, o, yout;
+  Buf zin, x0, bx, balt, bt1, bt2, bres, gnws, gnq, qk, vt, scores, P, o, yout;
+  struct PendStats { const void* ptr = nullptr; int M = 0, C = 0, nblk = 0; } pend;   // GroupNorm partials emitted by the last conv (gnq)
 };
 
 namespace {
@@ -209,11 +216,30 @@ void expected_keys(const k5_vae_config& c, std::vector<std::string>& out) {
   wb("decoder.conv_norm_out"); wb("decoder.conv_out.conv");
 }
 
+// GroupNorm statistics ride in the producing conv's epilogue when that conv ran on the 4-wave kernel: conv() records what it
+// emitted (tensor, rows, channels, blocks), the NEXT gn() uses it if it normalises exactly that tensor, and any conv or gn in
+// between clears the record (nothing else in this file writes an activation buffer between a conv and the norm that reads it).
 int gn(k5_vae* v, hipStream_t s, const GN& g, const void* x, void* out, int M, bool silu) {
+  const auto pend = v->pend;
+  v->pend = {};
   K5CHK(v->gnws.ensure(k5_groupnorm_workspace_bytes(M, v->G)));
+  if (pend.ptr == x && pend.M == M && pend.C == g.c && pend.nblk > 0)
+    return k5_launch_groupnorm_bf16_quads(x, g.g.as<float>(), g.b.as<float>(), out, M, g.c, v->G, 1e-6f, silu ? 1 : 0, g.c, g.c,
+                                          v->gnq.as<float>(), pend.nblk, v->gnws.as<float>(), s);
   return k5_launch_groupnorm_bf16(x, g.g.as<float>(), g.b.as<float>(), out, M, g.c, v->G, 1e-6f, silu ? 1 : 0, g.c, g.c, v->gnws.p, s);
 }
-int conv(hipStream_t s, const Conv& c, const void* x, void* out, int T, int H, int W, int up_t, int up_s, const void* resid) {
+int conv(k5_vae* v, hipStream_t s, const Conv& c, const void* x, void* out, int T, int H, int W, int up_t, int up_s, const void* resid) {
+  v->pend = {};
+  static const bool fused_stats = !(getenv("K5_VAE_GN_STATS") && atoi(getenv("K5_VAE_GN_STATS")) == 0);   // A/B switch for benchmarking
+  const long long M = (long long)(up_t == 2 ? 2 * T - 1 : T) * (up_s * H) * (up_s * W);
+  if (fused_stats && M < 0x7fffffffLL && (c.cout % 4) == 0) {
+    const int nblk = 2 * (int)((M + 255) / 256);
+    K5CHK(v->gnq.ensure((size_t)nblk * (c.cout / 4) * 2 * sizeof(float)));
+    const int r = k5_launch_conv3d_w4(x, c.w.p, c.b.as<float>(), out, T, H, W, c.cin_pad, c.cout, up_t, up_s, c.cout, resid, c.cout,
+                                      v->gnq.as<float>(), s);
+    if (r == K5_OK) { v->pend = {out, (int)M, c.cout, nblk}; return K5_OK; }
+    if (r != K5_ERR_UNSUPPORTED) return r;
+  }
   return k5_launch_conv3d_bf16(x, c.w.p, c.b.as<float>(), out, T, H, W, c.cin_pad, c.cout, up_t, up_s, c.cout, resid, c.cout, s);
 }
 
@@ -221,7 +247,7 @@ int conv(hipStream_t s, const Conv& c, const void* x, void* out, int T, int H, i
 int resnet(k5_vae* v, hipStream_t s, const Resnet& r, const void* x, void* out, int T, int H, int W) {
   const int M = T * H * W;
   K5CHK(gn(v, s, r.n1, x, v->bt1.p, M, true));
-  K5CHK(conv(s, r.c1, v->bt1.p, v->bt2.p, T, H, W, 1, 1, nullptr));
+  K5CHK(conv(v, s, r.c1, v->bt1.p, v->bt2.p, T, H, W, 1, 1, nullptr));
   K5CHK(gn(v, s, r.n2, v->bt2.p, v->bt1.p, M, true));
   const void* res = x;
   if (r.has_sc) {
@@ -229,7 +255,7 @@ int resnet(k5_vae* v, hipStream_t s, const Resnet& r, const void* x, void* out, 
                               K5_EPI_BIAS, nullptr, 0, nullptr, s));
     res = v->bres.p;
   }
-  return conv(s, r.c2, v->bt1.p, out, T, H, W, 1, 1, res);
+  return conv(v, s, r.c2, v->bt1.p, out, T, H, W, 1, 1, res);
 }
 
 int mid_attention(k5_vae* v, hipStream_t s, const MidAttn& a, void* h, int T, int H, int W) {
@@ -268,7 +294,7 @@ extern "C" int k5_vae_create(const k5_vae_config* cfg, k5_vae** out) {
   return K5_OK;
 }
 
-extern "C" void k5_vae_destroy(k5_vae* v) { delete v; /* device buffers are released with the process */ }
+extern "C" void k5_vae_destroy(k5_vae* v) { delete v; /* every Buf (weights and workspaces) frees its device memory */ }
 
 extern "C" int k5_vae_load_tensor(k5_vae* v, const char* key, const void* ptr, int dtype, const int64_t* shape, int rank) {
   if (!v || !key || !ptr || rank < 1 || rank > 5) return K5_ERR_ARG;
@@ -382,7 +408,7 @@ extern "C" int k5_vae_decode_tile(k5_vae* v, const float* z, int T, int H, int W
   HIPCHK(hipMemsetAsync(v->x0.p, 0, (size_t)M0 * 64 * 2, s));
   K5CHK(k5_launch_gemm_bf16(v->zin.p, v->pq.w.p, v->pq.b.as<float>(), v->x0.p, M0, Cz, v->pq.cin_pad, Cz, v->pq.cin_pad, 64, K5_EPI_BIAS,
                             nullptr, 0, nullptr, s));
-  K5CHK(conv(s, v->conv_in, v->x0.p, v->bx.p, T, H, W, 1, 1, nullptr));
+  K5CHK(conv(v, s, v->conv_in, v->x0.p, v->bx.p, T, H, W, 1, 1, nullptr));
   // mid block (vae.py:341-362): resnet -> attention -> resnet ; results ping-pong through bres-free buffers
   void* cur = v->bx.p;
   void* nxt = v->balt.p;
@@ -394,7 +420,7 @@ extern "C" int k5_vae_decode_tile(k5_vae* v, const float* z, int T, int H, int W
   for (int i = 0; i < 4; ++i) {
     for (auto& r : v->up_res[i]) { K5CHK(resnet(v, s, r, cur, nxt, t, h, w)); swap(); }
     if (v->ups[i].present) {
-      K5CHK(conv(s, v->ups[i].conv, cur, nxt, t, h, w, v->ups[i].up_t, v->ups[i].up_s, nullptr)); swap();
+      K5CHK(conv(v, s, v->ups[i].conv, cur, nxt, t, h, w, v->ups[i].up_t, v->ups[i].up_s, nullptr)); swap();
       if (v->ups[i].up_t == 2) t = 2 * t - 1;
       h *= v->ups[i].up_s; w *= v->ups[i].up_s;
     }
@@ -402,7 +428,7 @@ extern "C" int k5_vae_decode_tile(k5_vae* v, const float* z, int T, int H, int W
   const int M = t * h * w;
   K5CHK(gn(v, s, v->norm_out, cur, v->bt1.p, M, true));
   K5CHK(v->yout.ensure((size_t)M * c.out_channels * 2));
-  K5CHK(conv(s, v->conv_out, v->bt1.p, v->yout.p, t, h, w, 1, 1, nullptr));
+  K5CHK(conv(v, s, v->conv_out, v->bt1.p, v->yout.p, t, h, w, 1, 1, nullptr));
   K5CHK(k5_launch_mc_to_nchw(v->yout.p, out, c.out_channels, M, c.out_channels, s));
   return K5_OK;
 }
@@ -430,7 +456,7 @@ extern "C" int k5_vae_encode_tile(k5_vae* v, const float* x, int T, int H, int W
   K5CHK(v->xin.ensure((size_t)M0 * 64 * 2));
   for (Buf* b : {&v->bx, &v->balt, &v->bt1, &v->bt2, &v->bres}) K5CHK(b->ensure(maxel * 2));
   K5CHK(k5_launch_nchw_to_mc(x, v->xin.p, Cin, M0, 64, s));     // channels 3..63 zero: conv_in's weight is packed to 64 input channels
-  K5CHK(conv(s, v->e_conv_in, v->xin.p, v->bx.p, T, H, W, 1, 1, nullptr));
+  K5CHK(conv(v, s, v->e_conv_in, v->xin.p, v->bx.p, T, H, W, 1, 1, nullptr));
   void* cur = v->bx.p;
   void* nxt = v->balt.p;
   auto swap = [&]() { void* t_ = cur; cur = nxt; nxt = t_; };
@@ -450,7 +476,7 @@ extern "C" int k5_vae_encode_tile(k5_vae* v, const float* x, int T, int H, int W
   K5CHK(resnet(v, s, v->e_mid1, cur, nxt, t, h, w)); swap();
   const int M = t * h * w, C2 = 2 * c.latent_channels;
   K5CHK(gn(v, s, v->e_norm_out, cur, v->bt1.p, M, true));
-  K5CHK(conv(s, v->e_conv_out, v->bt1.p, v->bt2.p, t, h, w, 1, 1, nullptr));      // [M][2 Cz]
+  K5CHK(conv(v, s, v->e_conv_out, v->bt1.p, v->bt2.p, t, h, w, 1, 1, nullptr));      // [M][2 Cz]
   K5CHK(v->mom.ensure((size_t)M * C2 * 2));
   K5CHK(k5_launch_gemm_bf16(v->bt2.p, v->e_quant.w.p, v->e_quant.b.as<float>(), v->mom.p, M, C2, v->e_quant.cin_pad, C2, v->e_quant.cin_pad,
                             C2, K5_EPI_BIAS, nullptr, 0, nullptr, s));             // quant_conv 1x1x1

@@ -83,6 +83,40 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// statistics from the producing conv's epilogue: quads [nblk][C / 4][2] = (sum, sum of squares) per 128 rows and 4 consecutive
+// channels; group g owns quads g cg / 4 .. (g + 1) cg / 4 - 1 of every block.  Same double-precision tree as above.
+__global__ __launch_bounds__(1024) void gn_finalize_quads_kernel(const float* __restrict__ quads, float* __restrict__ stats, int nblk,
+                                                                 int C, int cg, double count, float eps) {
+  __shared__ double rs[1024], rq[1024];
+  const int g = blockIdx.x, tid = threadIdx.x, qpg = cg >> 2, nq = C >> 2;
+  const int n = nblk * qpg;
+  double s = 0.0, q = 0.0;
+  // only G workgroups exist, so each keeps many loads in flight: 1024 threads x 4 independent 8-B loads (up to 52 224 blocks at C = 128)
+  for (int e0 = tid; e0 < n; e0 += 4096) {
+    f32x2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + 1024 * u;
+      v[u] = e < n ? *reinterpret_cast<const f32x2*>(quads + ((size_t)(e / qpg) * nq + g * qpg + (e % qpg)) * 2) : f32x2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s += v[u][0]; q += v[u][1]; }
+  }
+  rs[tid] = s; rq[tid] = q;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double mean = rs[0] / count;
+    double var = rq[0] / count - mean * mean;
+    if (var < 0) var = 0;
+    stats[2 * g] = (float)mean;
+    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 // thread -> fixed 16-B chunk column (tid % nch; nch a power of two <= 256), rows strided: the eight channels' affine
 // y = v * (rstd gamma) + (beta - mean rstd gamma) is folded once per thread, SiLU = y * rcp(1 + exp2(-y log2 e)) on the
 // hardware exp2 / rcp (the result is rounded to bf16).  One 16-B load, ~50 VALU, one 16-B store per chunk: HBM-bound.
@@ -149,6 +183,48 @@ __global__ __launch_bounds__(256) void causal_softmax_kernel(const float* __rest
   for (int j = tid; j < ldp; j += 256) p[j] = f2bf(j < valid ? expf(s[j] - m) * inv : 0.f);
 }
 
+// the same, one read of the row: 1024 threads hold the row's valid scores in registers (NV per thread, NV * 1024 >= valid)
+template <int NV>
+__global__ __launch_bounds__(1024) void causal_softmax_reg_kernel(const float* __restrict__ sc, bf16_t* __restrict__ P, int S, int hw,
+                                                                  int lds, int ldp) {
+  __shared__ float red[16];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int valid = min(S, (row / hw + 1) * hw);
+  const float* s = sc + (size_t)row * lds;
+  float v[NV];
+  float m = -3.0e38f;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int j = tid + 1024 * u;
+    v[u] = j < valid ? s[j] : -3.0e38f;
+    m = fmaxf(m, v[u]);
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) { v[u] = tid + 1024 * u < valid ? expf(v[u] - m) : 0.f; sum += v[u]; }
+  sum = wave_sum(sum);
+  if (lane == 0) red[wv] = sum;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += red[w];
+  const float inv = 1.0f / tot;
+  bf16_t* p = P + (size_t)row * ldp;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int j = tid + 1024 * u;
+    if (j < ldp) p[j] = f2bf(v[u] * inv);
+  }
+  for (int j = tid + 1024 * NV; j < ldp; j += 1024) p[j] = f2bf(0.f);
+}
+
 // z (C,T,H,W) fp32 -> [M][Cpad] bf16, channels >= C zero
 __global__ __launch_bounds__(256) void nchw_to_mc_kernel(const float* __restrict__ z, bf16_t* __restrict__ out, int C, int64_t M, int Cpad) {
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < M * Cpad; g += (int64_t)gridDim.x * 256) {
@@ -192,17 +268,15 @@ inline int done() { return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 
 size_t k5_groupnorm_workspace_bytes(int M, int G) { return ((size_t)((M + GN_ROWS - 1) / GN_ROWS) * G * 2 + 2 * G) * sizeof(float); }
 
-int k5_launch_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
-                             int silu, int ldx, int ldo, void* workspace, hipStream_t s) {
-  if (M <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G)) return K5_ERR_ARG;
+namespace {
+bool gn_shape_ok(int M, int C, int G, int ldx, int ldo) {
+  if (M <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G)) return false;
   const int cg = C / G;
-  if ((C & 7) || (ldx & 7) || (ldo & 7) || cg < 4 || (cg & (cg - 1)) || (C >> 3) > 256 || ((C >> 3) & ((C >> 3) - 1))) return K5_ERR_UNSUPPORTED;
-  const int nblk = (M + GN_ROWS - 1) / GN_ROWS;
-  float* partial = (float*)workspace;
-  float* stats = partial + (size_t)nblk * G * 2;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, partial, M, C, ldx, G);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G), dim3(256), 0, s, partial, stats, nblk, G, (double)M * cg, eps);
-  const int nch = C >> 3;   // chunk columns per row: a power of two (checked above; C = 128 / 256 / 512 and the tiny test widths)
+  return !((C & 7) || (ldx & 7) || (ldo & 7) || cg < 4 || (cg & (cg - 1)) || (C >> 3) > 256 || ((C >> 3) & ((C >> 3) - 1)));
+}
+int gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, void* out, int M, int C, int G, int silu, int ldx,
+             int ldo, hipStream_t s) {
+  const int nch = C >> 3, cg = C / G;   // chunk columns per row: a power of two (C = 128 / 256 / 512 and the tiny test widths)
   int nch_sh = 0, cg_sh = 0;
   while ((1 << nch_sh) < nch) ++nch_sh;
   while ((1 << cg_sh) < cg) ++cg_sh;
@@ -214,10 +288,37 @@ int k5_launch_groupnorm_bf16(const void* x, const float* gamma, const float* bet
                           nch_sh, cg_sh, ldx, ldo, rows_per_block);
   return done();
 }
+}  // namespace
+
+int k5_launch_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
+                             int silu, int ldx, int ldo, void* workspace, hipStream_t s) {
+  if (M <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G)) return K5_ERR_ARG;
+  if (!gn_shape_ok(M, C, G, ldx, ldo)) return K5_ERR_UNSUPPORTED;
+  const int cg = C / G;
+  const int nblk = (M + GN_ROWS - 1) / GN_ROWS;
+  float* partial = (float*)workspace;
+  float* stats = partial + (size_t)nblk * G * 2;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, partial, M, C, ldx, G);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G), dim3(256), 0, s, partial, stats, nblk, G, (double)M * cg, eps);
+  return gn_apply(x, stats, gamma, beta, out, M, C, G, silu, ldx, ldo, s);
+}
+
+int k5_launch_groupnorm_bf16_quads(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
+                                   int silu, int ldx, int ldo, const float* quad_stats, int nblk, float* stats_ws, hipStream_t s) {
+  if (M <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || !quad_stats || !stats_ws || nblk <= 0) return K5_ERR_ARG;
+  if (!gn_shape_ok(M, C, G, ldx, ldo)) return K5_ERR_UNSUPPORTED;
+  const int cg = C / G;
+  hipLaunchKernelGGL(gn_finalize_quads_kernel, dim3(G), dim3(1024), 0, s, quad_stats, stats_ws, nblk, C, cg, (double)M * cg, eps);
+  return gn_apply(x, stats_ws, gamma, beta, out, M, C, G, silu, ldx, ldo, s);
+}
 
 int k5_launch_causal_softmax(const float* scores, void* P, int S, int hw, int lds, int ldp, hipStream_t s) {
   if (S <= 0 || hw <= 0 || ldp < S) return K5_ERR_ARG;
-  hipLaunchKernelGGL(causal_softmax_kernel, dim3(S), dim3(256), 0, s, scores, (bf16_t*)P, S, hw, lds, ldp);
+  // rows of up to 32 768 scores stay in registers (one read of the fp32 scores instead of three)
+  if (S > 4096 && S <= 8192) hipLaunchKernelGGL(causal_softmax_reg_kernel<8>, dim3(S), dim3(1024), 0, s, scores, (bf16_t*)P, S, hw, lds, ldp);
+  else if (S > 8192 && S <= 16384) hipLaunchKernelGGL(causal_softmax_reg_kernel<16>, dim3(S), dim3(1024), 0, s, scores, (bf16_t*)P, S, hw, lds, ldp);
+  else if (S > 16384 && S <= 32768) hipLaunchKernelGGL(causal_softmax_reg_kernel<32>, dim3(S), dim3(1024), 0, s, scores, (bf16_t*)P, S, hw, lds, ldp);
+  else hipLaunchKernelGGL(causal_softmax_kernel, dim3(S), dim3(256), 0, s, scores, (bf16_t*)P, S, hw, lds, ldp);
   return done();
 }
 

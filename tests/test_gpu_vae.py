@@ -134,6 +134,27 @@ def test_groupnorm_silu_kernel(M, C, G):
         assert err <= 2.0 ** -6 * max(1.0, ref.abs().max().item()), (M, C, G, silu, err)
 
 
+@pytest.mark.parametrize("S,hw", [(300, 100), (4608, 1536), (9000, 3000), (20000, 5000), (20000, 20000)])
+def test_causal_softmax_kernel(S, hw):
+    """k5_causal_softmax_bf16 (mid-block attention mask vae.py:110-122 + softmax): row i over columns j < (i // hw + 1) * hw, zeros
+    elsewhere up to ldp.  S = 300 takes the three-pass kernel, the others the register-resident ones (8 / 16 / 32 values per thread)."""
+    from kandinsky import _engine as E
+    g = torch.Generator(device="cuda").manual_seed(S)
+    ld = (S + 7) // 8 * 8
+    sc = torch.randn(S, ld, device="cuda", generator=g) * 3.0
+    P = torch.full((S, ld), float("nan"), dtype=torch.bfloat16, device="cuda")
+    E.check(E.lib().k5_causal_softmax_bf16(sc.data_ptr(), P.data_ptr(), S, hw, ld, ld, E.stream_ptr()), "k5_causal_softmax_bf16")
+    torch.cuda.synchronize()
+    rows = torch.arange(S, device="cuda")[:, None]
+    cols = torch.arange(ld, device="cuda")[None, :]
+    mask = (cols < (rows // hw + 1) * hw) & (cols < S)
+    ref = torch.softmax(sc.masked_fill(~mask, float("-inf")), dim=-1)
+    assert torch.isfinite(P.float()).all()
+    assert (P.float()[~mask] == 0).all()
+    assert (P.float() - ref).abs().max().item() <= 2 ** -8 * ref.max().item() + 1e-6          # one bf16 rounding of a probability
+    assert (P.float().sum(-1) - 1).abs().max().item() <= 2e-2
+
+
 def test_decode_tile_vs_oracle(vae):
     m, sd = vae
     z = torch.randn(1, 16, 3, 6, 5, generator=torch.Generator().manual_seed(1))
