@@ -153,6 +153,86 @@ __global__ __launch_bounds__(256) void conv3d_kernel(ConvP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cout = 3 (the decoder's conv_out, 128 -> 3 at full resolution, vae.py:689).  As an implicit-GEMM tile it spends 125 of 128 output
+// columns on zeros and gathers every input row 27 times through L2 (46 GB per launch, 6.2 ms per tile of the 5 s clip).  Here the
+// convolution is split the other way round:
+//     Y[pixel][(o, kh, kw)] = sum_c X[pixel][c] W[o][kt, kh, kw][c]     a GEMM with K = Cin only and N = 27 (padded to 32), on MFMA,
+//     out[p][o] = sum_kt sum_kh,kw Y_kt[p + (kh - 1, kw - 1)][(o, kh, kw)]   a 27-term shift-and-add per output, through LDS.
+// A workgroup owns 8 x 32 output pixels of one frame; per source frame kt it multiplies the 10 x 34 replicate-clamped input patch
+// (340 pixels = 22 m-tiles of 16, A fragments straight from global memory: 64 contiguous bytes per pixel and k-step) by the 27
+// weight rows of that kt (B fragments in registers), writes Y (fp32, 352 x 33 floats) to LDS, and every thread adds up its own
+// pixel's 27 entries (consecutive lanes = consecutive pixels = 33 floats apart: conflict-free).  Each input element is read
+// 3 x 1.33 times instead of 27; the MFMA work is 0.26 TFLOP instead of 6 padded.
+// (Two VALU formulations were measured first: v_dot2c_f32_bf16 / v_pk_fma_f32 with scalar weights, 5.3-7.1 ms per launch — bound by
+// the scalar weight loads, 20 KB of weights do not stay in the 16-KB scalar cache.)
+// ---------------------------------------------------------------------------------------------
+template <int KS>   // Cin = 32 KS
+__global__ __launch_bounds__(256) void conv3d_out3_kernel(ConvP p) {
+  constexpr int PW = 34, PH = 10, NPIX = PW * PH, MT = (NPIX + 15) / 16, YS = 33;
+  __shared__ float Y[MT * 16 * YS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lc = lane >> 4;
+  const int tiles_w = (p.Wo + 31) / 32, tiles_h = (p.Ho + 7) / 8;
+  const int tw = blockIdx.x % tiles_w, th = (blockIdx.x / tiles_w) % tiles_h, t = blockIdx.x / (tiles_w * tiles_h);
+  const int h0 = th * 8, w0 = tw * 32;
+  const int gr = tid >> 5, gc = tid & 31;             // this thread's output pixel in the gather phase
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int kt = 0; kt < 3; ++kt) {
+    const int ts = max(t + kt - 2, 0);                // causal: two replicated frames in front (vae.py:141-147)
+    bf16x8 bfr[2][KS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = 16 * j + l15;                     // column (o, kh, kw) = (n / 9, n % 9 / 3, n % 3); 27..31 are padding
+      const bf16_t* wp = p.W + ((size_t)(n < 27 ? n / 9 : 0) * 27 + 9 * kt + (n < 27 ? n % 9 : 0)) * p.Cin + 8 * lc;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bfr[j][ks] = *reinterpret_cast<const bf16x8*>(wp + 32 * ks);
+        if (n >= 27) bfr[j][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+    bf16x8 a[(MT + 3) / 4][KS];
+#pragma unroll
+    for (int i = 0; i < (MT + 3) / 4; ++i) {
+      const int mt = wave + 4 * i;
+      const int pix = min(16 * mt + l15, NPIX - 1), rr = pix / PW, cc = pix - rr * PW;
+      const int hs = min(max(h0 - 1 + rr, 0), p.Ho - 1), ws = min(max(w0 - 1 + cc, 0), p.Wo - 1);
+      const bf16_t* xp = p.X + (((size_t)ts * p.Ho + hs) * p.Wo + ws) * p.Cin + 8 * lc;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a[i][ks] = *reinterpret_cast<const bf16x8*>(xp + 32 * ks);
+    }
+    if (kt) __syncthreads();                          // the previous frame's Y has been gathered
+#pragma unroll
+    for (int i = 0; i < (MT + 3) / 4; ++i) {
+      const int mt = wave + 4 * i;
+      if (mt < MT) {
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bfr[0][ks], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bfr[1][ks], d1, 0, 0, 0);
+        }
+        float* yp = Y + (16 * mt + 4 * lc) * YS + l15;   // D: lane l15 = column, registers = rows (pixels) 4 lc .. 4 lc + 3
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { yp[e * YS] = d0[e]; yp[e * YS + 16] = d1[e]; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float* yq = Y + ((gr + kh) * PW + gc + kw) * YS + 3 * kh + kw;
+        acc[0] += yq[0]; acc[1] += yq[9]; acc[2] += yq[18];
+      }
+  }
+  const int h = h0 + gr, w = w0 + gc;
+  if (h < p.Ho && w < p.Wo) {
+    bf16_t* cp = p.C + ((size_t)(t * p.Ho + h) * p.Wo + w) * p.ldc;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) cp[o] = f2bf(acc[o] + p.bias[o]);
+  }
+}
+
 }  // namespace
 
 // X [Ts][Hs][Ws][Cin] bf16 ; W [Cout][27][Cin] bf16 ; bias fp32 [Cout] ; out [To*Ho*Wo][ldc] bf16
@@ -186,6 +266,14 @@ int k5_launch_conv3d_bf16_strided(const void* X, const void* W, const float* bia
   const long long M = (long long)p.To * p.Ho * p.Wo;
   if (M > 0x7fffffffLL) return K5_ERR_UNSUPPORTED;
   p.M = (int)M;
+  static const bool out3_ok = !(getenv("K5_CONV_OUT3") && atoi(getenv("K5_CONV_OUT3")) == 0);   // A/B switch for benchmarking
+  if (out3_ok && force != 1 && Cout == 3 && (Cin == 64 || Cin == 128) && !strided && up_t == 1 && up_s == 1 && !resid) {
+    const long long nwg = (long long)p.To * ((p.Ho + 7) / 8) * ((p.Wo + 31) / 32);
+    if (nwg > 0x7fffffffLL) return K5_ERR_UNSUPPORTED;
+    if (Cin == 128) hipLaunchKernelGGL(conv3d_out3_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(conv3d_out3_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+  }
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (Cout + BN - 1) / BN;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
   if (resid) hipLaunchKernelGGL(conv3d_kernel<true>, grid, block, 0, stream, p);

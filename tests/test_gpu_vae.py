@@ -115,6 +115,31 @@ def test_conv3d_four_wave_kernel(vae, Cin, Cout, up, dims):
         assert torch.equal(out, again)                                         # hand-counted waits: bit-reproducible
 
 
+@pytest.mark.parametrize("Cin,dims", [(128, (3, 6, 300)), (64, (2, 5, 19)), (128, (4, 3, 256)), (192, (2, 4, 40))])
+def test_conv3d_three_output_channels(vae, Cin, dims):
+    """The decoder's conv_out (Cin -> 3, vae.py:689) has its own kernel (conv3d.hip conv3d_out3_kernel: per source frame a K = Cin GEMM
+    onto the 27 (output, kh, kw) columns on MFMA, then a 27-term shift-and-add through LDS): several 8 x 32 tiles with ragged edges in
+    both directions, a single partial tile, Cin = 64 and 128; Cin = 192 is outside its range and takes the GEMM-tile kernel.
+    Replicate padding in H / W and the causal front padding in T are what the oracle does."""
+    from kandinsky import _engine as E
+    torch.manual_seed(2)
+    Ts, Hs, Ws = dims
+    x = bfr(torch.randn(1, Cin, Ts, Hs, Ws))
+    w = bfr(torch.randn(3, Cin, 3, 3, 3) * 0.05)
+    b = bfr(torch.randn(3) * 0.1)
+    ref = V.causal_conv3d({"c.conv.weight": w, "c.conv.bias": b}, "c", x, "bf16")
+    want = ref[0].permute(1, 2, 3, 0).reshape(-1, 3)
+    xd = x[0].permute(1, 2, 3, 0).contiguous().cuda().bfloat16()
+    wd = w.permute(0, 2, 3, 4, 1).reshape(3, 27 * Cin).contiguous().cuda().bfloat16()
+    bd = b.cuda()
+    out = torch.full((Ts * Hs * Ws, 3), float("nan"), dtype=torch.bfloat16, device="cuda")
+    E.check(E.lib().k5_conv3d_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), Ts, Hs, Ws, Cin, 3, 1, 1, 3, None, 3,
+                                   E.stream_ptr()))
+    torch.cuda.synchronize()
+    err = (out.float().cpu() - want).abs()
+    assert not (err > 2.0 ** -6 * want.abs().clamp(min=1.0)).any(), float(err.max())
+
+
 @pytest.mark.parametrize("M,C,G", [(90, 64, 16), (1000, 128, 16), (3000, 512, 32), (77, 256, 32)])
 def test_groupnorm_silu_kernel(M, C, G):
     from kandinsky import _engine as E
