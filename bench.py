@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--profile-level", type=int, default=2, choices=(0, 1, 2),
                     help="HIP events inside the timed region: 2 = around the roofline kernel only (default), 1 = every kernel family, 0 = none")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the separate per-family timing pass")
+    ap.add_argument("--sp-slices", type=int, default=1, help="sequence parallelism: exchange K / V^T of a block in this many slices and attend "
+                    "each slice as it lands (engine option sp_slices; 1 = one in-place all-gather per block)")
     ap.add_argument("--emulate-shard", type=int, default=0, metavar="P",
                     help="debug only (INVALID as a bench): per-rank compute of a P-GPU run on one GPU, collectives move nothing")
     ap.add_argument("--blocks", type=int, default=32, help="debug only: fewer visual blocks => INVALID as a bench")
@@ -168,6 +170,8 @@ def main():
         dit.enable_sequence_parallel(rank, world)
     if args.emulate_shard > 1:
         dit.set_option("emulate_world", args.emulate_shard)
+    if args.sp_slices > 1:
+        dit.set_option("sp_slices", args.sp_slices)
     if args.attn_online:
         dit.set_option("attn_mode", 1)
 
@@ -291,7 +295,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16+fp8ff (REDUCED PRECISION, not the headline)" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": wl["desc"], "tokens": N, "text_len": L, "forwards_per_step": fwd_per_step,
-                       "parallelism": "single GPU" if world == 1 else f"sequence-parallel x{world} (token shards, K/V all-gather)",
+                       "parallelism": "single GPU" if world == 1 else (f"sequence-parallel x{world} (token shards, K/V all-gather)" if args.sp_slices < 2 else
+                                       f"sequence-parallel x{world} (token shards, K/V exchange in {args.sp_slices} slices)"),
                        "visual_blocks": args.blocks, "magcache": bool(args.magcache)},
             "nfe_per_s": fwd_per_step * args.steps / dt,
             "step_tflop": step_flop / 1e12,

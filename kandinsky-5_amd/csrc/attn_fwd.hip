@@ -55,6 +55,9 @@ struct AttnP {
   // tile_skip_at (lets pass 2 of the sequence-parallel schedule walk "every chunk except mine").  state/flags: resume
   // from (flags & 1) and/or leave (flags & 2) the fp32 running state {O^T accumulators, m, l} instead of normalising.
   int tile_off0, tile_cnt, tile_skip_at, tile_skip_n;
+  // segmented walk (seg_len > 0; sliced K / V^T exchange of the sequence-parallel schedule): position e -> segment e / seg_len
+  // (segments >= seg_skip shift up by one: "every rank's slice except mine"), tile = tile_off0 + segment * seg_stride + e % seg_len
+  int seg_len, seg_stride, seg_skip;
   float* state; int flags;
   // job = (head, 256-query block) = job0 + workgroup index; RANGE launches may split every job's tile sequence `splits`
   // ways (workgroup g -> job job0 + g / splits, part g % splits): part 0 uses `state` (and is the only one that resumes),
@@ -132,6 +135,12 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   auto tile_of = [&](int e) -> int {                  // sequence position -> 64-key tile index (wave-uniform)
     if (SPARSE) return sp_list[e] & 0xffffff;
     if (!RANGE) return e;
+    if (p.seg_len > 0) {
+      int si = e / p.seg_len;
+      const int j = e - si * p.seg_len;
+      if (si >= p.seg_skip) ++si;
+      return p.tile_off0 + si * p.seg_stride + j;
+    }
     int t = e + p.tile_off0;
     if (t >= p.tile_skip_at) t += p.tile_skip_n;
     return t;
@@ -387,6 +396,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd32_kernel(AttnP p) {
   auto tile_of = [&](int e) -> int {                  // sequence position -> 64-key tile index (wave-uniform)
     if (SPARSE) return sp_list[e] & 0xffffff;
     if (!RANGE) return e;
+    if (p.seg_len > 0) {
+      int si = e / p.seg_len;
+      const int j = e - si * p.seg_len;
+      if (si >= p.seg_skip) ++si;
+      return p.tile_off0 + si * p.seg_stride + j;
+    }
     int t = e + p.tile_off0;
     if (t >= p.tile_skip_at) t += p.tile_skip_n;
     return t;
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd32_kernel(AttnP p) {
 // order, then (m, l) per (q, h, lane group g = 0..3) — l is that lane's partial sum, m is common to the four.
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, const float* split_state, long long split_stride,
                                                          int splits, int job0, int H, int q_len, int nqb, float c, bf16_t* O, int ldo,
-                                                         int bounded_all, const int* head_flags) {
+                                                         int bounded_all, const int* head_flags, float* state_out) {
   const int job = job0 + blockIdx.x, h = job / nqb, qb = job % nqb;
   const bool bounded = head_flags ? head_flags[h] == 1 : bounded_all != 0;   // fixed offset: every part's weight is 1
   const int q = qb * QB + threadIdx.x;
@@ -602,8 +617,15 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[e] += w[s] * v[e];
     }
+    if (state_out) { *reinterpret_cast<f32x4*>(state_out + o_off + d) = a; continue; }   // an intermediate pass: the merged state, not O
     u32x2 o = {pack_bf16x2(a[0] * inv, a[1] * inv), pack_bf16x2(a[2] * inv, a[3] * inv)};
     *reinterpret_cast<u32x2*>(op + d) = o;
+  }
+  if (state_out) {   // (m, l) of the merged parts in the layout the kernels resume from: m in all four slots, the row sum in slot 0
+    // (this thread read its own (q, h) entries above and is the only one to write them: state_out may be state0)
+    const float mm = bounded ? 0.f : m;
+    float* ml = state_out + ml_off;
+    ml[0] = mm; ml[1] = l; ml[2] = mm; ml[3] = 0.f; ml[4] = mm; ml[5] = 0.f; ml[6] = mm; ml[7] = 0.f;
   }
 }
 
@@ -674,7 +696,7 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* ws, bool k_prescaled,
-                                   const int* head_flags, int variant) {
+                                   const int* head_flags, int variant, const K5TileSegments* seg) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -690,12 +712,21 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.sp_list = nullptr; p.sp_cnt = nullptr; p.sp_stride = 0;
   const int total_tiles = (kv_len + KB - 1) / KB;
   if (tile_cnt < 0) tile_cnt = total_tiles - tile_off0;
-  if (tile_off0 < 0 || tile_skip_n < 0 || tile_off0 + tile_cnt + (tile_skip_at < total_tiles ? tile_skip_n : 0) > total_tiles) return K5_ERR_ARG;
+  p.seg_len = 0; p.seg_stride = 0; p.seg_skip = 0x7fffffff;
+  if (seg && seg->len > 0) {   // segmented walk: the last position must still be a real tile
+    if (tile_off0 < 0 || tile_cnt <= 0 || seg->stride < seg->len || seg->skip < 0) return K5_ERR_ARG;
+    int si = (tile_cnt - 1) / seg->len;
+    const int j = (tile_cnt - 1) - si * seg->len;
+    if (si >= seg->skip) ++si;
+    if ((long long)tile_off0 + (long long)si * seg->stride + j >= total_tiles) return K5_ERR_ARG;
+    p.seg_len = seg->len; p.seg_stride = seg->stride; p.seg_skip = seg->skip;
+    tile_skip_at = 0x7fffffff; tile_skip_n = 0;
+  } else if (tile_off0 < 0 || tile_skip_n < 0 || tile_off0 + tile_cnt + (tile_skip_at < total_tiles ? tile_skip_n : 0) > total_tiles) return K5_ERR_ARG;
   if ((flags & 3) && !state) return K5_ERR_ARG;
   p.tile_off0 = tile_off0; p.tile_cnt = tile_cnt; p.tile_skip_at = tile_skip_at; p.tile_skip_n = tile_skip_n;
   p.state = state; p.flags = flags;
   p.job0 = 0; p.splits = 1; p.split_state = nullptr; p.split_stride = 0;
-  const bool range = tile_off0 != 0 || tile_cnt != total_tiles || (flags & 3);
+  const bool range = tile_off0 != 0 || tile_cnt != total_tiles || (flags & 3) || p.seg_len > 0;
   if (k_prescaled && (kv_len % KB)) return K5_ERR_ARG;      // pre-scaled keys: whole key tiles only (no ragged-tile code)
   if ((head_flags || variant != K5_ATTN_AUTO) && !k_prescaled) return K5_ERR_ARG;
   // which softmax form(s) run: 1 = fixed offset, 0 = online max; per head when head_flags is given
@@ -718,13 +749,16 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   if (S > K5_ATTN_MAX_SPLITS) S = K5_ATTN_MAX_SPLITS;
   if (S > tile_cnt / 8) S = tile_cnt / 8;          // keep >= 8 key tiles per part
   static const bool no_balance = getenv("K5_ATTN_NO_BALANCE") != nullptr;   // A/B switch for benchmarking
-  if (!ws || (flags & 2) || S < 2 || no_balance) {
+  // a pass that leaves its state (flags & 2) is balanced the same way when the keys are pre-scaled (the engine's path): its merge
+  // writes the merged state instead of O
+  if (!ws || ((flags & 2) && !k_prescaled) || S < 2 || no_balance) {
     launch(jobs, range);
     return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
   }
   if (full > 0) launch(full, range);
   // tail jobs, S parts each: part 0 resumes the caller's state if there is one, every part leaves its state
   const long long stride = (long long)(k5_attention_state_bytes(H, q_len) / sizeof(float));
+  const bool to_state = (flags & 2) != 0;
   float* base = (flags & 1) ? state : ws;
   p.job0 = full; p.splits = S; p.state = base; p.split_state = ws + stride; p.split_stride = stride;
   p.flags = (flags & 1) | 2;
@@ -732,7 +766,7 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   // merge weights: 1 for the fixed-offset heads, exp2(m_s - max m) for the online ones (exp2 domain when the keys are pre-scaled)
   hipLaunchKernelGGL(attn_merge_kernel, dim3(rem), dim3(256), 0, stream, base, ws + stride, stride, S, full, H, q_len, p.nqb,
                      k_prescaled ? 1.f : p.c, (bf16_t*)O, ldo, (k_prescaled ? (run_fixed && !run_online) : bounded) ? 1 : 0,
-                     (k_prescaled && run_fixed && run_online) ? head_flags : nullptr);
+                     (k_prescaled && run_fixed && run_online) ? head_flags : nullptr, to_state ? state : nullptr);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -763,6 +797,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride;
   p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;
+  p.seg_len = 0; p.seg_stride = 0; p.seg_skip = 0x7fffffff;
   p.job0 = 0; p.splits = 1; p.split_state = nullptr; p.split_stride = 0;
   const dim3 grid(H * p.nqb), block(512);
   const bool bounded = score_bound > 0.f && score_bound * p.c <= K5_ATTN_EXP_LIMIT;

@@ -133,6 +133,10 @@ struct Comm {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;   // optional: sliced exchange
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   int open(const char* path) {
     if (lib) return K5_OK;
@@ -148,6 +152,8 @@ struct Comm {
     CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
     AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
     GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+    Send = (decltype(Send))dlsym(lib, "ncclSend"); Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
+    GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) {
       k5_set_error("RCCL library lacks a required nccl* symbol"); return K5_ERR_STATE;
     }
@@ -177,6 +183,40 @@ struct Comm {
     const ncclResult_t r = AllGather(b + (size_t)rank * count_per_rank * elem_bytes, b, count_per_rank * elem_bytes,
                                      ncclUint8, comm, s);
     if (r != ncclSuccess) { k5_set_error("ncclAllGather: %s", GetErrorString(r)); return K5_ERR_HIP; }
+    return K5_OK;
+  }
+  bool can_exchange() const { return loop || (Send && Recv && GroupStart && GroupEnd); }
+  // part of an in-place all-gather: the bytes [off, off + cnt) of every rank's slot (slot_bytes each, rank p's at p * slot_bytes)
+  // travel to every peer — one grouped send/recv per peer, i.e. all seven xGMI links of the GPU at once, so the first slice of ALL
+  // peers has landed when a fraction cnt / slot_bytes of the gather time has passed (a ring all-gather completes nothing early).
+  int slot_exchange(void* buf, size_t slot_bytes, size_t off, size_t cnt, hipStream_t s) {
+    char* b = (char*)buf;
+    if (cnt == 0 || world == 1) return K5_OK;
+    if (loop) {
+      loop->ptr[rank] = buf;
+      HIPCHK(hipEventRecord(loop->ready[rank], s));
+      pthread_barrier_wait(&loop->bar);
+      for (int p = 0; p < world; ++p) {
+        if (p == rank) continue;
+        HIPCHK(hipStreamWaitEvent(s, loop->ready[p], 0));
+        HIPCHK(hipMemcpyAsync(b + (size_t)p * slot_bytes + off, (const char*)loop->ptr[p] + (size_t)p * slot_bytes + off, cnt, hipMemcpyDeviceToDevice, s));
+      }
+      HIPCHK(hipEventRecord(loop->pulled[rank], s));
+      pthread_barrier_wait(&loop->bar);
+      for (int p = 0; p < world; ++p)
+        if (p != rank) HIPCHK(hipStreamWaitEvent(s, loop->pulled[p], 0));
+      return K5_OK;
+    }
+    if (!can_exchange()) { k5_set_error("RCCL library lacks ncclSend / ncclRecv / ncclGroup*"); return K5_ERR_STATE; }
+    ncclResult_t r = GroupStart();
+    for (int p = 0; p < world && r == ncclSuccess; ++p) {
+      if (p == rank) continue;
+      r = Send(b + (size_t)rank * slot_bytes + off, cnt, ncclUint8, p, comm, s);
+      if (r == ncclSuccess) r = Recv(b + (size_t)p * slot_bytes + off, cnt, ncclUint8, p, comm, s);
+    }
+    const ncclResult_t e = GroupEnd();
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) { k5_set_error("ncclSend/ncclRecv group: %s", GetErrorString(r)); return K5_ERR_HIP; }
     return K5_OK;
   }
 };
@@ -225,6 +265,8 @@ struct k5_dit {
   long long nabla_possible = 0;                    // profiling: 64x64 blocks the NABLA maps could have kept (kept: ws_attn_cnt[2])
   int attn_mode = 0;                               // K5_ATTN_AUTO / K5_ATTN_ONLINE (k5_dit_set_option "attn_mode")
   int sp_pass1_tiles = 0;                          // k5_dit_set_option "sp_pass1_tiles" (0 = all local key tiles)
+  int sp_slices = 1;                               // "sp_slices": the K / V^T exchange of a block in this many slices (dense attention)
+  hipEvent_t ev_slice[4] = {};                     // slice s of every peer has landed
   bool emulated = false;                           // "emulate_world": timing-only layout, results are garbage
   hipStream_t comm_stream = nullptr;              // all-gathers run here, overlapped with pass 1 of the attention
   hipEvent_t ev_k = nullptr, ev_v = nullptr, ev_gathered = nullptr, ev_stats = nullptr;
@@ -513,9 +555,19 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
                                  nullptr, 0, by_data ? kstat + (size_t)r * H : nullptr, d->ws_attn_part.as<float>()));
   }
   HIPCHK(hipEventRecord(d->ev_k, s));
+  // sliced exchange (dense attention, "sp_slices" = S > 1): the slot of every rank is S slices of rows_pad / S tokens; V^T is laid
+  // out slice-major inside the slot — [S][D][rows_pad / S] — so that a slice is contiguous on both operands (for the attention kernel
+  // these are simply P S chunks of rows_pad / S keys) and is projected by one GEMM per slice
+  const int S = (!nabla && d->sp_slices > 1 && P > 1) ? d->sp_slices : 1;
+  const int cols = rows_pad / S;   // tokens per slice (the caller sized rows_pad as a multiple of 64 S)
   {
     Scope sc(d, s, "gemm");
-    K5CHK(k5_launch_gemm_bf16(a.wv.p, h, a.bv.as<float>(), vtloc, D, rows, D, D, D, ldv, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+    for (int sl = 0; sl < S; ++sl) {
+      const int nsl = std::min(cols, rows - sl * cols);
+      if (nsl <= 0) break;
+      K5CHK(k5_launch_gemm_bf16(a.wv.p, (const bf16_t*)h + (size_t)sl * cols * D, a.bv.as<float>(), vtloc + (size_t)sl * D * cols, D, nsl, D, D, D,
+                                cols, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+    }
   }
   HIPCHK(hipEventRecord(d->ev_v, s));
   {
@@ -535,9 +587,19 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       K5CHK(d->comm.all_gather_inplace(kstat, (size_t)H, 4, cs));
       HIPCHK(hipEventRecord(d->ev_stats, cs));
     }
-    K5CHK(d->comm.all_gather_inplace(kfull, (size_t)rows_pad * D, 2, cs));
-    HIPCHK(hipStreamWaitEvent(cs, d->ev_v, 0));
-    K5CHK(d->comm.all_gather_inplace(vtfull, (size_t)D * ldv, 2, cs));
+    if (S == 1) {
+      K5CHK(d->comm.all_gather_inplace(kfull, (size_t)rows_pad * D, 2, cs));
+      HIPCHK(hipStreamWaitEvent(cs, d->ev_v, 0));
+      K5CHK(d->comm.all_gather_inplace(vtfull, (size_t)D * ldv, 2, cs));
+    } else {
+      const size_t slot = (size_t)rows_pad * D * 2, sl_bytes = (size_t)cols * D * 2;   // the same for K and for V^T
+      for (int sl = 0; sl < S; ++sl) {
+        K5CHK(d->comm.slot_exchange(kfull, slot, sl * sl_bytes, sl_bytes, cs));
+        if (sl == 0) HIPCHK(hipStreamWaitEvent(cs, d->ev_v, 0));
+        K5CHK(d->comm.slot_exchange(vtfull, slot, sl * sl_bytes, sl_bytes, cs));
+        HIPCHK(hipEventRecord(d->ev_slice[sl], cs));
+      }
+    }
   }
   HIPCHK(hipEventRecord(d->ev_gathered, cs));
   const int* hflags = nullptr;
@@ -573,27 +635,51 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     // ... while the main stream attends the local query rows to the LOCAL key chunk (pass 1, leaves the fp32 state),
     // then, once every chunk has arrived, to all the other chunks (pass 2, resumes the state and normalises).
     const int tpc = rows / 64, tpc_pad = rows_pad / 64, total = N / 64;
-    // Pass 1 exists to cover the gather, and it cannot be load-balanced (only a pass that normalises can split its tail jobs
-    // and merge them), so it should be no longer than the gather.  How long the gather takes is a property of the node (one
+    // Pass 1 exists to cover the gather (its tail jobs are split and merged back into the state like those of the final pass),
+    // so it should be no longer than the gather.  How long the gather takes is a property of the node (one
     // xGMI link per GPU pair: ~341 MB / (P x link rate) per block, i.e. about 0.4 of a rank's attention time at any P if a link
     // gives ~70 GB/s each way, much less if RCCL drives several paths) and cannot be measured here, so the default is the
     // safe one — all local key tiles — and k5_dit_set_option("sp_pass1_tiles") sets it on a real node (emulated, P = 2: 41
     // tiles instead of 372 take the step from 282 to 259 ms).
-    int k1 = d->sp_pass1_tiles > 0 ? d->sp_pass1_tiles : tpc;
+    int k1 = (d->sp_pass1_tiles > 0 && S == 1) ? d->sp_pass1_tiles : tpc;   // the sliced schedule attends all local tiles first
     k1 = k1 > tpc ? tpc : k1;
     K5CHK(d->ws_attn_state.ensure(k5_attention_state_bytes(H, rows)));
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     {
       Scope sc(d, s, "attn_self");
-      K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, rows_pad, (long long)D * ldv,
-                                           r * tpc_pad, k1, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s, nullptr, true, hflags, variant));
+      K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, S > 1 ? cols : ldv, D, 0.f, S > 1 ? cols : rows_pad,
+                                           S > 1 ? (long long)D * cols : (long long)D * ldv,
+                                           r * tpc_pad, k1, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s, d->ws_attn_bal.as<float>(), true, hflags, variant));
     }
-    HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
-    {
+    if (S == 1) {
+      HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, rows_pad, (long long)D * ldv,
                                            0, total - k1, r * tpc_pad, k1, d->ws_attn_state.as<float>(), 1, s, d->ws_attn_bal.as<float>(),
                                            true, hflags, variant));
+    } else {
+      // one pass per slice, as soon as that slice of every peer has landed: slice sl of rank p = key tiles [p tpc_pad + sl tps, + tps)
+      // (P - 1 segments: mine was pass 1; the last rank's slot may end early — it is the last segment, so the count is cut short).
+      // The state is resumed and saved between the passes (tail jobs balanced in every pass); the last one normalises.
+      const int tps = tpc_pad / S;
+      const int last_rank_tiles = total - (P - 1) * tpc_pad;                 // > 0 (checked by the caller)
+      int cnts[4] = {0, 0, 0, 0}, last_pass = 0;
+      for (int sl = 0; sl < S; ++sl) {
+        cnts[sl] = (P - 1) * tps;
+        if (r != P - 1) cnts[sl] -= tps - std::max(0, std::min(tps, last_rank_tiles - sl * tps));
+        if (cnts[sl] > 0) last_pass = sl;                                     // slice 0 always has tiles
+      }
+      for (int sl = 0; sl < S; ++sl) {
+        const int cnt = cnts[sl];
+        HIPCHK(hipStreamWaitEvent(s, d->ev_slice[sl], 0));
+        if (cnt <= 0) continue;
+        const K5TileSegments seg{tps, tpc_pad, r};
+        const bool fin = sl == last_pass;
+        Scope sc(d, s, "attn_self");
+        K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, cols, D, 0.f, cols, (long long)D * cols,
+                                             sl * tps, cnt, 0x7fffffff, 0, d->ws_attn_state.as<float>(), fin ? 1 : 3, s,
+                                             d->ws_attn_bal.as<float>(), true, hflags, variant, &seg));
+      }
     }
   }
   {
@@ -749,7 +835,8 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
   int n = N, n_pad = N, tok0 = 0;
   if (sp) {
     if (N % 64) { k5_set_error("sequence parallelism needs whole 64-token blocks (token count %d)", N); return K5_ERR_UNSUPPORTED; }
-    n_pad = ((N / 64 + P - 1) / P) * 64;
+    const int S = d->sp_slices > 1 ? d->sp_slices : 1;   // slots are whole slices (sliced K / V^T exchange, "sp_slices")
+    n_pad = ((N / 64 + P * S - 1) / (P * S)) * S * 64;
     tok0 = d->sp_rank * n_pad;
     n = N - tok0 < n_pad ? N - tok0 : n_pad;
     if ((long long)(P - 1) * n_pad >= N) { k5_set_error("sequence parallel x%d: %d token blocks leave a rank without work", P, N / 64); return K5_ERR_UNSUPPORTED; }
@@ -944,7 +1031,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
   for (auto& b : d->vblocks) { b.w1_f8.release(); b.w2_f8.release(); b.s1_f8.release(); b.s2_f8.release(); }
   if (d->graph_stream) { (void)hipStreamSynchronize(d->graph_stream); (void)hipStreamDestroy(d->graph_stream); (void)hipEventDestroy(d->ev_graph); }
   if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
-  for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered, d->ev_stats}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
+  for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered, d->ev_stats, d->ev_slice[0], d->ev_slice[1], d->ev_slice[2], d->ev_slice[3]}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
   auto rel_attn = [](AttnW& a) {
     DevBuf* bs[] = {&a.wqk, &a.wq, &a.wk, &a.wv, &a.wo, &a.bqk, &a.bq, &a.bk, &a.bv, &a.bo, &a.norm};
@@ -1233,6 +1320,7 @@ static int comm_common_init(k5_dit* d, int rank, int world) {
   HIPCHK(hipEventCreateWithFlags(&d->ev_v, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&d->ev_gathered, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&d->ev_stats, hipEventDisableTiming));
+  for (auto& e : d->ev_slice) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return K5_OK;
 }
 
@@ -1286,6 +1374,9 @@ extern "C" int k5_dit_comm_init_loopback(k5_dit* d, k5_loopback* lb, int rank) {
 //   "attn_mode"       0 = softmax form per head from the data (fixed offset where |q||k'| <= 90, online max elsewhere),
 //                     1 = online max everywhere (what a checkpoint with large QK-norm gains gets; bench.py --attn-online)
 //   "sp_pass1_tiles"  local key tiles attended before the K/V^T gather has landed (0 = all of the rank's own tiles)
+//   "sp_slices"       S in 1..4: exchange K / V^T of a block in S slices (grouped send/recv to every peer at once) and attend each
+//                     slice as it lands — the gather hides behind the attention of the slices before it (dense attention; NABLA and
+//                     S = 1 keep the single in-place all-gather).  Token slots become multiples of 64 S.
 //   "emulate_world"   TIMING ONLY, one GPU: lay the work out as rank 0 of a P-rank group while the communicator has one rank —
 //                     collectives move nothing, the other ranks' keys are never filled, RESULTS ARE GARBAGE; the handle is
 //                     marked (k5_dit_get_option "emulated" = 1) so that a bench can refuse to report it as a measurement
@@ -1297,6 +1388,11 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
     d->attn_mode = value; return K5_OK;
   }
   if (!strcmp(name, "sp_pass1_tiles")) { if (value < 0) return K5_ERR_ARG; d->sp_pass1_tiles = value; return K5_OK; }
+  if (!strcmp(name, "sp_slices")) {
+    if (value < 1 || value > 4) return K5_ERR_ARG;
+    if (value > 1 && d->comm.comm && !d->comm.can_exchange()) { k5_set_error("sp_slices > 1 needs ncclSend / ncclRecv / ncclGroup* in the RCCL library"); return K5_ERR_STATE; }
+    d->sp_slices = value; return K5_OK;
+  }
   if (!strcmp(name, "emulate_world")) {
     if (!d->comm.active() || d->comm.world != 1 || value < 1) { k5_set_error("emulate_world needs a world = 1 communicator"); return K5_ERR_STATE; }
     d->sp_world = value; d->emulated = value > 1;
@@ -1310,6 +1406,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   if (!d || !name || !value) return K5_ERR_ARG;
   if (!strcmp(name, "attn_mode")) *value = d->attn_mode;
   else if (!strcmp(name, "sp_pass1_tiles")) *value = d->sp_pass1_tiles;
+  else if (!strcmp(name, "sp_slices")) *value = d->sp_slices;
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
   else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }

@@ -25,11 +25,14 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
 // General form: process key tiles  e -> e + tile_off0 (+ tile_skip_n once >= tile_skip_at), e < tile_cnt (-1 = to the end);
 // flags & 1: resume from `state`, flags & 2: write `state` instead of O (k5_attention_state_bytes floats-as-bytes).
 size_t k5_attention_state_bytes(int H, int q_len);
+// segmented walk instead of the (offset, skip) one: position e -> tile_off0 + seg(e / len) * stride + e % len, where segments
+// >= skip shift up by one (the sequence-parallel schedule's "slice s of every rank's slot except mine"); tile_cnt positions
+struct K5TileSegments { int len, stride, skip; };
 int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* balance_ws = nullptr, bool k_prescaled = false,
-                                   const int* head_flags = nullptr, int variant = 0);
+                                   const int* head_flags = nullptr, int variant = 0, const K5TileSegments* segments = nullptr);
 size_t k5_attention_balance_bytes(int H, int q_len);
 // softmax form of the pre-scaled-key launches: AUTO = fixed offset where the bound (score_bound, or the per-head device
 // flags) allows it and the lazy online max elsewhere; ONLINE = the online max everywhere

@@ -10,24 +10,25 @@ host-side shard bookkeeping shared with the tests.
 """
 
 
-def token_shard(num_tokens: int, world: int, rank: int):
+def token_shard(num_tokens: int, world: int, rank: int, slices: int = 1):
     """(start, count) of the token rows owned by `rank` — the engine's layout (csrc/engine.hip forward_impl): whole 64-token
     blocks, ceil(blocks / world) per rank, the LAST rank takes what is left (3660 blocks over 8 ranks = 7 x 458 + 454), so the
-    slot size in the gather buffers is the same on every rank and only the tail of the last slot is unused."""
-    if world < 1 or not 0 <= rank < world:
+    slot size in the gather buffers is the same on every rank and only the tail of the last slot is unused.  With the sliced
+    K / V^T exchange (engine option "sp_slices" = slices > 1) a slot is a whole number of slices: a multiple of 64 * slices."""
+    if world < 1 or not 0 <= rank < world or slices < 1:
         raise ValueError("bad rank/world")
     if num_tokens % 64:
         raise ValueError(f"sequence parallelism needs whole 64-token blocks (token count {num_tokens})")
-    slot = -(-(num_tokens // 64) // world) * 64
+    slot = shard_slot(num_tokens, world, slices)
     if (world - 1) * slot >= num_tokens:
         raise ValueError(f"sequence parallel x{world}: {num_tokens // 64} token blocks leave a rank without work")
     start = rank * slot
     return start, min(slot, num_tokens - start)
 
 
-def shard_slot(num_tokens: int, world: int) -> int:
+def shard_slot(num_tokens: int, world: int, slices: int = 1) -> int:
     """rows of one rank's slot in the gather buffers (>= every rank's own count)"""
-    return -(-(num_tokens // 64) // world) * 64
+    return -(-(num_tokens // 64) // (world * slices)) * slices * 64
 
 
 class ParallelLayout:

@@ -23,8 +23,9 @@ def rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-def run_ranks(P, make_dit, call):
-    """P handles, rank r driven by thread r on its own stream; returns the per-rank results (raises the first error)."""
+def run_ranks(P, make_dit, call, slices=1):
+    """P handles, rank r driven by thread r on its own stream; returns the per-rank results (raises the first error).
+    slices > 1: the sliced K / V^T exchange (engine option "sp_slices")."""
     from kandinsky import _engine as E
     group = E.LoopbackGroup(P)
     dits = []
@@ -32,6 +33,8 @@ def run_ranks(P, make_dit, call):
         d = make_dit()
         d.engine("cuda:0")
         d.enable_loopback(group, r)
+        if slices > 1:
+            d.set_option("sp_slices", slices)
         dits.append(d)
     torch.cuda.synchronize()
     out, err = [None] * P, [None] * P
@@ -220,3 +223,69 @@ def test_config5_sequence_length_P_ranks_on_one_gpu(P, sparse, fp8):
         assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
     print(f"config-5 length, P={P} sparse={sparse} fp8={fp8}: sharded vs fused rel-L2 {rel(outs[0], fused):.3e}")
     assert rel(outs[0], fused) <= (2.5e-2 if fp8 else 6e-3), rel(outs[0], fused)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("P,T,S", [(2, 8, 2), (4, 8, 2), (2, 7, 2), (4, 7, 2), (2, 12, 3), (3, 11, 2)])
+def test_tiny_forward_sliced_exchange(golden_meta, tiny_sd, P, T, S):
+    """"sp_slices" = S: K / V^T of a block travel in S slices and every slice of all peers is attended as soon as it has landed
+    (state resumed between the passes).  Slots become multiples of 64 S tokens: T = 7 blocks, P = 4, S = 2 -> 2 + 2 + 2 + 1 (the last
+    rank owns half a slot: its second slice is empty on every peer's walk), T = 11, P = 3 -> 4 + 4 + 3, T = 12, S = 3 -> 6 + 6."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = tiny_cfg(golden_meta)
+    g = torch.Generator().manual_seed(200 + T)
+    x = torch.randn(T, 16, 16, 33, generator=g)
+    text, pooled = torch.randn(9, 96, generator=g), torch.randn(1, 48, generator=g)
+    pos = [torch.arange(T), torch.arange(8), torch.arange(8)]
+    t = torch.tensor([432.0])
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(tiny_sd, assign=True)
+        return d.to("cuda:0")
+
+    def call(d, r):
+        return d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(9), scale_factor=(1.0, 2.0, 2.0))
+
+    fused = call(make(), 0)
+    outs = run_ranks(P, make, call, slices=S)
+    for r in range(1, P):
+        assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
+    assert rel(outs[0], fused) <= 3e-3, rel(outs[0], fused)
+    ref = O.dit_forward(tiny_sd, O.DitConfig(**c), x, text, pooled, t, pos, torch.arange(9), (1.0, 2.0, 2.0), None, "bf16")
+    assert rel(outs[0], ref) <= 1.5e-2, rel(outs[0], ref)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("P,W,gain,S", [(8, 48, 1.0, 2), (4, 48, 3.0, 2), (4, 48, 1.0, 4)])
+def test_full_width_forward_sliced_exchange(P, W, gain, S):
+    """2B-Lite width, 2 visual blocks, the sliced exchange: (8, 48): 15 blocks in slots of 2 -> 7 x 2 + 1; gain 3 = online-max softmax
+    on every head (the state that travels between the slice passes carries the running maximum); S = 4 on 15 blocks over 4 ranks:
+    slots of 4 -> 4 + 4 + 4 + 3."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
+    sd = O.synthetic_state_dict(O.DitConfig(**c), seed=3)
+    if gain != 1.0:
+        for k in sd:
+            if k.endswith(("query_norm.weight", "key_norm.weight")):
+                sd[k] = sd[k] * gain
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(5, 16, W, 16, generator=g)
+    text, pooled = torch.randn(37, 3584, generator=g), torch.randn(1, 768, generator=g)
+    pos = [torch.arange(5), torch.arange(8), torch.arange(W // 2)]
+    t = torch.tensor([875.0])
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(sd, assign=True)
+        return d.to("cuda:0")
+
+    def call(d, r):
+        return d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(37), scale_factor=(1.0, 2.0, 2.0))
+
+    fused = call(make(), 0)
+    outs = run_ranks(P, make, call, slices=S)
+    for r in range(1, P):
+        assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
+    print(f"sliced exchange P={P} S={S} gain={gain}: sharded vs fused rel-L2 {rel(outs[0], fused):.3e}")
+    assert rel(outs[0], fused) <= (6e-3 if gain == 1.0 else 1.5e-2), rel(outs[0], fused)

@@ -113,6 +113,10 @@ def test_token_shard_contract():
     assert token_shard(234240, 8, 0) == (0, 458 * 64) and token_shard(234240, 8, 6) == (6 * 458 * 64, 458 * 64)
     assert token_shard(234240, 8, 7) == (7 * 458 * 64, 454 * 64)
     assert sum(token_shard(234240, 8, r)[1] for r in range(8)) == 234240
+    # sliced K / V^T exchange ("sp_slices" = 2): slots are whole slices (multiples of 128 tokens); 744 blocks over 8 ranks = 7 x 94 + 86
+    assert token_shard(47616, 8, 0, slices=2) == (0, 94 * 64) and token_shard(47616, 8, 7, slices=2) == (7 * 94 * 64, 86 * 64)
+    assert sum(token_shard(47616, 8, r, slices=2)[1] for r in range(8)) == 47616
+    assert token_shard(234240, 8, 7, slices=2) == (7 * 458 * 64, 454 * 64)          # 458 is already even
     assert token_shard(192, 2, 0) == (0, 128) and token_shard(192, 2, 1) == (128, 64)
     with pytest.raises(ValueError):
         token_shard(128, 2, 2)
