@@ -85,6 +85,16 @@ int k5_attention_bf16_prescaled(const void* Q, const void* Kc, const void* Vt, v
  * over the same grid; a workgroup exits at once unless its head is its form's.  head_flags NULL: variant 1 = online max
  * everywhere.  workspace: NULL or k5_attention_balance_size bytes (balanced launch). */
 int k5_attention_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* head_flags, void* stream);
+/* The same pair with PER-ROW softmax offsets (what the engine's single-GPU path runs): k5_attention_flags_rows also writes
+ * kmax[h] = max |k'_h| and keeps heads up to |q|max |k'|max <= 180 on the fixed-offset form; there query row q of head h runs on
+ * the constant offset max(0, |q| kmax[h] - 90) — exp2 cannot overflow whatever the data, and the result is exact unless the row's
+ * whole sum underflows (< 2^-60: its largest score lies more than 150 below its Cauchy-Schwarz bound).  A workgroup that meets
+ * such a row sets head_flags[h] = 0 and the online-max launch that follows in the same call redoes that head: head_flags is
+ * read and written. */
+int k5_attention_flags_rows(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* head_flags, float* kmax,
+                            void* stream);
+int k5_attention_bf16_prescaled_rows(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                     int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, void* workspace, void* stream);
 int k5_attention_bf16_prescaled_auto(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len,
                                      int ldq, int ldk, int ldvt, int ldo, const int* head_flags, int variant, void* workspace,
                                      void* stream);

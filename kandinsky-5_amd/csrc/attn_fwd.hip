@@ -38,6 +38,10 @@ constexpr int QB = 256;   // query rows per workgroup
 constexpr int KB = 64;    // keys per tile
 constexpr int TILE = 64 * 128;  // bytes of one [64][64] bf16 tile
 
+constexpr float K5_ATTN_EXP_LIMIT = 90.f;   // |exp2 argument| bound of the fixed-offset form: p <= 2^90, l <= 2^107, O <= 2^114
+constexpr float K5_ATTN_ROW_MIN = 8.6736174e-19f;   // 2^-60: a row sum below this (per-row offsets only) sends the head to the online form
+constexpr float K5_ATTN_ROWOFF_LIMIT = 180.f;   // heads whose bound |q|max |k'|max exceeds this go to the online form right away
+
 struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
   int H, q_len, kv_len, ldq, ldk, ldvt, ldo, nqb;
@@ -46,6 +50,12 @@ struct AttnP {
   // flag differs from my_flag exits at once, so a fixed-offset launch and an online-max launch over the same grid
   // partition the heads between them.  null = every head.
   const int* head_flags; int my_flag;
+  // fixed-offset form with PER-ROW offsets (pre-scaled keys): kmax[h] = max |k'_h| (with margin) -> query row q of head h runs with
+  // the constant offset max(0, |q| kmax[h] - K5_ATTN_EXP_LIMIT): exp2(s - offset) <= 2^90 whatever the data, and exact unless the
+  // row's whole sum underflows (l < 2^-60: the row's true maximum lies > 150 below its Cauchy-Schwarz bound) — a workgroup that
+  // sees that on a row with a non-zero offset sets its head's flag to 0 and the online-max launch that follows redoes the head.
+  // null = offset 0 for every row (what the flags then have to guarantee: bound <= K5_ATTN_EXP_LIMIT).
+  const float* kmax;
   // sequence-parallel layout of V^T: keys are split in chunks of vt_chunk_keys (multiple of 64) and chunk c
   // starts at Vt + c * vt_chunk_stride ([rank][H*64][ldvt] after an in-place all-gather); 0 = one chunk
   int vt_chunk_keys; long long vt_chunk_stride;
@@ -193,6 +203,30 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   // !BOUNDED: nm[qt] = MINUS the softmax offset of the lane's query (exp2 domain), four copies = the S^T accumulators' start
   f32x4 nm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   bool fresh = true;             // !BOUNDED, wave-uniform: no tile processed yet -> the first one SETS the offset
+  if (BOUNDED && PRE && p.kmax) {   // per-row constant offsets from |q_row| * max|k'| (see AttnP::kmax); 0 when the bound is <= 90
+    const float km = p.kmax[h];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float ss = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 w = __builtin_bit_cast(u32x4, qf[qt][ks]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+          ss = fmaf(lo, lo, fmaf(hi, hi, ss));
+        }
+      }
+      {   // the query's four lanes (l15 + 16 g) hold 16 of its 64 dimensions each
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+        ss = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+        ss = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+      }
+      const float off = fmaxf(sqrtf(ss) * km - K5_ATTN_EXP_LIMIT, 0.f);
+      nm[qt] = f32x4{-off, -off, -off, -off};
+    }
+  }
   f32x4 lt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   const bf16x8 onesf = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
   // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
@@ -233,8 +267,13 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {   // first k-step starts from the constant 0, or from minus the query's softmax offset
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), g));
+#ifdef K5_ATTN_NO_ROW_OFFSETS   // A/B build (tools/build_variant.sh): the fixed form's S^T starts from the inline constant 0
       st[kt][0] = mfma16(kf, qf[0][0], BOUNDED ? zero4 : nm[0]);
       st[kt][1] = mfma16(kf, qf[1][0], BOUNDED ? zero4 : nm[1]);
+#else
+      st[kt][0] = mfma16(kf, qf[0][0], (BOUNDED && !PRE) ? zero4 : nm[0]);   // BOUNDED && PRE: nm = minus the row's constant offset (0 without kmax)
+      st[kt][1] = mfma16(kf, qf[1][0], (BOUNDED && !PRE) ? zero4 : nm[1]);
+#endif
     }
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -335,6 +374,8 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(st_o + 16 * dt) = ot[dt][qt];
         st_ml[0] = BOUNDED ? 0.f : (fresh ? -1e30f : -nm[qt][0]);   // no tile seen: weight 0 in a merge, "still fresh" on resume
         st_ml[1] = g == 0 ? lt[qt][0] : 0.f;                    // slot 0 carries the whole row sum
+        // per-row offsets: a part whose own sum underflows flags the head (conservative: the row's total is at least this part's)
+        if (BOUNDED && PRE && p.kmax && nm[qt][0] < 0.f && lt[qt][0] < K5_ATTN_ROW_MIN && T > E0) const_cast<int*>(p.head_flags)[h] = 0;
       }
     return;
   }
@@ -345,6 +386,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     const float l_tot = lt[qt][0];   // the ones-MFMA left the whole row sum in every lane of the query's column
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int q = q0 + 16 * qt + l15;
+    if (BOUNDED && PRE && p.kmax && q < p.q_len && nm[qt][0] < 0.f && l_tot < K5_ATTN_ROW_MIN) const_cast<int*>(p.head_flags)[h] = 0;
     if (q < p.q_len) {
       bf16_t* op = p.O + (size_t)q * p.ldo + h * 64 + 4 * g;
 #pragma unroll
@@ -635,7 +677,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
 // every exp2 argument of head h lies in [-B, B], B = |q|max |k'|max; B <= limit -> flag 1 (fixed offset 0), else 0.
 // The statistics are consumed: reset to 0 for the next producer.  counters[0 / 1] count heads sent each way.
 __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstride, int H, float limit, int force_online,
-                                  int* flags, unsigned long long* counters) {
+                                  int* flags, unsigned long long* counters, float* kmax_out) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
   const float q2 = qstat[h];
@@ -644,6 +686,7 @@ __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstrid
   const float b = sqrtf(q2) * sqrtf(k2) * 1.002f;   // margin: fp32 rounding of the norms and of the MFMA accumulation
   const int fast = (!force_online && b <= limit) ? 1 : 0;   // NaN / inf compare false -> online
   flags[h] = fast;
+  if (kmax_out) kmax_out[h] = sqrtf(k2) * 1.002f;   // per-row offsets of the fixed-offset form: |q_row| * this - 90 (AttnP::kmax)
   if (counters) atomicAdd(counters + (fast ? 0 : 1), 1ull);
   qstat[h] = 0.f;
   for (int i = 0; i < nk; ++i) kstat[(size_t)i * kstride + h] = 0.f;
@@ -657,7 +700,6 @@ __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstrid
 // head_flags (device, [H], pre-scaled keys only): the same decision per head, taken on the device from the data
 // (k5_launch_attn_flags) — flag 1: fixed offset, flag 0: lazy online max; both variants are launched over the same grid and
 // each workgroup exits at once unless its head is its variant's.
-constexpr float K5_ATTN_EXP_LIMIT = 90.f;   // |exp2 argument| bound of the fixed-offset form: p <= 2^90, l <= 2^107, O <= 2^114
 
 size_t k5_attention_state_bytes(int H, int q_len) { return (size_t)q_len * H * (64 + 8) * sizeof(float); }
 
@@ -679,10 +721,11 @@ int attn_slots() {
 }  // namespace
 
 int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
-                         unsigned long long* counters, hipStream_t stream) {
+                         unsigned long long* counters, hipStream_t stream, float* kmax_out) {
   if (!qstat || !kstat || !flags || H <= 0 || nk <= 0) return K5_ERR_ARG;
-  hipLaunchKernelGGL(attn_flags_kernel, dim3((H + 63) / 64), dim3(64), 0, stream, qstat, kstat, nk, kstride, H, K5_ATTN_EXP_LIMIT,
-                     force_online, flags, counters);
+  // with kmax_out the attention runs per-row offsets: heads up to K5_ATTN_ROWOFF_LIMIT keep the fixed-offset form
+  hipLaunchKernelGGL(attn_flags_kernel, dim3((H + 63) / 64), dim3(64), 0, stream, qstat, kstat, nk, kstride, H,
+                     kmax_out ? K5_ATTN_ROWOFF_LIMIT : K5_ATTN_EXP_LIMIT, force_online, flags, counters, kmax_out);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -696,7 +739,7 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* ws, bool k_prescaled,
-                                   const int* head_flags, int variant, const K5TileSegments* seg) {
+                                   const int* head_flags, int variant, const K5TileSegments* seg, const float* kmax) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -706,6 +749,8 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.nqb = (q_len + QB - 1) / QB;
   p.c = 0.125f * 1.44269504088896340736f;
   p.head_flags = nullptr; p.my_flag = 0;
+  if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;   // per-row offsets need the per-head flags (late fallback)
+  p.kmax = kmax;
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   const dim3 block(512);
   const bool bounded = score_bound > 0.f && score_bound * p.c <= K5_ATTN_EXP_LIMIT;
@@ -783,7 +828,7 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
 int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled,
-                                    const int* head_flags, int variant) {
+                                    const int* head_flags, int variant, const float* kmax) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0 || (q_len % KB) || (kv_len % KB) || !list || !cnt) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -794,6 +839,8 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   p.nqb = (q_len + QB - 1) / QB;
   p.c = 0.125f * 1.44269504088896340736f;
   p.head_flags = nullptr; p.my_flag = 0;
+  if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;
+  p.kmax = kmax;
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride;
   p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;

@@ -265,6 +265,7 @@ struct k5_dit {
   long long nabla_possible = 0;                    // profiling: 64x64 blocks the NABLA maps could have kept (kept: ws_attn_cnt[2])
   int attn_mode = 0;                               // K5_ATTN_AUTO / K5_ATTN_ONLINE (k5_dit_set_option "attn_mode")
   int sp_pass1_tiles = 0;                          // k5_dit_set_option "sp_pass1_tiles" (0 = all local key tiles)
+  bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 180)
   int sp_slices = 1;                               // "sp_slices": the K / V^T exchange of a block in this many slices (dense attention)
   hipEvent_t ev_slice[4] = {};                     // slice s of every peer has landed
   bool emulated = false;                           // "emulate_world": timing-only layout, results are garbage
@@ -452,7 +453,7 @@ int ensure_zeroed(DevBuf& b, size_t n, hipStream_t s) {
 // statistics / flags / counters of the data-derived softmax bound; layout of ws_attn_stats: [q: Hh][k: sp_world x Hh]
 int ensure_attn_flags(k5_dit* d, hipStream_t s) {
   K5CHK(ensure_zeroed(d->ws_attn_stats, (size_t)d->Hh * (1 + d->sp_world) * 4, s));
-  K5CHK(d->ws_attn_flags.ensure((size_t)d->Hh * 4));
+  K5CHK(d->ws_attn_flags.ensure((size_t)d->Hh * 8));   // int flags[H] | float kmax[H] (per-row offsets of the fixed-offset form)
   K5CHK(d->ws_attn_part.ensure(k5_rmsnorm_stats_workspace_bytes(2 * d->Hh)));
   K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
   return K5_OK;
@@ -476,6 +477,9 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   const bool pre = !strcmp(fam_attn, "attn_self") && rows % 64 == 0;   // visual blocks only (not the text blocks)
   const bool by_data = pre && d->attn_mode == K5_ATTN_AUTO;            // per-head flags from the data
   const int* hflags = nullptr;
+  // per-row softmax offsets (single-launch-group path only): heads with a Cauchy-Schwarz bound up to 180 keep the fixed-offset
+  // kernel, each query row on its own constant offset |q| max|k'| - 90; the sequence-parallel passes keep the plain rule (<= 90)
+  const float* kmax = nullptr;
   {
     Scope sc(d, s, "elementwise");
     const int32_t hc[2] = {H, 2 * H};
@@ -486,7 +490,9 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D, stats, d->ws_attn_part.as<float>()));
     if (by_data) {
       hflags = d->ws_attn_flags.as<int>();
-      K5CHK(k5_launch_attn_flags(stats, stats + H, 1, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s));
+      float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
+      kmax = kmax_w;
+      K5CHK(k5_launch_attn_flags(stats, stats + H, 1, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w));
     }
   }
   const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
@@ -507,12 +513,12 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
     Scope sc(d, s, fam_attn);
     K5CHK(k5_launch_attention_bf16_sparse(qk, pre ? d->ws_kc.as<bf16_t>() : (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, pre ? D : 2 * D,
-                                          ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant));
+                                          ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant, kmax));
   } else {
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     Scope sc(d, s, fam_attn);
     K5CHK(k5_launch_attention_bf16_range(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, pre ? 0.f : a.score_bound, 0, 0, 0, -1,
-                                         0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), pre, hflags, variant));
+                                         0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), pre, hflags, variant, nullptr, kmax));
   }
   {
     Scope sc(d, s, "gemm");
@@ -1374,6 +1380,8 @@ extern "C" int k5_dit_comm_init_loopback(k5_dit* d, k5_loopback* lb, int rank) {
 //   "attn_mode"       0 = softmax form per head from the data (fixed offset where |q||k'| <= 90, online max elsewhere),
 //                     1 = online max everywhere (what a checkpoint with large QK-norm gains gets; bench.py --attn-online)
 //   "sp_pass1_tiles"  local key tiles attended before the K/V^T gather has landed (0 = all of the rank's own tiles)
+//   "attn_row_offsets" 1 (default) / 0: fixed-offset softmax with per-row offsets — heads whose bound max|q| max|k'| lies in (90, 180]
+//                     stay on the fast kernel (a row whose sum underflows sends its head to the online form late); 0 = the plain <= 90 rule
 //   "sp_slices"       S in 1..4: exchange K / V^T of a block in S slices (grouped send/recv to every peer at once) and attend each
 //                     slice as it lands — the gather hides behind the attention of the slices before it (dense attention; NABLA and
 //                     S = 1 keep the single in-place all-gather).  Token slots become multiples of 64 S.
@@ -1388,6 +1396,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
     d->attn_mode = value; return K5_OK;
   }
   if (!strcmp(name, "sp_pass1_tiles")) { if (value < 0) return K5_ERR_ARG; d->sp_pass1_tiles = value; return K5_OK; }
+  if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
   if (!strcmp(name, "sp_slices")) {
     if (value < 1 || value > 4) return K5_ERR_ARG;
     if (value > 1 && d->comm.comm && !d->comm.can_exchange()) { k5_set_error("sp_slices > 1 needs ncclSend / ncclRecv / ncclGroup* in the RCCL library"); return K5_ERR_STATE; }
@@ -1407,6 +1416,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   if (!strcmp(name, "attn_mode")) *value = d->attn_mode;
   else if (!strcmp(name, "sp_pass1_tiles")) *value = d->sp_pass1_tiles;
   else if (!strcmp(name, "sp_slices")) *value = d->sp_slices;
+  else if (!strcmp(name, "attn_row_offsets")) *value = d->row_offsets ? 1 : 0;
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
   else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }

@@ -72,6 +72,20 @@ int k5_attention_flags(float* qstat, float* kstat, int nk, int kstride, int H, i
   return ret(k5_launch_attn_flags(qstat, kstat, nk, kstride, H, force_online, flags, nullptr, (hipStream_t)stream), "k5_attention_flags");
 }
 
+// the same two with per-row offsets: k5_attention_flags_rows also writes kmax[H] and keeps heads up to a bound of 180 on the fixed
+// form; k5_attention_bf16_prescaled_rows runs them with it (head_flags is read AND, on a late fallback, written)
+int k5_attention_flags_rows(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags, float* kmax, void* stream) {
+  if (!kmax) return ret(K5_ERR_ARG, "k5_attention_flags_rows");
+  return ret(k5_launch_attn_flags(qstat, kstat, nk, kstride, H, force_online, flags, nullptr, (hipStream_t)stream, kmax), "k5_attention_flags_rows");
+}
+int k5_attention_bf16_prescaled_rows(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                     int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, void* workspace, void* stream) {
+  if (!head_flags || !kmax) return ret(K5_ERR_ARG, "k5_attention_bf16_prescaled_rows");
+  return ret(k5_launch_attention_bf16_range(Q, Kc, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, 0.f, 0, 0, 0, -1, 0x7fffffff, 0,
+                                            nullptr, 0, (hipStream_t)stream, (float*)workspace, true, head_flags, K5_ATTN_AUTO, nullptr, kmax),
+             "k5_attention_bf16_prescaled_rows");
+}
+
 int64_t k5_attention_balance_size(int H, int q_len) { return (int64_t)k5_attention_balance_bytes(H, q_len); }
 
 int k5_attention_bf16_balanced(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,

@@ -32,15 +32,19 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* balance_ws = nullptr, bool k_prescaled = false,
-                                   const int* head_flags = nullptr, int variant = 0, const K5TileSegments* segments = nullptr);
+                                   const int* head_flags = nullptr, int variant = 0, const K5TileSegments* segments = nullptr,
+                                   const float* row_offset_kmax = nullptr);
 size_t k5_attention_balance_bytes(int H, int q_len);
 // softmax form of the pre-scaled-key launches: AUTO = fixed offset where the bound (score_bound, or the per-head device
 // flags) allows it and the lazy online max elsewhere; ONLINE = the online max everywhere
 enum { K5_ATTN_AUTO = 0, K5_ATTN_ONLINE = 1 };
 // per-head flags from the |q|^2 / |k'|^2 maxima that k5_launch_rmsnorm_rope(stats) left (consumed: reset to 0); kstat holds
 // nk partial maxima at stride kstride floats; counters (optional, device u64[2]) += heads sent to {fixed, online}
+// kmax_out (nullable, H floats): max |k'_h| with margin for the per-row offsets of the fixed-offset form (row_offset_kmax of the
+// attention launchers); with it heads up to a bound of 180 (instead of 90) keep that form — a row whose sum underflows sends its
+// head to the online form late (the flag is rewritten by the attention kernel)
 int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
-                         unsigned long long* counters, hipStream_t stream);
+                         unsigned long long* counters, hipStream_t stream, float* kmax_out = nullptr);
 
 // ---- fp8 (e4m3) feed-forward path, opt-in (gemm_fp8.hip) ----
 int k5_launch_gemm_fp8(const void* A8, const void* W8, const float* w_scale, void* C, int M, int N, int K, int lda, int ldw, int ldc,
@@ -61,7 +65,7 @@ int k5_launch_nabla_count(const void* workspace, int H, int nqb, int nb, unsigne
 int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled = false,
-                                    const int* head_flags = nullptr, int variant = 0);
+                                    const int* head_flags = nullptr, int variant = 0, const float* row_offset_kmax = nullptr);
 
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,

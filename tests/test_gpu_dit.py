@@ -165,16 +165,20 @@ def _qk_gain_sd(cfg, case):
                 sd[k] = w
             elif case == "x2":
                 sd[k] = torch.full((64,), 2.0)
+            elif case == "x5":
+                sd[k] = torch.full((64,), 5.0)
             else:
                 raise ValueError(case)
     return sd
 
 
-@pytest.mark.parametrize("case,expect", [("n05", "fixed"), ("x2", "fixed"), ("ch8", "any"), ("x3", "online")])
-def test_full_width_qk_norm_gains_vs_oracle(case, expect):
+@pytest.mark.parametrize("case,expect,row_offsets", [("n05", "fixed", 1), ("x2", "fixed", 1), ("ch8", "any", 1), ("x3", "fixed", 1),
+                                                     ("x3", "online", 0), ("x5", "online", 1)])
+def test_full_width_qk_norm_gains_vs_oracle(case, expect, row_offsets):
     """The engine on QK-norm gains a trained checkpoint could have: N(1, 0.5), every gain 2 (|q||k'| = 64 * 4 * 0.18 = 46),
-    every gain 3 (104: just outside the fixed-offset window), one channel at 8 (the bound depends on how much of a row's
-    energy sits in that channel: heads fall on either side).  The softmax form is chosen per head ON THE
+    every gain 3 (104: outside the offset-0 window of 90, inside the per-row-offset one of 180 — fixed form with the engine's
+    default, online max with "attn_row_offsets" = 0), every gain 5 (288: online max), one channel at 8 (the bound depends on how
+    much of a row's energy sits in that channel: heads fall on either side).  The softmax form is chosen per head ON THE
     DEVICE from the data; the test states which one must have run and demands oracle parity either way (round 1 derived the
     bound from max|w| and never left the fixed-offset branch in any engine-level test)."""
     from kandinsky.models.dit import DiffusionTransformer3D
@@ -189,6 +193,8 @@ def test_full_width_qk_norm_gains_vs_oracle(case, expect):
     pos = [torch.arange(5), torch.arange(8), torch.arange(8)]
     t = torch.tensor([875.0])
     dit = dit.to("cuda:0")
+    dit.engine("cuda:0")
+    dit.set_option("attn_row_offsets", row_offsets)
     args = (x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(37))
     out = dit(*args, scale_factor=(1.0, 2.0, 2.0))
     n_fixed, n_online = dit.attn_variant_counts(reset=True)
@@ -217,7 +223,7 @@ def test_full_width_qk_norm_gains_vs_oracle(case, expect):
     dit.set_option("attn_mode", 0)
     assert dit.attn_variant_counts(reset=True) == (0, 0)                 # forced mode: no flags are computed
     assert rel(out_on, refp) <= tol16, rel(out_on, refp)
-    assert rel(out_on, out) <= 1e-2, rel(out_on, out)
+    assert rel(out_on, out) <= max(1e-2, 0.5 * noise), rel(out_on, out)    # two valid forms: apart by at most the case's own bf16 noise
 
 
 # ------------------------------------------------------------------------------------------ MagCache

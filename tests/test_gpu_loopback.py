@@ -135,7 +135,8 @@ def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain):
     one = make()
     fused = call(one, 0)
     n_fixed, n_online = one.attn_variant_counts()
-    assert (n_online == 0) if gain == 1.0 else (n_fixed == 0), (n_fixed, n_online)
+    assert n_online == 0, (n_fixed, n_online)     # gain 3 (bound 104): the single-handle path keeps the fixed form on per-row offsets;
+    # the sharded passes below use the plain <= 90 rule -> online max on every head: two different forms, same velocity
     outs = run_ranks(P, make, call)
     for r in range(1, P):
         assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"

@@ -234,3 +234,72 @@ def test_config5_size_both_forms_sampled_rows_vs_oracle(E):
     close(out[rows], ref, ulps=4, atol=5e-3, what="config-5 sampled rows")
     oc = run_auto(E, q, kc, torch.full_like(vt, 0.75), H, flags, 0, balanced=True)
     assert (oc.float() - 0.75).abs().max().item() <= 2 ** -8
+
+
+# ------------------------------------------------------------------------------------------ per-row offsets of the fixed-offset form
+def run_rows(E, q, kc, vt, H, flags, kmax, balanced=True):
+    Sq, Sk = q.shape[0], kc.shape[0]
+    out = torch.full((Sq, H * 64), float("nan"), dtype=BF, device="cuda")
+    L = E.lib()
+    ws = torch.empty(L.k5_attention_balance_size(H, Sq), dtype=torch.uint8, device="cuda") if balanced else None
+    E.check(L.k5_attention_bf16_prescaled_rows(q.data_ptr(), kc.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk, q.stride(0),
+                                               kc.stride(0), vt.stride(0), out.stride(0), flags.data_ptr(), kmax.data_ptr(),
+                                               None if ws is None else ws.data_ptr(), E.stream_ptr()), "k5_attention_bf16_prescaled_rows")
+    torch.cuda.synchronize()
+    return out
+
+
+def flags_rows(E, qf, kf, H):
+    qstat, kstat = (qf * qf).sum(-1).amax(0).contiguous().cuda(), (kf * kf).sum(-1).amax(0).contiguous().cuda()
+    flags = torch.zeros(H, dtype=torch.int32, device="cuda")
+    kmax = torch.zeros(H, device="cuda")
+    E.check(E.lib().k5_attention_flags_rows(qstat.data_ptr(), kstat.data_ptr(), 1, H, H, 0, flags.data_ptr(), kmax.data_ptr(), E.stream_ptr()))
+    torch.cuda.synchronize()
+    return flags, kmax
+
+
+@pytest.mark.parametrize("Sq,Sk,H", [(700 - 700 % 64 + 64, 1088, 4), (33280, 2048, 4)])
+def test_row_offsets_keep_large_norm_heads_on_the_fixed_form(E, Sq, Sk, H):
+    """Gains 1, 2, 3, 3.7 on heads 0..3: bounds 11.5 g^2 = 11.5 / 46 / 104 / 158 — all within 180, so k5_attention_flags_rows keeps
+    every head on the fixed-offset kernel, the last two on non-zero per-row offsets; parity with the oracle, flags untouched
+    afterwards (no row underflowed).  (33 280 x 4 heads = 520 jobs: whole rounds AND split tail jobs.)"""
+    g = torch.Generator().manual_seed(Sq)
+    gains = torch.tensor([1.0, 2.0, 3.0, 3.7])
+    def rmsn(x):
+        return gains[None, :, None] * x / x.pow(2).mean(-1, keepdim=True).sqrt()
+    q = bfr(rmsn(torch.randn(Sq, H, 64, generator=g)))
+    k = bfr(rmsn(torch.randn(Sk, H, 64, generator=g)) * O.SOFTMAX_C)
+    v = bfr(torch.randn(Sk, H, 64, generator=g))
+    flags, kmax = flags_rows(E, q, k, H)
+    assert flags.tolist() == [1, 1, 1, 1], flags
+    assert (kmax.cpu() * q.pow(2).sum(-1).amax(0).sqrt() > torch.tensor([0.0, 0.0, 90.0, 90.0])).all()    # heads 2, 3 really need an offset
+    out = run_rows(E, q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v), H, flags, kmax)
+    assert flags.tolist() == [1, 1, 1, 1], flags
+    rows = torch.arange(Sq) if Sq < 2000 else torch.tensor([0, 5, 255, 256, 4097, 20000, 32767, 32768, 33000, Sq - 1])
+    close(out[rows], O.sdpa(q[rows], k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="per-row offsets")
+
+
+def test_row_offsets_late_fallback_when_a_row_underflows(E):
+    """Head 0: every key points AWAY from every query (scores ~ -|q||k'| = -140 with a little noise), so the row maxima sit ~280
+    below the Cauchy-Schwarz bound the per-row offset (bound - 90 = 50) was built from: exp2(s - 50) underflows for every key, the
+    workgroups see l < 2^-60, set head_flags[0] = 0, and the online-max launch of the same call recomputes the head.  Head 1 is an
+    ordinary gain-3 head (bound 104) that stays on the fixed form.  Both must match the oracle."""
+    Sq, Sk, H = 768, 1024, 2
+    g = torch.Generator().manual_seed(9)
+    u = torch.randn(64, generator=g); u = u / u.norm()
+    q = torch.empty(Sq, H, 64); k = torch.empty(Sk, H, 64)
+    q[:, 0] = 28.0 * u + 0.5 * torch.randn(Sq, 64, generator=g)
+    k[:, 0] = -5.0 * u + 0.1 * torch.randn(Sk, 64, generator=g)          # exp2-domain keys: |q||k'| ~ 140
+    def rmsn(x, gain):
+        return gain * x / x.pow(2).mean(-1, keepdim=True).sqrt()
+    q[:, 1] = rmsn(torch.randn(Sq, 64, generator=g), 3.0)
+    k[:, 1] = rmsn(torch.randn(Sk, 64, generator=g), 3.0) * O.SOFTMAX_C
+    q, k = bfr(q), bfr(k)
+    v = bfr(torch.randn(Sk, H, 64, generator=g))
+    flags, kmax = flags_rows(E, q, k, H)
+    assert flags.tolist() == [1, 1], flags                                 # both bounds are <= 180: the fixed form is tried first
+    s0 = (q[:, 0] @ k[:, 0].t())
+    assert s0.max().item() < -100 and (kmax[0].item() * q[:, 0].norm(dim=-1).min().item()) > 130
+    out = run_rows(E, q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v), H, flags, kmax)
+    assert flags.tolist() == [0, 1], flags                                 # head 0 fell back late, head 1 did not
+    close(out, O.sdpa(q, k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="late fallback")
