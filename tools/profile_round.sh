@@ -5,10 +5,10 @@
 TAG=${1:-r01}
 export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT; cd /tmp
 # 1. kernel trace + stats of the bench command (no counters in this pass)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae > $OUT/${TAG}_bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-breakdown > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 # 2. HBM traffic counters, one per pass (2 visual blocks are enough: per-launch numbers)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-vae --blocks 2 > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-breakdown --blocks 2 > /dev/null 2>&1
 done
 # 3. issue / wait counters of the attention kernel, launched the way the engine launches it (fixed softmax offset, pre-scaled keys)
 export BOUNDED=1 PRESCALED=1
@@ -16,5 +16,17 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_lds -o p -- python $R/tools/attn_only.py 2 > /dev/null 2>&1
 # 4. VAE decode kernel stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_vae -o vae -- python $R/tools/vae_bench.py > $OUT/${TAG}_vae_under_rocprof.log 2>&1
+# 5. NABLA (10 s, 93 696 tokens) kernel stats: the map kernels next to the sparse attention
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_nabla -o nabla -- python $R/bench.py --workload 10s_nabla --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-breakdown > $OUT/${TAG}_nabla_under_rocprof.log 2>&1
 cd $R
 python tools/profile_summarize.py $TAG
+# 6. the other workloads and the emulated shard sizes, one JSON line each (no profiler)
+: > $OUT/${TAG}_workloads.jsonl; : > $OUT/${TAG}_shards.jsonl
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --attn-online 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --qk-gain 3 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --workload 5s_sft 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vae --workload 5s_distil 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
+python bench.py --steps 45 --warmup 5 --no-cpu-baseline --no-vae --magcache 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
+for np in 0.9 0.15 0.0; do python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-vae --workload 10s_nabla --nabla-p $np 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl; done
+for sh in 2 4 8; do for sl in 1 2; do python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --emulate-shard $sh --sp-slices $sl 2>/dev/null | grep "^{" >> $OUT/${TAG}_shards.jsonl; done; done
+wc -l $OUT/${TAG}_workloads.jsonl $OUT/${TAG}_shards.jsonl

@@ -42,6 +42,8 @@ def counters(d, want=None):
 rows = stats_md(f"{OUT}/prof_{tag}", f"{OUT}/{tag}_bench_kernel_stats.md",
                 f"bench.py --steps 2 --warmup 1 (config_5s_nocfg, 1x MI355X): rocprofv3 kernel stats")
 stats_md(f"{OUT}/prof_{tag}_vae", f"{OUT}/{tag}_vae_kernel_stats.md", "HunyuanVideo VAE decode of one 5 s clip (tools/vae_bench.py): rocprofv3 kernel stats")
+stats_md(f"{OUT}/prof_{tag}_nabla", f"{OUT}/{tag}_nabla_kernel_stats.md",
+         "bench.py --workload 10s_nabla --steps 1 --warmup 1 (config_10s_sft latent, 93 696 tokens, NABLA P = 0.9, 1x MI355X): rocprofv3 kernel stats")
 
 # ---- self-attention of one block from the kernel trace: the three launches bench.py's roofline sums ----
 def attention_block_md():
