@@ -25,7 +25,7 @@ python tools/profile_summarize.py $TAG
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --attn-online 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --qk-gain 3 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --workload 5s_sft 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vae --workload 5s_distil 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vae --workload 2s_256 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
 python bench.py --steps 45 --warmup 5 --no-cpu-baseline --no-vae --magcache 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
 for np in 0.9 0.15 0.0; do python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-vae --workload 10s_nabla --nabla-p $np 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl; done
 for sh in 2 4 8; do for sl in 1 2; do python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --emulate-shard $sh --sp-slices $sl 2>/dev/null | grep "^{" >> $OUT/${TAG}_shards.jsonl; done; done
