@@ -298,7 +298,9 @@ def main():
             "config": {"workload": wl["desc"], "tokens": N, "text_len": L, "forwards_per_step": fwd_per_step,
                        "parallelism": "single GPU" if world == 1 else (f"sequence-parallel x{world} (token shards, K/V all-gather)" if args.sp_slices < 2 else
                                        f"sequence-parallel x{world} (token shards, K/V exchange in {args.sp_slices} slices)"),
-                       "visual_blocks": args.blocks, "magcache": bool(args.magcache)},
+                       "visual_blocks": args.blocks, "magcache": bool(args.magcache),
+                       **({"emulated_shard": args.emulate_shard} if args.emulate_shard > 1 else {}),
+                       **({"sp_slices": args.sp_slices} if args.sp_slices > 1 or args.emulate_shard > 1 else {})},
             "nfe_per_s": fwd_per_step * args.steps / dt,
             "step_tflop": step_flop / 1e12,
             "model_tflops_per_gpu": step_flop * args.steps / dt / 1e12 / world,

@@ -379,7 +379,7 @@ int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, cons
   blocks = (blocks + unit - 1) / unit * unit;           // <= cap: cap is a multiple of unit
   hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)x, weight,
                      cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled, stats ? stats_ws : nullptr);
-  if (stats) hipLaunchKernelGGL(stats_reduce_kernel, dim3(blocks >= 512 ? 16 : 1), dim3(256), 0, s, stats_ws, (int)blocks, H, stats);
+  if (stats) hipLaunchKernelGGL(stats_reduce_kernel, dim3(blocks >= 2048 ? 64 : (blocks >= 512 ? 16 : 1)), dim3(256), 0, s, stats_ws, (int)blocks, H, stats);
   return done();
 }
 
