@@ -67,9 +67,11 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct HostTensor {  // staged state_dict entry (fp32 on host)
-  std::vector<float> data;
-  std::vector<int64_t> shape;
+struct HostTensor {  // staged state_dict entry: vectors (biases, norms) as fp32 on the host, matrices as a raw copy ON THE DEVICE in
+  std::vector<float> data;          // the checkpoint's dtype — they are converted / padded / concatenated by a device kernel
+  std::vector<int64_t> shape;       // (k5_launch_pack_matrix), so a checkpoint that already lives on the GPU never touches the host
+  DevBuf dev; int dtype = K5_F32;   // and a host one costs its own bytes once (round 1: everything through host fp32, 4 B/param)
+  size_t count() const { size_t n = 1; for (int64_t v : shape) n *= (size_t)v; return n; }
 };
 
 float half_to_float(uint16_t h) {
@@ -388,6 +390,21 @@ int upload_bias_bf16r(DevBuf& b, const float* src, size_t n) {  // fp32 array of
   return upload_f32(b, tmp.data(), n);
 }
 
+// staged matrix -> rows [row0, row0 + rows) of dst [total_rows][ld] (bf16 or fp32), on the device
+int pack_rows(DevBuf& dst, bool bf16, const HostTensor* t, size_t rows, size_t cols, size_t ld, size_t row0 = 0, size_t total_rows = 0) {
+  if (!t || !t->dev.p || t->count() != rows * cols) { k5_set_error("internal: matrix not staged on the device"); return K5_ERR_STATE; }
+  if (total_rows == 0) total_rows = rows;
+  const size_t es = bf16 ? 2 : 4;
+  K5CHK(dst.ensure(total_rows * ld * es));
+  return k5_launch_pack_matrix(t->dev.p, t->dtype, (char*)dst.p + row0 * ld * es, bf16 ? 1 : 0, (int64_t)rows, (int)cols, (int)ld, nullptr);
+}
+int pack_bf16(DevBuf& dst, const HostTensor* t, size_t rows, size_t cols, size_t ld, size_t row0 = 0, size_t total_rows = 0) {
+  return pack_rows(dst, true, t, rows, cols, ld, row0, total_rows);
+}
+int pack_f32(DevBuf& dst, const HostTensor* t, size_t rows, size_t cols, size_t row0 = 0, size_t total_rows = 0) {
+  return pack_rows(dst, false, t, rows, cols, cols, row0, total_rows);
+}
+
 const HostTensor* find(k5_dit* d, const std::string& k) {
   auto it = d->staged.find(k);
   return it == d->staged.end() ? nullptr : &it->second;
@@ -414,17 +431,16 @@ int pack_attn(k5_dit* d, const std::string& p, AttnW& a, bool fuse_qk) {
                    *bv = find(d, p + ".to_value.bias"), *bo = find(d, p + ".out_layer.bias"),
                    *nq = find(d, p + ".query_norm.weight"), *nk = find(d, p + ".key_norm.weight");
   if (fuse_qk) {
-    std::vector<float> w(2 * D * D), b(2 * D);
-    memcpy(w.data(), wq->data.data(), D * D * 4); memcpy(w.data() + D * D, wk->data.data(), D * D * 4);
+    std::vector<float> b(2 * D);
     memcpy(b.data(), bq->data.data(), D * 4); memcpy(b.data() + D, bk->data.data(), D * 4);
-    K5CHK(upload_bf16(a.wqk, w.data(), 2 * D, D, D));
+    K5CHK(pack_bf16(a.wqk, wq, D, D, D, 0, 2 * D)); K5CHK(pack_bf16(a.wqk, wk, D, D, D, D, 2 * D));
     K5CHK(upload_bias_bf16r(a.bqk, b.data(), 2 * D));
   } else {
-    K5CHK(upload_bf16(a.wq, wq->data.data(), D, D, D)); K5CHK(upload_bias_bf16r(a.bq, bq->data.data(), D));
-    K5CHK(upload_bf16(a.wk, wk->data.data(), D, D, D)); K5CHK(upload_bias_bf16r(a.bk, bk->data.data(), D));
+    K5CHK(pack_bf16(a.wq, wq, D, D, D)); K5CHK(upload_bias_bf16r(a.bq, bq->data.data(), D));
+    K5CHK(pack_bf16(a.wk, wk, D, D, D)); K5CHK(upload_bias_bf16r(a.bk, bk->data.data(), D));
   }
-  K5CHK(upload_bf16(a.wv, wv->data.data(), D, D, D)); K5CHK(upload_bias_bf16r(a.bv, bv->data.data(), D));
-  K5CHK(upload_bf16(a.wo, wo->data.data(), D, D, D)); K5CHK(upload_bias_bf16r(a.bo, bo->data.data(), D));
+  K5CHK(pack_bf16(a.wv, wv, D, D, D)); K5CHK(upload_bias_bf16r(a.bv, bv->data.data(), D));
+  K5CHK(pack_bf16(a.wo, wo, D, D, D)); K5CHK(upload_bias_bf16r(a.bo, bo->data.data(), D));
   std::vector<float> n(128);
   memcpy(n.data(), nq->data.data(), 64 * 4); memcpy(n.data() + 64, nk->data.data(), 64 * 4);
   K5CHK(upload_f32(a.norm, n.data(), 128));
@@ -1033,6 +1049,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
   d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_kc.release(); d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
   d->ws_attn_stats.release(); d->ws_attn_flags.release(); d->ws_attn_cnt.release(); d->ws_attn_part.release();
   for (auto& t : d->text_cache) { t.text.release(); t.pool.release(); }
+  for (auto& kv : d->staged) kv.second.dev.release();   // a handle destroyed before finalize still holds its staged matrices
   d->mag.residual[0].release(); d->mag.residual[1].release(); d->mag.pm_one.release();
   for (auto& b : d->vblocks) { b.w1_f8.release(); b.w2_f8.release(); b.s1_f8.release(); b.s2_f8.release(); }
   if (d->graph_stream) { (void)hipStreamSynchronize(d->graph_stream); (void)hipStreamDestroy(d->graph_stream); (void)hipEventDestroy(d->ev_graph); }
@@ -1058,6 +1075,17 @@ extern "C" int k5_dit_load_tensor(k5_dit* d, const char* key, const void* host_p
   HostTensor t;
   size_t n = 1;
   for (int i = 0; i < rank; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  if (dtype != K5_F32 && dtype != K5_BF16 && dtype != K5_F16) return K5_ERR_ARG;
+  if (rank == 2) {   // a matrix: raw copy to the device (D2D for a checkpoint that is already there), packed by k5_dit_finalize
+    const size_t bytes = n * (dtype == K5_F32 ? 4 : 2);
+    t.dtype = dtype;
+    K5CHK(t.dev.ensure(bytes));
+    HIPCHK(hipMemcpy(t.dev.p, host_ptr, bytes, hipMemcpyDefault));
+    auto old = d->staged.find(key);
+    if (old != d->staged.end()) old->second.dev.release();
+    d->staged[key] = t;
+    return K5_OK;
+  }
   t.data.resize(n);
   // hipMemcpyDefault: the source may be host memory (safetensors on CPU) or device memory
   if (dtype == K5_F32) HIPCHK(hipMemcpy(t.data.data(), host_ptr, n * 4, hipMemcpyDefault));
@@ -1107,31 +1135,31 @@ extern "C" int k5_dit_finalize(k5_dit* d) {
       !shape_is("pooled_text_embeddings.norm.weight", TD, 0) || !shape_is("pooled_text_embeddings.norm.bias", TD, 0) ||
       !shape_is("visual_embeddings.in_layer.bias", D, 0) || !shape_is("out_layer.out_layer.bias", d->Fout, 0))
     return K5_ERR_ARG;
-  K5CHK(upload_f32(d->time_w1, find(d, "time_embeddings.in_layer.weight")->data.data(), TD * D));
+  K5CHK(pack_f32(d->time_w1, find(d, "time_embeddings.in_layer.weight"), TD, D));
   K5CHK(upload_f32(d->time_b1, find(d, "time_embeddings.in_layer.bias")->data.data(), TD));
-  K5CHK(upload_f32(d->time_w2, find(d, "time_embeddings.out_layer.weight")->data.data(), TD * TD));
+  K5CHK(pack_f32(d->time_w2, find(d, "time_embeddings.out_layer.weight"), TD, TD));
   K5CHK(upload_f32(d->time_b2, find(d, "time_embeddings.out_layer.bias")->data.data(), TD));
-  K5CHK(upload_bf16(d->text_w, find(d, "text_embeddings.in_layer.weight")->data.data(), D, c.in_text_dim, c.in_text_dim));
+  K5CHK(pack_bf16(d->text_w, find(d, "text_embeddings.in_layer.weight"), D, c.in_text_dim, c.in_text_dim));
   K5CHK(upload_bias_bf16r(d->text_b, find(d, "text_embeddings.in_layer.bias")->data.data(), D));
   K5CHK(upload_f32(d->text_lnw, find(d, "text_embeddings.norm.weight")->data.data(), D));
   K5CHK(upload_f32(d->text_lnb, find(d, "text_embeddings.norm.bias")->data.data(), D));
-  K5CHK(upload_bf16(d->pool_w, find(d, "pooled_text_embeddings.in_layer.weight")->data.data(), TD, c.in_text_dim2, c.in_text_dim2));
+  K5CHK(pack_bf16(d->pool_w, find(d, "pooled_text_embeddings.in_layer.weight"), TD, c.in_text_dim2, c.in_text_dim2));
   K5CHK(upload_bias_bf16r(d->pool_b, find(d, "pooled_text_embeddings.in_layer.bias")->data.data(), TD));
   K5CHK(upload_f32(d->pool_lnw, find(d, "pooled_text_embeddings.norm.weight")->data.data(), TD));
   K5CHK(upload_f32(d->pool_lnb, find(d, "pooled_text_embeddings.norm.bias")->data.data(), TD));
-  K5CHK(upload_bf16(d->vis_w, find(d, "visual_embeddings.in_layer.weight")->data.data(), D, d->Kvis, d->KvisPad));
+  K5CHK(pack_bf16(d->vis_w, find(d, "visual_embeddings.in_layer.weight"), D, d->Kvis, d->KvisPad));
   K5CHK(upload_bias_bf16r(d->vis_b, find(d, "visual_embeddings.in_layer.bias")->data.data(), D));
-  K5CHK(upload_bf16(d->out_w, find(d, "out_layer.out_layer.weight")->data.data(), d->Fout, D, D));
+  K5CHK(pack_bf16(d->out_w, find(d, "out_layer.out_layer.weight"), d->Fout, D, D));
   K5CHK(upload_bias_bf16r(d->out_b, find(d, "out_layer.out_layer.bias")->data.data(), d->Fout));
 
   // stacked modulation
   d->mod_rows = (size_t)c.num_text_blocks * 6 * D + (size_t)c.num_visual_blocks * 9 * D + 2 * D;
-  std::vector<float> mw(d->mod_rows * TD), mb(d->mod_rows);
+  std::vector<float> mb(d->mod_rows);
   size_t off = 0;
   auto put_mod = [&](const std::string& p, size_t rows) -> bool {
     const HostTensor *w = find(d, p + ".weight"), *b = find(d, p + ".bias");
-    if (!w || !b || w->data.size() != rows * TD || b->data.size() != rows) { k5_set_error("shape mismatch for %s", p.c_str()); return false; }
-    memcpy(mw.data() + off * TD, w->data.data(), rows * TD * 4);
+    if (!w || !b || w->shape.size() != 2 || w->count() != rows * TD || b->data.size() != rows) { k5_set_error("shape mismatch for %s", p.c_str()); return false; }
+    if (pack_f32(d->mod_w, w, rows, TD, off, d->mod_rows) != K5_OK) return false;
     memcpy(mb.data() + off, b->data.data(), rows * 4);
     off += rows;
     return true;
@@ -1143,8 +1171,8 @@ extern "C" int k5_dit_finalize(k5_dit* d) {
     if (!put_mod(p + ".text_modulation.out_layer", 6 * D)) return K5_ERR_ARG;
     K5CHK(pack_attn(d, p + ".self_attention", d->tblocks[i].self_attn, true));
     if (!shape_ok(d, p + ".feed_forward.in_layer.weight", FF, D) || !shape_ok(d, p + ".feed_forward.out_layer.weight", D, FF)) return K5_ERR_ARG;
-    K5CHK(upload_bf16(d->tblocks[i].w1, find(d, p + ".feed_forward.in_layer.weight")->data.data(), FF, D, D));
-    K5CHK(upload_bf16(d->tblocks[i].w2, find(d, p + ".feed_forward.out_layer.weight")->data.data(), D, FF, FF));
+    K5CHK(pack_bf16(d->tblocks[i].w1, find(d, p + ".feed_forward.in_layer.weight"), FF, D, D));
+    K5CHK(pack_bf16(d->tblocks[i].w2, find(d, p + ".feed_forward.out_layer.weight"), D, FF, FF));
   }
   for (int i = 0; i < c.num_visual_blocks; ++i) {
     const std::string p = "visual_transformer_blocks." + std::to_string(i);
@@ -1153,13 +1181,14 @@ extern "C" int k5_dit_finalize(k5_dit* d) {
     K5CHK(pack_attn(d, p + ".self_attention", d->vblocks[i].self_attn, true));
     K5CHK(pack_attn(d, p + ".cross_attention", d->vblocks[i].cross_attn, false));
     if (!shape_ok(d, p + ".feed_forward.in_layer.weight", FF, D) || !shape_ok(d, p + ".feed_forward.out_layer.weight", D, FF)) return K5_ERR_ARG;
-    K5CHK(upload_bf16(d->vblocks[i].w1, find(d, p + ".feed_forward.in_layer.weight")->data.data(), FF, D, D));
-    K5CHK(upload_bf16(d->vblocks[i].w2, find(d, p + ".feed_forward.out_layer.weight")->data.data(), D, FF, FF));
+    K5CHK(pack_bf16(d->vblocks[i].w1, find(d, p + ".feed_forward.in_layer.weight"), FF, D, D));
+    K5CHK(pack_bf16(d->vblocks[i].w2, find(d, p + ".feed_forward.out_layer.weight"), D, FF, FF));
   }
   d->out_mod_off = off;
   if (!put_mod("out_layer.modulation.out_layer", 2 * D)) return K5_ERR_ARG;
-  K5CHK(upload_f32(d->mod_w, mw.data(), mw.size()));
   K5CHK(upload_f32(d->mod_b, mb.data(), mb.size()));
+  HIPCHK(hipDeviceSynchronize());   // the pack kernels read the staged device copies that are freed next
+  for (auto& kv : d->staged) kv.second.dev.release();
   d->staged.clear();
   d->finalized = true;
   return K5_OK;

@@ -111,6 +111,8 @@ int k5_launch_cfg_euler(float* img, const void* v_cond, const void* v_uncond, fl
                         hipStream_t stream, const float* dtvec = nullptr, const int* step = nullptr);
 // fp32 -> bf16 cast, bf16 -> fp32
 int k5_launch_cast_f32_bf16(const float* x, void* out, int64_t n, hipStream_t stream);
+// weight packing: src [rows][cols] (K5_F32 / K5_BF16 / K5_F16, device) -> dst [rows][ld] bf16 (RNE) or fp32, pad columns zeroed
+int k5_launch_pack_matrix(const void* src, int src_dtype, void* dst, int dst_bf16, int64_t rows, int cols, int ld, hipStream_t stream);
 
 // causal_hw > 0: frame-causal scores, tiles wholly at columns >= (row / causal_hw + 1) * causal_hw are skipped (left unwritten)
 int k5_launch_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc,

@@ -447,6 +447,40 @@ int k5_launch_cfg_euler(float* img, const void* vc, const void* vu, float w, flo
   return done();
 }
 
+namespace {
+// weight packing on the device (k5_dit_finalize): src [rows][cols] of dtype sdt (K5_F32 / K5_BF16 / K5_F16) -> dst [rows][ld] bf16 (RNE)
+// or fp32; the columns cols .. ld of a padded destination are zeroed
+template <bool DST_BF16>
+__global__ __launch_bounds__(256) void pack_matrix_kernel(const void* __restrict__ src, int sdt, void* __restrict__ dst, int64_t rows,
+                                                          int cols, int ld) {
+  const int64_t total = rows * ld;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const int64_t r = g / ld;
+    const int c = (int)(g - r * ld);
+    float v = 0.f;
+    if (c < cols) {
+      const int64_t si = r * cols + c;
+      if (sdt == K5_F32) v = reinterpret_cast<const float*>(src)[si];
+      else if (sdt == K5_BF16) v = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(src)[si] << 16);
+      else v = (float)reinterpret_cast<const _Float16*>(src)[si];
+    }
+    if (DST_BF16) reinterpret_cast<bf16_t*>(dst)[g] = f2bf(v);
+    else reinterpret_cast<float*>(dst)[g] = v;
+  }
+}
+}  // namespace
+
+int k5_launch_pack_matrix(const void* src, int src_dtype, void* dst, int dst_bf16, int64_t rows, int cols, int ld, hipStream_t s) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || ld < cols) return K5_ERR_ARG;
+  if (src_dtype != K5_F32 && src_dtype != K5_BF16 && src_dtype != K5_F16) return K5_ERR_ARG;
+  const int64_t total = rows * ld;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (dst_bf16) hipLaunchKernelGGL(pack_matrix_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, src, src_dtype, dst, rows, cols, ld);
+  else hipLaunchKernelGGL(pack_matrix_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, src, src_dtype, dst, rows, cols, ld);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
 int k5_launch_cast_f32_bf16(const float* x, void* out, int64_t n, hipStream_t s) {
   if (n <= 0) return K5_ERR_ARG;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, (bf16_t*)out, n);

@@ -50,6 +50,34 @@ def test_forward_tiny_vs_oracle_and_golden(tiny_dit, tiny_sd, cfg, golden):
     assert rel(ref16, golden["fwd.out"]) <= 3e-2
 
 
+def test_weights_pack_identically_from_host_or_device_in_any_dtype(tiny_sd, cfg, golden):
+    """k5_dit_load_tensor stages a matrix as a raw copy on the device (D2D for a checkpoint that already lives there) and
+    k5_dit_finalize converts / pads / concatenates it with a device kernel: the same bf16-representable checkpoint loaded from CPU
+    fp32, GPU fp32, GPU bf16, CPU bf16 and GPU fp16-of-the-bf16-values must give bit-identical forwards (the packed weights are the
+    same bits).  fp16 cannot hold every bf16 value, so its source is the fp16-AND-bf16 representable rounding of the checkpoint."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    base = {k: v.half().bfloat16().float() for k, v in tiny_sd.items()}     # representable in both 16-bit formats (tiny weights: no overflow)
+    assert all(torch.equal(v.half().float(), v) and torch.equal(v.bfloat16().float(), v) for v in base.values())
+    args = (golden["fwd.x"].cuda(), golden["fwd.text"].cuda(), golden["fwd.pooled"].cuda(), golden["fwd.time"], POS, torch.arange(7))
+
+    def run(sd, to_cuda):
+        d = DiffusionTransformer3D(**cfg)
+        d.load_state_dict(sd, assign=True)
+        if to_cuda:
+            d = d.to("cuda:0")
+        else:
+            d.engine("cuda:0")                       # parameters stay on the host: H2D of the raw bytes, then the same device pack
+        return d(*args, scale_factor=(1.0, 2.0, 2.0))
+
+    ref = run(base, False)
+    assert torch.isfinite(ref.float()).all()
+    for name, sd, to_cuda in (("gpu fp32", base, True), ("gpu bf16", {k: v.bfloat16() for k, v in base.items()}, True),
+                              ("cpu bf16", {k: v.bfloat16() for k, v in base.items()}, False),
+                              ("gpu fp16", {k: v.half() for k, v in base.items()}, True)):
+        out = run(sd, to_cuda)
+        assert torch.equal(out, ref), name
+
+
 def test_forward_accepts_bf16_text_and_16_channel_x(tiny_dit, golden):
     a = tiny_dit(golden["fwd.x"].cuda(), golden["fwd.text"].cuda(), golden["fwd.pooled"].cuda(), golden["fwd.time"],
                  POS, torch.arange(7), scale_factor=(1.0, 2.0, 2.0))
