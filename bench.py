@@ -271,7 +271,7 @@ def main():
     else:
         variant = (f"fixed-offset softmax on {n_fixed} and online-max on {n_online} of {n_fixed + n_online} (block, head) "
                    f"launches, chosen per head on the device: max|q|*max|k'| <= 180 keeps the fixed form (per-row offsets |q|*max|k'| - 90, "
-                   f"all zero when the bound is <= 90; the sequence-parallel passes use the plain <= 90 rule)")
+                   f"all zero when the bound is <= 90)")
     traffic = None   # HBM-side bytes per attention launch from the committed PMC profile (separate --pmc passes; cannot be
     try:             # collected inside a timed run) — only quoted for the exact workload it was measured on
         with open(os.path.join(ROOT, "profiles", "r02_attention_traffic.json")) as f:

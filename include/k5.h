@@ -95,6 +95,14 @@ int k5_attention_flags_rows(float* qstat, float* kstat, int nk, int kstride, int
                             void* stream);
 int k5_attention_bf16_prescaled_rows(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                      int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, void* workspace, void* stream);
+/* One pass of a multi-pass schedule (sequence parallelism: local keys first, gathered keys later) with per-row offsets: key tiles
+ * [tile_off0, tile_off0 + tile_cnt), flags & 1 = resume `state`, & 2 = leave it instead of writing O (k5_attention_state_size
+ * bytes).  late_pass 1 = not the last pass, 2 = the last: a row that underflows in any pass writes head_flags[h] = 2, every later
+ * fixed-offset launch and the online launches of the non-final passes then skip the head, and the online launch of the last pass
+ * recomputes it from scratch over all kv_len keys. */
+int k5_attention_bf16_prescaled_rows_pass(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                          int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, int tile_off0, int tile_cnt,
+                                          float* state, int flags, int late_pass, void* workspace, void* stream);
 int k5_attention_bf16_prescaled_auto(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len,
                                      int ldq, int ldk, int ldvt, int ldo, const int* head_flags, int variant, void* workspace,
                                      void* stream);

@@ -56,6 +56,11 @@ struct AttnP {
   // sees that on a row with a non-zero offset sets its head's flag to 0 and the online-max launch that follows redoes the head.
   // null = offset 0 for every row (what the flags then have to guarantee: bound <= K5_ATTN_EXP_LIMIT).
   const float* kmax;
+  // multi-pass schedules (sequence parallelism) with per-row offsets: 0 = single launch group (an underflowing row writes flag 0 and
+  // the online launch of the same call redoes the head), 1 = a pass that is not the last (the row writes flag 2 = "late": every
+  // later fixed-offset launch skips the head, the online launches of non-final passes skip it too), 2 = the last pass (the online
+  // launch recomputes a late head FROM SCRATCH over all late_total key tiles, ignoring the state the earlier passes left)
+  int late_pass, late_total;
   // sequence-parallel layout of V^T: keys are split in chunks of vt_chunk_keys (multiple of 64) and chunk c
   // starts at Vt + c * vt_chunk_stride ([rank][H*64][ldvt] after an in-place all-gather); 0 = one chunk
   int vt_chunk_keys; long long vt_chunk_stride;
@@ -113,7 +118,15 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   const int part = RANGE ? gid % p.splits : 0;
   const int lid = p.job0 + (RANGE ? gid / p.splits : gid);
   const int h = lid / p.nqb, qb = lid % p.nqb;
-  if (p.head_flags && p.head_flags[h] != p.my_flag) return;   // workgroup-uniform: the other variant's launch owns this head
+  bool late = false;   // online form, last pass, head flagged late: walk ALL key tiles from a fresh state
+  if (p.head_flags) {   // workgroup-uniform: the other variant's launch owns this head
+    const int hf = p.head_flags[h];
+    if (BOUNDED) { if (hf != 1) return; }
+    else {
+      if (hf == 1) return;
+      if (hf == 2) { if (p.late_pass != 2) return; late = true; }
+    }
+  }
   const int q0 = qb * QB + wave * 32;   // this wave: queries q0 .. q0+31 = two 16-query MFMA tiles (qt = 0, 1)
 
   // Q^T fragments (MFMA 16x16x32 B operand): lane (l15, g) holds Q[q0 + 16 qt + l15][32 ks + 8 g .. +8]
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   const uint32_t vlane = ((uint32_t)(h * 64 + lrow) * (uint32_t)p.ldvt + 8u * (lc ^ ((lrow >> 1) & 7))) * 2u;
   const uint32_t vlane_lin = ((uint32_t)(h * 64 + lrow) * (uint32_t)p.ldvt + 8u * lc) * 2u;   // ragged tile: register path
   const int* sp_list = SPARSE ? p.sp_list + (size_t)(h * p.nqb + qb) * p.sp_stride : nullptr;
-  const int Tall = SPARSE ? p.sp_cnt[h * p.nqb + qb] : p.tile_cnt;
+  const int Tall = SPARSE ? p.sp_cnt[h * p.nqb + qb] : ((!BOUNDED && late) ? p.late_total : p.tile_cnt);
   // this workgroup's share of the tile sequence: positions [E0, T)  (everything unless the job is split)
   const int E0 = RANGE ? (int)(((long long)Tall * part) / p.splits) : 0;
   const int T = RANGE ? (int)(((long long)Tall * (part + 1)) / p.splits) : Tall;
@@ -145,6 +158,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   auto tile_of = [&](int e) -> int {                  // sequence position -> 64-key tile index (wave-uniform)
     if (SPARSE) return sp_list[e] & 0xffffff;
     if (!RANGE) return e;
+    if (!BOUNDED && late) return e;
     if (p.seg_len > 0) {
       int si = e / p.seg_len;
       const int j = e - si * p.seg_len;
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   auto state_base = [&]() { return part == 0 ? p.state : p.split_state + (size_t)(part - 1) * p.split_stride; };
   auto state_o = [&](int qt) { return state_base() + (size_t)(q0 + 16 * qt + l15) * (p.H * 64) + h * 64 + 4 * g; };
   auto state_ml = [&](int qt) { return state_base() + (size_t)p.q_len * (p.H * 64) + (((size_t)(q0 + 16 * qt + l15) * p.H + h) * 4 + g) * 2; };
-  if (RANGE && (p.flags & 1) && part == 0) {   // resume: accumulators of an earlier launch over other key tiles
+  if (RANGE && (p.flags & 1) && part == 0 && !(!BOUNDED && late)) {   // resume: accumulators of an earlier launch over other key tiles
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
       if (q0 + 16 * qt + l15 < p.q_len) {
@@ -375,7 +389,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         st_ml[0] = BOUNDED ? 0.f : (fresh ? -1e30f : -nm[qt][0]);   // no tile seen: weight 0 in a merge, "still fresh" on resume
         st_ml[1] = g == 0 ? lt[qt][0] : 0.f;                    // slot 0 carries the whole row sum
         // per-row offsets: a part whose own sum underflows flags the head (conservative: the row's total is at least this part's)
-        if (BOUNDED && PRE && p.kmax && nm[qt][0] < 0.f && lt[qt][0] < K5_ATTN_ROW_MIN && T > E0) const_cast<int*>(p.head_flags)[h] = 0;
+        if (BOUNDED && PRE && p.kmax && nm[qt][0] < 0.f && lt[qt][0] < K5_ATTN_ROW_MIN && T > E0) const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
       }
     return;
   }
@@ -386,7 +400,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     const float l_tot = lt[qt][0];   // the ones-MFMA left the whole row sum in every lane of the query's column
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int q = q0 + 16 * qt + l15;
-    if (BOUNDED && PRE && p.kmax && q < p.q_len && nm[qt][0] < 0.f && l_tot < K5_ATTN_ROW_MIN) const_cast<int*>(p.head_flags)[h] = 0;
+    if (BOUNDED && PRE && p.kmax && q < p.q_len && nm[qt][0] < 0.f && l_tot < K5_ATTN_ROW_MIN) const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
     if (q < p.q_len) {
       bf16_t* op = p.O + (size_t)q * p.ldo + h * 64 + 4 * g;
 #pragma unroll
@@ -739,7 +753,7 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* ws, bool k_prescaled,
-                                   const int* head_flags, int variant, const K5TileSegments* seg, const float* kmax) {
+                                   const int* head_flags, int variant, const K5TileSegments* seg, const float* kmax, int late_pass) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -751,6 +765,8 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.head_flags = nullptr; p.my_flag = 0;
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;   // per-row offsets need the per-head flags (late fallback)
   p.kmax = kmax;
+  if (late_pass < 0 || late_pass > 2 || (late_pass && !kmax)) return K5_ERR_ARG;
+  p.late_pass = late_pass; p.late_total = (kv_len + KB - 1) / KB;
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   const dim3 block(512);
   const bool bounded = score_bound > 0.f && score_bound * p.c <= K5_ATTN_EXP_LIMIT;
@@ -840,7 +856,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   p.c = 0.125f * 1.44269504088896340736f;
   p.head_flags = nullptr; p.my_flag = 0;
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;
-  p.kmax = kmax;
+  p.kmax = kmax; p.late_pass = 0; p.late_total = 0;
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride;
   p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;

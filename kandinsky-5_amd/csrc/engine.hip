@@ -493,8 +493,8 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   const bool pre = !strcmp(fam_attn, "attn_self") && rows % 64 == 0;   // visual blocks only (not the text blocks)
   const bool by_data = pre && d->attn_mode == K5_ATTN_AUTO;            // per-head flags from the data
   const int* hflags = nullptr;
-  // per-row softmax offsets (single-launch-group path only): heads with a Cauchy-Schwarz bound up to 180 keep the fixed-offset
-  // kernel, each query row on its own constant offset |q| max|k'| - 90; the sequence-parallel passes keep the plain rule (<= 90)
+  // per-row softmax offsets: heads with a Cauchy-Schwarz bound up to 180 keep the fixed-offset kernel, each query row on its own
+  // constant offset |q| max|k'| - 90
   const float* kmax = nullptr;
   {
     Scope sc(d, s, "elementwise");
@@ -625,10 +625,15 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   }
   HIPCHK(hipEventRecord(d->ev_gathered, cs));
   const int* hflags = nullptr;
+  // per-row softmax offsets (§4.1) across the passes: a row that underflows in ANY pass marks its head late (flag 2), the fixed
+  // form then skips the head and the online form of the LAST pass recomputes it from scratch over all keys (late_pass 1 / 2)
+  const float* kmax = nullptr;
   if (by_data) {
     HIPCHK(hipStreamWaitEvent(s, d->ev_stats, 0));
     hflags = d->ws_attn_flags.as<int>();
-    K5CHK(k5_launch_attn_flags(qstat, kstat, P, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s));
+    float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
+    kmax = kmax_w;
+    K5CHK(k5_launch_attn_flags(qstat, kstat, P, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w));
   }
   const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
   if (nabla) {
@@ -671,14 +676,15 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, S > 1 ? cols : ldv, D, 0.f, S > 1 ? cols : rows_pad,
                                            S > 1 ? (long long)D * cols : (long long)D * ldv,
-                                           r * tpc_pad, k1, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s, d->ws_attn_bal.as<float>(), true, hflags, variant));
+                                           r * tpc_pad, k1, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s, d->ws_attn_bal.as<float>(), true, hflags, variant,
+                                           nullptr, kmax, kmax ? 1 : 0));
     }
     if (S == 1) {
       HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, rows_pad, (long long)D * ldv,
                                            0, total - k1, r * tpc_pad, k1, d->ws_attn_state.as<float>(), 1, s, d->ws_attn_bal.as<float>(),
-                                           true, hflags, variant));
+                                           true, hflags, variant, nullptr, kmax, kmax ? 2 : 0));
     } else {
       // one pass per slice, as soon as that slice of every peer has landed: slice sl of rank p = key tiles [p tpc_pad + sl tps, + tps)
       // (P - 1 segments: mine was pass 1; the last rank's slot may end early — it is the last segment, so the count is cut short).
@@ -700,7 +706,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
         Scope sc(d, s, "attn_self");
         K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, cols, D, 0.f, cols, (long long)D * cols,
                                              sl * tps, cnt, 0x7fffffff, 0, d->ws_attn_state.as<float>(), fin ? 1 : 3, s,
-                                             d->ws_attn_bal.as<float>(), true, hflags, variant, &seg));
+                                             d->ws_attn_bal.as<float>(), true, hflags, variant, &seg, kmax, kmax ? (fin ? 2 : 1) : 0));
       }
     }
   }

@@ -86,6 +86,17 @@ int k5_attention_bf16_prescaled_rows(const void* Q, const void* Kc, const void* 
              "k5_attention_bf16_prescaled_rows");
 }
 
+// one pass of a multi-pass schedule with per-row offsets (what the sequence-parallel engine runs): key tiles tile_off0 .. +tile_cnt,
+// flags & 1 resume / & 2 leave the state, late_pass 1 = not the last pass, 2 = the last (see include/k5.h)
+int k5_attention_bf16_prescaled_rows_pass(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                          int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, int tile_off0, int tile_cnt,
+                                          float* state, int flags, int late_pass, void* workspace, void* stream) {
+  if (!head_flags || !kmax) return ret(K5_ERR_ARG, "k5_attention_bf16_prescaled_rows_pass");
+  return ret(k5_launch_attention_bf16_range(Q, Kc, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, 0.f, 0, 0, tile_off0, tile_cnt, 0x7fffffff, 0,
+                                            state, flags, (hipStream_t)stream, (float*)workspace, true, head_flags, K5_ATTN_AUTO, nullptr, kmax,
+                                            late_pass), "k5_attention_bf16_prescaled_rows_pass");
+}
+
 int64_t k5_attention_balance_size(int H, int q_len) { return (int64_t)k5_attention_balance_bytes(H, q_len); }
 
 int k5_attention_bf16_balanced(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,

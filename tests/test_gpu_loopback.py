@@ -135,8 +135,8 @@ def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain):
     one = make()
     fused = call(one, 0)
     n_fixed, n_online = one.attn_variant_counts()
-    assert n_online == 0, (n_fixed, n_online)     # gain 3 (bound 104): the single-handle path keeps the fixed form on per-row offsets;
-    # the sharded passes below use the plain <= 90 rule -> online max on every head: two different forms, same velocity
+    assert n_online == 0, (n_fixed, n_online)     # gain 3 (bound 104): the fixed form on per-row offsets, in the single-handle path
+    # and in every pass of the sharded schedule below (same per-row offsets from the gathered max|k'|)
     outs = run_ranks(P, make, call)
     for r in range(1, P):
         assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"

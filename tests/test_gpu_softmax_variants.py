@@ -303,3 +303,44 @@ def test_row_offsets_late_fallback_when_a_row_underflows(E):
     out = run_rows(E, q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v), H, flags, kmax)
     assert flags.tolist() == [0, 1], flags                                 # head 0 fell back late, head 1 did not
     close(out, O.sdpa(q, k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="late fallback")
+
+
+@pytest.mark.parametrize("bad_half", ["first", "both"])
+def test_row_offsets_late_fallback_across_passes(E, bad_half):
+    """The sequence-parallel schedule's form of the same thing (k5_attention_bf16_prescaled_rows_pass): pass A over the first half of
+    the keys leaves the fp32 state, pass B resumes it over the second half and normalises.  Head 0's keys of the first half point
+    away from every query (its rows underflow in pass A: head_flags[0] = 2, 'late'); in "first" its second-half keys are ordinary,
+    in "both" they point away too.  Either way every later fixed-offset launch skips the head, pass A's and B's states of that head
+    are ignored, and the ONLINE launch of the last pass recomputes it from scratch over all keys.  Head 1 (gain 3) stays fixed."""
+    Sq, Sk, H = 512, 2048, 2
+    g = torch.Generator().manual_seed(21)
+    u = torch.randn(64, generator=g); u = u / u.norm()
+    q = torch.empty(Sq, H, 64); k = torch.empty(Sk, H, 64)
+    q[:, 0] = 28.0 * u + 0.5 * torch.randn(Sq, 64, generator=g)
+    k[:, 0] = -5.0 * u + 0.1 * torch.randn(Sk, 64, generator=g)
+    if bad_half == "first":
+        k[Sk // 2:, 0] = 0.5 * torch.randn(Sk // 2, 64, generator=g)     # ordinary keys: the row's true maximum lives in pass B
+    def rmsn(x, gain):
+        return gain * x / x.pow(2).mean(-1, keepdim=True).sqrt()
+    q[:, 1] = rmsn(torch.randn(Sq, 64, generator=g), 3.0)
+    k[:, 1] = rmsn(torch.randn(Sk, 64, generator=g), 3.0) * O.SOFTMAX_C
+    q, k = bfr(q), bfr(k)
+    v = bfr(torch.randn(Sk, H, 64, generator=g))
+    flags, kmax = flags_rows(E, q, k, H)
+    assert flags.tolist() == [1, 1], flags
+    qd, kd, vt = q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
+    out = torch.full((Sq, H * 64), float("nan"), dtype=BF, device="cuda")
+    L = E.lib()
+    state = torch.zeros(L.k5_attention_state_size(H, Sq) // 4, device="cuda")
+    ws = torch.empty(L.k5_attention_balance_size(H, Sq), dtype=torch.uint8, device="cuda")
+    T = Sk // 64
+    def run_pass(t0, cnt, fl, late):
+        E.check(L.k5_attention_bf16_prescaled_rows_pass(qd.data_ptr(), kd.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk, qd.stride(0),
+                                                        kd.stride(0), vt.stride(0), out.stride(0), flags.data_ptr(), kmax.data_ptr(), t0, cnt,
+                                                        state.data_ptr(), fl, late, ws.data_ptr(), E.stream_ptr()), "rows_pass")
+        torch.cuda.synchronize()
+    run_pass(0, T // 2, 2, 1)
+    assert flags.tolist() == [2, 1], flags            # head 0 went late in pass A
+    run_pass(T // 2, T - T // 2, 1, 2)
+    assert flags.tolist() == [2, 1], flags
+    close(out, O.sdpa(q, k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what=f"late fallback across passes ({bad_half})")
