@@ -52,9 +52,15 @@ extern "C" int k5_abi_version(void) { return 1; }
 
 namespace {
 
-struct DevBuf {
+struct DevBuf {   // owning device buffer (move-only): freed with whatever holds it — the handle, a staged tensor, a block's weights
   void* p = nullptr;
   size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
+  ~DevBuf() { release(); }
   int ensure(size_t n) {
     if (n <= bytes) return K5_OK;
     if (p) (void)hipFree(p);
@@ -1087,9 +1093,7 @@ extern "C" int k5_dit_load_tensor(k5_dit* d, const char* key, const void* host_p
     t.dtype = dtype;
     K5CHK(t.dev.ensure(bytes));
     HIPCHK(hipMemcpy(t.dev.p, host_ptr, bytes, hipMemcpyDefault));
-    auto old = d->staged.find(key);
-    if (old != d->staged.end()) old->second.dev.release();
-    d->staged[key] = t;
+    d->staged[key] = std::move(t);
     return K5_OK;
   }
   t.data.resize(n);
