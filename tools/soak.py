@@ -43,5 +43,45 @@ for i in range(max(3, reps // 20)):
 nd = sum(0 if torch.equal(o, outs[0]) else 1 for o in outs[1:])
 print(f"2-step sample, 4 visual blocks, N = 47616: {nd} of {len(outs) - 1} repeats differ; finite = {bool(torch.isfinite(outs[0]).all())}")
 bad += nd
+# round 2: per-row softmax offsets (QK-norm gain 3), NABLA map + sparse attention, the VAE tile (conv_out kernel, GroupNorm statistics
+# from the conv epilogue, causal scores / softmax), the fp32-score GEMM
+dit.init_synthetic(dev, seed=0, qk_gain=3.0)
+outs = []
+for i in range(3):
+    lat = lat0.clone()
+    dit.sample(lat, [1.0, 0.9, 0.8], te, te, vpos, torch.arange(256), torch.arange(256), 1.0, scale_factor=(1.0, 2.0, 2.0), sparse_params=None)
+    outs.append(lat.clone())
+nd = sum(0 if torch.equal(o, outs[0]) else 1 for o in outs[1:])
+print(f"2-step sample, QK-norm gain 3 (per-row offsets): {nd} of {len(outs) - 1} repeats differ; variants {dit.attn_variant_counts()}")
+bad += nd
+dit.init_synthetic(dev, seed=0)
+sp = {"P": 0.15, "wT": 11, "wH": 3, "wW": 3, "to_fractal": True}
+outs = []
+for i in range(3):
+    lat = lat0.clone()
+    dit.sample(lat, [1.0, 0.9, 0.8], te, te, vpos, torch.arange(256), torch.arange(256), 1.0, scale_factor=(1.0, 2.0, 2.0), sparse_params=sp)
+    outs.append(lat.clone())
+nd = sum(0 if torch.equal(o, outs[0]) else 1 for o in outs[1:])
+print(f"2-step sample, NABLA P = 0.15: {nd} of {len(outs) - 1} repeats differ; finite = {bool(torch.isfinite(outs[0]).all())}")
+bad += nd
+del dit
+q = torch.randn(6144, 512, device="cuda").to(BF); k = torch.randn(6144, 512, device="cuda").to(BF)
+def scores():
+    out = torch.zeros(6144, 6144, device="cuda")
+    E.check(E.lib().k5_gemm_bf16_f32out(q.data_ptr(), k.data_ptr(), out.data_ptr(), 6144, 6144, 512, 512, 512, 6144, 0.044, 2048, E.stream_ptr()))
+    torch.cuda.synchronize()
+    return out
+first = scores()
+nd = sum(0 if torch.equal(scores(), first) else 1 for _ in range(reps // 5))
+print(f"fp32-score GEMM 6144^2 x 512, frame-causal: {nd} of {reps // 5} repeats differ")
+bad += nd
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from vae_bench import synthetic_vae
+vae = synthetic_vae("cuda:0")
+z = torch.randn(1, 16, 5, 64, 96, device="cuda")
+first = vae._decode_tile(z).clone()
+nd = sum(0 if torch.equal(vae._decode_tile(z), first) else 1 for _ in range(max(3, reps // 20)))
+print(f"VAE tile (5,64,96): {nd} of {max(3, reps // 20)} repeats differ; finite = {bool(torch.isfinite(first.float()).all())}")
+bad += nd
 print("FAILED" if bad else "all reproducible")
 sys.exit(1 if bad else 0)
