@@ -15,6 +15,8 @@
 // (t, h, w) coordinates are derived once per output tile.
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "k5_common.h"
 #include "k5_kernels.h"
 
@@ -325,7 +327,11 @@ int k5_launch_conv3d_w4(const void* X, const void* W, const float* bias, void* o
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  if ((long long)p.tiles_m * p.tiles_n < num_cu) return K5_ERR_UNSUPPORTED;   // less than one round: the small tiles fill the chip better
+  // from 5/8 of a round up (measured on the tile shapes of the tiling policy, tools/vae_shapes.py: (5,64,96) 103.7 -> 102.2 ms,
+  // (6,52,84) 92.6 -> 90.9, (5,64,64) 70.0 -> 68.5, (5,32,32) 21.3 -> 20.2; round 1 required a whole round); below that the
+  // 128 x 128 tiles fill the chip better.  K5_CONV_MIN_FILL8 = n: n/8 of a round (A/B switch for benchmarking)
+  static const int min_fill8 = getenv("K5_CONV_MIN_FILL8") ? atoi(getenv("K5_CONV_MIN_FILL8")) : 5;
+  if ((long long)p.tiles_m * p.tiles_n * 8 < (long long)num_cu * min_fill8) return K5_ERR_UNSUPPORTED;
   p.quad_stats = quad_stats;
   if (quad_stats) {
     if (Cout == 128) return resid ? launch_conv_w4<4, true, true>(p, num_cu, stream) : launch_conv_w4<4, false, true>(p, num_cu, stream);
