@@ -85,36 +85,43 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 
 // statistics from the producing conv's epilogue: quads [nblk][C / 4][2] = (sum, sum of squares) per 128 rows and 4 consecutive
 // channels; group g owns quads g cg / 4 .. (g + 1) cg / 4 - 1 of every block.  Same double-precision tree as above.
-__global__ __launch_bounds__(1024) void gn_finalize_quads_kernel(const float* __restrict__ quads, float* __restrict__ stats, int nblk,
-                                                                 int C, int cg, double count, float eps) {
-  __shared__ double rs[1024], rq[1024];
-  const int g = blockIdx.x, tid = threadIdx.x, qpg = cg >> 2, nq = C >> 2;
+constexpr int GNQ_SPLIT = 16;   // workgroups per group in the first level
+// level 1: workgroup (g, s) folds slice s of the group's nblk * cg/4 quad entries in double precision -> part[(g * GNQ_SPLIT + s) * 2]
+__global__ __launch_bounds__(256) void gn_fold_quads_kernel(const float* __restrict__ quads, double* __restrict__ part, int nblk, int C, int cg) {
+  __shared__ double rs[256], rq[256];
+  const int g = blockIdx.x / GNQ_SPLIT, sl = blockIdx.x % GNQ_SPLIT, tid = threadIdx.x, qpg = cg >> 2, nq = C >> 2;
   const int n = nblk * qpg;
+  const int e_lo = (int)((long long)n * sl / GNQ_SPLIT), e_hi = (int)((long long)n * (sl + 1) / GNQ_SPLIT);
   double s = 0.0, q = 0.0;
-  // only G workgroups exist, so each keeps many loads in flight: 1024 threads x 4 independent 8-B loads (up to 52 224 blocks at C = 128)
-  for (int e0 = tid; e0 < n; e0 += 4096) {
+  for (int e0 = e_lo + tid; e0 < e_hi; e0 += 1024) {   // 4 independent 8-B loads in flight per thread
     f32x2 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = e0 + 1024 * u;
-      v[u] = e < n ? *reinterpret_cast<const f32x2*>(quads + ((size_t)(e / qpg) * nq + g * qpg + (e % qpg)) * 2) : f32x2{0.f, 0.f};
+      const int e = e0 + 256 * u;
+      v[u] = e < e_hi ? *reinterpret_cast<const f32x2*>(quads + ((size_t)(e / qpg) * nq + g * qpg + (e % qpg)) * 2) : f32x2{0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { s += v[u][0]; q += v[u][1]; }
   }
   rs[tid] = s; rq[tid] = q;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
+  for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
     __syncthreads();
   }
-  if (tid == 0) {
-    const double mean = rs[0] / count;
-    double var = rq[0] / count - mean * mean;
-    if (var < 0) var = 0;
-    stats[2 * g] = (float)mean;
-    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
-  }
+  if (tid == 0) { part[(size_t)blockIdx.x * 2] = rs[0]; part[(size_t)blockIdx.x * 2 + 1] = rq[0]; }
+}
+// level 2: one thread per group adds its GNQ_SPLIT partial pairs in order -> (mean, rstd)
+__global__ void gn_finalize_quads_kernel(const double* __restrict__ part, float* __restrict__ stats, int G, double count, float eps) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < GNQ_SPLIT; ++i) { s += part[((size_t)g * GNQ_SPLIT + i) * 2]; q += part[((size_t)g * GNQ_SPLIT + i) * 2 + 1]; }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0) var = 0;
+  stats[2 * g] = (float)mean;
+  stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // thread -> fixed 16-B chunk column (tid % nch; nch a power of two <= 256), rows strided: the eight channels' affine
@@ -266,7 +273,11 @@ inline int done() { return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 
 }  // namespace
 
-size_t k5_groupnorm_workspace_bytes(int M, int G) { return ((size_t)((M + GN_ROWS - 1) / GN_ROWS) * G * 2 + 2 * G) * sizeof(float); }
+size_t k5_groupnorm_workspace_bytes(int M, int G) {
+  const size_t own = ((size_t)((M + GN_ROWS - 1) / GN_ROWS) * G * 2 + 2 * G) * sizeof(float);   // partials + (mean, rstd) of the two-pass form
+  const size_t quads = 2 * 64 * sizeof(float) + (size_t)64 * GNQ_SPLIT * 2 * sizeof(double);      // (mean, rstd) + first-level partials of the fused form
+  return own > quads ? own : quads;
+}
 
 namespace {
 bool gn_shape_ok(int M, int C, int G, int ldx, int ldo) {
@@ -308,7 +319,10 @@ int k5_launch_groupnorm_bf16_quads(const void* x, const float* gamma, const floa
   if (M <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || !quad_stats || !stats_ws || nblk <= 0) return K5_ERR_ARG;
   if (!gn_shape_ok(M, C, G, ldx, ldo)) return K5_ERR_UNSUPPORTED;
   const int cg = C / G;
-  hipLaunchKernelGGL(gn_finalize_quads_kernel, dim3(G), dim3(1024), 0, s, quad_stats, stats_ws, nblk, C, cg, (double)M * cg, eps);
+  // stats_ws: [2 G floats (mean, rstd)] [G * GNQ_SPLIT * 2 doubles]  (k5_groupnorm_workspace_bytes reserves both)
+  double* part = reinterpret_cast<double*>(stats_ws + 2 * 64);
+  hipLaunchKernelGGL(gn_fold_quads_kernel, dim3(G * GNQ_SPLIT), dim3(256), 0, s, quad_stats, part, nblk, C, cg);
+  hipLaunchKernelGGL(gn_finalize_quads_kernel, dim3(1), dim3(64), 0, s, part, stats_ws, G, (double)M * cg, eps);
   return gn_apply(x, stats_ws, gamma, beta, out, M, C, G, silu, ldx, ldo, s);
 }
 
