@@ -84,7 +84,7 @@ K5_DEV float wave_max_dpp(float v) {
 // in registers.  Round 1 gave every row its own wave and re-read the head's whole key-mean matrix (187 KB at nb = 1464) from
 // L2 per row — 7.7 GB per layer, the kernel's time; here a key mean is loaded once per R rows, the dot products run on
 // v_dot2c_f32_bf16 (both operands ARE bf16), and the bisection works on registers with DPP reductions, the R rows in
-// lockstep (R independent reduction chains in flight).  1.02 -> see DESIGN §4.3 ms per layer at nb = 1464.
+// lockstep (R independent reduction chains in flight).  1.02 -> 0.69 ms per layer at nb = 1464 (profiles/r02_nabla_kernel_stats.md).
 template <int NV, int R>
 __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
   __shared__ __attribute__((aligned(16))) bf16_t sq[4 * R * 64];   // the block's 4 R query-block means
