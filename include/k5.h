@@ -54,6 +54,13 @@ int k5_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, int N, in
 /* P_bf16[i][j] = softmax_j(scores[i][j]) over the frame-causal columns j < (i / hw + 1) * hw, 0 elsewhere (j < ldp) — the masked
  * softmax of the same mid-block attention (mask: prepare_causal_attention_mask, vae.py:110-122).  scores fp32 [S][lds]. */
 int k5_causal_softmax_bf16(const float* scores, void* P, int S, int hw, int lds, int ldp, void* stream);
+/* The whole mid-block attention in one kernel for C = 512 (one head; the scores are never materialised):
+ * O[i] = softmax_j<lim(i) (scale * q_i . k_j) V[j], lim(i) = (i / hw + 1) * hw — diffusers `Attention` + the frame-causal mask,
+ * kandinsky/models/vae.py:110-122,341-362.  q, k: [S][ldqk] bf16 (512 columns each; k may be q + 512 of one [S][1024] buffer),
+ * vt: V transposed [512][ldvt] bf16 with ldvt >= ceil(S / 32) * 32 (columns S .. ldvt must hold FINITE values — they are multiplied
+ * by a probability of exactly 0; the engine zero-fills them), o: [S][ldo]. */
+int k5_vae_attention512_bf16(const void* q, const void* k, const void* vt, void* o, int S, int hw, int ldqk, int ldvt, int ldo,
+                             float scale, void* stream);
 
 /* O[q][h*64+d] = softmax(Q K^T / 8) V per head (head_dim 64, non-causal, fp32 softmax).
  * Replaces FA(q,k,v): nn.py:201 (text self-attn), :254 (visual self-attn), :336 (cross-attn).

@@ -25,6 +25,11 @@ int k5_causal_softmax_bf16(const float* scores, void* P, int S, int hw, int lds,
   return ret(k5_launch_causal_softmax(scores, P, S, hw, lds, ldp, (hipStream_t)stream), "k5_causal_softmax_bf16");
 }
 
+int k5_vae_attention512_bf16(const void* q, const void* k, const void* vt, void* o, int S, int hw, int ldqk, int ldvt, int ldo,
+                             float scale, void* stream) {
+  return ret(k5_launch_vae_attention512(q, k, vt, o, S, hw, ldqk, ldvt, ldo, scale, (hipStream_t)stream), "k5_vae_attention512_bf16");
+}
+
 int k5_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc, float alpha,
                         int causal_hw, void* stream) {
   return ret(k5_launch_gemm_bf16_f32out(A, W, C, M, N, K, lda, ldw, ldc, alpha, causal_hw, (hipStream_t)stream), "k5_gemm_bf16_f32out");

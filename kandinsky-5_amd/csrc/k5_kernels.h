@@ -134,6 +134,9 @@ int k5_launch_groupnorm_bf16(const void* x, const float* gamma, const float* bet
 int k5_launch_groupnorm_bf16_quads(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
                                    int silu, int ldx, int ldo, const float* quad_stats, int nblk, float* stats_ws, hipStream_t s);
 int k5_launch_causal_softmax(const float* scores, void* P, int S, int hw, int lds, int ldp, hipStream_t s);
+// the mid block's attention in one kernel for C = 512 (vae_attn.hip): q, k [S][ldqk], vt [512][ldvt >= ceil(S/32)*32], o [S][ldo]
+int k5_launch_vae_attention512(const void* q, const void* k, const void* vt, void* o, int S, int hw, int ldqk, int ldvt, int ldo,
+                               float scale, hipStream_t stream);
 int k5_launch_nchw_to_mc(const float* z, void* out, int C, int64_t M, int Cpad, hipStream_t s);
 int k5_launch_mc_to_nchw(const void* x, void* out, int C, int64_t M, int ldx, hipStream_t s);
 int k5_launch_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, hipStream_t s);

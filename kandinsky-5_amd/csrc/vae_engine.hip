@@ -259,13 +259,19 @@ int resnet(k5_vae* v, hipStream_t s, const Resnet& r, const void* x, void* out, 
 }
 
 int mid_attention(k5_vae* v, hipStream_t s, const MidAttn& a, void* h, int T, int H, int W) {
-  const int C = a.gn.c, S = T * H * W, Sp = (int)rup(S, 8);
-  K5CHK(v->qk.ensure((size_t)S * 2 * C * 2)); K5CHK(v->vt.ensure((size_t)C * Sp * 2));
-  K5CHK(v->scores.ensure((size_t)S * Sp * 4)); K5CHK(v->P.ensure((size_t)S * Sp * 2)); K5CHK(v->o.ensure((size_t)S * C * 2));
+  static const bool flash_ok = !(getenv("K5_VAE_FLASH") && atoi(getenv("K5_VAE_FLASH")) == 0);   // A/B switch for benchmarking
+  const bool flash = flash_ok && a.gn.c == 512;   // one kernel, no score matrix (vae_attn.hip); other widths: GEMM - softmax - GEMM
+  const int C = a.gn.c, S = T * H * W, Sp = (int)rup(S, flash ? 32 : 8);
+  K5CHK(v->qk.ensure((size_t)S * 2 * C * 2)); K5CHK(v->vt.ensure((size_t)C * Sp * 2)); K5CHK(v->o.ensure((size_t)S * C * 2));
+  if (!flash) { K5CHK(v->scores.ensure((size_t)S * Sp * 4)); K5CHK(v->P.ensure((size_t)S * Sp * 2)); }
   K5CHK(gn(v, s, a.gn, h, v->bt1.p, S, false));
   K5CHK(k5_launch_gemm_bf16(v->bt1.p, a.wqk.p, a.bqk.as<float>(), v->qk.p, S, 2 * C, C, C, C, 2 * C, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   HIPCHK(hipMemsetAsync(v->vt.p, 0, (size_t)C * Sp * 2, s));
   K5CHK(k5_launch_gemm_bf16(a.wv.p, v->bt1.p, a.bv.as<float>(), v->vt.p, C, S, C, C, C, Sp, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+  if (flash) {
+    K5CHK(k5_launch_vae_attention512(v->qk.p, v->qk.as<bf16_t>() + C, v->vt.p, v->o.p, S, H * W, 2 * C, Sp, C, 1.0f / sqrtf((float)C), s));
+    return k5_launch_gemm_bf16(v->o.p, a.wo.p, a.bo.as<float>(), h, S, C, C, C, C, C, K5_EPI_GATE, h, C, a.ones.as<float>(), s);
+  }
   K5CHK(k5_launch_gemm_bf16_f32out(v->qk.p, v->qk.as<bf16_t>() + C, v->scores.as<float>(), S, S, C, 2 * C, 2 * C, Sp,
                                     1.0f / sqrtf((float)C), H * W, s));   // frame-causal: key frames after the query's are never read
   K5CHK(k5_launch_causal_softmax(v->scores.as<float>(), v->P.p, S, H * W, Sp, Sp, s));

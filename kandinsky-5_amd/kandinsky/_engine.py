@@ -62,6 +62,7 @@ SYMBOLS = {
     "k5_gemm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "k5_gemm_bf16_f32out": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "k5_causal_softmax_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "k5_vae_attention512_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "k5_attention_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k5_attention_state_size": (_I64, [_I, _I]),
     "k5_attention_bf16_range": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P, _I, _P]),

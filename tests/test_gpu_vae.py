@@ -2,6 +2,7 @@
 oracle/vae_oracle.py in bf16-autocast mode.  Tolerance: relative L2 <= 2e-2 on decoded tiles (bf16 activations through
 ~30 conv / GroupNorm layers; the bf16 oracle itself sits ~1e-2 from the fp32 oracle), blends bit-exact."""
 import json
+import math
 import os
 
 import pytest
@@ -178,6 +179,36 @@ def test_causal_softmax_kernel(S, hw):
     assert (P.float()[~mask] == 0).all()
     assert (P.float() - ref).abs().max().item() <= 2 ** -8 * ref.max().item() + 1e-6          # one bf16 rounding of a probability
     assert (P.float().sum(-1) - 1).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("S,hw", [(4608, 1536), (3000, 700), (2048, 2048), (1000, 37), (6144, 6144 // 5 + 1)])
+def test_mid_block_attention_kernel_c512(S, hw):
+    """k5_vae_attention512_bf16 (one head, d = 512, frame-causal, scores never materialised) against fp32 softmax(scale q k^T + mask) v
+    of the same bf16 q, k, v: frame boundaries inside 32-key tiles and 64-query blocks (hw = 700, 37), S not a multiple of 64 / 32,
+    a single frame (no masking at all), activation-sized logits (|s| up to ~20 after the 1/sqrt(512) scale)."""
+    from kandinsky import _engine as E
+    g = torch.Generator(device="cuda").manual_seed(S + hw)
+    C = 512
+    qk = (torch.randn(S, 2 * C, device="cuda", generator=g) * 1.5).bfloat16()
+    v = torch.randn(S, C, device="cuda", generator=g).bfloat16()
+    ldvt = (S + 31) // 32 * 32
+    vt = torch.full((C, ldvt), 3.0e30, dtype=torch.bfloat16, device="cuda")            # pad columns: finite garbage, weight exactly 0
+    vt[:, :S] = v.t()
+    out = torch.full((S, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    scale = 1.0 / math.sqrt(C)
+    E.check(E.lib().k5_vae_attention512_bf16(qk.data_ptr(), qk.data_ptr() + 2 * C, vt.data_ptr(), out.data_ptr(), S, hw, 2 * C, ldvt, C,
+                                             scale, E.stream_ptr()), "k5_vae_attention512_bf16")
+    torch.cuda.synchronize()
+    q, k = qk[:, :C].float(), qk[:, C:].float()
+    rows = torch.arange(S, device="cuda")[:, None]
+    cols = torch.arange(S, device="cuda")[None, :]
+    sc = (q @ k.t()) * scale
+    sc = sc.masked_fill(cols >= (rows // hw + 1) * hw, float("-inf"))
+    ref = torch.softmax(sc, dim=-1) @ v.float()
+    assert torch.isfinite(out.float()).all()
+    err = (out.float() - ref).abs()
+    tol = 2.0 ** -6 * ref.abs() + 6e-3         # bf16 probabilities and outputs: two roundings on top of the fp32 reference
+    assert not (err > tol).any(), (float(err.max()), int((err > tol).sum()))
 
 
 def test_decode_tile_vs_oracle(vae):
