@@ -146,6 +146,10 @@ __global__ __launch_bounds__(256) void vae_attn512_kernel(VaP p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) VA_MF(st[i & 1][(i >> 1) & 1], fr[bt & 1][i], qf[4 * bt + (i >> 1)]);
     }
+    // the staging registers of the last batch are dead for the compiler from here on: nothing it schedules next may overwrite them
+    // while the last MFMAs still read their operands
+    asm volatile("s_nop 7" : "+v"(fr[1][0]), "+v"(fr[1][1]), "+v"(fr[1][2]), "+v"(fr[1][3]), "+v"(fr[1][4]), "+v"(fr[1][5]), "+v"(fr[1][6]),
+                 "+v"(fr[1][7]) :: "memory");   // (operands: keeps them allocated up to here)
 #endif
 #ifndef VA_NO_ASM_PV
     // first V^T batch (d tiles 0..7) in flight during the softmax
@@ -210,6 +214,8 @@ __global__ __launch_bounds__(256) void vae_attn512_kernel(VaP p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) VA_MFA(ot[8 * bt + i], fr[bt & 1][i], pf);
     }
+    asm volatile("s_nop 7" : "+v"(fr[1][0]), "+v"(fr[1][1]), "+v"(fr[1][2]), "+v"(fr[1][3]), "+v"(fr[1][4]), "+v"(fr[1][5]), "+v"(fr[1][6]),
+                 "+v"(fr[1][7]), "+v"(pf) :: "memory");   // as above (the probability fragment and the staging registers die here)
 #endif
     __syncthreads();   // vmcnt(0) + barrier: tile t + 1 has landed, tile t's buffer is free
   };
