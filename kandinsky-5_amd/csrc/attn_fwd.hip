@@ -61,6 +61,9 @@ struct AttnP {
   // later fixed-offset launch skips the head, the online launches of non-final passes skip it too), 2 = the last pass (the online
   // launch recomputes a late head FROM SCRATCH over all late_total key tiles, ignoring the state the earlier passes left)
   int late_pass, late_total;
+  // cross-attention (keys not pre-scaled): RMSNorm of the query rows fused into the Q-fragment load — q = bf16(v * rsqrt(mean v^2 + eps) * w),
+  // nn.py:35-40 without RoPE — instead of a pass over the (N, 1792) projection; 64 weights, null = Q is used as it is
+  const float* q_norm_w;
   // sequence-parallel layout of V^T: keys are split in chunks of vt_chunk_keys (multiple of 64) and chunk c
   // starts at Vt + c * vt_chunk_stride ([rank][H*64][ldvt] after an in-place all-gather); 0 = one chunk
   int vt_chunk_keys; long long vt_chunk_stride;
@@ -136,6 +139,38 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     const bf16_t* qp = p.Q + (size_t)min(q0 + 16 * qt + l15, p.q_len - 1) * p.ldq + h * 64 + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+  }
+  if (!PRE && p.q_norm_w) {   // fused RMSNorm(q): the query's 64 dimensions sit in its four lanes (l15 + 16 g), 16 each
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float v[16], ss = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 w4 = __builtin_bit_cast(u32x4, qf[qt][ks]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[8 * ks + 2 * j] = __uint_as_float(w4[j] << 16);
+          v[8 * ks + 2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u);
+          ss += v[8 * ks + 2 * j] * v[8 * ks + 2 * j] + v[8 * ks + 2 * j + 1] * v[8 * ks + 2 * j + 1];
+        }
+      }
+      {
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+        ss = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+        ss = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+      }
+      const float rs = rsqrtf(ss * (1.0f / 64.0f) + 1.1920928955078125e-07f);   // eps = finfo(fp32).eps, as rmsnorm_rope_kernel
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(p.q_norm_w + 32 * ks + 8 * g), wb = *reinterpret_cast<const f32x4*>(p.q_norm_w + 32 * ks + 8 * g + 4);
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = __fmul_rn(__fmul_rn(v[8 * ks + j], rs), j < 4 ? wa[j] : wb[j - 4]);
+        const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+        qf[qt][ks] = __builtin_bit_cast(bf16x8, pk);
+      }
+    }
   }
   // loader mapping: 512 threads, one 16-B chunk of K and one of V^T each per tile
   const int lrow = tid >> 3, lc = tid & 7;
@@ -753,7 +788,8 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* ws, bool k_prescaled,
-                                   const int* head_flags, int variant, const K5TileSegments* seg, const float* kmax, int late_pass) {
+                                   const int* head_flags, int variant, const K5TileSegments* seg, const float* kmax, int late_pass,
+                                   const float* q_norm_w) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -767,6 +803,9 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.kmax = kmax;
   if (late_pass < 0 || late_pass > 2 || (late_pass && !kmax)) return K5_ERR_ARG;
   p.late_pass = late_pass; p.late_total = (kv_len + KB - 1) / KB;
+  p.q_norm_w = q_norm_w;
+  if (q_norm_w && (k_prescaled || !(score_bound > 0.f && score_bound * p.c <= K5_ATTN_EXP_LIMIT)))
+    return K5_ERR_UNSUPPORTED;   // the fused query norm lives in the fixed-offset 16x16x32 kernel of the unscaled-key path only
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   const dim3 block(512);
   const bool bounded = score_bound > 0.f && score_bound * p.c <= K5_ATTN_EXP_LIMIT;
@@ -856,7 +895,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   p.c = 0.125f * 1.44269504088896340736f;
   p.head_flags = nullptr; p.my_flag = 0;
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;
-  p.kmax = kmax; p.late_pass = 0; p.late_total = 0;
+  p.kmax = kmax; p.late_pass = 0; p.late_total = 0; p.q_norm_w = nullptr;
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride;
   p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;

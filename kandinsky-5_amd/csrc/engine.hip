@@ -733,14 +733,21 @@ int run_cross_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h,
     K5CHK(k5_launch_gemm_bf16(text, a.wk.p, a.bk.as<float>(), ck, L, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
     K5CHK(k5_launch_gemm_bf16(a.wv.p, text, a.bv.as<float>(), cvt, D, L, D, D, D, ldvt, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
   }
+  // RMSNorm of the queries (no RoPE in cross-attention, nn.py:330-334) is fused into the attention kernel's Q-fragment load when the
+  // weight-derived bound admits the fixed-offset kernel: one pass over the (rows, D) projection less per block
+  const bool fuse_qnorm = a.score_bound > 0.f && a.score_bound * K5_SOFTMAX_C <= 90.f;
   {
     Scope sc(d, s, "elementwise");
-    K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), nullptr, nullptr, rows, H, D, nullptr, s));
+    if (!fuse_qnorm) K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), nullptr, nullptr, rows, H, D, nullptr, s));
     K5CHK(k5_launch_rmsnorm_rope(ck, a.norm.as<float>() + 64, nullptr, nullptr, L, H, D, nullptr, s));
   }
   {
     Scope sc(d, s, "attn_cross");
-    K5CHK(k5_launch_attention_bf16_bounded(q, ck, cvt, o, H, rows, L, D, D, ldvt, D, a.score_bound, s));
+    if (fuse_qnorm)
+      K5CHK(k5_launch_attention_bf16_range(q, ck, cvt, o, H, rows, L, D, D, ldvt, D, a.score_bound, 0, 0, 0, -1, 0x7fffffff, 0, nullptr, 0, s,
+                                           nullptr, false, nullptr, K5_ATTN_AUTO, nullptr, nullptr, 0, a.norm.as<float>()));
+    else
+      K5CHK(k5_launch_attention_bf16_bounded(q, ck, cvt, o, H, rows, L, D, D, ldvt, D, a.score_bound, s));
   }
   {
     Scope sc(d, s, "gemm");

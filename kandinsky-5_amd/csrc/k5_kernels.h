@@ -33,7 +33,9 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* balance_ws = nullptr, bool k_prescaled = false,
                                    const int* head_flags = nullptr, int variant = 0, const K5TileSegments* segments = nullptr,
-                                   const float* row_offset_kmax = nullptr, int late_pass = 0);   // late_pass: AttnP::late_pass (multi-pass + per-row offsets)
+                                   const float* row_offset_kmax = nullptr, int late_pass = 0,   // late_pass: AttnP::late_pass (multi-pass + per-row offsets)
+                                   const float* q_norm_w = nullptr);   // fused RMSNorm of the query rows (cross-attention); K5_ERR_UNSUPPORTED unless
+                                                                       // the keys are unscaled and score_bound selects the fixed-offset kernel
 size_t k5_attention_balance_bytes(int H, int q_len);
 // softmax form of the pre-scaled-key launches: AUTO = fixed offset where the bound (score_bound, or the per-head device
 // flags) allows it and the lazy online max elsewhere; ONLINE = the online max everywhere
