@@ -237,3 +237,23 @@ def test_hot_kernels_keep_their_register_budget():
         assert v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
     for k, v in kernels("attn_fwd32_kernel").items():
         assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0, (k, v)
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r02_bench.json is the JSON line `python bench.py` printed on an MI355X at the end of the round: the keys the driver
+    reads (task statement, bench.py contract) and the two blocks this tier adds must all be there and consistent with each other."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "steps/s" and d["higher_is_better"] is True and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "INVALID_AS_BENCH" not in d
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6                       # value = steps / time
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["flop_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] > 4 * 47616 * 28 * 64 * 2                 # HBM-side bytes >= the algorithmic ones
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
