@@ -382,14 +382,6 @@ int upload_f32(DevBuf& b, const float* src, size_t n) {
   HIPCHK(hipMemcpy(b.p, src, n * 4, hipMemcpyHostToDevice));
   return K5_OK;
 }
-int upload_bf16(DevBuf& b, const float* src, size_t rows, size_t cols, size_t cols_pad) {
-  std::vector<uint16_t> tmp(rows * cols_pad, 0);
-  for (size_t r = 0; r < rows; ++r)
-    for (size_t c = 0; c < cols; ++c) tmp[r * cols_pad + c] = f32_to_bf16_rne(src[r * cols + c]);
-  K5CHK(b.ensure(tmp.size() * 2));
-  HIPCHK(hipMemcpy(b.p, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
-  return K5_OK;
-}
 int upload_bias_bf16r(DevBuf& b, const float* src, size_t n) {  // fp32 array of bf16-rounded values
   std::vector<float> tmp(n);
   for (size_t i = 0; i < n; ++i) tmp[i] = bf16_round_host(src[i]);

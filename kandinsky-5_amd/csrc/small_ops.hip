@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
   const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int c = (int)(g0 & 7);
   const int head = (int)((g0 >> 3) % H);
-  const int row_step = (int)(stride / (H * 8));
   const float* w = weight + (head / heads_per_weight) * 64 + 8 * c;
   float wv[8];
 #pragma unroll
