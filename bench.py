@@ -124,6 +124,8 @@ def main():
                     "each slice as it lands (engine option sp_slices; 1 = one in-place all-gather per block)")
     ap.add_argument("--emulate-shard", type=int, default=0, metavar="P",
                     help="debug only (INVALID as a bench): per-rank compute of a P-GPU run on one GPU, collectives move nothing")
+    ap.add_argument("--engine-option", action="append", default=[], metavar="NAME=INT",
+                    help="A/B switch: k5_dit_set_option(NAME, INT) before the run (recorded in config.engine_options)")
     ap.add_argument("--blocks", type=int, default=32, help="debug only: fewer visual blocks => INVALID as a bench")
     ap.add_argument("--attn-online", action="store_true",
                     help="run every self-attention head on the online-max softmax kernel (what heads whose |q||k| bound exceeds "
@@ -172,6 +174,8 @@ def main():
         dit.set_option("emulate_world", args.emulate_shard)
     if args.sp_slices > 1:
         dit.set_option("sp_slices", args.sp_slices)
+    for kv in args.engine_option:
+        dit.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if args.attn_online:
         dit.set_option("attn_mode", 1)
 
@@ -300,7 +304,8 @@ def main():
                                        f"sequence-parallel x{world} (token shards, K/V exchange in {args.sp_slices} slices)"),
                        "visual_blocks": args.blocks, "magcache": bool(args.magcache),
                        **({"emulated_shard": args.emulate_shard} if args.emulate_shard > 1 else {}),
-                       **({"sp_slices": args.sp_slices} if args.sp_slices > 1 or args.emulate_shard > 1 else {})},
+                       **({"sp_slices": args.sp_slices} if args.sp_slices > 1 or args.emulate_shard > 1 else {}),
+                       **({"engine_options": args.engine_option} if args.engine_option else {})},
             "nfe_per_s": fwd_per_step * args.steps / dt,
             "step_tflop": step_flop / 1e12,
             "model_tflops_per_gpu": step_flop * args.steps / dt / 1e12 / world,

@@ -110,6 +110,16 @@ int k5_attention_bf16_prescaled_rows(const void* Q, const void* Kc, const void* 
 int k5_attention_bf16_prescaled_rows_pass(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                           int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, int tile_off0, int tile_cnt,
                                           float* state, int flags, int late_pass, void* workspace, void* stream);
+/* The same pass with the reference's norm_qk + apply_rotary of the QUERIES (nn.py:193-197, 239-243) done inside the kernel's Q load:
+ * Q holds the raw query projection, q_norm_w the 64 RMSNorm weights, q_cos / q_sin [q_len][32] fp32 the rotary table
+ * (k5_rope_table).  There is no max|q|^2 statistic then: call k5_attention_flags_rows with a zero query statistic (every head
+ * starts on the fixed form) and the fixed-offset workgroups decide per head — a row whose bound |q| max|k'| exceeds 180 sets
+ * head_flags[h] = 0 and the online launch of the same call owns the head.  head_flags and kmax both null: online max everywhere.
+ * tile_cnt -1 = all key tiles from tile_off0 (single pass: state null, flags 0, late_pass 0). */
+int k5_attention_bf16_prescaled_qnorm_pass(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                           int ldk, int ldvt, int ldo, const float* q_norm_w, const float* q_cos, const float* q_sin,
+                                           int* head_flags, const float* kmax, int tile_off0, int tile_cnt, float* state, int flags,
+                                           int late_pass, void* workspace, void* stream);
 int k5_attention_bf16_prescaled_auto(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len,
                                      int ldq, int ldk, int ldvt, int ldo, const int* head_flags, int variant, void* workspace,
                                      void* stream);

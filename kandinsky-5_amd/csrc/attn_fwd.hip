@@ -64,6 +64,13 @@ struct AttnP {
   // cross-attention (keys not pre-scaled): RMSNorm of the query rows fused into the Q-fragment load — q = bf16(v * rsqrt(mean v^2 + eps) * w),
   // nn.py:35-40 without RoPE — instead of a pass over the (N, 1792) projection; 64 weights, null = Q is used as it is
   const float* q_norm_w;
+  // visual self-attention (pre-scaled keys): with q_cos / q_sin ([row][32] fp32) the same load also applies the rotary embedding
+  // (apply_rotary, nn.py:193-197) — the whole norm_qk + RoPE of the QUERIES happens here, once per workgroup, and the pass over the
+  // (N, 1792) query projection is gone.  There is then no max|q_h|^2 statistic before the launch, so the head-level choice
+  // "bound <= 180 -> fixed-offset form" is taken by the fixed-offset workgroups themselves: a workgroup with a row whose bound
+  // |q| max|k'| exceeds 180 sets its head's flag to 0 (the online-max launch that follows owns the head) and exits before any work.
+  const float* q_cos; const float* q_sin;
+  unsigned long long* variant_counters;   // [fixed, online] heads (diagnostics): moved when a head flips
   // sequence-parallel layout of V^T: keys are split in chunks of vt_chunk_keys (multiple of 64) and chunk c
   // starts at Vt + c * vt_chunk_stride ([rank][H*64][ldvt] after an in-place all-gather); 0 = one chunk
   int vt_chunk_keys; long long vt_chunk_stride;
@@ -139,6 +146,47 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     const bf16_t* qp = p.Q + (size_t)min(q0 + 16 * qt + l15, p.q_len - 1) * p.ldq + h * 64 + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+  }
+  if (PRE && p.q_norm_w) {   // fused norm_qk + apply_rotary of the queries, same arithmetic and rounding points as rmsnorm_rope_kernel
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float v[16], ss = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 w4 = __builtin_bit_cast(u32x4, qf[qt][ks]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[8 * ks + 2 * j] = __uint_as_float(w4[j] << 16);
+          v[8 * ks + 2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u);
+          ss += v[8 * ks + 2 * j] * v[8 * ks + 2 * j] + v[8 * ks + 2 * j + 1] * v[8 * ks + 2 * j + 1];
+        }
+      }
+      {
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+        ss = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+        ss = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+      }
+      const float rs = rsqrtf(ss * (1.0f / 64.0f) + 1.1920928955078125e-07f);
+      const int row = min(q0 + 16 * qt + l15, p.q_len - 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(p.q_norm_w + 32 * ks + 8 * g), wb = *reinterpret_cast<const f32x4*>(p.q_norm_w + 32 * ks + 8 * g + 4);
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.q_cos + (size_t)row * 32 + 16 * ks + 4 * g);
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(p.q_sin + (size_t)row * 32 + 16 * ks + 4 * g);
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = bf_round(__fmul_rn(__fmul_rn(v[8 * ks + j], rs), j < 4 ? wa[j] : wb[j - 4]));   // .type_as(q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x0 = y[2 * j], x1 = y[2 * j + 1];
+          y[2 * j] = __fadd_rn(__fmul_rn(cs[j], x0), __fmul_rn(-sn[j], x1));
+          y[2 * j + 1] = __fadd_rn(__fmul_rn(sn[j], x0), __fmul_rn(cs[j], x1));
+        }
+        const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+        qf[qt][ks] = __builtin_bit_cast(bf16x8, pk);
+      }
+    }
   }
   if (!PRE && p.q_norm_w) {   // fused RMSNorm(q): the query's 64 dimensions sit in its four lanes (l15 + 16 g), 16 each
 #pragma unroll
@@ -252,6 +300,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   // !BOUNDED: nm[qt] = MINUS the softmax offset of the lane's query (exp2 domain), four copies = the S^T accumulators' start
   f32x4 nm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   bool fresh = true;             // !BOUNDED, wave-uniform: no tile processed yet -> the first one SETS the offset
+  bool over_limit = false;
   if (BOUNDED && PRE && p.kmax) {   // per-row constant offsets from |q_row| * max|k'| (see AttnP::kmax); 0 when the bound is <= 90
     const float km = p.kmax[h];
 #pragma unroll
@@ -272,8 +321,19 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
         ss = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
       }
-      const float off = fmaxf(sqrtf(ss) * km - K5_ATTN_EXP_LIMIT, 0.f);
+      const float bnd = sqrtf(ss) * km;
+      const float off = fmaxf(bnd - K5_ATTN_EXP_LIMIT, 0.f);
       nm[qt] = f32x4{-off, -off, -off, -off};
+      over_limit |= (q0 + 16 * qt + l15 < p.q_len) && !(bnd <= K5_ATTN_ROWOFF_LIMIT);   // NaN counts as over
+    }
+  }
+  if (BOUNDED && PRE && p.kmax && p.q_norm_w) {   // no max|q|^2 statistic preceded this launch (fused query norm): the head-level choice is taken here
+    if (__syncthreads_or(over_limit ? 1 : 0)) {
+      if (tid == 0 && atomicCAS(const_cast<int*>(p.head_flags) + h, 1, 0) == 1 && p.variant_counters) {
+        atomicAdd(p.variant_counters + 1, 1ull);
+        atomicAdd(p.variant_counters, ~0ull);   // - 1
+      }
+      return;
     }
   }
   f32x4 lt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -789,7 +849,7 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* ws, bool k_prescaled,
                                    const int* head_flags, int variant, const K5TileSegments* seg, const float* kmax, int late_pass,
-                                   const float* q_norm_w) {
+                                   const K5QueryNorm* qn) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -803,9 +863,15 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.kmax = kmax;
   if (late_pass < 0 || late_pass > 2 || (late_pass && !kmax)) return K5_ERR_ARG;
   p.late_pass = late_pass; p.late_total = (kv_len + KB - 1) / KB;
-  p.q_norm_w = q_norm_w;
-  if (q_norm_w && (k_prescaled || !(score_bound > 0.f && score_bound * p.c <= K5_ATTN_EXP_LIMIT)))
-    return K5_ERR_UNSUPPORTED;   // the fused query norm lives in the fixed-offset 16x16x32 kernel of the unscaled-key path only
+  p.q_norm_w = qn ? qn->w : nullptr; p.q_cos = qn ? qn->cos : nullptr; p.q_sin = qn ? qn->sin : nullptr;
+  p.variant_counters = qn ? qn->counters : nullptr;
+  if (p.q_norm_w) {
+    if (k_prescaled) {   // visual self-attention: norm + RoPE; both forms carry it; with per-row offsets the fixed form decides per head
+      if (!p.q_cos || !p.q_sin || (kmax && !head_flags)) return K5_ERR_ARG;
+    } else if (!(score_bound > 0.f && score_bound * p.c <= K5_ATTN_EXP_LIMIT)) {
+      return K5_ERR_UNSUPPORTED;   // unscaled keys (cross-attention): only the fixed-offset 16x16x32 kernel carries the fused norm
+    }
+  }
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   const dim3 block(512);
   const bool bounded = score_bound > 0.f && score_bound * p.c <= K5_ATTN_EXP_LIMIT;
@@ -895,7 +961,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   p.c = 0.125f * 1.44269504088896340736f;
   p.head_flags = nullptr; p.my_flag = 0;
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;
-  p.kmax = kmax; p.late_pass = 0; p.late_total = 0; p.q_norm_w = nullptr;
+  p.kmax = kmax; p.late_pass = 0; p.late_total = 0; p.q_norm_w = nullptr; p.q_cos = p.q_sin = nullptr; p.variant_counters = nullptr;
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride;
   p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;

@@ -273,6 +273,7 @@ struct k5_dit {
   long long nabla_possible = 0;                    // profiling: 64x64 blocks the NABLA maps could have kept (kept: ws_attn_cnt[2])
   int attn_mode = 0;                               // K5_ATTN_AUTO / K5_ATTN_ONLINE (k5_dit_set_option "attn_mode")
   int sp_pass1_tiles = 0;                          // k5_dit_set_option "sp_pass1_tiles" (0 = all local key tiles)
+  bool fuse_qnorm = true;                          // "attn_fuse_qnorm": norm_qk + RoPE of the visual queries inside the attention kernel
   bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 180)
   int sp_slices = 1;                               // "sp_slices": the K / V^T exchange of a block in this many slices (dense attention)
   hipEvent_t ev_slice[4] = {};                     // slice s of every peer has landed
@@ -494,14 +495,22 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   // per-row softmax offsets: heads with a Cauchy-Schwarz bound up to 180 keep the fixed-offset kernel, each query row on its own
   // constant offset |q| max|k'| - 90
   const float* kmax = nullptr;
+  // dense visual blocks: norm_qk + RoPE of the queries happen in the attention kernel's Q load ("attn_fuse_qnorm")
+  const bool fuse_q = pre && !nabla && d->fuse_qnorm && ((by_data && d->row_offsets) || d->attn_mode == K5_ATTN_ONLINE);
+  if (by_data) K5CHK(ensure_attn_flags(d, s));   // before the counters' address is taken
+  const K5QueryNorm qn{a.norm.as<float>(), cosT, sinT, by_data ? d->ws_attn_cnt.as<unsigned long long>() : nullptr};
   {
     Scope sc(d, s, "elementwise");
     const int32_t hc[2] = {H, 2 * H};
     void* kc = nullptr;   // NABLA: the block map needs the unscaled keys -> the scaled copy goes to its own buffer
     if (pre && nabla) { K5CHK(d->ws_kc.ensure((size_t)rows * D * 2)); kc = d->ws_kc.p; }
     float* stats = nullptr;
-    if (by_data) { K5CHK(ensure_attn_flags(d, s)); stats = d->ws_attn_stats.as<float>(); }   // [q heads | k' heads] = the call's 2H heads
-    K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D, stats, d->ws_attn_part.as<float>()));
+    if (by_data) stats = d->ws_attn_stats.as<float>();   // [q heads | k' heads] = the call's 2H heads
+    if (fuse_q)   // keys only; the query statistic stays 0 (the fixed-offset workgroups take the head-level decision, K5QueryNorm)
+      K5CHK(k5_launch_rmsnorm_rope((bf16_t*)qk + D, a.norm.as<float>() + 64, cosT, sinT, rows, H, 2 * D, nullptr, s, K5_SOFTMAX_C, 0, nullptr, 0,
+                                   stats ? stats + H : nullptr, d->ws_attn_part.as<float>()));
+    else
+      K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D, stats, d->ws_attn_part.as<float>()));
     if (by_data) {
       hflags = d->ws_attn_flags.as<int>();
       float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
@@ -532,7 +541,8 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     Scope sc(d, s, fam_attn);
     K5CHK(k5_launch_attention_bf16_range(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, pre ? 0.f : a.score_bound, 0, 0, 0, -1,
-                                         0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), pre, hflags, variant, nullptr, kmax));
+                                         0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), pre, hflags, variant, nullptr, kmax, 0,
+                                         fuse_q ? &qn : nullptr));
   }
   {
     Scope sc(d, s, "gemm");
@@ -594,7 +604,10 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(h, wq, a.bqk.as<float>(), q, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   }
-  {
+  const bool fuse_q = pre && d->fuse_qnorm && ((by_data && d->row_offsets) || d->attn_mode == K5_ATTN_ONLINE);   // see run_self_attention
+  const K5QueryNorm qn{a.norm.as<float>(), cosT, sinT, by_data ? d->ws_attn_cnt.as<unsigned long long>() : nullptr};
+  const K5QueryNorm* qnp = fuse_q ? &qn : nullptr;
+  if (!fuse_q) {
     Scope sc(d, s, "elementwise");
     K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), cosT, sinT, rows, H, D, nullptr, s, 1.f, 0x7fffffff, nullptr, 0, qstat, d->ws_attn_part.as<float>()));
   }
@@ -675,14 +688,14 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, S > 1 ? cols : ldv, D, 0.f, S > 1 ? cols : rows_pad,
                                            S > 1 ? (long long)D * cols : (long long)D * ldv,
                                            r * tpc_pad, k1, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s, d->ws_attn_bal.as<float>(), true, hflags, variant,
-                                           nullptr, kmax, kmax ? 1 : 0));
+                                           nullptr, kmax, kmax ? 1 : 0, qnp));
     }
     if (S == 1) {
       HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, rows_pad, (long long)D * ldv,
                                            0, total - k1, r * tpc_pad, k1, d->ws_attn_state.as<float>(), 1, s, d->ws_attn_bal.as<float>(),
-                                           true, hflags, variant, nullptr, kmax, kmax ? 2 : 0));
+                                           true, hflags, variant, nullptr, kmax, kmax ? 2 : 0, qnp));
     } else {
       // one pass per slice, as soon as that slice of every peer has landed: slice sl of rank p = key tiles [p tpc_pad + sl tps, + tps)
       // (P - 1 segments: mine was pass 1; the last rank's slot may end early — it is the last segment, so the count is cut short).
@@ -704,7 +717,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
         Scope sc(d, s, "attn_self");
         K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, cols, D, 0.f, cols, (long long)D * cols,
                                              sl * tps, cnt, 0x7fffffff, 0, d->ws_attn_state.as<float>(), fin ? 1 : 3, s,
-                                             d->ws_attn_bal.as<float>(), true, hflags, variant, &seg, kmax, kmax ? (fin ? 2 : 1) : 0));
+                                             d->ws_attn_bal.as<float>(), true, hflags, variant, &seg, kmax, kmax ? (fin ? 2 : 1) : 0, qnp));
       }
     }
   }
@@ -735,9 +748,10 @@ int run_cross_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h,
   }
   {
     Scope sc(d, s, "attn_cross");
+    const K5QueryNorm qn{a.norm.as<float>(), nullptr, nullptr, nullptr};
     if (fuse_qnorm)
       K5CHK(k5_launch_attention_bf16_range(q, ck, cvt, o, H, rows, L, D, D, ldvt, D, a.score_bound, 0, 0, 0, -1, 0x7fffffff, 0, nullptr, 0, s,
-                                           nullptr, false, nullptr, K5_ATTN_AUTO, nullptr, nullptr, 0, a.norm.as<float>()));
+                                           nullptr, false, nullptr, K5_ATTN_AUTO, nullptr, nullptr, 0, &qn));
     else
       K5CHK(k5_launch_attention_bf16_bounded(q, ck, cvt, o, H, rows, L, D, D, ldvt, D, a.score_bound, s));
   }
@@ -1420,6 +1434,8 @@ extern "C" int k5_dit_comm_init_loopback(k5_dit* d, k5_loopback* lb, int rank) {
 //   "sp_pass1_tiles"  local key tiles attended before the K/V^T gather has landed (0 = all of the rank's own tiles)
 //   "attn_row_offsets" 1 (default) / 0: fixed-offset softmax with per-row offsets — heads whose bound max|q| max|k'| lies in (90, 180]
 //                     stay on the fast kernel (a row whose sum underflows sends its head to the online form late); 0 = the plain <= 90 rule
+//   "attn_fuse_qnorm" 1 (default) / 0: dense visual self-attention applies norm_qk + RoPE of the QUERIES inside the attention kernel's
+//                     Q-fragment load (K5QueryNorm; needs attn_row_offsets or attn_mode 1), 0 = the standalone pass over q
 //   "sp_slices"       S in 1..4: exchange K / V^T of a block in S slices (grouped send/recv to every peer at once) and attend each
 //                     slice as it lands — the gather hides behind the attention of the slices before it (dense attention; NABLA and
 //                     S = 1 keep the single in-place all-gather).  Token slots become multiples of 64 S.
@@ -1435,6 +1451,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   }
   if (!strcmp(name, "sp_pass1_tiles")) { if (value < 0) return K5_ERR_ARG; d->sp_pass1_tiles = value; return K5_OK; }
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
+  if (!strcmp(name, "attn_fuse_qnorm")) { d->fuse_qnorm = value != 0; return K5_OK; }
   if (!strcmp(name, "sp_slices")) {
     if (value < 1 || value > 4) return K5_ERR_ARG;
     if (value > 1 && d->comm.comm && !d->comm.can_exchange()) { k5_set_error("sp_slices > 1 needs ncclSend / ncclRecv / ncclGroup* in the RCCL library"); return K5_ERR_STATE; }
@@ -1455,6 +1472,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "sp_pass1_tiles")) *value = d->sp_pass1_tiles;
   else if (!strcmp(name, "sp_slices")) *value = d->sp_slices;
   else if (!strcmp(name, "attn_row_offsets")) *value = d->row_offsets ? 1 : 0;
+  else if (!strcmp(name, "attn_fuse_qnorm")) *value = d->fuse_qnorm ? 1 : 0;
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
   else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }

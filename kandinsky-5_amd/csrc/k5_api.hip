@@ -102,6 +102,21 @@ int k5_attention_bf16_prescaled_rows_pass(const void* Q, const void* Kc, const v
                                             late_pass), "k5_attention_bf16_prescaled_rows_pass");
 }
 
+// the same pass with norm_qk + apply_rotary of the QUERIES fused into the kernel's Q load (K5QueryNorm): Q holds the raw projection.
+// head_flags + kmax (k5_attention_flags_rows with a ZERO query statistic: every head starts on the fixed form) -> the fixed-offset
+// workgroups decide per head (a row bound above 180 flips the flag to 0); both null -> online max everywhere.
+int k5_attention_bf16_prescaled_qnorm_pass(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                           int ldk, int ldvt, int ldo, const float* q_norm_w, const float* q_cos, const float* q_sin,
+                                           int* head_flags, const float* kmax, int tile_off0, int tile_cnt, float* state, int flags,
+                                           int late_pass, void* workspace, void* stream) {
+  if (!q_norm_w || !q_cos || !q_sin || (!head_flags != !kmax)) return ret(K5_ERR_ARG, "k5_attention_bf16_prescaled_qnorm_pass");
+  const K5QueryNorm qn{q_norm_w, q_cos, q_sin, nullptr};
+  return ret(k5_launch_attention_bf16_range(Q, Kc, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, 0.f, 0, 0, tile_off0, tile_cnt, 0x7fffffff, 0,
+                                            state, flags, (hipStream_t)stream, (float*)workspace, true, head_flags,
+                                            head_flags ? K5_ATTN_AUTO : K5_ATTN_ONLINE, nullptr, kmax, late_pass, &qn),
+             "k5_attention_bf16_prescaled_qnorm_pass");
+}
+
 int64_t k5_attention_balance_size(int H, int q_len) { return (int64_t)k5_attention_balance_bytes(H, q_len); }
 
 int k5_attention_bf16_balanced(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,

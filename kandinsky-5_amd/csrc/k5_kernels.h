@@ -28,14 +28,18 @@ size_t k5_attention_state_bytes(int H, int q_len);
 // segmented walk instead of the (offset, skip) one: position e -> tile_off0 + seg(e / len) * stride + e % len, where segments
 // >= skip shift up by one (the sequence-parallel schedule's "slice s of every rank's slot except mine"); tile_cnt positions
 struct K5TileSegments { int len, stride, skip; };
+// norm_qk (+ apply_rotary) of the QUERY rows fused into the attention kernel's Q-fragment load: Q then holds the raw projection.
+// w: 64 RMSNorm weights.  cos / sin null: cross-attention (unscaled keys; K5_ERR_UNSUPPORTED unless score_bound selects the fixed-offset
+// kernel).  cos / sin [row][32] fp32: visual self-attention (pre-scaled keys); with row_offset_kmax the fixed-offset workgroups then
+// decide per head themselves (a row bound above 180 flips the head's flag to the online form; counters [fixed, online] follow).
+struct K5QueryNorm { const float* w; const float* cos; const float* sin; unsigned long long* counters; };
 int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* balance_ws = nullptr, bool k_prescaled = false,
                                    const int* head_flags = nullptr, int variant = 0, const K5TileSegments* segments = nullptr,
                                    const float* row_offset_kmax = nullptr, int late_pass = 0,   // late_pass: AttnP::late_pass (multi-pass + per-row offsets)
-                                   const float* q_norm_w = nullptr);   // fused RMSNorm of the query rows (cross-attention); K5_ERR_UNSUPPORTED unless
-                                                                       // the keys are unscaled and score_bound selects the fixed-offset kernel
+                                   const K5QueryNorm* query_norm = nullptr);   // fused norm_qk (+ RoPE) of the query rows, see K5QueryNorm
 size_t k5_attention_balance_bytes(int H, int q_len);
 // softmax form of the pre-scaled-key launches: AUTO = fixed offset where the bound (score_bound, or the per-head device
 // flags) allows it and the lazy online max elsewhere; ONLINE = the online max everywhere

@@ -344,3 +344,127 @@ def test_row_offsets_late_fallback_across_passes(E, bad_half):
     run_pass(T // 2, T - T // 2, 1, 2)
     assert flags.tolist() == [2, 1], flags
     close(out, O.sdpa(q, k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what=f"late fallback across passes ({bad_half})")
+
+
+# ------------------------------------------------------------------------------------------ norm_qk + RoPE of the queries fused into the Q load
+def run_qnorm(E, qraw, w, cos, sin, kc, vt, H, flags, kmax, passes=None):
+    """k5_attention_bf16_prescaled_qnorm_pass: one launch over all keys, or (passes = [(tile0, cnt, state_flags, late_pass), ...]) a
+    multi-pass schedule with the fp32 state between the passes."""
+    Sq, Sk = qraw.shape[0], kc.shape[0]
+    out = torch.full((Sq, H * 64), float("nan"), dtype=BF, device="cuda")
+    L = E.lib()
+    ws = torch.empty(L.k5_attention_balance_size(H, Sq), dtype=torch.uint8, device="cuda")
+    state = torch.zeros(L.k5_attention_state_size(H, Sq) // 4, device="cuda") if passes else None
+    for (t0, cnt, fl, late) in (passes or [(0, -1, 0, 0)]):
+        E.check(L.k5_attention_bf16_prescaled_qnorm_pass(qraw.data_ptr(), kc.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk, qraw.stride(0),
+                                                         kc.stride(0), vt.stride(0), out.stride(0), w.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                         None if flags is None else flags.data_ptr(), None if kmax is None else kmax.data_ptr(),
+                                                         t0, cnt, None if state is None else state.data_ptr(), fl, late, ws.data_ptr(),
+                                                         E.stream_ptr()), "k5_attention_bf16_prescaled_qnorm_pass")
+        torch.cuda.synchronize()
+    return out
+
+
+def qnorm_case(Sq, Sk, H, head_gain, seed, row_scale=None):
+    """raw query projection (any scale: the norm removes it), RMSNorm weights w (one set for all heads, as in the model) x per-head
+    gain folded into the raw keys instead (so heads differ in their bound), rotary table, pre-scaled normed keys, values"""
+    g = torch.Generator().manual_seed(seed)
+    qraw = bfr(torch.randn(Sq, H, 64, generator=g) * 2.5)
+    if row_scale is not None:
+        qraw = bfr(qraw * row_scale[:, None, None])
+    w = torch.randn(64, generator=g).abs() * 0.3 + 0.85
+    ang = torch.randn(Sq, 32, generator=g) * 3.0
+    cos, sin = torch.cos(ang), torch.sin(ang)
+    k = torch.randn(Sk, H, 64, generator=g)
+    k = bfr(head_gain[None, :, None] * k / k.pow(2).mean(-1, keepdim=True).sqrt() * O.SOFTMAX_C)
+    v = bfr(torch.randn(Sk, H, 64, generator=g))
+    return qraw, w, cos, sin, k, v
+
+
+def normed_queries(E, qraw, w, cos, sin, H):
+    """the standalone kernel's result on the same raw queries (its oracle parity: test_gpu_kernels.py)"""
+    qd = qraw.reshape(qraw.shape[0], -1).cuda().to(BF).clone()
+    wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()
+    E.rmsnorm_rope_(qd, wd, cd, sd, heads=H)
+    torch.cuda.synchronize()
+    return qd
+
+
+def kflags(E, k, H):
+    """k5_attention_flags_rows with a zero query statistic: every head starts on the fixed form, kmax = max|k'_h| with margin"""
+    kstat = (k * k).sum(-1).amax(0).contiguous().cuda()
+    qstat = torch.zeros(H, device="cuda")
+    flags = torch.zeros(H, dtype=torch.int32, device="cuda")
+    kmax = torch.zeros(H, device="cuda")
+    E.check(E.lib().k5_attention_flags_rows(qstat.data_ptr(), kstat.data_ptr(), 1, H, H, 0, flags.data_ptr(), kmax.data_ptr(), E.stream_ptr()))
+    torch.cuda.synchronize()
+    return flags, kmax
+
+
+@pytest.mark.parametrize("Sq,Sk,H", [(768, 1088, 4), (33280, 2048, 4)])
+def test_fused_query_norm_matches_the_standalone_norm(E, Sq, Sk, H):
+    """Heads with key gains 1, 5, 10, 16 (|q| ~ 9-10.5, |k'| = 1.44 gain: bounds ~ 15 / 76 / 150 / 240): the first three stay on the fixed
+    form (the third on non-zero per-row offsets), and the kernel's own decision sends the last one to the online form.  Reference:
+    the attention on the queries the standalone norm kernel wrote (same arithmetic: equal up to the rounding of a few fp32 sums),
+    and the oracle."""
+    qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([1.0, 5.0, 10.0, 16.0]), Sq)
+    qn = normed_queries(E, qraw, w, cos, sin, H)
+    qnf = qn.float().cpu().reshape(Sq, H, 64)
+    bound = qnf.norm(dim=-1).amax(0) * k.norm(dim=-1).amax(0)
+    assert bound[2] > 95 and bound[2] < 175 and bound[3] > 190 and bound[1] < 88, bound
+    wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()
+    kd, vt = k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
+    flags, kmax = kflags(E, k, H)
+    assert flags.tolist() == [1, 1, 1, 1]
+    out = run_qnorm(E, qraw.reshape(Sq, -1).cuda().to(BF), wd, cd, sd, kd, vt, H, flags, kmax)
+    assert flags.tolist() == [1, 1, 1, 0], flags                       # decided by the fixed-offset workgroups themselves
+    f2, kmax2 = flags_rows(E, qnf, k, H)
+    assert f2.tolist() == [1, 1, 1, 0]                                   # ... as the statistics-based rule decides on the normed queries
+    ref_k = run_rows(E, qn, kd, vt, H, f2, kmax2)
+    diff = (out.float() - ref_k.float()).abs()
+    # equal except where an fp32 sum of the norm rounded the other way (one bf16 ulp of one query element; peaky heads amplify it)
+    assert diff.max().item() <= 0.1 and (diff > 0).float().mean().item() < 2e-3, (diff.max().item(), (diff > 0).float().mean().item())
+    rows = torch.arange(Sq) if Sq < 2000 else torch.tensor([0, 5, 255, 256, 4097, 20000, 32767, 32768, 33000, Sq - 1])
+    close(out[rows], O.sdpa(qnf[rows], k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="fused query norm")
+    # forced online max (no flags): the same queries through the other form
+    out_on = run_qnorm(E, qraw.reshape(Sq, -1).cuda().to(BF), wd, cd, sd, kd, vt, H, None, None)
+    close(out_on[rows], O.sdpa(qnf[rows], k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="fused query norm, online")
+
+
+def test_fused_query_norm_one_large_row_flips_its_head(E):
+    """The decision is per HEAD although it is taken per workgroup: w has one large channel and a single query row (in the last
+    256-row block) has its energy in that channel, so only that row's bound exceeds 180 — its workgroup flips the flag after most
+    others of the head have already finished in the fixed form; the online launch then recomputes the whole head."""
+    Sq, Sk, H = 2048, 1024, 2
+    qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([7.0, 7.0]), 5)
+    w[7] = 3.0
+    qraw[Sq - 3, 0] = 0.01 * qraw[Sq - 3, 0]
+    qraw[Sq - 3, 0, 7] = 30.0                                           # after the norm: ~ 8 * 3 = 24 in channel 7, |q| |k'| ~ 24 * 10 = 240
+    qraw = bfr(qraw)
+    qn = normed_queries(E, qraw, w, cos, sin, H)
+    qnf = qn.float().cpu().reshape(Sq, H, 64)
+    b = qnf.norm(dim=-1) * k.norm(dim=-1).amax(0)[None]
+    assert (b[:, 0] > 185).sum() == 1 and b[Sq - 3, 0] > 185 and b[:, 1].max() < 175, (b[:, 0].topk(3), b[:, 1].max())
+    wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()
+    kd, vt = k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
+    flags, kmax = kflags(E, k, H)
+    out = run_qnorm(E, qraw.reshape(Sq, -1).cuda().to(BF), wd, cd, sd, kd, vt, H, flags, kmax)
+    assert flags.tolist() == [0, 1], flags
+    close(out, O.sdpa(qnf, k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="one large row")
+
+
+def test_fused_query_norm_across_passes(E):
+    """The sequence-parallel schedule: pass A (first half of the keys, state out, late_pass 1), pass B (resume, normalise, late_pass 2).
+    Head 2 flips to the online form in pass A by the kernel's own decision and stays there in pass B."""
+    Sq, Sk, H = 1024, 2048, 3
+    qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([2.0, 10.0, 16.0]), 77)
+    qn = normed_queries(E, qraw, w, cos, sin, H)
+    qnf = qn.float().cpu().reshape(Sq, H, 64)
+    wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()
+    kd, vt = k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
+    flags, kmax = kflags(E, k, H)
+    T = Sk // 64
+    out = run_qnorm(E, qraw.reshape(Sq, -1).cuda().to(BF), wd, cd, sd, kd, vt, H, flags, kmax,
+                    passes=[(0, T // 2, 2, 1), (T // 2, T - T // 2, 1, 2)])
+    assert flags.tolist() == [1, 1, 0], flags
+    close(out, O.sdpa(qnf, k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="fused query norm across passes")
