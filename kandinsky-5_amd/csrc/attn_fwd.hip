@@ -117,7 +117,9 @@ constexpr float ONLINE_THR = 60.f;
 #ifndef K5_ONLINE_WPS
 #define K5_ONLINE_WPS 2   // waves per SIMD the online-max instantiations are compiled for: 2 = up to 256 VGPRs, one workgroup per CU (at 4 = 128 VGPRs the allocator spills the cold path into the tile loop: 4x slower, measured)
 #endif
-template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false>
+// QN: the norm_qk + RoPE of the queries is fused into the Q load (K5QueryNorm, pre-scaled keys).  A template parameter and not a runtime
+// branch: with the code merely PRESENT the compiler schedules the tile loop of the plain form differently (same instructions, +1 % time).
+template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false, bool QN = false>
 __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_kernel(AttnP p) {
   static_assert(BOUNDED || PRE, "the online-max form of this kernel takes pre-scaled keys (attn_fwd32_kernel serves the rest)");
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
@@ -147,7 +149,20 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
   }
-  if (PRE && p.q_norm_w) {   // fused norm_qk + apply_rotary of the queries, same arithmetic and rounding points as rmsnorm_rope_kernel
+  if (PRE && QN) {   // fused norm_qk + apply_rotary of the queries, same arithmetic and rounding points as rmsnorm_rope_kernel
+    // every load first (weights, both query tiles' table rows: none depends on q), so that the prologue is ONE memory round trip
+    f32x4 wa[2], wb[2], cs[2][2], sn[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      wa[ks] = *reinterpret_cast<const f32x4*>(p.q_norm_w + 32 * ks + 8 * g);
+      wb[ks] = *reinterpret_cast<const f32x4*>(p.q_norm_w + 32 * ks + 8 * g + 4);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int row = min(q0 + 16 * qt + l15, p.q_len - 1);
+        cs[qt][ks] = *reinterpret_cast<const f32x4*>(p.q_cos + (size_t)row * 32 + 16 * ks + 4 * g);
+        sn[qt][ks] = *reinterpret_cast<const f32x4*>(p.q_sin + (size_t)row * 32 + 16 * ks + 4 * g);
+      }
+    }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float v[16], ss = 0.f;
@@ -168,20 +183,16 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         ss = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
       }
       const float rs = rsqrtf(ss * (1.0f / 64.0f) + 1.1920928955078125e-07f);
-      const int row = min(q0 + 16 * qt + l15, p.q_len - 1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const f32x4 wa = *reinterpret_cast<const f32x4*>(p.q_norm_w + 32 * ks + 8 * g), wb = *reinterpret_cast<const f32x4*>(p.q_norm_w + 32 * ks + 8 * g + 4);
-        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.q_cos + (size_t)row * 32 + 16 * ks + 4 * g);
-        const f32x4 sn = *reinterpret_cast<const f32x4*>(p.q_sin + (size_t)row * 32 + 16 * ks + 4 * g);
         float y[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = bf_round(__fmul_rn(__fmul_rn(v[8 * ks + j], rs), j < 4 ? wa[j] : wb[j - 4]));   // .type_as(q)
+        for (int j = 0; j < 8; ++j) y[j] = bf_round(__fmul_rn(__fmul_rn(v[8 * ks + j], rs), j < 4 ? wa[ks][j] : wb[ks][j - 4]));   // .type_as(q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float x0 = y[2 * j], x1 = y[2 * j + 1];
-          y[2 * j] = __fadd_rn(__fmul_rn(cs[j], x0), __fmul_rn(-sn[j], x1));
-          y[2 * j + 1] = __fadd_rn(__fmul_rn(sn[j], x0), __fmul_rn(cs[j], x1));
+          y[2 * j] = __fadd_rn(__fmul_rn(cs[qt][ks][j], x0), __fmul_rn(-sn[qt][ks][j], x1));
+          y[2 * j + 1] = __fadd_rn(__fmul_rn(sn[qt][ks][j], x0), __fmul_rn(cs[qt][ks][j], x1));
         }
         const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
         qf[qt][ks] = __builtin_bit_cast(bf16x8, pk);
@@ -239,8 +250,8 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   const int T = RANGE ? (int)(((long long)Tall * (part + 1)) / p.splits) : Tall;
   const int nfull = p.kv_len / KB;                    // key tiles with all 64 keys valid (NABLA: all of them)
   auto tile_of = [&](int e) -> int {                  // sequence position -> 64-key tile index (wave-uniform)
-    if (SPARSE) return sp_list[e] & 0xffffff;
-    if (!RANGE) return e;
+    if (SPARSE) return sp_list[e] & 0xffffff;   // scalar loads (s_load): keep every int* store / atomic of this kernel BEHIND the tile loop,
+    if (!RANGE) return e;                       // or they become vector loads whose vmcnt wait drains the tile DMA as well
     if (!BOUNDED && late) return e;
     if (p.seg_len > 0) {
       int si = e / p.seg_len;
@@ -324,18 +335,16 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
       const float bnd = sqrtf(ss) * km;
       const float off = fmaxf(bnd - K5_ATTN_EXP_LIMIT, 0.f);
       nm[qt] = f32x4{-off, -off, -off, -off};
-      over_limit |= (q0 + 16 * qt + l15 < p.q_len) && !(bnd <= K5_ATTN_ROWOFF_LIMIT);   // NaN counts as over
+      if (QN) over_limit |= (q0 + 16 * qt + l15 < p.q_len) && !(bnd <= K5_ATTN_ROWOFF_LIMIT);   // NaN counts as over
     }
   }
-  if (BOUNDED && PRE && p.kmax && p.q_norm_w) {   // no max|q|^2 statistic preceded this launch (fused query norm): the head-level choice is taken here
-    if (__syncthreads_or(over_limit ? 1 : 0)) {
-      if (tid == 0 && atomicCAS(const_cast<int*>(p.head_flags) + h, 1, 0) == 1 && p.variant_counters) {
-        atomicAdd(p.variant_counters + 1, 1ull);
-        atomicAdd(p.variant_counters, ~0ull);   // - 1
-      }
-      return;
-    }
-  }
+  // Fused query norm: no max|q|^2 statistic preceded this launch, so the head-level choice is taken here — a wave that holds a row
+  // above the limit flips its head's flag to the online form AFTER its tile loop (below), and whatever the fixed-offset launch wrote for
+  // the head is overwritten by the online launch that follows.  Why not an early, workgroup-uniform exit: (a) the vote needs a static
+  // LDS variable, and next to one the compiler waits for the tile DMA right after issuing it; (b) an atomic on an int* BEFORE the loop
+  // turns the NABLA list loads (int*, scalar loads) into vector loads whose vmcnt wait drains the DMA as well.  Either costs 6-14 %
+  // of the whole kernel (measured, same box) — tests/test_abi_and_host.py pins the prefetch distance in the ISA.
+  const bool wave_over = BOUNDED && PRE && QN && p.kmax && __any(over_limit);
   f32x4 lt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   const bf16x8 onesf = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
   // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
@@ -473,6 +482,10 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     tile_step(std::integral_constant<int, 0>{}, e);
     if (e + 1 >= T) break;
     tile_step(std::integral_constant<int, 1>{}, e + 1);
+  }
+  if (BOUNDED && PRE && QN && wave_over && lane == 0 && atomicCAS(const_cast<int*>(p.head_flags) + h, 1, 0) == 1 && p.variant_counters) {
+    atomicAdd(p.variant_counters + 1, 1ull);
+    atomicAdd(p.variant_counters, ~0ull);   // - 1
   }
   if (RANGE && (p.flags & 2)) {   // leave the running state for a later launch; no output yet
 #pragma unroll
@@ -902,8 +915,13 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
     const dim3 grid(njobs);
     if (k_prescaled) {   // always the RANGE instantiation (a superset; with the plain one the register allocator spills)
       p.head_flags = (run_fixed && run_online) ? head_flags : nullptr;
-      if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true>), grid, block, 0, stream, p); }
-      if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, false, true, true>), grid, block, 0, stream, p); }
+      if (p.q_norm_w) {
+        if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true, true>), grid, block, 0, stream, p); }
+        if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, false, true, true, true>), grid, block, 0, stream, p); }
+      } else {
+        if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true>), grid, block, 0, stream, p); }
+        if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, false, true, true>), grid, block, 0, stream, p); }
+      }
     }
     else if (bounded) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), grid, block, 0, stream, p);
     else if (use_range) hipLaunchKernelGGL((attn_fwd32_kernel<false, false, true>), grid, block, 0, stream, p);

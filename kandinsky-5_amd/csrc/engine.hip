@@ -273,7 +273,7 @@ struct k5_dit {
   long long nabla_possible = 0;                    // profiling: 64x64 blocks the NABLA maps could have kept (kept: ws_attn_cnt[2])
   int attn_mode = 0;                               // K5_ATTN_AUTO / K5_ATTN_ONLINE (k5_dit_set_option "attn_mode")
   int sp_pass1_tiles = 0;                          // k5_dit_set_option "sp_pass1_tiles" (0 = all local key tiles)
-  bool fuse_qnorm = true;                          // "attn_fuse_qnorm": norm_qk + RoPE of the visual queries inside the attention kernel
+  int fuse_qnorm = 0;                              // "attn_fuse_qnorm": norm_qk + RoPE of the visual queries inside the attention kernel
   bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 180)
   int sp_slices = 1;                               // "sp_slices": the K / V^T exchange of a block in this many slices (dense attention)
   hipEvent_t ev_slice[4] = {};                     // slice s of every peer has landed
@@ -604,7 +604,9 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(h, wq, a.bqk.as<float>(), q, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   }
-  const bool fuse_q = pre && d->fuse_qnorm && ((by_data && d->row_offsets) || d->attn_mode == K5_ATTN_ONLINE);   // see run_self_attention
+  // see run_self_attention; here only with "attn_fuse_qnorm" = 2: every pass of the schedule redoes the norm, and at shard sizes that
+  // costs what the standalone pass over the local queries does (emulated P = 8: 82.8 vs 82.6 ms per step)
+  const bool fuse_q = pre && d->fuse_qnorm > 1 && ((by_data && d->row_offsets) || d->attn_mode == K5_ATTN_ONLINE);
   const K5QueryNorm qn{a.norm.as<float>(), cosT, sinT, by_data ? d->ws_attn_cnt.as<unsigned long long>() : nullptr};
   const K5QueryNorm* qnp = fuse_q ? &qn : nullptr;
   if (!fuse_q) {
@@ -1434,8 +1436,10 @@ extern "C" int k5_dit_comm_init_loopback(k5_dit* d, k5_loopback* lb, int rank) {
 //   "sp_pass1_tiles"  local key tiles attended before the K/V^T gather has landed (0 = all of the rank's own tiles)
 //   "attn_row_offsets" 1 (default) / 0: fixed-offset softmax with per-row offsets — heads whose bound max|q| max|k'| lies in (90, 180]
 //                     stay on the fast kernel (a row whose sum underflows sends its head to the online form late); 0 = the plain <= 90 rule
-//   "attn_fuse_qnorm" 1 (default) / 0: dense visual self-attention applies norm_qk + RoPE of the QUERIES inside the attention kernel's
-//                     Q-fragment load (K5QueryNorm; needs attn_row_offsets or attn_mode 1), 0 = the standalone pass over q
+//   "attn_fuse_qnorm" 0 (default): norm_qk + RoPE of the visual queries is a standalone pass; 1 = dense visual self-attention on ONE rank
+//                     applies it inside the attention kernel's Q-fragment load (K5QueryNorm; needs attn_row_offsets or attn_mode 1);
+//                     2 = under sequence parallelism too.  Measured neutral (elementwise -2.0 ms, attention +0.6 .. +3.4 ms per step
+//                     depending on how the compiler schedules the tile loop of the extra instantiation), hence opt-in.
 //   "sp_slices"       S in 1..4: exchange K / V^T of a block in S slices (grouped send/recv to every peer at once) and attend each
 //                     slice as it lands — the gather hides behind the attention of the slices before it (dense attention; NABLA and
 //                     S = 1 keep the single in-place all-gather).  Token slots become multiples of 64 S.
@@ -1451,7 +1455,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   }
   if (!strcmp(name, "sp_pass1_tiles")) { if (value < 0) return K5_ERR_ARG; d->sp_pass1_tiles = value; return K5_OK; }
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
-  if (!strcmp(name, "attn_fuse_qnorm")) { d->fuse_qnorm = value != 0; return K5_OK; }
+  if (!strcmp(name, "attn_fuse_qnorm")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->fuse_qnorm = value; return K5_OK; }
   if (!strcmp(name, "sp_slices")) {
     if (value < 1 || value > 4) return K5_ERR_ARG;
     if (value > 1 && d->comm.comm && !d->comm.can_exchange()) { k5_set_error("sp_slices > 1 needs ncclSend / ncclRecv / ncclGroup* in the RCCL library"); return K5_ERR_STATE; }
@@ -1472,7 +1476,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "sp_pass1_tiles")) *value = d->sp_pass1_tiles;
   else if (!strcmp(name, "sp_slices")) *value = d->sp_slices;
   else if (!strcmp(name, "attn_row_offsets")) *value = d->row_offsets ? 1 : 0;
-  else if (!strcmp(name, "attn_fuse_qnorm")) *value = d->fuse_qnorm ? 1 : 0;
+  else if (!strcmp(name, "attn_fuse_qnorm")) *value = d->fuse_qnorm;
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
   else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }

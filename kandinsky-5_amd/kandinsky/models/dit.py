@@ -315,6 +315,8 @@ class DiffusionTransformer3D(nn.Module):
     def set_option(self, name, value):
         """k5_dit_set_option: "attn_mode" (0 = softmax form per head from the data, 1 = online max everywhere),
         "attn_row_offsets" (1 = per-row offsets keep heads with a bound up to 180 on the fixed-offset kernel; default),
+        "attn_fuse_qnorm" (1 = norm_qk + RoPE of the visual queries inside the attention kernel, 2 = under sequence parallelism too;
+        default 0, measured neutral),
         "sp_slices" (sequence parallelism: exchange K / V^T in this many slices, attend each as it lands; default 1),
         "sp_pass1_tiles", "emulate_world" (timing only)."""
         E.check(E.lib().k5_dit_set_option(self._handle, name.encode(), int(value)), f"k5_dit_set_option({name})")

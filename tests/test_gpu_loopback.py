@@ -23,7 +23,7 @@ def rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-def run_ranks(P, make_dit, call, slices=1):
+def run_ranks(P, make_dit, call, slices=1, options=None):
     """P handles, rank r driven by thread r on its own stream; returns the per-rank results (raises the first error).
     slices > 1: the sliced K / V^T exchange (engine option "sp_slices")."""
     from kandinsky import _engine as E
@@ -35,6 +35,8 @@ def run_ranks(P, make_dit, call, slices=1):
         d.enable_loopback(group, r)
         if slices > 1:
             d.set_option("sp_slices", slices)
+        for k, v in (options or {}).items():
+            d.set_option(k, v)
         dits.append(d)
     torch.cuda.synchronize()
     out, err = [None] * P, [None] * P
@@ -105,11 +107,15 @@ def test_tiny_forward_P_ranks_on_one_gpu(golden_meta, tiny_sd, P, T, sparse):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("P,W,gain", [(2, 32, 1.0), (4, 32, 1.0), (8, 48, 1.0), (4, 32, 3.0)])
-def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain):
+@pytest.mark.parametrize("P,W,gain,qfuse", [(2, 32, 1.0, 0), (4, 32, 1.0, 0), (8, 48, 1.0, 0), (4, 32, 3.0, 0),
+                                            (8, 48, 1.0, 2), (4, 32, 3.0, 2), (2, 32, 5.0, 2)])
+def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain, qfuse):
     """2B-Lite width (28 heads, D = 1792), 2 visual blocks, latent (5,16,W): 10 blocks (P=2: 5+5, P=4: 3+3+3+1) or 15 blocks
     (P=8: 7 x 2 + 1).  gain 3 on the QK-norm weights sends every head to the online-max softmax: the per-head flags come from
-    the gathered |k'|^2 maxima of ALL ranks, and both attention passes must take the same form."""
+    the gathered |k'|^2 maxima of ALL ranks, and both attention passes must take the same form.
+    qfuse = 2 ("attn_fuse_qnorm"; the single handle then runs with 1): the queries are normalised inside the attention kernel — every
+    pass of the sharded schedule redoes it from the raw projection, and at gain 5 (bound 288) the fixed-offset workgroups of pass 1
+    send every head to the online form."""
     from kandinsky.models.dit import DiffusionTransformer3D
     c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
     cfg = O.DitConfig(**c)
@@ -133,11 +139,15 @@ def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain):
         return d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(37), scale_factor=(1.0, 2.0, 2.0))
 
     one = make()
+    one.engine("cuda:0")
+    one.set_option("attn_fuse_qnorm", min(qfuse, 1))
     fused = call(one, 0)
     n_fixed, n_online = one.attn_variant_counts()
-    assert n_online == 0, (n_fixed, n_online)     # gain 3 (bound 104): the fixed form on per-row offsets, in the single-handle path
-    # and in every pass of the sharded schedule below (same per-row offsets from the gathered max|k'|)
-    outs = run_ranks(P, make, call)
+    if gain <= 3.0:
+        assert n_online == 0, (n_fixed, n_online)     # gain 3 (bound 104): the fixed form on per-row offsets, in the single-handle path
+    else:                                              # and in every pass of the sharded schedule below (same offsets from the gathered max|k'|)
+        assert n_fixed == 0, (n_fixed, n_online)
+    outs = run_ranks(P, make, call, options={"attn_fuse_qnorm": qfuse})
     for r in range(1, P):
         assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
     xin = torch.cat([x, torch.zeros(5, 16, W, 17)], dim=-1)
@@ -146,9 +156,10 @@ def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain):
         ref = O.dit_forward(sd, cfg, xin, text, pooled, t, pos, torch.arange(37), (1.0, 2.0, 2.0), None, "bf16")
     finally:
         O.PRESCALE_K = False
-    print(f"P={P} gain={gain}: sharded vs fused rel-L2 {rel(outs[0], fused):.3e}; sharded vs oracle {rel(outs[0], ref):.3e}, fused vs oracle {rel(fused, ref):.3e}")
-    assert rel(outs[0], fused) <= (6e-3 if gain == 1.0 else 1.5e-2), rel(outs[0], fused)
-    assert rel(outs[0], ref) <= (1.5e-2 if gain == 1.0 else 3e-2), rel(outs[0], ref)
+    print(f"P={P} gain={gain} qfuse={qfuse}: sharded vs fused rel-L2 {rel(outs[0], fused):.3e}; sharded vs oracle {rel(outs[0], ref):.3e}, fused vs oracle {rel(fused, ref):.3e}")
+    # larger gains = peakier softmax = more bf16 noise in the oracle itself (tests/test_gpu_dit.py measures it per case)
+    assert rel(outs[0], fused) <= {1.0: 6e-3, 3.0: 1.5e-2, 5.0: 4e-2}[gain], rel(outs[0], fused)
+    assert rel(outs[0], ref) <= {1.0: 1.5e-2, 3.0: 3e-2, 5.0: 8e-2}[gain], rel(outs[0], ref)
 
 
 @pytest.mark.timeout(600)

@@ -433,8 +433,9 @@ def test_fused_query_norm_matches_the_standalone_norm(E, Sq, Sk, H):
 
 def test_fused_query_norm_one_large_row_flips_its_head(E):
     """The decision is per HEAD although it is taken per workgroup: w has one large channel and a single query row (in the last
-    256-row block) has its energy in that channel, so only that row's bound exceeds 180 — its workgroup flips the flag after most
-    others of the head have already finished in the fixed form; the online launch then recomputes the whole head."""
+    256-row block) has its energy in that channel, so only that row's bound exceeds 180 — its wave flips the flag at the end of its
+    tile loop, after most other workgroups of the head have already finished in the fixed form; the online launch then recomputes
+    the whole head."""
     Sq, Sk, H = 2048, 1024, 2
     qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([7.0, 7.0]), 5)
     w[7] = 3.0
@@ -455,7 +456,9 @@ def test_fused_query_norm_one_large_row_flips_its_head(E):
 
 def test_fused_query_norm_across_passes(E):
     """The sequence-parallel schedule: pass A (first half of the keys, state out, late_pass 1), pass B (resume, normalise, late_pass 2).
-    Head 2 flips to the online form in pass A by the kernel's own decision and stays there in pass B."""
+    Head 2 leaves the fixed form in pass A by the kernel's own decision — flag 0 (online from pass A on) or, when a row of another
+    wave underflowed on its over-large offset first, flag 2 (late: recomputed from scratch by the online launch of pass B); both are
+    the online form on all keys."""
     Sq, Sk, H = 1024, 2048, 3
     qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([2.0, 10.0, 16.0]), 77)
     qn = normed_queries(E, qraw, w, cos, sin, H)
@@ -466,5 +469,5 @@ def test_fused_query_norm_across_passes(E):
     T = Sk // 64
     out = run_qnorm(E, qraw.reshape(Sq, -1).cuda().to(BF), wd, cd, sd, kd, vt, H, flags, kmax,
                     passes=[(0, T // 2, 2, 1), (T // 2, T - T // 2, 1, 2)])
-    assert flags.tolist() == [1, 1, 0], flags
+    assert flags.tolist()[:2] == [1, 1] and flags.tolist()[2] in (0, 2), flags
     close(out, O.sdpa(qnf, k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="fused query norm across passes")

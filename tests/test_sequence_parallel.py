@@ -127,7 +127,11 @@ def test_token_shard_contract():
 
 
 @pytest.mark.gpu
-def test_engine_sharded_path_world1_rccl_matches_fused(golden, golden_meta, tiny_sd):
+@pytest.mark.parametrize("qfuse", [0, 2])
+def test_engine_sharded_path_world1_rccl_matches_fused(golden, golden_meta, tiny_sd, qfuse):
+    """Bit-identical to the single-handle path when both normalise the queries in the same place ("attn_fuse_qnorm": 0 = the
+    standalone pass on both, 2 = inside the attention kernel on both; the defaults differ — fused on one rank, standalone in the sharded
+    schedule — and then a query element may round the other way, tests/test_gpu_loopback.py bounds that)."""
     from kandinsky.models.dit import DiffusionTransformer3D
     c = dict(golden_meta["tiny_config"])
     pos = [torch.arange(2), torch.arange(8), torch.arange(8)]
@@ -139,6 +143,8 @@ def test_engine_sharded_path_world1_rccl_matches_fused(golden, golden_meta, tiny
         dit = DiffusionTransformer3D(**c)
         dit.load_state_dict(tiny_sd, assign=True)
         dit = dit.to("cuda:0")
+        dit.engine("cuda:0")
+        dit.set_option("attn_fuse_qnorm", qfuse)
         if sp:
             dit.enable_sequence_parallel(0, 1, device="cuda:0")
         outs.append(dit(x, text, pooled, torch.tensor([432.0]), pos, torch.arange(9), scale_factor=(1.0, 2.0, 2.0)))
