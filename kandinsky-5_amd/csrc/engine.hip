@@ -264,7 +264,9 @@ struct k5_dit {
   bool use_graph = false;                          // k5_sample replays one captured step (k5_dit_set_graph)
   hipStream_t graph_stream = nullptr;              // capture needs a real stream: the caller's may be the legacy null stream
   hipEvent_t ev_graph = nullptr;
-  DevBuf ws_kc;                                    // NABLA: keys pre-multiplied by the softmax scale (separate from the map's keys)
+  DevBuf ws_kc;                                    // NABLA: keys pre-multiplied by the softmax scale (separate from the map's keys);
+                                                   // under sequence parallelism the reverse: the rank's UNSCALED keys (the scaled ones are gathered)
+  DevBuf ws_kmeans;                                // NABLA under sequence parallelism: gathered key-block means [P][H][slot blocks][64]
   DevBuf ws_attn_bal;                              // states of the split tail jobs (k5_launch_attention_bf16_range, balanced)
   // data-derived softmax bound of the visual self-attention (pre-scaled keys): per-head max |q|^2 [Hh] | max |k'|^2 [P][Hh]
   // (fp32, filled by the rmsnorm/RoPE kernel, consumed by k5_launch_attn_flags), the per-head variant flags [Hh] (int) and
@@ -569,20 +571,37 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   bf16_t* vtloc = vtfull + (size_t)r * D * ldv;
   const bf16_t* wq = a.wqk.as<bf16_t>();
   const bf16_t* wk = wq + (size_t)D * D;
-  // dense: pre-scaled keys, softmax form per head from the data (the |k'|^2 maxima of all ranks are gathered with the keys);
-  // NABLA under SP keeps unscaled keys (the map is computed from them) and the weight-derived bound
-  const bool pre = !nabla;
-  const bool by_data = pre && d->attn_mode == K5_ATTN_AUTO;
+  // pre-scaled keys, softmax form per head from the data (the |k'|^2 maxima of all ranks are gathered with the keys) — dense AND
+  // NABLA.  The NABLA map is computed from the UNSCALED keys, of which it only needs the 64-token block means: the unscaled
+  // keys stay local (ws_kc), their means (28 x 64 values per block) travel with the gather, and the gathered keys are the scaled ones —
+  // the same kernels, flags and per-row offsets as on one GPU (round 1 / early round 2: unscaled keys, weight-derived bound, and
+  // with it the online-max 32x32 kernel for any checkpoint whose QK-norm gains exceed max|w_q| max|w_k| = 3.96).
+  const bool pre = true;
+  const bool by_data = d->attn_mode == K5_ATTN_AUTO;
   float *qstat = nullptr, *kstat = nullptr;
   if (by_data) { K5CHK(ensure_attn_flags(d, s)); qstat = d->ws_attn_stats.as<float>(); kstat = qstat + H; }
+  const int slot_blocks = rows_pad / 64;
+  bf16_t* kun = kloc;                       // where the projection + norm + RoPE of the local keys happen
+  bf16_t* kmeans = nullptr;                 // NABLA: [P][H][slot_blocks][64] key-block means, this rank's slot filled here
+  if (nabla) {
+    K5CHK(d->ws_kc.ensure((size_t)rows * D * 2));
+    K5CHK(d->ws_kmeans.ensure((size_t)P * H * slot_blocks * 64 * 2));
+    kun = d->ws_kc.as<bf16_t>();
+    kmeans = d->ws_kmeans.as<bf16_t>();
+  }
   {
     Scope sc(d, s, "gemm");
-    K5CHK(k5_launch_gemm_bf16(h, wk, a.bqk.as<float>() + D, kloc, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    K5CHK(k5_launch_gemm_bf16(h, wk, a.bqk.as<float>() + D, kun, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   }
   {
     Scope sc(d, s, "elementwise");
-    K5CHK(k5_launch_rmsnorm_rope(kloc, a.norm.as<float>() + 64, cosT, sinT, rows, H, D, nullptr, s, K5_SOFTMAX_C, pre ? 0 : 0x7fffffff,
-                                 nullptr, 0, by_data ? kstat + (size_t)r * H : nullptr, d->ws_attn_part.as<float>()));
+    // dense: scaled in place; NABLA: unscaled in place (kun), the scaled copy goes to this rank's slot of the gather buffer
+    K5CHK(k5_launch_rmsnorm_rope(kun, a.norm.as<float>() + 64, cosT, sinT, rows, H, D, nullptr, s, K5_SOFTMAX_C, 0,
+                                 nabla ? kloc : nullptr, nabla ? D : 0, by_data ? kstat + (size_t)r * H : nullptr, d->ws_attn_part.as<float>()));
+  }
+  if (nabla) {
+    Scope sc(d, s, "nabla_map");
+    K5CHK(k5_launch_nabla_block_means(kun, D, H, rows / 64, slot_blocks, kmeans + (size_t)r * H * slot_blocks * 64, s));
   }
   HIPCHK(hipEventRecord(d->ev_k, s));
   // sliced exchange (dense attention, "sp_slices" = S > 1): the slot of every rank is S slices of rows_pad / S tokens; V^T is laid
@@ -606,7 +625,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   }
   // see run_self_attention; here only with "attn_fuse_qnorm" = 2: every pass of the schedule redoes the norm, and at shard sizes that
   // costs what the standalone pass over the local queries does (emulated P = 8: 82.8 vs 82.6 ms per step)
-  const bool fuse_q = pre && d->fuse_qnorm > 1 && ((by_data && d->row_offsets) || d->attn_mode == K5_ATTN_ONLINE);
+  const bool fuse_q = !nabla && d->fuse_qnorm > 1 && ((by_data && d->row_offsets) || d->attn_mode == K5_ATTN_ONLINE);
   const K5QueryNorm qn{a.norm.as<float>(), cosT, sinT, by_data ? d->ws_attn_cnt.as<unsigned long long>() : nullptr};
   const K5QueryNorm* qnp = fuse_q ? &qn : nullptr;
   if (!fuse_q) {
@@ -622,6 +641,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       K5CHK(d->comm.all_gather_inplace(kstat, (size_t)H, 4, cs));
       HIPCHK(hipEventRecord(d->ev_stats, cs));
     }
+    if (nabla) K5CHK(d->comm.all_gather_inplace(kmeans, (size_t)H * slot_blocks * 64, 2, cs));
     if (S == 1) {
       K5CHK(d->comm.all_gather_inplace(kfull, (size_t)rows_pad * D, 2, cs));
       HIPCHK(hipStreamWaitEvent(cs, d->ev_v, 0));
@@ -651,14 +671,16 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
   if (nabla) {
     // NABLA under sequence parallelism: the map rows of this rank's query blocks need the block means of
-    // ALL keys -> wait for the gathered K, then select (local query blocks x all key blocks) and run the list-driven
-    // attention on the chunked V^T layout.  (Single pass: the per-row kept set is not known before the gather.)
+    // ALL keys -> wait for the gather, bring the gathered means into the map's layout, select (local query blocks x all key
+    // blocks) and run the list-driven attention on the chunked V^T layout.  (Single pass: the per-row kept set is not known
+    // before the gather.)
     HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
     const int nb = N / 64;
     K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
     {
       Scope sc(d, s, "nabla_map");
-      K5CHK(k5_launch_nabla_select_rect(q, kfull, D, D, H, rows, r * (rows_pad / 64), N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
+      K5CHK(k5_launch_nabla_key_means_from_slots(kmeans, H, nb, slot_blocks, d->ws_nabla.p, s));
+      K5CHK(k5_launch_nabla_select_rect(q, nullptr, D, 0, H, rows, r * slot_blocks, N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
                                         nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s));
     }
     if (d->profiling) {
@@ -669,8 +691,8 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     const int *list, *cnt;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
     Scope sc(d, s, "attn_self");
-    K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, a.score_bound, list, cnt, nb, rows_pad,
-                                          (long long)D * ldv, s));
+    K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
+                                          (long long)D * ldv, s, true, hflags, variant, kmax));
   } else {
     // ... while the main stream attends the local query rows to the LOCAL key chunk (pass 1, leaves the fp32 state),
     // then, once every chunk has arrived, to all the other chunks (pass 2, resumes the state and normalises).
@@ -1073,7 +1095,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
                    &d->ws_vel_u};
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_kc.release(); d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_kc.release(); d->ws_kmeans.release(); d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
   d->ws_attn_stats.release(); d->ws_attn_flags.release(); d->ws_attn_cnt.release(); d->ws_attn_part.release();
   for (auto& t : d->text_cache) { t.text.release(); t.pool.release(); }
   for (auto& kv : d->staged) kv.second.dev.release();   // a handle destroyed before finalize still holds its staged matrices

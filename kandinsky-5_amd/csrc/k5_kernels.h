@@ -65,6 +65,10 @@ void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned lon
                               const int** cnt);
 int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
                                 int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s);
+// sequence parallelism: a rank's key-block means (k5_launch_nabla_block_means into its slot of a [P][H][slot_blocks][64] buffer),
+// gathered, re-laid into the workspace (k5_launch_nabla_key_means_from_slots); k5_launch_nabla_select_rect(k = nullptr) selects from them
+int k5_launch_nabla_block_means(const void* x, int ld, int H, int nblocks, int stride_blocks, void* out, hipStream_t s);
+int k5_launch_nabla_key_means_from_slots(const void* gathered, int H, int nb, int slot_blocks, void* workspace, hipStream_t s);
 int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void* out, hipStream_t s);
 // *acc += number of kept (query block, key block) pairs of the map in `workspace` (H x nqb rows)
 int k5_launch_nabla_count(const void* workspace, int H, int nqb, int nb, unsigned long long* acc, hipStream_t s);

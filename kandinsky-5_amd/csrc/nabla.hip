@@ -37,6 +37,17 @@ __global__ __launch_bounds__(256) void block_mean_kernel(const bf16_t* __restric
   }
 }
 
+// sequence parallelism: key-block means gathered as per-rank slots [P][H][slot][64] -> the map's layout [H][nb][64]
+// (block b lives in slot b / slot_blocks; only the last slot may be short, so the padded index of a real block is its global index)
+__global__ __launch_bounds__(256) void means_relayout_kernel(const bf16_t* __restrict__ g, bf16_t* __restrict__ out, int H, int nb, int slot_blocks) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // one 16-B chunk each: (h, b, c) with c in 0..7
+  if (idx >= H * nb * 8) return;
+  const int c = idx & 7, b = (idx >> 3) % nb, h = (idx >> 3) / nb;
+  const int sl = b / slot_blocks, jj = b - sl * slot_blocks;
+  *reinterpret_cast<u32x4*>(out + ((size_t)h * nb + b) * 64 + 8 * c) =
+      *reinterpret_cast<const u32x4*>(g + (((size_t)sl * H + h) * slot_blocks + jj) * 64 + 8 * c);
+}
+
 struct SelP {
   const bf16_t* qa; const bf16_t* ka;   // [H][nb][64]
   unsigned long long* bits;             // [H][nb][nw]
@@ -292,11 +303,28 @@ size_t k5_nabla_workspace_bytes(int H, int nb) {
 // q: [Nq][ldq] bf16 = the query rows handled here (global 64-token blocks [q_block0, q_block0 + Nq/64)), k: [N][ldk] = all
 // keys; both after norm_qk + RoPE, fractal token order.  Fills the workspace (regions sized for Nq == N, rows indexed by
 // the local query block) with: qa|ka means, block bitmap, per-row counts, per-workgroup union lists.
+// block means of `nblocks` 64-token blocks of x [nblocks * 64][ld] (H heads of 64) -> out[(h * stride_blocks + b) * 64 ...]
+int k5_launch_nabla_block_means(const void* x, int ld, int H, int nblocks, int stride_blocks, void* out, hipStream_t s) {
+  if (H <= 0 || nblocks <= 0 || stride_blocks < nblocks || (ld & 7)) return K5_ERR_ARG;
+  hipLaunchKernelGGL(block_mean_kernel, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, H, stride_blocks, ld);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
+// gathered per-rank means [P][H][slot_blocks][64] -> the key-means region of `workspace` ([H][nb][64]); then
+// k5_launch_nabla_select_rect(..., k = nullptr) selects from them
+int k5_launch_nabla_key_means_from_slots(const void* gathered, int H, int nb, int slot_blocks, void* workspace, hipStream_t s) {
+  if (H <= 0 || nb <= 0 || slot_blocks <= 0 || !gathered || !workspace) return K5_ERR_ARG;
+  bf16_t* ka = (bf16_t*)((char*)workspace + (size_t)H * nb * 64 * 2);
+  hipLaunchKernelGGL(means_relayout_kernel, dim3((H * nb * 8 + 255) / 256), dim3(256), 0, s, (const bf16_t*)gathered, ka, H, nb, slot_blocks);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
+// k == nullptr: the key-block means are already in the workspace (k5_launch_nabla_key_means_from_slots)
 int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
                                 int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s) {
   if (H <= 0 || N <= 0 || Nq <= 0 || (N % 64) || (Nq % 64) || T * Hb * Wb * 64 != N) return K5_ERR_ARG;
   if (q_block0 < 0 || q_block0 * 64 + Nq > N) return K5_ERR_ARG;
-  if ((ldq & 7) || (ldk & 7)) return K5_ERR_ALIGN;
+  if ((ldq & 7) || (k && (ldk & 7))) return K5_ERR_ALIGN;
   const int nb = N / 64, nqb = Nq / 64, nw = (nb + 63) / 64, ng = (nqb + 3) / 4;
   if (nb > SEL_MAXNB) return K5_ERR_UNSUPPORTED;
   char* ws = (char*)workspace;
@@ -307,7 +335,7 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   int* list = (int*)ws; ws += (size_t)H * ((nb + 3) / 4) * nb * 4;
   int* cnt = (int*)ws;
   hipLaunchKernelGGL(block_mean_kernel, dim3(nqb), dim3(256), 0, s, (const bf16_t*)q, qa, H, nqb, ldq);
-  hipLaunchKernelGGL(block_mean_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)k, ka, H, nb, ldk);
+  if (k) hipLaunchKernelGGL(block_mean_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)k, ka, H, nb, ldk);
   SelP p;
   p.qa = qa; p.ka = ka; p.bits = bits; p.kv_nb = kv_nb; p.H = H; p.nb = nb; p.nw = nw; p.T = T; p.Hb = Hb; p.Wb = Wb;
   p.wT = wT; p.wH = wH; p.wW = wW; p.target = (float)(1.0 - (double)P);

@@ -162,6 +162,50 @@ def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain, qfuse):
     assert rel(outs[0], ref) <= {1.0: 1.5e-2, 3.0: 3e-2, 5.0: 8e-2}[gain], rel(outs[0], ref)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("P,gain", [(2, 1.0), (4, 3.0), (3, 5.0)])
+def test_full_width_nabla_P_ranks_on_one_gpu(P, gain):
+    """NABLA under sequence parallelism at 2B-Lite width (2 visual blocks, latent (8,16,32) -> 16 blocks of 64 tokens): the ranks
+    gather the SCALED keys plus the 64-token block means of their unscaled keys (all the map needs), so the sharded path runs the
+    same pre-scaled kernels, per-head flags and per-row offsets as one GPU — at gain 3 (bound 104) every head must stay on the
+    fixed-offset form in BOTH paths, at gain 5 (288) every head must take the online form.  Ranks bit-identical; against the
+    single-handle run: same map up to threshold ties, same arithmetic up to summation order."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
+    sd = O.synthetic_state_dict(O.DitConfig(**c), seed=3)
+    if gain != 1.0:
+        for k in sd:
+            if k.endswith(("query_norm.weight", "key_norm.weight")):
+                sd[k] = sd[k] * gain
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(8, 16, 32, 16, generator=g)
+    text, pooled = torch.randn(37, 3584, generator=g), torch.randn(1, 768, generator=g)
+    pos = [torch.arange(8), torch.arange(8), torch.arange(16)]
+    t = torch.tensor([875.0])
+    sp = {"P": 0.7, "wT": 3, "wH": 3, "wW": 3, "to_fractal": True}
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(sd, assign=True)
+        return d.to("cuda:0")
+
+    def call(d, r):
+        out = d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(37), scale_factor=(1.0, 2.0, 2.0), sparse_params=sp)
+        return out, d.attn_variant_counts()
+
+    fused, counts1 = call(make(), 0)
+    res = run_ranks(P, make, call)
+    outs = [o for o, _ in res]
+    for r in range(1, P):
+        assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
+    for n_fixed, n_online in [counts1] + [cnt for _, cnt in res]:
+        assert n_fixed + n_online == 2 * 28
+        assert (n_online == 0) if gain <= 3.0 else (n_fixed == 0), (gain, n_fixed, n_online)
+    print(f"NABLA P={P} gain={gain}: sharded vs single handle rel-L2 {rel(outs[0], fused):.3e}")
+    assert torch.isfinite(outs[0].float()).all()
+    assert rel(outs[0], fused) <= {1.0: 6e-3, 3.0: 1.5e-2, 5.0: 4e-2}[gain], rel(outs[0], fused)
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("P,w", [(2, 1.0), (4, 5.0)])
 def test_tiny_sampler_P_ranks_on_one_gpu(golden_meta, tiny_sd, P, w):
