@@ -281,7 +281,7 @@ struct k5_dit {
   hipEvent_t ev_slice[4] = {};                     // slice s of every peer has landed
   bool emulated = false;                           // "emulate_world": timing-only layout, results are garbage
   hipStream_t comm_stream = nullptr;              // all-gathers run here, overlapped with pass 1 of the attention
-  hipEvent_t ev_k = nullptr, ev_v = nullptr, ev_gathered = nullptr, ev_stats = nullptr;
+  hipEvent_t ev_k = nullptr, ev_v = nullptr, ev_gathered = nullptr, ev_stats = nullptr, ev_means = nullptr;
   // NABLA: fractal token permutation (cached per shape) and the selection workspace
   DevBuf ws_perm, ws_nabla; int perm_shape[3] = {0, 0, 0}; bool key_fractal = false;
   // rope cache keys
@@ -641,7 +641,10 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       K5CHK(d->comm.all_gather_inplace(kstat, (size_t)H, 4, cs));
       HIPCHK(hipEventRecord(d->ev_stats, cs));
     }
-    if (nabla) K5CHK(d->comm.all_gather_inplace(kmeans, (size_t)H * slot_blocks * 64, 2, cs));
+    if (nabla) {   // 28 x 64 values per block: lands long before the keys, and the map is computed while they travel
+      K5CHK(d->comm.all_gather_inplace(kmeans, (size_t)H * slot_blocks * 64, 2, cs));
+      HIPCHK(hipEventRecord(d->ev_means, cs));
+    }
     if (S == 1) {
       K5CHK(d->comm.all_gather_inplace(kfull, (size_t)rows_pad * D, 2, cs));
       HIPCHK(hipStreamWaitEvent(cs, d->ev_v, 0));
@@ -671,10 +674,9 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
   if (nabla) {
     // NABLA under sequence parallelism: the map rows of this rank's query blocks need the block means of
-    // ALL keys -> wait for the gather, bring the gathered means into the map's layout, select (local query blocks x all key
-    // blocks) and run the list-driven attention on the chunked V^T layout.  (Single pass: the per-row kept set is not known
-    // before the gather.)
-    HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
+    // ALL keys -> wait for the gathered means, bring them into the map's layout, select (local query blocks x all key blocks)
+    // while K' / V^T are still on their way; then the list-driven attention on the chunked V^T layout (single pass).
+    HIPCHK(hipStreamWaitEvent(s, d->ev_means, 0));
     const int nb = N / 64;
     K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
     {
@@ -690,6 +692,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     }
     const int *list, *cnt;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
+    HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
     Scope sc(d, s, "attn_self");
     K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
                                           (long long)D * ldv, s, true, hflags, variant, kmax));
@@ -1103,7 +1106,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
   for (auto& b : d->vblocks) { b.w1_f8.release(); b.w2_f8.release(); b.s1_f8.release(); b.s2_f8.release(); }
   if (d->graph_stream) { (void)hipStreamSynchronize(d->graph_stream); (void)hipStreamDestroy(d->graph_stream); (void)hipEventDestroy(d->ev_graph); }
   if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
-  for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered, d->ev_stats, d->ev_slice[0], d->ev_slice[1], d->ev_slice[2], d->ev_slice[3]}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
+  for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered, d->ev_stats, d->ev_means, d->ev_slice[0], d->ev_slice[1], d->ev_slice[2], d->ev_slice[3]}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
   auto rel_attn = [](AttnW& a) {
     DevBuf* bs[] = {&a.wqk, &a.wq, &a.wk, &a.wv, &a.wo, &a.bqk, &a.bq, &a.bk, &a.bv, &a.bo, &a.norm};
@@ -1402,6 +1405,7 @@ static int comm_common_init(k5_dit* d, int rank, int world) {
   HIPCHK(hipEventCreateWithFlags(&d->ev_v, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&d->ev_gathered, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&d->ev_stats, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&d->ev_means, hipEventDisableTiming));
   for (auto& e : d->ev_slice) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return K5_OK;
 }
