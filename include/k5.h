@@ -151,6 +151,19 @@ int k5_nabla_select_rect_bf16(const void* q, const void* k, int ldq, int ldk, in
 int k5_attention_nabla_rect_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int Nq, int N, int ldq,
                                  int ldk, int ldvt, int ldo, float score_bound, const void* workspace, int vt_chunk_keys,
                                  int64_t vt_chunk_stride, void* stream);
+/* Sequence-parallel NABLA as the engine runs it.  k5_nabla_select_rect_local_bf16: k5_nabla_select_rect_bf16 with the key blocks
+ * [local_block0, + local_blocks) — the rank's own, in place before the gather — leading every (head, 256-query group) list.
+ * k5_attention_nabla_rect_prescaled_pass: the list-driven attention on keys pre-multiplied by log2(e)/8, per-head flags and per-row
+ * offsets as in k5_attention_bf16_prescaled_rows; pass 0 = the whole lists in one launch group; 1 = only the leading local entries,
+ * leaving the fp32 state (k5_attention_state_size bytes) and no output; 2 = the remaining entries, resuming the state, writing O.
+ * A row that underflows on its per-row offset in pass 1 sets head_flags[h] = 2 and the online launch of pass 2 recomputes the head
+ * over its whole lists.  Replaces nablaT_v2 + flex_attention (kandinsky/models/utils.py:136-163, nn.py:257-280) on a token shard. */
+int k5_nabla_select_rect_local_bf16(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
+                                    int Wb, int wT, int wH, int wW, float P, void* workspace, int local_block0, int local_blocks,
+                                    void* stream);
+int k5_attention_nabla_rect_prescaled_pass(const void* Q, const void* Kc, const void* Vt, void* O, int H, int Nq, int N, int ldq, int ldk,
+                                           int ldvt, int ldo, const void* workspace, int vt_chunk_keys, int64_t vt_chunk_stride,
+                                           int* head_flags, const float* kmax, int pass, float* state, void* stream);
 int k5_nabla_mask_rect_u8(const void* workspace, int H, int q_blocks, int num_blocks, void* out_u8, void* stream);
 
 /* Dense k5_attention_bf16 with a caller-proved bound |q.k| <= score_bound for every (query, key) pair

@@ -49,6 +49,7 @@ struct AttnP {
   // per-head variant selection (engine: decided on the device from the data, attn_flags_kernel): a workgroup whose head's
   // flag differs from my_flag exits at once, so a fixed-offset launch and an online-max launch over the same grid
   // partition the heads between them.  null = every head.
+  const int* sp_begin;   // SPARSE + RANGE, nullable: per workgroup the list position this launch starts from (sp_cnt = where it ends)
   const int* head_flags; int my_flag;
   // fixed-offset form with PER-ROW offsets (pre-scaled keys): kmax[h] = max |k'_h| (with margin) -> query row q of head h runs with
   // the constant offset max(0, |q| kmax[h] - K5_ATTN_EXP_LIMIT): exp2(s - offset) <= 2^90 whatever the data, and exact unless the
@@ -117,6 +118,21 @@ constexpr float ONLINE_THR = 60.f;
 #ifndef K5_ONLINE_WPS
 #define K5_ONLINE_WPS 2   // waves per SIMD the online-max instantiations are compiled for: 2 = up to 256 VGPRs, one workgroup per CU (at 4 = 128 VGPRs the allocator spills the cold path into the tile loop: 4x slower, measured)
 #endif
+// Layout of the resumable fp32 state (k5_attention_state_bytes): the accumulators of one (head, 256-query) job are 64 KB in the order
+// the 16x16x32 kernel's lanes hold them — [16-row group][d tile of 16][lane group g = (d >> 2) & 3][row & 15][4 floats] — so that one
+// store instruction of a wave is 1 KB contiguous (round 2 had [q][H * 64]: 64-B pieces at 7-KB strides, 0.56 TB/s measured; the state
+// round trip of the sequence-parallel passes was 6 % of a shard's step).  (m, l) pairs follow: [16-row group][slot 0..3][row & 15][2].
+// Every reader / writer — both kernel forms and the merge — goes through these two functions.
+// (float indices; < 2^31 up to 1.6 M query rows x 28 heads)
+__device__ __forceinline__ uint32_t st_o_off(int q, int h, int d, int nqb) {   // d % 4 == 0
+  const uint32_t qb = (uint32_t)q >> 8, r = (uint32_t)q & 255u;
+  return ((((uint32_t)(h * nqb) + qb) * 16u + (r >> 4)) * 4u + ((uint32_t)d >> 4)) * 256u + (((uint32_t)d >> 2) & 3u) * 64u + (r & 15u) * 4u;
+}
+__device__ __forceinline__ uint32_t st_ml_off(int q, int h, int slot, int nqb, int H) {
+  const uint32_t qb = (uint32_t)q >> 8, r = (uint32_t)q & 255u;
+  return (uint32_t)(H * nqb) * (256u * 64u) + ((((uint32_t)(h * nqb) + qb) * 16u + (r >> 4)) * 4u + (uint32_t)slot) * 32u + (r & 15u) * 2u;
+}
+
 // QN: the norm_qk + RoPE of the queries is fused into the Q load (K5QueryNorm, pre-scaled keys).  A template parameter and not a runtime
 // branch: with the code merely PRESENT the compiler schedules the tile loop of the plain form differently (same instructions, +1 % time).
 template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false, bool QN = false>
@@ -246,8 +262,10 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   const int* sp_list = SPARSE ? p.sp_list + (size_t)(h * p.nqb + qb) * p.sp_stride : nullptr;
   const int Tall = SPARSE ? p.sp_cnt[h * p.nqb + qb] : ((!BOUNDED && late) ? p.late_total : p.tile_cnt);
   // this workgroup's share of the tile sequence: positions [E0, T)  (everything unless the job is split)
-  const int E0 = RANGE ? (int)(((long long)Tall * part) / p.splits) : 0;
-  const int T = RANGE ? (int)(((long long)Tall * (part + 1)) / p.splits) : Tall;
+  // SPARSE + RANGE: the launch covers the list positions [B0, Tall) (B0 > 0: the second pass of a two-pass list walk)
+  const int B0 = (SPARSE && RANGE && p.sp_begin && !(!BOUNDED && late)) ? min(p.sp_begin[h * p.nqb + qb], Tall) : 0;
+  const int E0 = RANGE ? B0 + (int)(((long long)(Tall - B0) * part) / p.splits) : 0;
+  const int T = RANGE ? B0 + (int)(((long long)(Tall - B0) * (part + 1)) / p.splits) : Tall;
   const int nfull = p.kv_len / KB;                    // key tiles with all 64 keys valid (NABLA: all of them)
   auto tile_of = [&](int e) -> int {                  // sequence position -> 64-key tile index (wave-uniform)
     if (SPARSE) return sp_list[e] & 0xffffff;   // scalar loads (s_load): keep every int* store / atomic of this kernel BEHIND the tile loop,
@@ -349,17 +367,21 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   const bf16x8 onesf = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
   // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
   auto state_base = [&]() { return part == 0 ? p.state : p.split_state + (size_t)(part - 1) * p.split_stride; };
-  auto state_o = [&](int qt) { return state_base() + (size_t)(q0 + 16 * qt + l15) * (p.H * 64) + h * 64 + 4 * g; };
-  auto state_ml = [&](int qt) { return state_base() + (size_t)p.q_len * (p.H * 64) + (((size_t)(q0 + 16 * qt + l15) * p.H + h) * 4 + g) * 2; };
+  // st_o_off / st_ml_off of (q0 + 16 qt + l15, h, 4 g): everything but the lane term is wave-uniform
+  const uint32_t st_job = ((uint32_t)(h * p.nqb + qb) * 16u + 2u * (uint32_t)wave) * 4u;
+  auto state_o = [&](int qt) { return state_base() + ((st_job + 4u * (uint32_t)qt) * 256u + (uint32_t)lane * 4u); };   // + 256 dt: the d tile
+  auto state_ml = [&](int qt, int slot) {
+    return state_base() + ((uint32_t)(p.H * p.nqb) * (256u * 64u) + (st_job + 4u * (uint32_t)qt + (uint32_t)slot) * 32u + (uint32_t)l15 * 2u);
+  };
   if (RANGE && (p.flags & 1) && part == 0 && !(!BOUNDED && late)) {   // resume: accumulators of an earlier launch over other key tiles
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
       if (q0 + 16 * qt + l15 < p.q_len) {
-        const float* st_o = state_o(qt); const float* st_ml = state_ml(qt);
+        const float* st_o = state_o(qt);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) ot[dt][qt] = *reinterpret_cast<const f32x4*>(st_o + 16 * dt);
-        if (!BOUNDED) { const float m = st_ml[0]; nm[qt] = f32x4{-m, -m, -m, -m}; }
-        { const float* b4 = st_ml - 2 * g; const float L = (b4[1] + b4[3]) + (b4[5] + b4[7]); lt[qt] = f32x4{L, L, L, L}; }   // the four slots' row sums
+        for (int dt = 0; dt < 4; ++dt) ot[dt][qt] = *reinterpret_cast<const f32x4*>(st_o + 256 * dt);
+        if (!BOUNDED) { const float m = state_ml(qt, g)[0]; nm[qt] = f32x4{-m, -m, -m, -m}; }
+        { const float L = (state_ml(qt, 0)[1] + state_ml(qt, 1)[1]) + (state_ml(qt, 2)[1] + state_ml(qt, 3)[1]); lt[qt] = f32x4{L, L, L, L}; }   // the four slots' row sums
       }
     if (!BOUNDED) {   // a state left by a launch that saw no tile carries m = -1e30: still fresh (wave-uniform by construction:
       fresh = __all(nm[0][0] > 1e29f && nm[1][0] > 1e29f);   // every query of a wave sees the same tiles; rows >= q_len keep 0)
@@ -367,6 +389,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     }
   }
 
+  bool seen = !SPARSE && T > E0;   // wave-uniform: this wave's queries saw at least one key tile in this launch
   if (T > E0) load_tile(E0, 0);
   __syncthreads();   // drains the DMA (vmcnt) and publishes the tile
   // one key tile; BUF (LDS double-buffer half) is a compile-time constant so that every ds_read address is
@@ -378,6 +401,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     const char* cK = sK + buf * TILE;
     const char* cV = sV + buf * TILE;
     if (!SPARSE || (sp_list[e] & my_bit)) {   // wave-uniform: skip kv blocks this query block did not select
+    if (SPARSE) seen = true;
     {
     // ---- S^T = K Q^T : four 16-key x two 16-query MFMA tiles, two k-steps over d; K fragments streamed from LDS ----
     f32x4 st[4][2];
@@ -491,13 +515,13 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
       if (q0 + 16 * qt + l15 < p.q_len) {
-        float* st_o = state_o(qt); float* st_ml = state_ml(qt);
+        float* st_o = state_o(qt); float* st_ml = state_ml(qt, g);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(st_o + 16 * dt) = ot[dt][qt];
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(st_o + 256 * dt) = ot[dt][qt];
         st_ml[0] = BOUNDED ? 0.f : (fresh ? -1e30f : -nm[qt][0]);   // no tile seen: weight 0 in a merge, "still fresh" on resume
         st_ml[1] = g == 0 ? lt[qt][0] : 0.f;                    // slot 0 carries the whole row sum
         // per-row offsets: a part whose own sum underflows flags the head (conservative: the row's total is at least this part's)
-        if (BOUNDED && PRE && p.kmax && nm[qt][0] < 0.f && lt[qt][0] < K5_ATTN_ROW_MIN && T > E0) const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
+        if (BOUNDED && PRE && p.kmax && nm[qt][0] < 0.f && lt[qt][0] < K5_ATTN_ROW_MIN && seen) const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
       }
     return;
   }
@@ -611,15 +635,15 @@ __global__ __launch_bounds__(512, 4) void attn_fwd32_kernel(AttnP p) {
   const float mc_fixed = 0.f;
   // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
   auto state_base = [&]() { return part == 0 ? p.state : p.split_state + (size_t)(part - 1) * p.split_stride; };
-  auto state_o = [&]() { return state_base() + (size_t)(q0 + l31) * (p.H * 64) + h * 64 + 4 * hi; };
-  auto state_ml = [&]() { return state_base() + (size_t)p.q_len * (p.H * 64) + (((size_t)(q0 + l31) * p.H + h) * 4 + hi) * 2; };
+  auto state_o = [&](int d) { return state_base() + st_o_off(q0 + l31, h, d, p.nqb); };   // d = 32 dd + 8 rg + 4 hi: this lane's 4 floats
+  auto state_ml = [&](int slot) { return state_base() + st_ml_off(q0 + l31, h, slot, p.nqb, p.H); };
   if (RANGE && (p.flags & 1) && part == 0 && q0 + l31 < p.q_len) {   // resume: accumulators of an earlier launch over other key tiles
-    const float* st_o = state_o(); const float* st_ml = state_ml();
+    const float* st_ml = state_ml(hi);
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(st_o + 32 * d + 8 * rg);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(state_o(32 * d + 8 * rg + 4 * hi));
 #pragma unroll
         for (int e = 0; e < 4; ++e) ot[d][4 * rg + e] = v[e];
       }
@@ -711,16 +735,17 @@ __global__ __launch_bounds__(512, 4) void attn_fwd32_kernel(AttnP p) {
   }
   if (RANGE && (p.flags & 2)) {   // leave the running state for a later launch; no output yet
     if (q0 + l31 < p.q_len) {
-      float* st_o = state_o(); float* st_ml = state_ml();
+      float* st_ml = state_ml(hi);
+      float* st_m2 = state_ml(hi + 2);
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const f32x4 v = {ot[d][4 * rg], ot[d][4 * rg + 1], ot[d][4 * rg + 2], ot[d][4 * rg + 3]};
-          *reinterpret_cast<f32x4*>(st_o + 32 * d + 8 * rg) = v;
+          *reinterpret_cast<f32x4*>(state_o(32 * d + 8 * rg + 4 * hi)) = v;
         }
       st_ml[0] = m_run; st_ml[1] = l_run;
-      st_ml[4] = m_run; st_ml[5] = 0.f;   // slots 2, 3 (the 16x16 kernel's lane groups): no contribution
+      st_m2[0] = m_run; st_m2[1] = 0.f;   // slots 2, 3 (the 16x16 kernel's lane groups): no contribution
     }
     return;
   }
@@ -748,8 +773,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd32_kernel(AttnP p) {
 
 // Merge the per-part running states of the split jobs [job0, job0 + njobs) and write their normalised rows of O.
 // One workgroup per job, one thread per query: O = sum_s w_s O_s / sum_s w_s l_s,  w_s = exp2((m_s - max m) c)  (w_s = 1 when
-// the softmax offset is fixed).  State layout as written by attn_fwd_kernel: O^T accumulators [q][H*64] fp32 in natural d
-// order, then (m, l) per (q, h, lane group g = 0..3) — l is that lane's partial sum, m is common to the four.
+// the softmax offset is fixed).  State layout: st_o_off / st_ml_off — (m, l) per (q, h, slot 0..3): l is that lane group's partial
+// sum, m is common to the four.
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, const float* split_state, long long split_stride,
                                                          int splits, int job0, int H, int q_len, int nqb, float c, bf16_t* O, int ldo,
                                                          int bounded_all, const int* head_flags, float* state_out) {
@@ -757,18 +782,17 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
   const bool bounded = head_flags ? head_flags[h] == 1 : bounded_all != 0;   // fixed offset: every part's weight is 1
   const int q = qb * QB + threadIdx.x;
   if (q >= q_len) return;
-  const size_t o_off = (size_t)q * (H * 64) + h * 64;
-  const size_t ml_off = (size_t)q_len * (H * 64) + ((size_t)q * H + h) * 8;
+  const size_t ml0 = st_ml_off(q, h, 0, nqb, H), ml1 = st_ml_off(q, h, 1, nqb, H), ml2 = st_ml_off(q, h, 2, nqb, H), ml3 = st_ml_off(q, h, 3, nqb, H);
   float w[8], m = -3.0e38f, l = 0.f;
   for (int s = 0; s < splits; ++s) {
     const float* st = s == 0 ? state0 : split_state + (size_t)(s - 1) * split_stride;
-    w[s] = st[ml_off];                       // m_s for now
+    w[s] = st[ml0];                          // m_s for now
     if (!bounded) m = fmaxf(m, w[s]);
   }
   for (int s = 0; s < splits; ++s) {
     const float* st = s == 0 ? state0 : split_state + (size_t)(s - 1) * split_stride;
     w[s] = bounded ? 1.f : __builtin_amdgcn_exp2f((w[s] - m) * c);
-    l += w[s] * ((st[ml_off + 1] + st[ml_off + 3]) + (st[ml_off + 5] + st[ml_off + 7]));
+    l += w[s] * ((st[ml0 + 1] + st[ml1 + 1]) + (st[ml2 + 1] + st[ml3 + 1]));
   }
   const float inv = l > 0.f ? 1.0f / l : 0.f;
   bf16_t* op = O + (size_t)q * ldo + h * 64;
@@ -777,19 +801,19 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < splits; ++s) {
       const float* st = s == 0 ? state0 : split_state + (size_t)(s - 1) * split_stride;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(st + o_off + d);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(st + st_o_off(q, h, d, nqb));
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[e] += w[s] * v[e];
     }
-    if (state_out) { *reinterpret_cast<f32x4*>(state_out + o_off + d) = a; continue; }   // an intermediate pass: the merged state, not O
+    if (state_out) { *reinterpret_cast<f32x4*>(state_out + st_o_off(q, h, d, nqb)) = a; continue; }   // an intermediate pass: the merged state, not O
     u32x2 o = {pack_bf16x2(a[0] * inv, a[1] * inv), pack_bf16x2(a[2] * inv, a[3] * inv)};
     *reinterpret_cast<u32x2*>(op + d) = o;
   }
   if (state_out) {   // (m, l) of the merged parts in the layout the kernels resume from: m in all four slots, the row sum in slot 0
     // (this thread read its own (q, h) entries above and is the only one to write them: state_out may be state0)
     const float mm = bounded ? 0.f : m;
-    float* ml = state_out + ml_off;
-    ml[0] = mm; ml[1] = l; ml[2] = mm; ml[3] = 0.f; ml[4] = mm; ml[5] = 0.f; ml[6] = mm; ml[7] = 0.f;
+    state_out[ml0] = mm; state_out[ml0 + 1] = l; state_out[ml1] = mm; state_out[ml1 + 1] = 0.f;
+    state_out[ml2] = mm; state_out[ml2 + 1] = 0.f; state_out[ml3] = mm; state_out[ml3 + 1] = 0.f;
   }
 }
 
@@ -823,7 +847,7 @@ __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstrid
 // (k5_launch_attn_flags) — flag 1: fixed offset, flag 0: lazy online max; both variants are launched over the same grid and
 // each workgroup exits at once unless its head is its variant's.
 
-size_t k5_attention_state_bytes(int H, int q_len) { return (size_t)q_len * H * (64 + 8) * sizeof(float); }
+size_t k5_attention_state_bytes(int H, int q_len) { return (size_t)H * ((q_len + QB - 1) / QB) * QB * (64 + 8) * sizeof(float); }   // st_o_off / st_ml_off
 
 // Workspace of the balanced launcher below: up to K5_ATTN_MAX_SPLITS - 1 extra states + (when the caller passes no state
 // of its own) one base state.
@@ -967,7 +991,7 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
 int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled,
-                                    const int* head_flags, int variant, const float* kmax) {
+                                    const int* head_flags, int variant, const float* kmax, const K5SparsePass* pass, float* ws) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0 || (q_len % KB) || (kv_len % KB) || !list || !cnt) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -981,8 +1005,12 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;
   p.kmax = kmax; p.late_pass = 0; p.late_total = 0; p.q_norm_w = nullptr; p.q_cos = p.q_sin = nullptr; p.variant_counters = nullptr;
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
-  p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride;
+  p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride; p.sp_begin = nullptr;
   p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;
+  if (pass) {   // one pass of a two-pass walk of the lists (sequence parallelism): [begin, cnt) of every list, fp32 state in / out
+    if (!k_prescaled || !pass->state || (pass->flags & ~3) || pass->late_pass < 0 || pass->late_pass > 2 || (pass->late_pass && !kmax)) return K5_ERR_ARG;
+    p.sp_begin = pass->begin; p.state = pass->state; p.flags = pass->flags; p.late_pass = pass->late_pass;
+  }
   p.seg_len = 0; p.seg_stride = 0; p.seg_skip = 0x7fffffff;
   p.job0 = 0; p.splits = 1; p.split_state = nullptr; p.split_stride = 0;
   const dim3 grid(H * p.nqb), block(512);
@@ -991,8 +1019,40 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
     const bool run_fixed = head_flags ? variant == K5_ATTN_AUTO : (variant == K5_ATTN_AUTO && bounded);
     const bool run_online = head_flags ? true : !run_fixed;
     p.head_flags = (run_fixed && run_online) ? head_flags : nullptr;
-    if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, true, false, true>), grid, block, 0, stream, p); }
-    if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, true, false, true>), grid, block, 0, stream, p); }
+    auto launch = [&](int njobs, bool rangek) {
+      const dim3 g(njobs);
+      if (rangek) {
+        if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, true, true, true>), g, block, 0, stream, p); }
+        if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, true, true, true>), g, block, 0, stream, p); }
+      } else {
+        if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, true, false, true>), g, block, 0, stream, p); }
+        if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, true, false, true>), g, block, 0, stream, p); }
+      }
+    };
+    // balanced like the dense launches: the (head, 256-query) jobs of the last, partly filled round of resident workgroups are cut
+    // S ways along their lists (every part leaves its fp32 state) and merged — 2576 jobs of a 4-GPU shard of the 10 s clip are 5.03
+    // rounds: without this the launch takes 6
+    const int jobs = H * p.nqb, slots = attn_slots();
+    const int full = jobs / slots * slots, rem = jobs - full;
+    int S = rem > 0 ? slots / rem : 1;
+    if (S > K5_ATTN_MAX_SPLITS) S = K5_ATTN_MAX_SPLITS;
+    static const bool no_balance = getenv("K5_ATTN_NO_BALANCE") != nullptr;   // A/B switch for benchmarking
+    if (!ws || S < 2 || no_balance) {
+      launch(jobs, pass != nullptr);
+    } else {
+      if (full > 0) launch(full, pass != nullptr);
+      const long long stride = (long long)(k5_attention_state_bytes(H, q_len) / sizeof(float));
+      const int flags = p.flags;
+      float* state = p.state;
+      const bool to_state = (flags & 2) != 0;
+      float* base = (flags & 1) ? state : ws;
+      p.job0 = full; p.splits = S; p.state = base; p.split_state = ws + stride; p.split_stride = stride;
+      p.flags = (flags & 1) | 2;
+      launch(rem * S, true);
+      hipLaunchKernelGGL(attn_merge_kernel, dim3(rem), dim3(256), 0, stream, base, ws + stride, stride, S, full, H, q_len, p.nqb, 1.f,
+                         (bf16_t*)O, ldo, (run_fixed && !run_online) ? 1 : 0, (run_fixed && run_online) ? head_flags : nullptr,
+                         to_state ? state : nullptr);
+    }
   } else if (bounded) {
     hipLaunchKernelGGL((attn_fwd_kernel<true, true, false>), grid, block, 0, stream, p);
   } else {

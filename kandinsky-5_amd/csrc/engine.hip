@@ -275,6 +275,7 @@ struct k5_dit {
   long long nabla_possible = 0;                    // profiling: 64x64 blocks the NABLA maps could have kept (kept: ws_attn_cnt[2])
   int attn_mode = 0;                               // K5_ATTN_AUTO / K5_ATTN_ONLINE (k5_dit_set_option "attn_mode")
   int sp_pass1_tiles = 0;                          // k5_dit_set_option "sp_pass1_tiles" (0 = all local key tiles)
+  int sp_nabla_passes = 1;                         // "sp_nabla_passes" = 2: NABLA under sequence parallelism attends the rank's own key blocks during the gather
   int fuse_qnorm = 0;                              // "attn_fuse_qnorm": norm_qk + RoPE of the visual queries inside the attention kernel
   bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 180)
   int sp_slices = 1;                               // "sp_slices": the K / V^T exchange of a block in this many slices (dense attention)
@@ -537,6 +538,8 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     const int *list, *cnt;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
     Scope sc(d, s, fam_attn);
+    // (no tail balancing here: 10 248 jobs are 20 rounds of unequal lists — measured -0.6 % at density 0.81, +1 % at 0.12, +2.4 % at
+    // 0.05; a token shard's 5 rounds are another matter, run_self_attention_sp)
     K5CHK(k5_launch_attention_bf16_sparse(qk, pre ? d->ws_kc.as<bf16_t>() : (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, pre ? D : 2 * D,
                                           ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant, kmax));
   } else {
@@ -683,19 +686,38 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       Scope sc(d, s, "nabla_map");
       K5CHK(k5_launch_nabla_key_means_from_slots(kmeans, H, nb, slot_blocks, d->ws_nabla.p, s));
       K5CHK(k5_launch_nabla_select_rect(q, nullptr, D, 0, H, rows, r * slot_blocks, N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
-                                        nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s));
+                                        nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, r * slot_blocks, rows / 64));   // own key blocks lead the lists
     }
     if (d->profiling) {
       K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
       K5CHK(k5_launch_nabla_count(d->ws_nabla.p, H, rows / 64, nb, d->ws_attn_cnt.as<unsigned long long>() + 2, s));
       d->nabla_possible += (long long)H * (rows / 64) * nb;
     }
-    const int *list, *cnt;
-    k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
-    HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
-    Scope sc(d, s, "attn_self");
-    K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
-                                          (long long)D * ldv, s, true, hflags, variant, kmax));
+    const int *list, *cnt, *cnt_local;
+    k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt, &cnt_local);
+    K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
+    if (d->sp_nabla_passes > 1 && P > 1) {
+      // two passes over every list: the rank's own key blocks (they lead the lists; K' / V^T of them are in place) while the other
+      // ranks' keys travel — state out —, then the rest once the gather has landed (resume, normalise); late fallback as in the dense
+      // schedule (a head whose row underflows on its per-row offset in pass 1 is recomputed from scratch by the online form of pass 2)
+      K5CHK(d->ws_attn_state.ensure(k5_attention_state_bytes(H, rows)));
+      {
+        const K5SparsePass p1{nullptr, d->ws_attn_state.as<float>(), 2, kmax ? 1 : 0};
+        Scope sc(d, s, "attn_self");
+        K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt_local, nb, rows_pad,
+                                              (long long)D * ldv, s, true, hflags, variant, kmax, &p1, d->ws_attn_bal.as<float>()));
+      }
+      HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
+      const K5SparsePass p2{cnt_local, d->ws_attn_state.as<float>(), 1, kmax ? 2 : 0};
+      Scope sc(d, s, "attn_self");
+      K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
+                                            (long long)D * ldv, s, true, hflags, variant, kmax, &p2, d->ws_attn_bal.as<float>()));
+    } else {
+      HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
+      Scope sc(d, s, "attn_self");
+      K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
+                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, d->ws_attn_bal.as<float>()));
+    }
   } else {
     // ... while the main stream attends the local query rows to the LOCAL key chunk (pass 1, leaves the fp32 state),
     // then, once every chunk has arrived, to all the other chunks (pass 2, resumes the state and normalises).
@@ -1466,6 +1488,9 @@ extern "C" int k5_dit_comm_init_loopback(k5_dit* d, k5_loopback* lb, int rank) {
 //                     applies it inside the attention kernel's Q-fragment load (K5QueryNorm; needs attn_row_offsets or attn_mode 1);
 //                     2 = under sequence parallelism too.  Measured neutral (elementwise -2.0 ms, attention +0.6 .. +3.4 ms per step
 //                     depending on how the compiler schedules the tile loop of the extra instantiation), hence opt-in.
+//   "sp_nabla_passes" 1 (default) / 2: NABLA under sequence parallelism walks every list in one pass after the gather, or in two — the
+//                     rank's own key blocks while the other ranks' keys travel, the rest after the gather (costs 12 % of the attention
+//                     in compute, emulated P = 4; pays when the exposed part of the gather is longer than that — a property of the node)
 //   "sp_slices"       S in 1..4: exchange K / V^T of a block in S slices (grouped send/recv to every peer at once) and attend each
 //                     slice as it lands — the gather hides behind the attention of the slices before it (dense attention; NABLA and
 //                     S = 1 keep the single in-place all-gather).  Token slots become multiples of 64 S.
@@ -1481,6 +1506,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   }
   if (!strcmp(name, "sp_pass1_tiles")) { if (value < 0) return K5_ERR_ARG; d->sp_pass1_tiles = value; return K5_OK; }
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
+  if (!strcmp(name, "sp_nabla_passes")) { if (value < 1 || value > 2) return K5_ERR_ARG; d->sp_nabla_passes = value; return K5_OK; }
   if (!strcmp(name, "attn_fuse_qnorm")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->fuse_qnorm = value; return K5_OK; }
   if (!strcmp(name, "sp_slices")) {
     if (value < 1 || value > 4) return K5_ERR_ARG;
@@ -1503,6 +1529,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "sp_slices")) *value = d->sp_slices;
   else if (!strcmp(name, "attn_row_offsets")) *value = d->row_offsets ? 1 : 0;
   else if (!strcmp(name, "attn_fuse_qnorm")) *value = d->fuse_qnorm;
+  else if (!strcmp(name, "sp_nabla_passes")) *value = d->sp_nabla_passes;
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
   else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }

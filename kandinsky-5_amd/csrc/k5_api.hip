@@ -164,6 +164,29 @@ int k5_attention_nabla_rect_bf16(const void* Q, const void* K, const void* Vt, v
              "k5_attention_nabla_rect_bf16");
 }
 
+// what the sequence-parallel engine runs: the map with the rank's own key blocks leading every list, and the list-driven attention on
+// pre-scaled keys with per-head flags / per-row offsets — in one pass (pass = 0) or two (1: the leading local entries, state out;
+// 2: the rest, state in, normalise; a head whose row underflows in pass 1 goes late and is recomputed by the online form of pass 2)
+int k5_nabla_select_rect_local_bf16(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
+                                    int Wb, int wT, int wH, int wW, float P, void* workspace, int local_block0, int local_blocks,
+                                    void* stream) {
+  return ret(k5_launch_nabla_select_rect(q, k, ldq, ldk, H, Nq, q_block0, N, T, Hb, Wb, wT, wH, wW, P, workspace,
+                                         (hipStream_t)stream, local_block0, local_blocks), "k5_nabla_select_rect_local_bf16");
+}
+int k5_attention_nabla_rect_prescaled_pass(const void* Q, const void* Kc, const void* Vt, void* O, int H, int Nq, int N, int ldq, int ldk,
+                                           int ldvt, int ldo, const void* workspace, int vt_chunk_keys, int64_t vt_chunk_stride,
+                                           int* head_flags, const float* kmax, int pass, float* state, void* stream) {
+  if (!workspace || N <= 0 || (N % 64) || pass < 0 || pass > 2 || (pass && !state) || !head_flags || !kmax)
+    return ret(K5_ERR_ARG, "k5_attention_nabla_rect_prescaled_pass");
+  const int *list, *cnt, *cnt_local;
+  k5_nabla_workspace_views(const_cast<void*>(workspace), H, N / 64, nullptr, nullptr, &list, &cnt, &cnt_local);
+  const K5SparsePass p1{nullptr, state, 2, 1}, p2{cnt_local, state, 1, 2};
+  return ret(k5_launch_attention_bf16_sparse(Q, Kc, Vt, O, H, Nq, N, ldq, ldk, ldvt, ldo, 0.f, list, pass == 1 ? cnt_local : cnt, N / 64,
+                                             vt_chunk_keys, (long long)vt_chunk_stride, (hipStream_t)stream, true, head_flags, K5_ATTN_AUTO,
+                                             kmax, pass == 0 ? nullptr : (pass == 1 ? &p1 : &p2)),
+             "k5_attention_nabla_rect_prescaled_pass");
+}
+
 int k5_nabla_mask_rect_u8(const void* workspace, int H, int q_blocks, int num_blocks, void* out_u8, void* stream) {
   return ret(k5_launch_nabla_mask_u8(workspace, H, q_blocks, num_blocks, out_u8, (hipStream_t)stream), "k5_nabla_mask_rect_u8");
 }

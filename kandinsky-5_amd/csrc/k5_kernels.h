@@ -28,6 +28,9 @@ size_t k5_attention_state_bytes(int H, int q_len);
 // segmented walk instead of the (offset, skip) one: position e -> tile_off0 + seg(e / len) * stride + e % len, where segments
 // >= skip shift up by one (the sequence-parallel schedule's "slice s of every rank's slot except mine"); tile_cnt positions
 struct K5TileSegments { int len, stride, skip; };
+// one pass of a two-pass walk of the NABLA lists (pre-scaled keys): list positions [begin[w], cnt[w]) of workgroup w (begin null: 0);
+// state (k5_attention_state_bytes) is resumed with flags & 1 and left — no output — with flags & 2; late_pass as in the range launcher
+struct K5SparsePass { const int* begin; float* state; int flags; int late_pass; };
 // norm_qk (+ apply_rotary) of the QUERY rows fused into the attention kernel's Q-fragment load: Q then holds the raw projection.
 // w: 64 RMSNorm weights.  cos / sin null: cross-attention (unscaled keys; K5_ERR_UNSUPPORTED unless score_bound selects the fixed-offset
 // kernel).  cos / sin [row][32] fp32: visual self-attention (pre-scaled keys); with row_offset_kmax the fixed-offset workgroups then
@@ -62,9 +65,10 @@ size_t k5_nabla_workspace_bytes(int H, int nb);
 int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,
                            int wW, float P, void* workspace, hipStream_t s);
 void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned long long** bits, const int** kv_nb, const int** list,
-                              const int** cnt);
+                              const int** cnt, const int** cnt_local = nullptr);
 int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
-                                int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s);
+                                int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s,
+                                int local_block0 = 0, int local_blocks = 0);   // > 0: these key blocks lead every list (cnt_local of them)
 // sequence parallelism: a rank's key-block means (k5_launch_nabla_block_means into its slot of a [P][H][slot_blocks][64] buffer),
 // gathered, re-laid into the workspace (k5_launch_nabla_key_means_from_slots); k5_launch_nabla_select_rect(k = nullptr) selects from them
 int k5_launch_nabla_block_means(const void* x, int ld, int H, int nblocks, int stride_blocks, void* out, hipStream_t s);
@@ -75,7 +79,8 @@ int k5_launch_nabla_count(const void* workspace, int H, int nqb, int nb, unsigne
 int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled = false,
-                                    const int* head_flags = nullptr, int variant = 0, const float* row_offset_kmax = nullptr);
+                                    const int* head_flags = nullptr, int variant = 0, const float* row_offset_kmax = nullptr,
+                                    const K5SparsePass* pass = nullptr, float* balance_ws = nullptr);   // k5_attention_balance_bytes; pre-scaled keys
 
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,

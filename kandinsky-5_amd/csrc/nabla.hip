@@ -221,31 +221,43 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
   }
 }
 
-// per (h, group of 4 query blocks): list[(h*ng+g)*nb + e] = kv_block | membership << 24 ; cnt[h*ng+g]
+// per (h, group of 4 query blocks): list[(h*ng+g)*nb + e] = kv_block | membership << 24 ; cnt[h*ng+g].
+// Sequence parallelism: the key blocks [loc0, loc0 + locn) — the rank's own, already in place before the gather — come FIRST and
+// cnt_local[h*ng+g] says how many they are: the attention runs them as a first pass while the other ranks' keys travel.
 __global__ __launch_bounds__(256) void nabla_union_kernel(const unsigned long long* __restrict__ bits, int* __restrict__ list,
-                                                          int* __restrict__ cnt, int H, int nqb, int nb, int nw, int ng) {
+                                                          int* __restrict__ cnt, int* __restrict__ cnt_local, int H, int nqb, int nb,
+                                                          int nw, int ng, int loc0, int locn) {
   const int lane = threadIdx.x & 63;
   const int gi = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gi >= H * ng) return;
   const int h = gi / ng, g = gi % ng;
   int pos = 0;
-  for (int c = 0; c < nw; ++c) {
-    unsigned long long w[4], u = 0;
+  for (int sweep = locn > 0 ? 0 : 1; sweep < 2; ++sweep) {
+    for (int c = 0; c < nw; ++c) {
+      // bit mask of the local blocks inside word c
+      const int lo = max(loc0 - 64 * c, 0), hi = min(loc0 + locn - 64 * c, 64);
+      unsigned long long lm = 0ull;
+      if (locn > 0 && hi > lo) lm = (hi - lo == 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+      const unsigned long long take = sweep == 0 ? lm : ~lm;
+      if (!take) continue;
+      unsigned long long w[4], u = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qb = 4 * g + r;
-      w[r] = qb < nqb ? bits[((size_t)h * nqb + qb) * nw + c] : 0ull;
-      u |= w[r];
-    }
-    if ((u >> lane) & 1ull) {
-      int mem = 0;
+      for (int r = 0; r < 4; ++r) {
+        const int qb = 4 * g + r;
+        w[r] = qb < nqb ? bits[((size_t)h * nqb + qb) * nw + c] & take : 0ull;
+        u |= w[r];
+      }
+      if ((u >> lane) & 1ull) {
+        int mem = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mem |= (int)((w[r] >> lane) & 1ull) << r;
-      list[(size_t)gi * nb + pos + __popcll(u & ((1ull << lane) - 1ull))] = (c * 64 + lane) | (mem << 24);
+        for (int r = 0; r < 4; ++r) mem |= (int)((w[r] >> lane) & 1ull) << r;
+        list[(size_t)gi * nb + pos + __popcll(u & ((1ull << lane) - 1ull))] = (c * 64 + lane) | (mem << 24);
+      }
+      pos += __popcll(u);
     }
-    pos += __popcll(u);
+    if (sweep == 0 && lane == 0) cnt_local[gi] = pos;
   }
-  if (lane == 0) cnt[gi] = pos;
+  if (lane == 0) { cnt[gi] = pos; if (locn <= 0) cnt_local[gi] = 0; }
 }
 
 __global__ __launch_bounds__(256) void nabla_expand_kernel(const unsigned long long* __restrict__ bits, unsigned char* __restrict__ out,
@@ -297,7 +309,7 @@ size_t k5_nabla_workspace_bytes(int H, int nb) {
          + (size_t)H * nb * nw * 8         // bits
          + (size_t)H * nb * 4              // kv_nb
          + (size_t)H * ng * nb * 4         // union lists
-         + (size_t)H * ng * 4 + 256;       // counts
+         + (size_t)2 * H * ng * 4 + 256;   // counts, counts of the leading local entries (sequence parallelism)
 }
 
 // q: [Nq][ldq] bf16 = the query rows handled here (global 64-token blocks [q_block0, q_block0 + Nq/64)), k: [N][ldk] = all
@@ -321,7 +333,8 @@ int k5_launch_nabla_key_means_from_slots(const void* gathered, int H, int nb, in
 
 // k == nullptr: the key-block means are already in the workspace (k5_launch_nabla_key_means_from_slots)
 int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
-                                int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s) {
+                                int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s, int local_block0, int local_blocks) {
+  if (local_blocks < 0 || local_block0 < 0 || (local_blocks > 0 && local_block0 + local_blocks > N / 64)) return K5_ERR_ARG;
   if (H <= 0 || N <= 0 || Nq <= 0 || (N % 64) || (Nq % 64) || T * Hb * Wb * 64 != N) return K5_ERR_ARG;
   if (q_block0 < 0 || q_block0 * 64 + Nq > N) return K5_ERR_ARG;
   if ((ldq & 7) || (k && (ldk & 7))) return K5_ERR_ALIGN;
@@ -334,6 +347,7 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   int* kv_nb = (int*)ws; ws += (size_t)H * nb * 4;
   int* list = (int*)ws; ws += (size_t)H * ((nb + 3) / 4) * nb * 4;
   int* cnt = (int*)ws;
+  int* cnt_local = cnt + (size_t)H * ((nb + 3) / 4);
   hipLaunchKernelGGL(block_mean_kernel, dim3(nqb), dim3(256), 0, s, (const bf16_t*)q, qa, H, nqb, ldq);
   if (k) hipLaunchKernelGGL(block_mean_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)k, ka, H, nb, ldk);
   SelP p;
@@ -353,18 +367,19 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   else if (nv <= 24) launch(std::integral_constant<int, 24>{}, std::integral_constant<int, 4>{});
   else if (nv <= 32) launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 2>{});
   else launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 1>{});
-  hipLaunchKernelGGL(nabla_union_kernel, dim3((H * ng + 3) / 4), dim3(256), 0, s, bits, list, cnt, H, nqb, nb, nw, ng);
+  hipLaunchKernelGGL(nabla_union_kernel, dim3((H * ng + 3) / 4), dim3(256), 0, s, bits, list, cnt, cnt_local, H, nqb, nb, nw, ng, local_block0,
+                     local_blocks);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
 int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,
                            int wW, float P, void* workspace, hipStream_t s) {
-  return k5_launch_nabla_select_rect(q, k, ldq, ldk, H, N, 0, N, T, Hb, Wb, wT, wH, wW, P, workspace, s);
+  return k5_launch_nabla_select_rect(q, k, ldq, ldk, H, N, 0, N, T, Hb, Wb, wT, wH, wW, P, workspace, s, 0, 0);
 }
 
 // views into the workspace filled above
 void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned long long** bits, const int** kv_nb, const int** list,
-                              const int** cnt) {
+                              const int** cnt, const int** cnt_local) {
   const size_t nw = (nb + 63) / 64, ng = (nb + 3) / 4;
   char* ws = (char*)workspace + (size_t)2 * H * nb * 64 * 2;
   if (bits) *bits = (const unsigned long long*)ws;
@@ -374,4 +389,5 @@ void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned lon
   if (list) *list = (const int*)ws;
   ws += (size_t)H * ng * nb * 4;
   if (cnt) *cnt = (const int*)ws;
+  if (cnt_local) *cnt_local = (const int*)ws + (size_t)H * ng;
 }

@@ -91,6 +91,8 @@ SYMBOLS = {
     "k5_nabla_mask_u8": (_I, [_P, _I, _I, _P, _P]),
     "k5_nabla_select_rect_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "k5_attention_nabla_rect_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I64, _P]),
+    "k5_nabla_select_rect_local_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P]),
+    "k5_attention_nabla_rect_prescaled_pass": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I64, _P, _P, _I, _P, _P]),
     "k5_nabla_mask_rect_u8": (_I, [_P, _I, _I, _I, _P, _P]),
     "k5_attention_bf16_bounded": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "k5_ln_modulate_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -301,7 +301,7 @@ def test_attention_tile_prefetch_survives_the_compiler():
         return res
     # <BOUNDED, SPARSE, RANGE, PRE, QN>: dense fixed / online, the same with the fused query norm, NABLA fixed (all on pre-scaled keys)
     for tag, pick in (("ILb1ELb0ELb1ELb1ELb0E", min), ("ILb0ELb0ELb1ELb1ELb0E", min), ("ILb1ELb0ELb1ELb1ELb1E", min),
-                      ("ILb0ELb0ELb1ELb1ELb1E", min), ("ILb1ELb1ELb0ELb1ELb0E", max)):
+                      ("ILb0ELb0ELb1ELb1ELb1E", min), ("ILb1ELb1ELb0ELb1ELb0E", max), ("ILb1ELb1ELb1ELb1ELb0E", max)):
         need = 24
         body = [v for k, v in kernels.items() if tag in k]
         assert len(body) == 1, tag

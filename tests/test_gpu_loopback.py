@@ -163,13 +163,16 @@ def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain, qfuse):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("P,gain", [(2, 1.0), (4, 3.0), (3, 5.0)])
-def test_full_width_nabla_P_ranks_on_one_gpu(P, gain):
+@pytest.mark.parametrize("P,gain,passes", [(2, 1.0, 2), (4, 3.0, 2), (3, 5.0, 2), (4, 3.0, 1), (8, 1.0, 2)])
+def test_full_width_nabla_P_ranks_on_one_gpu(P, gain, passes):
     """NABLA under sequence parallelism at 2B-Lite width (2 visual blocks, latent (8,16,32) -> 16 blocks of 64 tokens): the ranks
     gather the SCALED keys plus the 64-token block means of their unscaled keys (all the map needs), so the sharded path runs the
     same pre-scaled kernels, per-head flags and per-row offsets as one GPU — at gain 3 (bound 104) every head must stay on the
     fixed-offset form in BOTH paths, at gain 5 (288) every head must take the online form.  Ranks bit-identical; against the
-    single-handle run: same map up to threshold ties, same arithmetic up to summation order."""
+    single-handle run: same map up to threshold ties, same arithmetic up to summation order.
+    passes = 2 ("sp_nabla_passes"; default 1): every list is walked in two passes — the rank's own key blocks first (while the
+    gather is in flight), the rest after it, with the fp32 state in between; P = 8 on 16 blocks: two blocks per rank, so most
+    (head, query group) lists have few or no local entries (an empty first pass must leave a usable state)."""
     from kandinsky.models.dit import DiffusionTransformer3D
     c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
     sd = O.synthetic_state_dict(O.DitConfig(**c), seed=3)
@@ -194,7 +197,7 @@ def test_full_width_nabla_P_ranks_on_one_gpu(P, gain):
         return out, d.attn_variant_counts()
 
     fused, counts1 = call(make(), 0)
-    res = run_ranks(P, make, call)
+    res = run_ranks(P, make, call, options={"sp_nabla_passes": passes})
     outs = [o for o, _ in res]
     for r in range(1, P):
         assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
@@ -203,7 +206,8 @@ def test_full_width_nabla_P_ranks_on_one_gpu(P, gain):
         assert (n_online == 0) if gain <= 3.0 else (n_fixed == 0), (gain, n_fixed, n_online)
     print(f"NABLA P={P} gain={gain}: sharded vs single handle rel-L2 {rel(outs[0], fused):.3e}")
     assert torch.isfinite(outs[0].float()).all()
-    assert rel(outs[0], fused) <= {1.0: 6e-3, 3.0: 1.5e-2, 5.0: 4e-2}[gain], rel(outs[0], fused)
+    # gain 5: logits 25x those of gain 1 — two valid summation orders of a softmax that peaky differ by the oracle's own bf16 noise
+    assert rel(outs[0], fused) <= {1.0: 6e-3, 3.0: 1.5e-2, 5.0: 6e-2}[gain], rel(outs[0], fused)
 
 
 @pytest.mark.timeout(600)

@@ -275,3 +275,77 @@ def test_nabla_config4_size_properties(E):
     assert floor <= dens[0.0] <= floor + 1.0 / nb + 1e-6          # STA window + at most the top-1 block per row
     assert dens[0.0] < dens[0.9] <= 1.0
     print(f"config-4 map density: STA floor {floor:.4f}, P=0 {dens[0.0]:.4f}, P=0.9 {dens[0.9]:.4f}")
+
+
+def _flags_rows(E, qf, kf, H):
+    qstat, kstat = (qf * qf).sum(-1).amax(0).contiguous().cuda(), (kf * kf).sum(-1).amax(0).contiguous().cuda()
+    flags = torch.zeros(H, dtype=torch.int32, device="cuda")
+    kmax = torch.zeros(H, device="cuda")
+    E.check(E.lib().k5_attention_flags_rows(qstat.data_ptr(), kstat.data_ptr(), 1, H, H, 0, flags.data_ptr(), kmax.data_ptr(), E.stream_ptr()))
+    torch.cuda.synchronize()
+    return flags, kmax
+
+
+@pytest.mark.parametrize("case", ["gain1", "gain3", "late"])
+def test_two_pass_list_walk_on_prescaled_keys(E, case):
+    """The sequence-parallel engine's NABLA attention at kernel level: rank r's own key blocks lead every list
+    (k5_nabla_select_rect_local_bf16), pass 1 attends them and leaves the fp32 state, pass 2 resumes over the rest — against the
+    one-pass walk of the same lists and against the oracle's masked attention.  "gain3": bound 104, the fixed form on per-row
+    offsets in both passes.  "late": head 0's LOCAL keys point away from every query — its rows underflow in pass 1 (flag 2), and the
+    online launch of pass 2 must recompute the head over its whole lists, ignoring the state pass 1 left."""
+    T, Hb, Wb, H, P = 8, 2, 2, 2, 4
+    nb, N = 32, 2048
+    n = N // P
+    g = torch.Generator().manual_seed(33)
+    gain = {"gain1": 1.0, "gain3": 3.0, "late": 3.0}[case]
+    def rmsn(x):
+        return gain * x / x.pow(2).mean(-1, keepdim=True).sqrt()
+    L = E.lib()
+    for r in (1, 3):
+        q, k, v = bfr(rmsn(torch.randn(N, H, 64, generator=g))), bfr(rmsn(torch.randn(N, H, 64, generator=g))), bfr(torch.randn(N, H, 64, generator=g))
+        if case == "late":      # head 0: queries along u, the rank's own keys along -u (scores ~ -|q||k'| = -140), the others ordinary
+            u = torch.randn(64, generator=g); u = u / u.norm()
+            q[:, 0] = bfr(28.0 * u + 0.5 * torch.randn(N, 64, generator=g))
+            k[r * n:(r + 1) * n, 0] = bfr((-5.0 * u + 0.1 * torch.randn(n, 64, generator=g)) / O.SOFTMAX_C)
+        kc = bfr(k * O.SOFTMAX_C)
+        qloc = q[r * n:(r + 1) * n]
+        qd, kd, kcd = qloc.reshape(n, -1).cuda().to(BF), k.reshape(N, -1).cuda().to(BF), kc.reshape(N, -1).cuda().to(BF)
+        vt = v.reshape(N, -1).t().contiguous().cuda().to(BF)
+        vt_chunks = vt.reshape(H * 64, P, n).permute(1, 0, 2).contiguous()
+        ws = torch.empty(L.k5_nabla_workspace_size(H, nb), dtype=torch.uint8, device="cuda")
+        E.check(L.k5_nabla_select_rect_local_bf16(qd.data_ptr(), kd.data_ptr(), qd.stride(0), kd.stride(0), H, n, r * (n // 64), N, T, Hb, Wb,
+                                                  3, 1, 1, 0.5, ws.data_ptr(), r * (n // 64), n // 64, E.stream_ptr()))
+        nqb = n // 64
+        m = torch.empty(H, nqb, nb, dtype=torch.uint8, device="cuda")
+        E.check(L.k5_nabla_mask_rect_u8(ws.data_ptr(), H, nqb, nb, m.data_ptr(), E.stream_ptr()))
+        m = m.bool().cpu()
+        assert m.any(-1).all()
+        if case == "late":      # the scenario needs local blocks in head 0's lists (the STA window guarantees them)
+            assert m[0, :, r * nqb:(r + 1) * nqb].any(-1).all()
+
+        def run(passes):
+            flags, kmax = _flags_rows(E, qloc, kc, H)
+            assert flags.tolist() == [1, 1]
+            o = torch.full((n, H * 64), float("nan"), dtype=BF, device="cuda")
+            state = torch.zeros(L.k5_attention_state_size(H, n) // 4, device="cuda")
+            for ps in passes:
+                E.check(L.k5_attention_nabla_rect_prescaled_pass(qd.data_ptr(), kcd.data_ptr(), vt_chunks.data_ptr(), o.data_ptr(), H, n, N,
+                                                                 qd.stride(0), kcd.stride(0), n, o.stride(0), ws.data_ptr(), n, H * 64 * n,
+                                                                 flags.data_ptr(), kmax.data_ptr(), ps, state.data_ptr(), E.stream_ptr()))
+                torch.cuda.synchronize()
+                if ps == 1 and case == "late":
+                    assert flags.tolist() == [2, 1], flags          # head 0 went late in the first pass
+            return o, flags.tolist()
+        one, f1 = run([0])
+        two, f2 = run([1, 2])
+        assert f1 == ([1, 1] if case != "late" else f1) and f2 == ([1, 1] if case != "late" else [2, 1]), (f1, f2)
+        # oracle: softmax over the kept blocks of each 64-query row, exp2 domain on the pre-scaled keys
+        mask = m.repeat_interleave(64, 1).repeat_interleave(64, 2)                  # [H][n][N]
+        s = torch.einsum("qhd,khd->hqk", qloc, kc)
+        s = s.masked_fill(~mask, float("-inf"))
+        pr = torch.exp2(s - s.amax(-1, keepdim=True))
+        ref = torch.einsum("hqk,khd->qhd", bfr(pr) / bfr(pr).sum(-1, keepdim=True), v).reshape(n, -1)
+        for name, got in (("one pass", one), ("two passes", two)):
+            err = (got.float().cpu() - ref).abs()
+            assert err.max().item() <= 2e-2 + 2 ** -6 * ref.abs().max().item(), (case, r, name, err.max().item())
+        assert (one.float() - two.float()).abs().max().item() <= 2e-2
