@@ -29,4 +29,6 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vae --workload 2s_2
 python bench.py --steps 45 --warmup 5 --no-cpu-baseline --no-vae --magcache 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
 for np in 0.9 0.15 0.0; do python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-vae --workload 10s_nabla --nabla-p $np 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl; done
 for sh in 2 4 8; do for sl in 1 2; do python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --emulate-shard $sh --sp-slices $sl 2>/dev/null | grep "^{" >> $OUT/${TAG}_shards.jsonl; done; done
+# 7. NABLA under sequence parallelism: the 10 s clip as rank 0 of 4 (BASELINE config 4), near-dense and STA-only maps, one / two passes
+for np in 0.9 0.0; do for ps in 1 2; do python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vae --workload 10s_nabla --nabla-p $np --emulate-shard 4 --engine-option sp_nabla_passes=$ps 2>/dev/null | grep "^{" >> $OUT/${TAG}_shards.jsonl; done; done
 wc -l $OUT/${TAG}_workloads.jsonl $OUT/${TAG}_shards.jsonl
