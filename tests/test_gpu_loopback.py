@@ -285,6 +285,50 @@ def test_config5_sequence_length_P_ranks_on_one_gpu(P, sparse, fp8):
     assert rel(outs[0], fused) <= (2.5e-2 if fp8 else 6e-3), rel(outs[0], fused)
 
 
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("passes,gain", [(1, 1.0), (2, 1.0), (2, 3.0)])
+def test_config4_nabla_sequence_length_4_ranks_on_one_gpu(passes, gain):
+    """BASELINE's 10 s configuration (config_10s_sft: NABLA, 768x512 -> latent (61, 64, 96) -> 93 696 tokens = 1464 blocks, SP x 4)
+    at its real sequence length, 2B-Lite width, one visual block, the config's NABLA parameters.  A rank's sparse attention launch
+    has 92 x 28 = 2576 (head, 256-query) jobs = 5 whole rounds of resident workgroups + 16 tail jobs that the balanced launch cuts
+    along their lists and merges — the mix of whole and split jobs that neither the tiny shapes (all tail) nor the config-5 length
+    (no split) reach; passes = 2: the two-pass list walk on top of it; gain 3: per-row softmax offsets in every part."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=1, num_text_blocks=1)
+    sd = O.synthetic_state_dict(O.DitConfig(**c), seed=4)
+    if gain != 1.0:
+        for k in sd:
+            if k.endswith(("query_norm.weight", "key_norm.weight")):
+                sd[k] = sd[k] * gain
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(61, 64, 96, 16, generator=g)
+    text, pooled = torch.randn(48, 3584, generator=g), torch.randn(1, 768, generator=g)
+    pos = [torch.arange(61), torch.arange(32), torch.arange(48)]
+    t = torch.tensor([600.0])
+    sp = {"P": 0.9, "wT": 11, "wH": 3, "wW": 3, "to_fractal": True}
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(sd, assign=True)
+        return d.to("cuda:0")
+
+    def call(d, r):
+        out = d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(48), scale_factor=(1.0, 2.0, 2.0), sparse_params=sp)
+        return out, d.attn_variant_counts()
+
+    one = make()
+    fused, cnt1 = call(one, 0)
+    one._destroy_engine(force=True)
+    assert torch.isfinite(fused.float()).all() and cnt1 == (28, 0)
+    res = run_ranks(4, make, call, options={"sp_nabla_passes": passes})
+    outs = [o for o, _ in res]
+    for r in range(1, 4):
+        assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
+    assert all(cnt == (28, 0) for _, cnt in res), [cnt for _, cnt in res]
+    print(f"config-4 length, NABLA, passes={passes} gain={gain}: sharded vs single handle rel-L2 {rel(outs[0], fused):.3e}")
+    assert rel(outs[0], fused) <= (6e-3 if gain == 1.0 else 1.5e-2), rel(outs[0], fused)
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("P,T,S", [(2, 8, 2), (4, 8, 2), (2, 7, 2), (4, 7, 2), (2, 12, 3), (3, 11, 2)])
 def test_tiny_forward_sliced_exchange(golden_meta, tiny_sd, P, T, S):
