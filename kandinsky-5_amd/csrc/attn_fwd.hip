@@ -135,9 +135,14 @@ __device__ __forceinline__ uint32_t st_ml_off(int q, int h, int slot, int nqb, i
 
 // QN: the norm_qk + RoPE of the queries is fused into the Q load (K5QueryNorm, pre-scaled keys).  A template parameter and not a runtime
 // branch: with the code merely PRESENT the compiler schedules the tile loop of the plain form differently (same instructions, +1 % time).
-template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false, bool QN = false>
+// HALF (NABLA on one GPU): the workgroup is launched with 256 threads = 4 waves = 128 query rows, i.e. TWO 64-query rows of the block
+// map share a key-tile list instead of four — a wave only computes the tiles its own row selected, so the launch's efficiency is
+// (sum of the rows' lists) / (rows x their union), and two rows' union is tighter than four rows'.  Every wave then brings in two
+// 1-KB pieces of K and of V^T per tile (twice the L2 -> LDS traffic per FLOP; four workgroups per CU instead of two).
+template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false, bool QN = false, bool HALF = false>
 __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_kernel(AttnP p) {
   static_assert(BOUNDED || PRE, "the online-max form of this kernel takes pre-scaled keys (attn_fwd32_kernel serves the rest)");
+  static_assert(!HALF || (SPARSE && PRE && !RANGE && !QN), "128-query workgroups: the list-driven single-launch form only");
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
   char* sK = smem;
   char* sV = smem + 2 * TILE;
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
       if (hf == 2) { if (p.late_pass != 2) return; late = true; }
     }
   }
-  const int q0 = qb * QB + wave * 32;   // this wave: queries q0 .. q0+31 = two 16-query MFMA tiles (qt = 0, 1)
+  const int q0 = qb * (HALF ? QB / 2 : QB) + wave * 32;   // this wave: queries q0 .. q0+31 = two 16-query MFMA tiles (qt = 0, 1)
 
   // Q^T fragments (MFMA 16x16x32 B operand): lane (l15, g) holds Q[q0 + 16 qt + l15][32 ks + 8 g .. +8]
   bf16x8 qf[2][2];
@@ -299,6 +304,12 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     if (PRE) {   // whole tiles only (launcher): constant per-lane offsets, the tile rides in the instruction's SGPR offset: no address VALU
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_void_t*)(sK + buf * TILE + wave_u * 1024), 16, kvoff, (uint32_t)kv0 * kstride, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_void_t*)(sV + buf * TILE + wave_u * 1024), 16, vlane, (uint32_t)(vsrc - Vb), 0, 0);
+      if (HALF) {   // four waves: rows 32..63 of both tiles as well (the swizzles only involve row bits 1..4: same lane offsets + 32 rows)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_void_t*)(sK + buf * TILE + (wave_u + 4) * 1024), 16, kvoff + 32u * kstride,
+                                                 (uint32_t)kv0 * kstride, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_void_t*)(sV + buf * TILE + (wave_u + 4) * 1024), 16, vlane + 64u * (uint32_t)p.ldvt,
+                                                 (uint32_t)(vsrc - Vb), 0, 0);
+      }
       return;
     }
     __builtin_amdgcn_global_load_lds((gbl_void_t*)(Kb + ((uint32_t)min(kv0 + lrow, p.kv_len - 1) * kstride + klane)),
@@ -991,7 +1002,8 @@ int k5_launch_attention_bf16_chunked(const void* Q, const void* K, const void* V
 int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled,
-                                    const int* head_flags, int variant, const float* kmax, const K5SparsePass* pass, float* ws) {
+                                    const int* head_flags, int variant, const float* kmax, const K5SparsePass* pass, float* ws,
+                                    int group_rows) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0 || (q_len % KB) || (kv_len % KB) || !list || !cnt) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -999,7 +1011,9 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   AttnP p;
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
   p.H = H; p.q_len = q_len; p.kv_len = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
-  p.nqb = (q_len + QB - 1) / QB;
+  if (group_rows != 4 && (group_rows != 2 || !k_prescaled || pass || ws)) return K5_ERR_ARG;   // lists of 2 rows: 128-query workgroups
+  const bool half = group_rows == 2;
+  p.nqb = half ? (q_len + QB / 2 - 1) / (QB / 2) : (q_len + QB - 1) / QB;
   p.c = 0.125f * 1.44269504088896340736f;
   p.head_flags = nullptr; p.my_flag = 0;
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;
@@ -1021,7 +1035,10 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
     p.head_flags = (run_fixed && run_online) ? head_flags : nullptr;
     auto launch = [&](int njobs, bool rangek) {
       const dim3 g(njobs);
-      if (rangek) {
+      if (half) {
+        if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, true, false, true, false, true>), g, dim3(256), 0, stream, p); }
+        if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, true, false, true, false, true>), g, dim3(256), 0, stream, p); }
+      } else if (rangek) {
         if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, true, true, true>), g, block, 0, stream, p); }
         if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, true, true, true>), g, block, 0, stream, p); }
       } else {

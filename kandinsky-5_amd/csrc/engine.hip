@@ -275,6 +275,15 @@ struct k5_dit {
   long long nabla_possible = 0;                    // profiling: 64x64 blocks the NABLA maps could have kept (kept: ws_attn_cnt[2])
   int attn_mode = 0;                               // K5_ATTN_AUTO / K5_ATTN_ONLINE (k5_dit_set_option "attn_mode")
   int sp_pass1_tiles = 0;                          // k5_dit_set_option "sp_pass1_tiles" (0 = all local key tiles)
+  // "nabla_group_rows": 64-query rows per key-tile list = per attention workgroup (one GPU).  4: 256-query workgroups; 2: 128-query
+  // workgroups (tighter lists: -17 % attention at kept density 0.05, -8 % at 0.12, +3 % at 0.81; bit-identical results); 0 (default):
+  // chosen per forward from the kept density of the PREVIOUS forward's first map (counted on the device, copied to pinned host memory
+  // without a synchronisation: a stale or missing value only costs speed)
+  int nabla_group_rows = 0, nabla_grp_now = 4;
+  DevBuf ws_nabla_kept;                            // u64 kept-block count of the forward's first NABLA map
+  unsigned long long* h_nabla_kept = nullptr;      // its pinned host copy
+  long long nabla_hint_possible = 0;               // blocks that map could have kept
+  bool nabla_hint_pending = false;
   int sp_nabla_passes = 1;                         // "sp_nabla_passes" = 2: NABLA under sequence parallelism attends the rank's own key blocks during the gather
   int fuse_qnorm = 0;                              // "attn_fuse_qnorm": norm_qk + RoPE of the visual queries inside the attention kernel
   bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 180)
@@ -524,16 +533,26 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
   if (nabla) {  // nablaT_v2 map (utils.py:136-163) + block-sparse attention (nn.py:257-280)
     const int nb = rows / 64;
+    const int grp = pre ? d->nabla_grp_now : 4;   // 64-query rows per key-tile list = per attention workgroup
     K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
     {
       Scope sc(d, s, "nabla_map");
-      K5CHK(k5_launch_nabla_select(qk, (const bf16_t*)qk + D, 2 * D, 2 * D, H, rows, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
-                                   nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s));
+      K5CHK(k5_launch_nabla_select_rect(qk, (const bf16_t*)qk + D, 2 * D, 2 * D, H, rows, 0, rows, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
+                                        nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, 0, 0, grp));
     }
     if (d->profiling) {   // realised density of the map (bench.py: attention FLOPs actually done)
       K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
       K5CHK(k5_launch_nabla_count(d->ws_nabla.p, H, nb, nb, d->ws_attn_cnt.as<unsigned long long>() + 2, s));
       d->nabla_possible += (long long)H * nb * nb;
+    }
+    if (d->nabla_hint_pending && d->nabla_group_rows == 0) {   // the forward's first map: its density steers the NEXT forward's workgroup size
+      d->nabla_hint_pending = false;
+      K5CHK(d->ws_nabla_kept.ensure(8));
+      if (!d->h_nabla_kept) { HIPCHK(hipHostMalloc((void**)&d->h_nabla_kept, 8, hipHostMallocDefault)); *d->h_nabla_kept = 0ull; }
+      HIPCHK(hipMemsetAsync(d->ws_nabla_kept.p, 0, 8, s));
+      K5CHK(k5_launch_nabla_count(d->ws_nabla.p, H, nb, nb, d->ws_nabla_kept.as<unsigned long long>(), s));
+      HIPCHK(hipMemcpyAsync(d->h_nabla_kept, d->ws_nabla_kept.p, 8, hipMemcpyDeviceToHost, s));
+      d->nabla_hint_possible = (long long)H * nb * nb;
     }
     const int *list, *cnt;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
@@ -541,7 +560,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     // (no tail balancing here: 10 248 jobs are 20 rounds of unequal lists — measured -0.6 % at density 0.81, +1 % at 0.12, +2.4 % at
     // 0.05; a token shard's 5 rounds are another matter, run_self_attention_sp)
     K5CHK(k5_launch_attention_bf16_sparse(qk, pre ? d->ws_kc.as<bf16_t>() : (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, pre ? D : 2 * D,
-                                          ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant, kmax));
+                                          ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant, kmax, nullptr, nullptr, grp));
   } else {
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     Scope sc(d, s, fam_attn);
@@ -917,6 +936,14 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
                  int text_slot = -1) {
   const k5_dit_config& c = d->cfg;
   if (!d->finalized) { k5_set_error("k5_dit_forward before k5_dit_finalize"); return K5_ERR_STATE; }
+  if (a->attention_type == 1) {   // NABLA workgroup size of this forward (see nabla_group_rows)
+    d->nabla_grp_now = d->nabla_group_rows ? d->nabla_group_rows : 4;
+    if (d->nabla_group_rows == 0 && d->h_nabla_kept && d->nabla_hint_possible > 0) {
+      const unsigned long long kept = *(volatile unsigned long long*)d->h_nabla_kept;   // whatever has landed: no synchronisation
+      if (kept > 0 && (double)kept < 0.5 * (double)d->nabla_hint_possible) d->nabla_grp_now = 2;
+    }
+    d->nabla_hint_pending = true;
+  }
   if (a->attention_type != 0 && a->attention_type != 1) { k5_set_error("attention_type must be 0 (flash) or 1 (nabla)"); return K5_ERR_ARG; }
   if (c.patch_size[0] != 1 || c.patch_size[1] != 2 || c.patch_size[2] != 2) return K5_ERR_UNSUPPORTED;
   const int Tp = a->T, Hp = a->H / 2, Wp = a->W / 2;
@@ -1120,7 +1147,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
                    &d->ws_vel_u};
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
-  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_kc.release(); d->ws_kmeans.release(); d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
+  d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_kc.release(); d->ws_kmeans.release(); d->ws_nabla_kept.release(); if (d->h_nabla_kept) { (void)hipHostFree(d->h_nabla_kept); d->h_nabla_kept = nullptr; } d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
   d->ws_attn_stats.release(); d->ws_attn_flags.release(); d->ws_attn_cnt.release(); d->ws_attn_part.release();
   for (auto& t : d->text_cache) { t.text.release(); t.pool.release(); }
   for (auto& kv : d->staged) kv.second.dev.release();   // a handle destroyed before finalize still holds its staged matrices
@@ -1488,6 +1515,8 @@ extern "C" int k5_dit_comm_init_loopback(k5_dit* d, k5_loopback* lb, int rank) {
 //                     applies it inside the attention kernel's Q-fragment load (K5QueryNorm; needs attn_row_offsets or attn_mode 1);
 //                     2 = under sequence parallelism too.  Measured neutral (elementwise -2.0 ms, attention +0.6 .. +3.4 ms per step
 //                     depending on how the compiler schedules the tile loop of the extra instantiation), hence opt-in.
+//   "nabla_group_rows" 0 (default) / 2 / 4: 64-query rows per NABLA key-tile list = per attention workgroup on one GPU; 0 picks 2 (128-query
+//                     workgroups) when the previous forward's first map kept less than half of its blocks, else 4; same bits either way
 //   "sp_nabla_passes" 1 (default) / 2: NABLA under sequence parallelism walks every list in one pass after the gather, or in two — the
 //                     rank's own key blocks while the other ranks' keys travel, the rest after the gather (costs 12 % of the attention
 //                     in compute, emulated P = 4; pays when the exposed part of the gather is longer than that — a property of the node)
@@ -1506,6 +1535,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   }
   if (!strcmp(name, "sp_pass1_tiles")) { if (value < 0) return K5_ERR_ARG; d->sp_pass1_tiles = value; return K5_OK; }
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
+  if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }
   if (!strcmp(name, "sp_nabla_passes")) { if (value < 1 || value > 2) return K5_ERR_ARG; d->sp_nabla_passes = value; return K5_OK; }
   if (!strcmp(name, "attn_fuse_qnorm")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->fuse_qnorm = value; return K5_OK; }
   if (!strcmp(name, "sp_slices")) {
@@ -1530,6 +1560,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "attn_row_offsets")) *value = d->row_offsets ? 1 : 0;
   else if (!strcmp(name, "attn_fuse_qnorm")) *value = d->fuse_qnorm;
   else if (!strcmp(name, "sp_nabla_passes")) *value = d->sp_nabla_passes;
+  else if (!strcmp(name, "nabla_group_rows")) *value = d->nabla_group_rows;
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
   else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }

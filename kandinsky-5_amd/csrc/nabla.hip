@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
 // cnt_local[h*ng+g] says how many they are: the attention runs them as a first pass while the other ranks' keys travel.
 __global__ __launch_bounds__(256) void nabla_union_kernel(const unsigned long long* __restrict__ bits, int* __restrict__ list,
                                                           int* __restrict__ cnt, int* __restrict__ cnt_local, int H, int nqb, int nb,
-                                                          int nw, int ng, int loc0, int locn) {
+                                                          int nw, int ng, int loc0, int locn, int G) {
   const int lane = threadIdx.x & 63;
   const int gi = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gi >= H * ng) return;
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256) void nabla_union_kernel(const unsigned long lo
       unsigned long long w[4], u = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qb = 4 * g + r;
-        w[r] = qb < nqb ? bits[((size_t)h * nqb + qb) * nw + c] & take : 0ull;
+        const int qb = G * g + r;
+        w[r] = (r < G && qb < nqb) ? bits[((size_t)h * nqb + qb) * nw + c] & take : 0ull;
         u |= w[r];
       }
       if ((u >> lane) & 1ull) {
@@ -304,12 +304,12 @@ int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void*
 }
 
 size_t k5_nabla_workspace_bytes(int H, int nb) {
-  const size_t nw = (nb + 63) / 64, ng = (nb + 3) / 4;
+  const size_t nw = (nb + 63) / 64;
   return (size_t)2 * H * nb * 64 * 2      // qa, ka
          + (size_t)H * nb * nw * 8         // bits
          + (size_t)H * nb * 4              // kv_nb
-         + (size_t)H * ng * nb * 4         // union lists
-         + (size_t)2 * H * ng * 4 + 256;   // counts, counts of the leading local entries (sequence parallelism)
+         + (size_t)H * ((nb + 1) / 2) * nb * 4         // union lists (sized for lists per 2 rows; per 4 rows uses half)
+         + (size_t)2 * H * ((nb + 1) / 2) * 4 + 256;   // counts, counts of the leading local entries (sequence parallelism)
 }
 
 // q: [Nq][ldq] bf16 = the query rows handled here (global 64-token blocks [q_block0, q_block0 + Nq/64)), k: [N][ldk] = all
@@ -333,21 +333,24 @@ int k5_launch_nabla_key_means_from_slots(const void* gathered, int H, int nb, in
 
 // k == nullptr: the key-block means are already in the workspace (k5_launch_nabla_key_means_from_slots)
 int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
-                                int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s, int local_block0, int local_blocks) {
+                                int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s, int local_block0, int local_blocks,
+                                int group_rows) {
+  if (group_rows != 2 && group_rows != 4) return K5_ERR_ARG;
   if (local_blocks < 0 || local_block0 < 0 || (local_blocks > 0 && local_block0 + local_blocks > N / 64)) return K5_ERR_ARG;
   if (H <= 0 || N <= 0 || Nq <= 0 || (N % 64) || (Nq % 64) || T * Hb * Wb * 64 != N) return K5_ERR_ARG;
   if (q_block0 < 0 || q_block0 * 64 + Nq > N) return K5_ERR_ARG;
   if ((ldq & 7) || (k && (ldk & 7))) return K5_ERR_ALIGN;
-  const int nb = N / 64, nqb = Nq / 64, nw = (nb + 63) / 64, ng = (nqb + 3) / 4;
+  const int nb = N / 64, nqb = Nq / 64, nw = (nb + 63) / 64, ng = (nqb + group_rows - 1) / group_rows;
+  const size_t ngmax = (size_t)(nb + 1) / 2;   // region sizes (k5_nabla_workspace_bytes / _views)
   if (nb > SEL_MAXNB) return K5_ERR_UNSUPPORTED;
   char* ws = (char*)workspace;
   bf16_t* qa = (bf16_t*)ws; ws += (size_t)H * nb * 64 * 2;
   bf16_t* ka = (bf16_t*)ws; ws += (size_t)H * nb * 64 * 2;
   unsigned long long* bits = (unsigned long long*)ws; ws += (size_t)H * nb * nw * 8;
   int* kv_nb = (int*)ws; ws += (size_t)H * nb * 4;
-  int* list = (int*)ws; ws += (size_t)H * ((nb + 3) / 4) * nb * 4;
+  int* list = (int*)ws; ws += (size_t)H * ngmax * nb * 4;
   int* cnt = (int*)ws;
-  int* cnt_local = cnt + (size_t)H * ((nb + 3) / 4);
+  int* cnt_local = cnt + (size_t)H * ngmax;
   hipLaunchKernelGGL(block_mean_kernel, dim3(nqb), dim3(256), 0, s, (const bf16_t*)q, qa, H, nqb, ldq);
   if (k) hipLaunchKernelGGL(block_mean_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)k, ka, H, nb, ldk);
   SelP p;
@@ -368,19 +371,19 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   else if (nv <= 32) launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 2>{});
   else launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 1>{});
   hipLaunchKernelGGL(nabla_union_kernel, dim3((H * ng + 3) / 4), dim3(256), 0, s, bits, list, cnt, cnt_local, H, nqb, nb, nw, ng, local_block0,
-                     local_blocks);
+                     local_blocks, group_rows);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
 int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,
                            int wW, float P, void* workspace, hipStream_t s) {
-  return k5_launch_nabla_select_rect(q, k, ldq, ldk, H, N, 0, N, T, Hb, Wb, wT, wH, wW, P, workspace, s, 0, 0);
+  return k5_launch_nabla_select_rect(q, k, ldq, ldk, H, N, 0, N, T, Hb, Wb, wT, wH, wW, P, workspace, s, 0, 0, 4);
 }
 
 // views into the workspace filled above
 void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned long long** bits, const int** kv_nb, const int** list,
                               const int** cnt, const int** cnt_local) {
-  const size_t nw = (nb + 63) / 64, ng = (nb + 3) / 4;
+  const size_t nw = (nb + 63) / 64, ng = (nb + 1) / 2;   // region sizes
   char* ws = (char*)workspace + (size_t)2 * H * nb * 64 * 2;
   if (bits) *bits = (const unsigned long long*)ws;
   ws += (size_t)H * nb * nw * 8;

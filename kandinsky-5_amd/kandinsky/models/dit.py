@@ -317,6 +317,9 @@ class DiffusionTransformer3D(nn.Module):
         "attn_row_offsets" (1 = per-row offsets keep heads with a bound up to 180 on the fixed-offset kernel; default),
         "attn_fuse_qnorm" (1 = norm_qk + RoPE of the visual queries inside the attention kernel, 2 = under sequence parallelism too;
         default 0, measured neutral),
+        "nabla_group_rows" (NABLA on one GPU: 64-query rows per key-tile list / attention workgroup; 0 = by the previous forward's
+        kept density (default), 2, 4 — same bits), "sp_nabla_passes" (NABLA under sequence parallelism: 2 = attend the rank's own
+        key blocks while the gather is in flight; default 1),
         "sp_slices" (sequence parallelism: exchange K / V^T in this many slices, attend each as it lands; default 1),
         "sp_pass1_tiles", "emulate_world" (timing only)."""
         E.check(E.lib().k5_dit_set_option(self._handle, name.encode(), int(value)), f"k5_dit_set_option({name})")

@@ -299,9 +299,11 @@ def test_attention_tile_prefetch_survives_the_compiler():
             if dma and blocks[name]["loop"]:
                 res.append(walk(name, dma[-1] + 1, {name}))
         return res
-    # <BOUNDED, SPARSE, RANGE, PRE, QN>: dense fixed / online, the same with the fused query norm, NABLA fixed (all on pre-scaled keys)
-    for tag, pick in (("ILb1ELb0ELb1ELb1ELb0E", min), ("ILb0ELb0ELb1ELb1ELb0E", min), ("ILb1ELb0ELb1ELb1ELb1E", min),
-                      ("ILb0ELb0ELb1ELb1ELb1E", min), ("ILb1ELb1ELb0ELb1ELb0E", max), ("ILb1ELb1ELb1ELb1ELb0E", max)):
+    # <BOUNDED, SPARSE, RANGE, PRE, QN, HALF>: dense fixed / online, the same with the fused query norm, NABLA fixed: one launch, one pass of
+    # the sharded schedule, 128-query workgroups (all on pre-scaled keys)
+    for tag, pick in (("ILb1ELb0ELb1ELb1ELb0ELb0E", min), ("ILb0ELb0ELb1ELb1ELb0ELb0E", min), ("ILb1ELb0ELb1ELb1ELb1ELb0E", min),
+                      ("ILb0ELb0ELb1ELb1ELb1ELb0E", min), ("ILb1ELb1ELb0ELb1ELb0ELb0E", max), ("ILb1ELb1ELb1ELb1ELb0ELb0E", max),
+                      ("ILb1ELb1ELb0ELb1ELb0ELb1E", max)):
         need = 24
         body = [v for k, v in kernels.items() if tag in k]
         assert len(body) == 1, tag

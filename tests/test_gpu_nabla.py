@@ -349,3 +349,36 @@ def test_two_pass_list_walk_on_prescaled_keys(E, case):
             err = (got.float().cpu() - ref).abs()
             assert err.max().item() <= 2e-2 + 2 ** -6 * ref.abs().max().item(), (case, r, name, err.max().item())
         assert (one.float() - two.float()).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("gain", [1.0, 3.0, 5.0])
+def test_lists_per_two_rows_give_the_same_bits(gain):
+    """"nabla_group_rows" = 2: key-tile lists per TWO 64-query rows and 128-query attention workgroups instead of four / 256.  A
+    64-query row attends its own kept blocks in ascending order either way (the other rows' blocks of the shared list are skipped),
+    so the result must be BIT-identical to the default — at gain 1 (offset 0), gain 3 (per-row offsets) and gain 5 (online form)."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
+    sd = O.synthetic_state_dict(O.DitConfig(**c), seed=3)
+    if gain != 1.0:
+        for k in sd:
+            if k.endswith(("query_norm.weight", "key_norm.weight")):
+                sd[k] = sd[k] * gain
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(9, 16, 32, 16, generator=g)                      # 18 blocks of 64 tokens: an odd count of 128-query groups' rows
+    text, pooled = torch.randn(37, 3584, generator=g), torch.randn(1, 768, generator=g)
+    pos = [torch.arange(9), torch.arange(8), torch.arange(16)]
+    t = torch.tensor([875.0])
+    sp = {"P": 0.6, "wT": 3, "wH": 3, "wW": 3, "to_fractal": True}
+    outs = []
+    for grp in (4, 2):
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(sd, assign=True)
+        d = d.to("cuda:0")
+        d.engine("cuda:0")
+        d.set_option("nabla_group_rows", grp)
+        outs.append(d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(37), scale_factor=(1.0, 2.0, 2.0), sparse_params=sp))
+        n_fixed, n_online = d.attn_variant_counts()
+        assert (n_online == 0) if gain <= 3.0 else (n_fixed == 0), (gain, grp, n_fixed, n_online)
+        del d
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
