@@ -491,6 +491,20 @@ int ensure_attn_flags(k5_dit* d, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 struct NablaArgs { int T, Hb, Wb, wT, wH, wW; float P; };
 
+// the forward's first NABLA map (nqb query-block rows x nb key blocks per head, in ws_nabla): its kept density steers the NEXT forward's
+// attention workgroup size (nabla_group_rows = 0)
+int nabla_density_hint(k5_dit* d, int H, int nqb, int nb, hipStream_t s) {
+  if (!d->nabla_hint_pending || d->nabla_group_rows != 0) return K5_OK;
+  d->nabla_hint_pending = false;
+  K5CHK(d->ws_nabla_kept.ensure(8));
+  if (!d->h_nabla_kept) { HIPCHK(hipHostMalloc((void**)&d->h_nabla_kept, 8, hipHostMallocDefault)); *d->h_nabla_kept = 0ull; }
+  HIPCHK(hipMemsetAsync(d->ws_nabla_kept.p, 0, 8, s));
+  K5CHK(k5_launch_nabla_count(d->ws_nabla.p, H, nqb, nb, d->ws_nabla_kept.as<unsigned long long>(), s));
+  HIPCHK(hipMemcpyAsync(d->h_nabla_kept, d->ws_nabla_kept.p, 8, hipMemcpyDeviceToHost, s));
+  d->nabla_hint_possible = (long long)H * nqb * nb;
+  return K5_OK;
+}
+
 int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, void* qk, void* vt,
                        void* o, const float* cosT, const float* sinT, void* resid, const float* gate,
                        const char* fam_attn, const NablaArgs* nabla = nullptr) {
@@ -545,15 +559,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
       K5CHK(k5_launch_nabla_count(d->ws_nabla.p, H, nb, nb, d->ws_attn_cnt.as<unsigned long long>() + 2, s));
       d->nabla_possible += (long long)H * nb * nb;
     }
-    if (d->nabla_hint_pending && d->nabla_group_rows == 0) {   // the forward's first map: its density steers the NEXT forward's workgroup size
-      d->nabla_hint_pending = false;
-      K5CHK(d->ws_nabla_kept.ensure(8));
-      if (!d->h_nabla_kept) { HIPCHK(hipHostMalloc((void**)&d->h_nabla_kept, 8, hipHostMallocDefault)); *d->h_nabla_kept = 0ull; }
-      HIPCHK(hipMemsetAsync(d->ws_nabla_kept.p, 0, 8, s));
-      K5CHK(k5_launch_nabla_count(d->ws_nabla.p, H, nb, nb, d->ws_nabla_kept.as<unsigned long long>(), s));
-      HIPCHK(hipMemcpyAsync(d->h_nabla_kept, d->ws_nabla_kept.p, 8, hipMemcpyDeviceToHost, s));
-      d->nabla_hint_possible = (long long)H * nb * nb;
-    }
+    K5CHK(nabla_density_hint(d, H, nb, nb, s));
     const int *list, *cnt;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
     Scope sc(d, s, fam_attn);
@@ -700,12 +706,15 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     // while K' / V^T are still on their way; then the list-driven attention on the chunked V^T layout (single pass).
     HIPCHK(hipStreamWaitEvent(s, d->ev_means, 0));
     const int nb = N / 64;
+    // sparse maps: 128-query workgroups (lists per two rows, see nabla_group_rows) — without the split-job / two-pass machinery, which
+    // lives on the 256-query form; dense maps: that form, balanced
+    const int grp = (d->nabla_grp_now == 2 && d->sp_nabla_passes == 1) ? 2 : 4;
     K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
     {
       Scope sc(d, s, "nabla_map");
       K5CHK(k5_launch_nabla_key_means_from_slots(kmeans, H, nb, slot_blocks, d->ws_nabla.p, s));
       K5CHK(k5_launch_nabla_select_rect(q, nullptr, D, 0, H, rows, r * slot_blocks, N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
-                                        nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, r * slot_blocks, rows / 64));   // own key blocks lead the lists
+                                        nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, r * slot_blocks, rows / 64, grp));   // own key blocks lead the lists
     }
     if (d->profiling) {
       K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
@@ -715,7 +724,13 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     const int *list, *cnt, *cnt_local;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt, &cnt_local);
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
-    if (d->sp_nabla_passes > 1 && P > 1) {
+    K5CHK(nabla_density_hint(d, H, rows / 64, nb, s));
+    if (grp == 2) {
+      HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
+      Scope sc(d, s, "attn_self");
+      K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
+                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, nullptr, 2));
+    } else if (d->sp_nabla_passes > 1 && P > 1) {
       // two passes over every list: the rank's own key blocks (they lead the lists; K' / V^T of them are in place) while the other
       // ranks' keys travel — state out —, then the rest once the gather has landed (resume, normalise); late fallback as in the dense
       // schedule (a head whose row underflows on its per-row offset in pass 1 is recomputed from scratch by the online form of pass 2)

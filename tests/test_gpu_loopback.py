@@ -163,8 +163,9 @@ def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain, qfuse):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("P,gain,passes", [(2, 1.0, 2), (4, 3.0, 2), (3, 5.0, 2), (4, 3.0, 1), (8, 1.0, 2)])
-def test_full_width_nabla_P_ranks_on_one_gpu(P, gain, passes):
+@pytest.mark.parametrize("P,gain,passes,grp", [(2, 1.0, 2, 4), (4, 3.0, 2, 4), (3, 5.0, 2, 4), (4, 3.0, 1, 4), (8, 1.0, 2, 4),
+                                                (4, 3.0, 1, 2), (3, 5.0, 1, 2), (8, 1.0, 1, 2)])
+def test_full_width_nabla_P_ranks_on_one_gpu(P, gain, passes, grp):
     """NABLA under sequence parallelism at 2B-Lite width (2 visual blocks, latent (8,16,32) -> 16 blocks of 64 tokens): the ranks
     gather the SCALED keys plus the 64-token block means of their unscaled keys (all the map needs), so the sharded path runs the
     same pre-scaled kernels, per-head flags and per-row offsets as one GPU — at gain 3 (bound 104) every head must stay on the
@@ -172,7 +173,9 @@ def test_full_width_nabla_P_ranks_on_one_gpu(P, gain, passes):
     single-handle run: same map up to threshold ties, same arithmetic up to summation order.
     passes = 2 ("sp_nabla_passes"; default 1): every list is walked in two passes — the rank's own key blocks first (while the
     gather is in flight), the rest after it, with the fp32 state in between; P = 8 on 16 blocks: two blocks per rank, so most
-    (head, query group) lists have few or no local entries (an empty first pass must leave a usable state)."""
+    (head, query group) lists have few or no local entries (an empty first pass must leave a usable state).
+    grp = 2 ("nabla_group_rows"): key-tile lists per two 64-query rows and 128-query attention workgroups on the ranks (what the
+    engine picks by itself for sparse maps)."""
     from kandinsky.models.dit import DiffusionTransformer3D
     c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
     sd = O.synthetic_state_dict(O.DitConfig(**c), seed=3)
@@ -197,7 +200,7 @@ def test_full_width_nabla_P_ranks_on_one_gpu(P, gain, passes):
         return out, d.attn_variant_counts()
 
     fused, counts1 = call(make(), 0)
-    res = run_ranks(P, make, call, options={"sp_nabla_passes": passes})
+    res = run_ranks(P, make, call, options={"sp_nabla_passes": passes, "nabla_group_rows": grp})
     outs = [o for o, _ in res]
     for r in range(1, P):
         assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
