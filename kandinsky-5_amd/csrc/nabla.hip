@@ -95,7 +95,8 @@ K5_DEV float wave_max_dpp(float v) {
 // in registers.  Round 1 gave every row its own wave and re-read the head's whole key-mean matrix (187 KB at nb = 1464) from
 // L2 per row — 7.7 GB per layer, the kernel's time; here a key mean is loaded once per R rows, the dot products run on
 // v_dot2c_f32_bf16 (both operands ARE bf16), and the bisection works on registers with DPP reductions, the R rows in
-// lockstep (R independent reduction chains in flight).  1.02 -> 0.69 ms per layer at nb = 1464 (profiles/r02_nabla_kernel_stats.md).
+// lockstep (R independent reduction chains in flight).  1.02 -> 0.69 ms per layer at nb = 1464 (profiles/r02_nabla_kernel_stats.md);
+// with R = 4 the dot products moved to v_mfma_f32_4x4x4_16b_bf16 (below): 0.69 -> 0.63.
 template <int NV, int R>
 __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
   __shared__ __attribute__((aligned(16))) bf16_t sq[4 * R * 64];   // the block's 4 R query-block means
@@ -122,6 +123,28 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
     u32x4 kk[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) kk[c] = *reinterpret_cast<const u32x4*>(kp + 8 * c);
+    if constexpr (R == 4) {
+      // four query rows x this lane's key on the matrix core: v_mfma_f32_4x4x4_16b_bf16 = 16 independent 4x4x4 blocks, block b = lane >> 2.
+      // A: lane (b, i) holds query row i's k-slice, B: lane (b, j) holds key 4 b + j's k-slice, D: lane (b, j) register i = row i x its
+      // key — exactly the pv[r][v] layout (tools/probes/mfma_4x4x4_layout.hip).  16 k-steps of 4 instead of 4 x 32 quarter-rate
+      // v_dot2c per key (49 k of the kernel's ~145 k cycles per wave).
+      typedef __attribute__((ext_vector_type(4))) short bf16x4s;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const bf16_t* qrow = sq + (wave * R + (lane & 3)) * 64;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const u32x4 qq = *reinterpret_cast<const u32x4*>(qrow + 8 * c);
+        const u32x2 alo = {qq[0], qq[1]}, ahi = {qq[2], qq[3]}, blo = {kk[c][0], kk[c][1]}, bhi = {kk[c][2], kk[c][3]};
+        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bf16x4s, alo), __builtin_bit_cast(bf16x4s, blo), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bf16x4s, ahi), __builtin_bit_cast(bf16x4s, bhi), acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float lg = j < p.nb ? bf_round(acc[r]) * 0.125f : -3.0e38f;
+        pv[r][v] = lg;
+        mx[r] = fmaxf(mx[r], lg);
+      }
+    } else
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       float d = 0.f;
