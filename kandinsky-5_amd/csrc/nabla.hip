@@ -96,7 +96,8 @@ K5_DEV float wave_max_dpp(float v) {
 // L2 per row — 7.7 GB per layer, the kernel's time; here a key mean is loaded once per R rows, the dot products run on
 // v_dot2c_f32_bf16 (both operands ARE bf16), and the bisection works on registers with DPP reductions, the R rows in
 // lockstep (R independent reduction chains in flight).  1.02 -> 0.69 ms per layer at nb = 1464 (profiles/r02_nabla_kernel_stats.md);
-// with R = 4 the dot products moved to v_mfma_f32_4x4x4_16b_bf16 (below): 0.69 -> 0.63.
+// with R = 4 the dot products moved to v_mfma_f32_4x4x4_16b_bf16 (below): 0.69 -> 0.63; the bisection without per-row branches and with
+// its compares in SGPR pairs: -> 0.56.
 template <int NV, int R>
 __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
   __shared__ __attribute__((aligned(16))) bf16_t sq[4 * R * 64];   // the block's 4 R query-block means
@@ -183,20 +184,47 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
     target_base[r] = 0.f;
   }
   // smallest value v* with  sum_{p <= v*} p  >= target  (bisection over the bit pattern of non-negative floats), R rows in lockstep
+  // The interval [0, 0x7f800000] halves every step, so every row takes the same 31 steps: no per-row branch — the R rows' compare /
+  // select / add chains and DPP reductions sit in ONE basic block and interleave (with a branch per row every v_cmp -> v_cndmask pair
+  // went through VCC back to back: 29 hazard nops per row and step).  Padding lanes hold exactly 0: they add nothing on either side.
   bool more = true;
   while (more) {
+    float g[R];
+    unsigned mid[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { mid[r] = lo[r] + ((hi[r] - lo[r]) >> 1); g[r] = 0.f; }
+    if constexpr (R == 4) {
+      // four compares into four SGPR pairs, then the four selects: through VCC the compiler emits v_cmp / s_nop / v_cndmask one element at
+      // a time (gfx950 wants two wait states between a VALU write of a mask and the VALU that reads it; here three instructions lie between)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float t0, t1, t2, t3;
+        unsigned long long m0, m1, m2, m3;
+        asm("v_cmp_ge_u32_e64 %4, %8, %12\n\t"
+            "v_cmp_ge_u32_e64 %5, %9, %13\n\t"
+            "v_cmp_ge_u32_e64 %6, %10, %14\n\t"
+            "v_cmp_ge_u32_e64 %7, %11, %15\n\t"
+            "v_cndmask_b32_e64 %0, 0, %12, %4\n\t"
+            "v_cndmask_b32_e64 %1, 0, %13, %5\n\t"
+            "v_cndmask_b32_e64 %2, 0, %14, %6\n\t"
+            "v_cndmask_b32_e64 %3, 0, %15, %7"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+            : "s"(mid[0]), "s"(mid[1]), "s"(mid[2]), "s"(mid[3]), "v"(pv[0][v]), "v"(pv[1][v]), "v"(pv[2][v]), "v"(pv[3][v]));
+        g[0] += t0; g[1] += t1; g[2] += t2; g[3] += t3;
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)      // v outer, r inner: R independent add chains side by side
+#pragma unroll
+        for (int r = 0; r < R; ++r) g[r] += __float_as_uint(pv[r][v]) <= mid[r] ? pv[r][v] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) g[r] = wave_sum_dpp(g[r]);
     more = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (lo[r] < hi[r]) {   // wave-uniform
-        const unsigned mid = lo[r] + ((hi[r] - lo[r]) >> 1);
-        float g = 0.f;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) g += (__float_as_uint(pv[r][v]) <= mid && v * 64 + lane < p.nb) ? pv[r][v] : 0.f;
-        g = wave_sum_dpp(g);
-        if (g >= p.target) hi[r] = mid; else lo[r] = mid + 1;
-        more = more || lo[r] < hi[r];
-      }
+      if (lo[r] < hi[r]) { if (g[r] >= p.target) hi[r] = mid[r]; else lo[r] = mid[r] + 1; }   // wave-uniform selects
+      more = more || lo[r] < hi[r];
     }
   }
 #pragma unroll
