@@ -35,6 +35,9 @@ WORKLOADS = {
     "10s_nabla": dict(latent=(61, 64, 96), L=256, Lnull=32, w=1.0, attn="nabla",
                       desc="config_10s_sft.yaml attention (NABLA P=0.9, wT=11, wH=wW=3) on the 768x512 10 s latent (61,64,96,16), "
                            "93696 tokens, guidance 1.0; map density depends on the (random) weights and is reported"),
+    "10s_hd_nabla": dict(latent=(61, 96, 160), L=256, Lnull=32, w=1.0, attn="nabla",
+                         desc="BASELINE config 5's shape: NABLA on the 1280x768 10 s latent (61,96,160,16), 234240 tokens = 3660 blocks, guidance "
+                              "1.0 (meant for --emulate-shard 4 / real ranks: one CFG branch of the SP x 4 + CFG x 2 plan)"),
     "2s_256": dict(latent=(13, 32, 32), L=256, Lnull=32, w=1.0, attn="flash",
                    desc="config_5s_distil.yaml plumbing case: 256x256 2 s latent (13,32,32,16), 3328 tokens"),
 }

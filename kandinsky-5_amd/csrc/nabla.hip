@@ -124,14 +124,14 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
     u32x4 kk[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) kk[c] = *reinterpret_cast<const u32x4*>(kp + 8 * c);
-    if constexpr (R == 4) {
-      // four query rows x this lane's key on the matrix core: v_mfma_f32_4x4x4_16b_bf16 = 16 independent 4x4x4 blocks, block b = lane >> 2.
+    if constexpr (R == 4 || R == 2) {
+      // four query rows (R = 2: the two rows twice) x this lane's key on the matrix core: v_mfma_f32_4x4x4_16b_bf16 = 16 independent 4x4x4 blocks, block b = lane >> 2.
       // A: lane (b, i) holds query row i's k-slice, B: lane (b, j) holds key 4 b + j's k-slice, D: lane (b, j) register i = row i x its
       // key — exactly the pv[r][v] layout (tools/probes/mfma_4x4x4_layout.hip).  16 k-steps of 4 instead of 4 x 32 quarter-rate
       // v_dot2c per key (49 k of the kernel's ~145 k cycles per wave).
       typedef __attribute__((ext_vector_type(4))) short bf16x4s;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const bf16_t* qrow = sq + (wave * R + (lane & 3)) * 64;
+      const bf16_t* qrow = sq + (wave * R + (lane & (R - 1))) * 64;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const u32x4 qq = *reinterpret_cast<const u32x4*>(qrow + 8 * c);
@@ -408,7 +408,7 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   p.qa = qa; p.ka = ka; p.bits = bits; p.kv_nb = kv_nb; p.H = H; p.nb = nb; p.nw = nw; p.T = T; p.Hb = Hb; p.Wb = Wb;
   p.wT = wT; p.wH = wH; p.wW = wW; p.target = (float)(1.0 - (double)P);
   p.nqb = nqb; p.qb0 = q_block0;
-  // values per lane NV = ceil(nb / 64) rounded up to an instantiated size; rows per wave R = 4 (2, then 1, for the largest maps: registers)
+  // values per lane NV = ceil(nb / 64) rounded up to an instantiated size; rows per wave R = 4 (2 for the largest maps: registers)
   const int nv = nw;
   auto launch = [&](auto NVC, auto RC) {
     constexpr int NV = decltype(NVC)::value, R = decltype(RC)::value;
@@ -419,8 +419,10 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   else if (nv <= 8) launch(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
   else if (nv <= 16) launch(std::integral_constant<int, 16>{}, std::integral_constant<int, 4>{});
   else if (nv <= 24) launch(std::integral_constant<int, 24>{}, std::integral_constant<int, 4>{});
-  else if (nv <= 32) launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 2>{});
-  else launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 1>{});
+  // (round 2 until late: <32, 2> and <64, 1>; four / two rows per wave share the key-mean loads and take the MFMA path —
+  // 3660 blocks, a 4-GPU shard of the 1280x768 10 s clip: 82.4 -> 60.2 ms of map per step)
+  else if (nv <= 32) launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 4>{});
+  else launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{});
   hipLaunchKernelGGL(nabla_union_kernel, dim3((H * ng + 3) / 4), dim3(256), 0, s, bits, list, cnt, cnt_local, H, nqb, nb, nw, ng, local_block0,
                      local_blocks, group_rows);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;

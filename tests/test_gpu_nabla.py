@@ -50,7 +50,11 @@ def _cdf_at_entries(q, k, mode="bf16"):
 
 
 @pytest.mark.parametrize("grid,window,P,H", [((6, 2, 2), (3, 1, 1), 0.7, 2), ((10, 3, 4), (5, 3, 3), 0.9, 3),
-                                             ((4, 2, 3), (11, 3, 3), 0.5, 1), ((3, 1, 1), (1, 1, 1), 0.9, 2)])
+                                             ((4, 2, 3), (11, 3, 3), 0.5, 1), ((3, 1, 1), (1, 1, 1), 0.9, 2),
+                                             # one case per register-resident instantiation of the select kernel (values per lane x rows
+                                             # per wave): 600 blocks <16,4>, 1464 (the 10 s clip) <24,4>, 1600 <32,4>, 2100 <64,2>
+                                             ((25, 4, 6), (5, 3, 3), 0.9, 2), ((61, 4, 6), (11, 3, 3), 0.9, 2),
+                                             ((25, 8, 8), (11, 3, 3), 0.9, 1), ((35, 6, 10), (5, 3, 3), 0.8, 1)])
 @pytest.mark.parametrize("data", ["exact", "random"])
 def test_nabla_map_matches_oracle(E, grid, window, P, H, data):
     """k5_nabla_select_bf16 vs oracle.nabla_block_mask, entry by entry.
@@ -97,7 +101,8 @@ def test_nabla_map_matches_oracle(E, grid, window, P, H, data):
             assert near[h, i, j] or (int(tied.sum()) > 1 and lo <= thr <= hi), (h, i, j, float(cdf[h, i, j]), thr, int(tied.sum()))
     # how MANY entries may differ: integer logits make large tie groups (every member of a group straddling the cut may flip,
     # checked one by one above), random logits at most a few entries next to the cut per row
-    assert diff.float().mean().item() <= (3e-2 if data == "exact" else 5e-3), (int(diff.sum()), diff.numel())
+    # (the tie groups of integer logits grow with the row length: up to a tenth of a 2100-block row ties at the cut)
+    assert diff.float().mean().item() <= ((3e-2 if nb < 1000 else 1e-1) if data == "exact" else 5e-3), (int(diff.sum()), diff.numel())
     assert (got & sta[None]).sum() == sta.sum() * H                     # the STA window is always kept
     assert got.any(-1).all()                                            # every row keeps at least one block
 
