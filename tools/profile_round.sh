@@ -31,4 +31,6 @@ for np in 0.9 0.15 0.0; do python bench.py --steps 4 --warmup 2 --no-cpu-baselin
 for sh in 2 4 8; do for sl in 1 2; do python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --emulate-shard $sh --sp-slices $sl 2>/dev/null | grep "^{" >> $OUT/${TAG}_shards.jsonl; done; done
 # 7. NABLA under sequence parallelism: the 10 s clip as rank 0 of 4 (BASELINE config 4), near-dense and STA-only maps, one / two passes
 for np in 0.9 0.0; do for ps in 1 2; do python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vae --workload 10s_nabla --nabla-p $np --emulate-shard 4 --engine-option sp_nabla_passes=$ps 2>/dev/null | grep "^{" >> $OUT/${TAG}_shards.jsonl; done; done
+# 8. BASELINE config 5's shape (1280x768, 10 s: 3660 blocks) as rank 0 of 4, STA-only and near-dense maps
+for np in 0.0 0.9; do python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-vae --workload 10s_hd_nabla --nabla-p $np --emulate-shard 4 2>/dev/null | grep "^{" >> $OUT/${TAG}_shards.jsonl; done
 wc -l $OUT/${TAG}_workloads.jsonl $OUT/${TAG}_shards.jsonl
