@@ -1304,6 +1304,9 @@ extern "C" int k5_dit_finalize(k5_dit* d) {
   HIPCHK(hipDeviceSynchronize());   // the pack kernels read the staged device copies that are freed next
   for (auto& kv : d->staged) kv.second.dev.release();
   d->staged.clear();
+  // the NABLA density hint's device counter and pinned host copy exist before any forward (no allocation inside a stream capture)
+  K5CHK(d->ws_nabla_kept.ensure(8));
+  if (!d->h_nabla_kept) { HIPCHK(hipHostMalloc((void**)&d->h_nabla_kept, 8, hipHostMallocDefault)); *d->h_nabla_kept = 0ull; }
   d->finalized = true;
   return K5_OK;
 }

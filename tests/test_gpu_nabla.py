@@ -387,3 +387,29 @@ def test_lists_per_two_rows_give_the_same_bits(gain):
         del d
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_nabla_graph_captured_step_is_bit_identical(tiny_sd, golden, golden_meta):
+    """NABLA through k5_dit_set_graph: the captured step contains the map kernels, the density-hint count and its device-to-pinned-host
+    copy (buffers allocated at finalize, nothing inside the capture) — the replayed steps must equal the eager loop bit for bit (the
+    hint only picks the attention workgroup size, which does not change the result)."""
+    from kandinsky.config import Conf
+    from kandinsky.generation_utils import generate
+    from kandinsky.models.dit import DiffusionTransformer3D
+    attn = golden_meta["nabla_attention"]
+    conf = Conf({"model": {"dit_params": {"patch_size": [1, 2, 2]}, "attention": attn}, "metrics": {"scale_factor": [1.0, 2.0, 2.0]}})
+    pos = [torch.arange(6), torch.arange(16), torch.arange(16)]
+    te = {"text_embeds": golden["fwd.text"].cuda(), "pooled_embed": golden["fwd.pooled"].cuda()}
+    ne = {"text_embeds": golden["gen.null_text"].cuda(), "pooled_embed": golden["gen.null_pooled"].cuda()}
+    outs = []
+    for graph in (False, True):
+        dit = DiffusionTransformer3D(**dict(golden_meta["tiny_config"]))
+        dit.load_state_dict(tiny_sd, assign=True)
+        dit = dit.to("cuda:0")
+        dit.engine("cuda:0")
+        dit.set_graph(graph)
+        outs.append(generate(dit, "cuda:0", (6, 32, 32, 16), 5, te, ne, pos, torch.arange(7), torch.arange(4), 2.0, 5.0, conf,
+                             noise=golden["gen.nabla.noise"]))
+        del dit
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
