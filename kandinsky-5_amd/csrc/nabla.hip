@@ -193,25 +193,38 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
     unsigned mid[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { mid[r] = lo[r] + ((hi[r] - lo[r]) >> 1); g[r] = 0.f; }
+    // four compares into four SGPR pairs, then the four selects: through VCC the compiler emits v_cmp / s_nop / v_cndmask one element at
+    // a time (gfx950 wants two wait states between a VALU write of a mask and the VALU that reads it; here three instructions lie between)
+    auto select4 = [](unsigned ma, unsigned mb, unsigned mc, unsigned md, float a, float b, float c, float d, float& ta, float& tb,
+                      float& tc, float& td) __attribute__((always_inline)) {
+      unsigned long long m0, m1, m2, m3;
+      asm("v_cmp_ge_u32_e64 %4, %8, %12\n\t"
+          "v_cmp_ge_u32_e64 %5, %9, %13\n\t"
+          "v_cmp_ge_u32_e64 %6, %10, %14\n\t"
+          "v_cmp_ge_u32_e64 %7, %11, %15\n\t"
+          "v_cndmask_b32_e64 %0, 0, %12, %4\n\t"
+          "v_cndmask_b32_e64 %1, 0, %13, %5\n\t"
+          "v_cndmask_b32_e64 %2, 0, %14, %6\n\t"
+          "v_cndmask_b32_e64 %3, 0, %15, %7"
+          : "=&v"(ta), "=&v"(tb), "=&v"(tc), "=&v"(td), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+          : "s"(ma), "s"(mb), "s"(mc), "s"(md), "v"(a), "v"(b), "v"(c), "v"(d));
+    };
     if constexpr (R == 4) {
-      // four compares into four SGPR pairs, then the four selects: through VCC the compiler emits v_cmp / s_nop / v_cndmask one element at
-      // a time (gfx950 wants two wait states between a VALU write of a mask and the VALU that reads it; here three instructions lie between)
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         float t0, t1, t2, t3;
-        unsigned long long m0, m1, m2, m3;
-        asm("v_cmp_ge_u32_e64 %4, %8, %12\n\t"
-            "v_cmp_ge_u32_e64 %5, %9, %13\n\t"
-            "v_cmp_ge_u32_e64 %6, %10, %14\n\t"
-            "v_cmp_ge_u32_e64 %7, %11, %15\n\t"
-            "v_cndmask_b32_e64 %0, 0, %12, %4\n\t"
-            "v_cndmask_b32_e64 %1, 0, %13, %5\n\t"
-            "v_cndmask_b32_e64 %2, 0, %14, %6\n\t"
-            "v_cndmask_b32_e64 %3, 0, %15, %7"
-            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-            : "s"(mid[0]), "s"(mid[1]), "s"(mid[2]), "s"(mid[3]), "v"(pv[0][v]), "v"(pv[1][v]), "v"(pv[2][v]), "v"(pv[3][v]));
+        select4(mid[0], mid[1], mid[2], mid[3], pv[0][v], pv[1][v], pv[2][v], pv[3][v], t0, t1, t2, t3);
         g[0] += t0; g[1] += t1; g[2] += t2; g[3] += t3;
       }
+    } else if constexpr (R == 2 && NV % 2 == 0) {   // two rows x two consecutive values per batch; two accumulators per row
+      float g2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < NV; v += 2) {
+        float t0, t1, t2, t3;
+        select4(mid[0], mid[1], mid[0], mid[1], pv[0][v], pv[1][v], pv[0][v + 1], pv[1][v + 1], t0, t1, t2, t3);
+        g[0] += t0; g[1] += t1; g2[0] += t2; g2[1] += t3;
+      }
+      g[0] += g2[0]; g[1] += g2[1];
     } else {
 #pragma unroll
       for (int v = 0; v < NV; ++v)      // v outer, r inner: R independent add chains side by side
