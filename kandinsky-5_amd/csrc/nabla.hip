@@ -55,6 +55,7 @@ struct SelP {
   int H, nb, nw, T, Hb, Wb, wT, wH, wW;
   int nqb, qb0;                         // query blocks handled here: global blocks [qb0, qb0 + nqb) (sequence parallel: the rank's rows)
   float target;                         // 1 - P
+  unsigned magic_hw, magic_w;           // ceil(2^32 / (Hb Wb)), ceil(2^32 / Wb): floor(n / d) = umulhi(n, magic) while n d < 2^32
 };
 
 constexpr int SEL_MAXNB = 4096;
@@ -255,7 +256,8 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
     int m0 = 1;
     if (vstar > 0.f) { const float need = (p.target - base) / vstar; m0 = (int)ceilf(need); if (m0 < 1) m0 = 1; }
     // emit bits, 64 kv blocks per word (word c = this lane's value v = c)
-    const int ti = i / (p.Hb * p.Wb), hi_ = (i / p.Wb) % p.Hb, wi = i % p.Wb;
+    const int hw_blocks = p.Hb * p.Wb;
+    const int ti = i / hw_blocks, hi_ = (i / p.Wb) % p.Hb, wi = i % p.Wb;
     int tie_seen = 0, kept = 0;
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
@@ -266,7 +268,10 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
         const unsigned vb = __float_as_uint(pv[r][c]);
         tie = vb == vbits;
         keep = vb > vbits;
-        const int tj = j / (p.Hb * p.Wb), hj = (j / p.Wb) % p.Hb, wj = j % p.Wb;
+        // block coordinates by multiply-high with host-made reciprocals (exact for j < 2^16, divisors <= 2^12): the three runtime
+        // integer divisions per entry were ~60 instructions of this loop's ~90
+        const int tj = hw_blocks == 1 ? j : (int)__umulhi((unsigned)j, p.magic_hw), rj = j - tj * hw_blocks;   // (a divisor of 1 has no 32-bit magic)
+        const int hj = p.Wb == 1 ? rj : (int)__umulhi((unsigned)rj, p.magic_w), wj = rj - hj * p.Wb;
         keep = keep || (abs(ti - tj) <= p.wT / 2 && abs(hi_ - hj) <= p.wH / 2 && abs(wi - wj) <= p.wW / 2);
       }
       const unsigned long long tmask = __ballot(tie);
@@ -421,6 +426,8 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   p.qa = qa; p.ka = ka; p.bits = bits; p.kv_nb = kv_nb; p.H = H; p.nb = nb; p.nw = nw; p.T = T; p.Hb = Hb; p.Wb = Wb;
   p.wT = wT; p.wH = wH; p.wW = wW; p.target = (float)(1.0 - (double)P);
   p.nqb = nqb; p.qb0 = q_block0;
+  p.magic_hw = (unsigned)(((1ull << 32) + (unsigned long long)(Hb * Wb) - 1) / (unsigned long long)(Hb * Wb));
+  p.magic_w = (unsigned)(((1ull << 32) + (unsigned long long)Wb - 1) / (unsigned long long)Wb);
   // values per lane NV = ceil(nb / 64) rounded up to an instantiated size; rows per wave R = 4 (2 for the largest maps: registers)
   const int nv = nw;
   auto launch = [&](auto NVC, auto RC) {
