@@ -275,11 +275,13 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
         keep = keep || (abs(ti - tj) <= p.wT / 2 && abs(hi_ - hj) <= p.wH / 2 && abs(wi - wj) <= p.wW / 2);
       }
       const unsigned long long tmask = __ballot(tie);
-      if (tie) {
-        const int rank = tie_seen + __popcll(tmask & ((1ull << lane) - 1ull)) + 1;
-        keep = keep || rank >= m0;
+      if (tmask) {   // wave-uniform and rare: values equal to the cut
+        if (tie) {
+          const int rank = tie_seen + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tmask, 0u)) + 1;
+          keep = keep || rank >= m0;
+        }
+        tie_seen += __popcll(tmask);
       }
-      tie_seen += __popcll(tmask);
       const unsigned long long w = __ballot(keep);
       kept += __popcll(w);
       if (lane == 0) p.bits[((size_t)h * p.nqb + il) * p.nw + c] = w;
