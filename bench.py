@@ -49,7 +49,7 @@ def flops_forward(N, L, D=1792, FF=7168, blocks=32):
     return blocks * (2 * N * (6 * D * D + 2 * D * FF) + 2 * L * 2 * D * D + 4 * N * N * D + 4 * N * L * D) + 0.2e12
 
 
-def cpu_baseline(N, budget_s=5.0):   # the full-size sample runs ~3.5x slower than the 1024-token calibration predicts
+def cpu_baseline(N, budget_s=3.0):   # the full-size sample runs ~3.5x slower than the 1024-token calibration predicts
     """The CPU oracle (own fp32 restatement pinned against the reference, oracle/k5_oracle.py) on the host
     cores: ONE full-width decoder block of the 32 at the workload's token count, extrapolated x32 (the text
     blocks / embeddings are <0.1 % of the FLOPs).  If one block at N would exceed the budget, a query-row
@@ -103,10 +103,22 @@ def cpu_baseline(N, budget_s=5.0):   # the full-size sample runs ~3.5x slower th
     t_s = time.perf_counter() - t0
     # k/v projections were done on all N rows; scale the row-proportional part only
     t_block = t_s * (fl(N, N) / (fl(N, nq) + 2 * (N - nq) * 2 * D * D))
+    # BASELINE config 1 (config_5s_distil: (13,32,32) latent = 3328 tokens, the reference's own CPU-runnable case) IN FULL, no
+    # extrapolation: 32 complete decoder-block evaluations at N = 3328 (one block's weights reused: the arithmetic and its cost are
+    # those of the 32 distinct blocks; the two text blocks / embeddings are < 0.2 % of a forward)
+    n1 = 13 * 16 * 16
+    x1, c1 = torch.randn(n1, D, generator=g), (torch.ones(n1, 32), torch.zeros(n1, 32))
+    t0 = time.perf_counter()
+    for _ in range(32):
+        x1 = O.decoder_block(sd, "visual_transformer_blocks.0", x1, text, temb, c1[0], c1[1], cfg, "fp32")
+    t_c1 = time.perf_counter() - t0
     return {"value": 1.0 / (32 * t_block), "unit": "steps/s", "cores": cores, "host_cpus": ncpu, "kind": "port",
             "sample": f"fp32 torch-CPU oracle, 1 of 32 decoder blocks, {nq} of {N} query rows against all {N} keys "
                       f"({t_s:.1f} s measured), scaled to the full block and x32 blocks",
-            "ms_per_step": 32 * t_block * 1e3}
+            "ms_per_step": 32 * t_block * 1e3,
+            "config1_forward_s": t_c1,
+            "config1_sample": f"BASELINE config 1 (256x256 2 s latent (13,32,32), {n1} tokens): 32 full decoder blocks timed in full, "
+                              f"{cores} threads; x16 steps (NFE 16) = {16 * t_c1:.0f} s per clip on this host"}
 
 
 def main():
@@ -225,6 +237,7 @@ def main():
 
     FAMS = ("attn_self", "attn_cross", "attn_text", "gemm", "elementwise", "prologue", "epilogue", "comm", "nabla_map")
     fam = {f: dit.get_profile(f) for f in FAMS}
+    self_blocks = dit.get_profile("self_blocks")[1]      # visual blocks whose self-attention ran inside the timed region
     fam_steps = args.steps
     n_fixed, n_online = dit.attn_variant_counts()
     nabla_counts = dit.nabla_block_counts() if wl["attn"] == "nabla" else None
@@ -264,7 +277,9 @@ def main():
     # algorithmic FLOPs of the self-attention on THIS rank, from the launches actually MADE (MagCache skips whole block
     # stacks; under sequence parallelism a block's attention is two timed launches: local chunk, then the gathered chunks):
     #   dense: 4 * N^2 * 64 * 28 / shard per block;  NABLA: that times the kept fraction of 64x64 blocks, counted on the device
-    blocks_run = attn_n / (2 if (sp_on and wl["attn"] == "flash") else 1)
+    #   the number of blocks comes from the engine's own counter (a block is 1 timed launch group on one GPU, 2 under sequence
+    #   parallelism, 1 + S with a sliced exchange, 2 with the two-pass NABLA list walk: dividing launches by a guess inflated `frac`)
+    blocks_run = self_blocks
     density = None
     if wl["attn"] == "nabla":
         kept, possible = nabla_counts
@@ -279,14 +294,27 @@ def main():
         variant = (f"fixed-offset softmax on {n_fixed} and online-max on {n_online} of {n_fixed + n_online} (block, head) "
                    f"launches, chosen per head on the device: max|q|*max|k'| <= 180 keeps the fixed form (per-row offsets |q|*max|k'| - 90, "
                    f"all zero when the bound is <= 90)")
-    traffic = None   # HBM-side bytes per attention launch from the committed PMC profile (separate --pmc passes; cannot be
-    try:             # collected inside a timed run) — only quoted for the exact workload it was measured on
-        with open(os.path.join(ROOT, "profiles", "r02_attention_traffic.json")) as f:
-            tj = json.load(f)
-        if tj.get("tokens") == N and world == 1 and wl["attn"] == "flash" and not args.attn_online and n_online == 0:
-            traffic = tj["bytes_per_launch"]
-    except Exception:
-        pass
+    traffic, traffic_source = None, None   # HBM-side bytes per attention launch: NOT measured in this run (PMC counters need their own
+    for tf in ("r03_attention_traffic.json", "r02_attention_traffic.json"):   # rocprofv3 --pmc passes) but read from the committed profile,
+        try:                                                                  # and only quoted for the exact workload it was measured on
+            with open(os.path.join(ROOT, "profiles", tf)) as f:
+                tj = json.load(f)
+            if tj.get("tokens") == N and world == 1 and wl["attn"] == "flash" and not args.attn_online and n_online == 0:
+                traffic, traffic_source = tj["bytes_per_launch"], f"profiles/{tf} (rocprofv3 --pmc passes of an earlier run of this command, not this run)"
+                break
+        except Exception:
+            pass
+    # the GEMM family (q|k, V^T, out, cross q/out, FF1, FF2 of the visual blocks: 2 * rows * (6 D^2 + 2 D FF) per block on this rank's
+    # rows; text-side projections are < 0.1 %) — on the sparse configurations it, not the attention, is the largest family
+    g_ms, g_n = fam_break["gemm"]
+    rows_rank = N / shard
+    gemm_flop_step = self_blocks / max(args.steps, 1) * 2 * rows_rank * (6 * 1792 * 1792 + 2 * 1792 * 7168)   # blocks per step x FLOPs per block
+    gemm_roof = None
+    if g_ms and gemm_flop_step:
+        g_ach = gemm_flop_step / (g_ms / fam_steps * 1e-3) / 1e12
+        gemm_roof = {"bound": "mfma", "kernel": "gemm_bf16_w4_kernel / k8 / glds (all linear layers of the visual blocks)", "achieved": g_ach,
+                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": g_ach / PEAK_BF16_TFLOPS, "ms_per_step": g_ms / fam_steps,
+                     "source": "separate per-family pass" if fam_break is not fam else "timed region"}
     invalid = []
     if args.emulate_shard > 1 or dit.get_option("emulated"):
         invalid.append("emulated shard layout (timing only, results garbage)")
@@ -296,6 +324,14 @@ def main():
         invalid.append("reduced precision (fp8 feed-forward)")
     step_flop = fwd_per_step * flops_forward(N, L, blocks=args.blocks)
     assert torch.isfinite(latent).all(), "latent diverged"
+    rank_check = None
+    if world > 1:   # every rank applies the same Euler update to the same gathered velocity: the latents must be BIT-identical
+        cs = torch.stack([latent.double().sum(), latent.double().abs().sum(), latent.view(torch.int32).sum(dtype=torch.int64).double()])
+        allcs = [torch.empty_like(cs) for _ in range(world)]
+        torch.distributed.all_gather(allcs, cs)
+        same = all(torch.equal(allcs[0], c) for c in allcs)
+        rank_check = {"latent_checksums_identical_on_all_ranks": bool(same), "checksum": [float(v) for v in allcs[0].tolist()]}
+        assert same, f"ranks disagree on the latent: {[c.tolist() for c in allcs]}"
 
     if rank == 0:
         out = {
@@ -314,9 +350,11 @@ def main():
             "model_tflops_per_gpu": step_flop * args.steps / dt / 1e12 / world,
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (visual self-attention, one balanced launch group per block)",
                          "variant": variant, "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "flop_per_launch": attn_flop * blocks_run / max(attn_n, 1), "avg_launch_ms": attn_ms / max(attn_n, 1),
-                         "launches": attn_n, "blocks_run": blocks_run, "kept_block_density": density},
+                         "launches": attn_n, "blocks_run": blocks_run, "launches_per_block": attn_n / max(blocks_run, 1),
+                         "kept_block_density": density},
+            "roofline_gemm": gemm_roof,
             "kernel_time_ms_per_step": {k: v[0] / fam_steps for k, v in fam_break.items() if v[1]},
             "kernel_time_source": ("HIP events inside the timed region" if fam_break is fam else
                                    f"attn_self: HIP events inside the timed region; other families: separate {fam_steps}-step pass with an "
@@ -326,6 +364,8 @@ def main():
                            "note": "50 x measured ms_per_step + measured HunyuanVideo VAE decode (14 temporal tiles, uint8 out); "
                                    "text encoding excluded (no weights offline); reference README: 77 s on 1xH100 incl. text encoder"},
         }
+        if rank_check is not None:
+            out["rank_check"] = rank_check
         if invalid:
             out["INVALID_AS_BENCH"] = invalid
         if not args.no_cpu_baseline and world == 1:

@@ -29,6 +29,9 @@ typedef enum {
 typedef enum { K5_F32 = 0, K5_BF16 = 1, K5_F16 = 2 } k5_dtype;
 typedef enum { K5_EPI_BIAS = 0, K5_EPI_BIAS_M = 1, K5_EPI_GELU = 2, K5_EPI_GATE = 3, K5_EPI_F32 = 4 /* internal */ } k5_epilogue;
 
+/* bumped whenever an entry point is added or changes meaning; the host binding checks it BEFORE binding symbols, so that a stale
+ * libk5.so fails with a clear message instead of a missing-symbol lookup (round 3: 3) */
+#define K5_ABI_VERSION 3
 int k5_abi_version(void);
 const char* k5_last_error(void);
 
@@ -321,6 +324,17 @@ int64_t k5_groupnorm_workspace_size(int M, int G);
 int k5_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
                       int silu, void* workspace, void* stream);
 
+/* The production pairing of the two (vae.py:246-263: GroupNorm -> SiLU -> conv, the norm reading what the previous conv wrote): the
+ * conv also emits the GroupNorm statistics of the outputs it STORES — per 128 rows and 4 consecutive channels (sum, sum of squares),
+ * quad_stats: k5_conv3d_stats_size(M, Cout) bytes, M = To*Ho*Wo — and k5_groupnorm_bf16_quads normalises from them without a
+ * statistics pass of its own (workspace as for k5_groupnorm_bf16).  Only the 4-wave implicit-GEMM kernel emits statistics:
+ * K5_ERR_UNSUPPORTED (nothing launched) outside its range (Cin % 128, Cout = 128 or % 256, >= 5/8 of a round of 256-row tiles). */
+int64_t k5_conv3d_stats_size(int M, int Cout);
+int k5_conv3d_bf16_stats(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin, int Cout,
+                         int up_t, int up_s, int ldc, const void* resid, int ldr, float* quad_stats, void* stream);
+int k5_groupnorm_bf16_quads(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
+                            int silu, const float* quad_stats, void* workspace, void* stream);
+
 typedef struct k5_vae k5_vae;
 typedef struct k5_vae_config {   /* AutoencoderKLHunyuanVideo.__init__ kwargs, vae.py:709-731 */
   int latent_channels, out_channels;
@@ -343,6 +357,11 @@ int k5_vae_decode_tile(k5_vae* vae, const float* z, int T, int H, int W, void* o
  * = the moments [mean | logvar] the reference hands to DiagonalGaussianDistribution. */
 int k5_vae_encode_tile(k5_vae* vae, const float* x, int T, int H, int W, void* out, void* stream);
 int k5_vae_has_encoder(k5_vae* vae);
+/* Diagnostics: launches per kernel route since the last reset — out8 = {conv on 128x128 tiles, conv 4-wave, conv 4-wave + GroupNorm
+ * statistics, conv_out3, GroupNorm from the conv's statistics, GroupNorm with its own statistics pass, mid attention in one kernel
+ * (C = 512), mid attention as GEMM-softmax-GEMM}.  Lets a parity test assert that the kernels the timed decode runs are the ones it
+ * checked (tests/test_gpu_vae.py::test_production_tile_vs_reference_golden). */
+int k5_vae_path_counts(k5_vae* vae, long long* out8, int reset);
 /* blend_t / blend_v / blend_h (vae.py:908-936) on contiguous bf16 tensors viewed as [outer][len][inner]:
  * b[:, y, :] = a[:, len_a-extent+y, :]*(1-y/extent) + b[:, y, :]*(y/extent), y < extent (eager bf16 rounding) */
 int k5_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, void* stream);
@@ -387,7 +406,9 @@ int k5_dit_magcache_state(k5_dit* dit, int* cnt, long long* n_ran, long long* n_
 /* per-kernel-family accumulated GPU time of the last forward(s), measured with hipEvents on the
  * engine's stream when profiling is enabled.  names: "attn_self","attn_cross","gemm","elementwise",...
  * level 0 = off, 1 = every family (an event pair per family switch: ~15 per block, the stream drains at each one),
- * 2 = only "attn_self", the roofline kernel (one pair per block) — what bench.py keeps on inside its timed region. */
+ * 2 = only "attn_self", the roofline kernel (one pair per block) — what bench.py keeps on inside its timed region.
+ * The pseudo-family "self_blocks" returns (0 ms, the number of visual blocks whose self-attention ran while profiling was on):
+ * a block's attention is 1 timed scope on one GPU, 2 under sequence parallelism, 1 + S with a sliced exchange — FLOPs are per block. */
 int k5_dit_set_profiling(k5_dit* dit, int level);
 int k5_dit_get_profile(k5_dit* dit, const char* family, double* total_ms, int64_t* launches);
 int k5_dit_reset_profile(k5_dit* dit);

@@ -518,7 +518,11 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     if (e + 1 >= T) break;
     tile_step(std::integral_constant<int, 1>{}, e + 1);
   }
-  if (BOUNDED && PRE && QN && wave_over && lane == 0 && atomicCAS(const_cast<int*>(p.head_flags) + h, 1, 0) == 1 && p.variant_counters) {
+  // In a multi-pass schedule (late_pass != 0) the flip writes the LATE flag: the launches of a pass are balanced as fixed(full),
+  // online(full), fixed(tail), online(tail), so a flip that comes from a tail job lands after online(full) has skipped the head —
+  // its full jobs keep fixed-form state (relative to the per-row offsets), which the online form of a later pass must not resume
+  // as offset 0.  Flag 2 = every later launch skips the head and the last pass's online launch recomputes it from scratch.
+  if (BOUNDED && PRE && QN && wave_over && lane == 0 && atomicCAS(const_cast<int*>(p.head_flags) + h, 1, p.late_pass ? 2 : 0) == 1 && p.variant_counters) {
     atomicAdd(p.variant_counters + 1, 1ull);
     atomicAdd(p.variant_counters, ~0ull);   // - 1
   }

@@ -237,6 +237,10 @@ __global__ __launch_bounds__(256) void conv3d_out3_kernel(ConvP p) {
 
 // X [Ts][Hs][Ws][Cin] bf16 ; W [Cout][27][Cin] bf16 ; bias fp32 [Cout] ; out [To*Ho*Wo][ldc] bf16
 // (To,Ho,Wo) = (Ts,Hs,Ws) scaled by the folded nearest upsample: Ho = up_s*Hs, Wo = up_s*Ws, To = up_t==2 ? 2*Ts-1 : Ts.
+static thread_local int g_conv_last_kind = -1;
+int k5_conv3d_last_kind() { return g_conv_last_kind; }
+void k5_conv3d_set_last_kind(int kind) { g_conv_last_kind = kind; }
+
 int k5_launch_conv3d_bf16(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin,
                           int Cout, int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream) {
   return k5_launch_conv3d_bf16_strided(X, W, bias, out, Ts, Hs, Ws, Cin, Cout, up_t, up_s, 1, 1, ldc, resid, ldr, stream);
@@ -272,10 +276,12 @@ int k5_launch_conv3d_bf16_strided(const void* X, const void* W, const float* bia
     if (nwg > 0x7fffffffLL) return K5_ERR_UNSUPPORTED;
     if (Cin == 128) hipLaunchKernelGGL(conv3d_out3_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(conv3d_out3_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    k5_conv3d_set_last_kind(K5_CONV_KIND_OUT3);
     return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
   }
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (Cout + BN - 1) / BN;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  k5_conv3d_set_last_kind(K5_CONV_KIND_TILE128);
   if (resid) hipLaunchKernelGGL(conv3d_kernel<true>, grid, block, 0, stream, p);
   else hipLaunchKernelGGL(conv3d_kernel<false>, grid, block, 0, stream, p);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;

@@ -333,6 +333,7 @@ int k5_launch_conv3d_w4(const void* X, const void* W, const float* bias, void* o
   static const int min_fill8 = getenv("K5_CONV_MIN_FILL8") ? atoi(getenv("K5_CONV_MIN_FILL8")) : 5;
   if ((long long)p.tiles_m * p.tiles_n * 8 < (long long)num_cu * min_fill8) return K5_ERR_UNSUPPORTED;
   p.quad_stats = quad_stats;
+  k5_conv3d_set_last_kind(quad_stats ? K5_CONV_KIND_W4_STATS : K5_CONV_KIND_W4);
   if (quad_stats) {
     if (Cout == 128) return resid ? launch_conv_w4<4, true, true>(p, num_cu, stream) : launch_conv_w4<4, false, true>(p, num_cu, stream);
     return resid ? launch_conv_w4<8, true, true>(p, num_cu, stream) : launch_conv_w4<8, false, true>(p, num_cu, stream);

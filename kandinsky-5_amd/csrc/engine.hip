@@ -31,7 +31,7 @@ void k5_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* k5_last_error(void) { return g_err; }
-extern "C" int k5_abi_version(void) { return 1; }
+extern "C" int k5_abi_version(void) { return K5_ABI_VERSION; }
 
 #define HIPCHK(x)                                                                          \
   do {                                                                                     \
@@ -323,6 +323,7 @@ struct k5_dit {
   // profiling
   int profiling = 0;                               // 0 off, 1 every kernel family, 2 only the visual self-attention (the roofline kernel)
   std::map<std::string, Prof> prof;
+  long long prof_self_blocks = 0;                  // visual blocks whose self-attention ran while profiling was on ("self_blocks")
   struct Pending { std::string fam; hipEvent_t a, b; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> ev_pool;
@@ -1086,6 +1087,7 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     const float* vcos = d->ws_vcos.as<float>() + (size_t)tok0 * 32;
     const float* vsin = d->ws_vsin.as<float>() + (size_t)tok0 * 32;
     K5CHK(ln_mod(d, s, d->ws_vis.p, m, d->ws_h.p, n));
+    if (d->profiling) ++d->prof_self_blocks;   // bench.py: FLOPs of the roofline kernel = per-block FLOPs x the blocks that RAN
     if (sp) {
       K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, n_pad, N, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D, nabla ? &na : nullptr));
     } else {
@@ -1613,10 +1615,15 @@ extern "C" int k5_dit_nabla_block_counts(k5_dit* d, long long* kept, long long* 
 }
 
 extern "C" int k5_dit_set_profiling(k5_dit* d, int level) { if (!d || level < 0 || level > 2) return K5_ERR_ARG; d->profiling = level; return K5_OK; }
-extern "C" int k5_dit_reset_profile(k5_dit* d) { if (!d) return K5_ERR_ARG; drain_profile(d); d->prof.clear(); return K5_OK; }
+extern "C" int k5_dit_reset_profile(k5_dit* d) { if (!d) return K5_ERR_ARG; drain_profile(d); d->prof.clear(); d->prof_self_blocks = 0; return K5_OK; }
 extern "C" int k5_dit_get_profile(k5_dit* d, const char* family, double* total_ms, int64_t* launches) {
   if (!d || !family) return K5_ERR_ARG;
   drain_profile(d);
+  if (!strcmp(family, "self_blocks")) {   // not a kernel family: how many visual blocks ran their self-attention under profiling
+    if (total_ms) *total_ms = 0.0;
+    if (launches) *launches = d->prof_self_blocks;
+    return K5_OK;
+  }
   auto it = d->prof.find(family);
   if (total_ms) *total_ms = it == d->prof.end() ? 0.0 : it->second.ms;
   if (launches) *launches = it == d->prof.end() ? 0 : it->second.n;

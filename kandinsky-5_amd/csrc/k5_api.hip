@@ -276,6 +276,22 @@ int k5_conv3d_strided_bf16(const void* X, const void* W, const float* bias, void
              "k5_conv3d_strided_bf16");
 }
 
+int64_t k5_conv3d_stats_size(int M, int Cout) { return (int64_t)2 * ((M + 255) / 256) * (Cout / 4) * 2 * (int64_t)sizeof(float); }
+
+int k5_conv3d_bf16_stats(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin, int Cout,
+                         int up_t, int up_s, int ldc, const void* resid, int ldr, float* quad_stats, void* stream) {
+  if (!quad_stats || (Cout & 3)) return K5_ERR_ARG;
+  const int st = k5_launch_conv3d_w4(X, W, bias, out, Ts, Hs, Ws, Cin, Cout, up_t, up_s, ldc, resid, ldr, quad_stats, (hipStream_t)stream);
+  return st == K5_ERR_UNSUPPORTED ? st : ret(st, "k5_conv3d_bf16_stats");   // outside the 4-wave kernel's range: no statistics, caller's business
+}
+
+int k5_groupnorm_bf16_quads(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps, int silu,
+                            const float* quad_stats, void* workspace, void* stream) {
+  if (!quad_stats || !workspace) return K5_ERR_ARG;
+  return ret(k5_launch_groupnorm_bf16_quads(x, gamma, beta, out, M, C, G, eps, silu, C, C, quad_stats, 2 * ((M + 255) / 256), (float*)workspace,
+                                            (hipStream_t)stream), "k5_groupnorm_bf16_quads");
+}
+
 int64_t k5_groupnorm_workspace_size(int M, int G) { return (int64_t)k5_groupnorm_workspace_bytes(M, G); }
 
 int k5_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,

@@ -144,6 +144,11 @@ int k5_launch_conv3d_bf16(const void* X, const void* W, const float* bias, void*
                           int Cout, int up_t, int up_s, int ldc, const void* resid, int ldr, hipStream_t stream);
 int k5_launch_conv3d_bf16_strided(const void* X, const void* W, const float* bias, void* out, int Ts, int Hs, int Ws, int Cin,
                                   int Cout, int up_t, int up_s, int st_t, int st_s, int ldc, const void* resid, int ldr, hipStream_t stream);
+// which kernel the LAST conv launcher call of this host thread took (diagnostics: the VAE engine counts them per handle so that a
+// parity test can assert the production kernels ran, tests/test_gpu_vae.py)
+enum { K5_CONV_KIND_TILE128 = 0, K5_CONV_KIND_W4 = 1, K5_CONV_KIND_W4_STATS = 2, K5_CONV_KIND_OUT3 = 3 };
+int k5_conv3d_last_kind();
+void k5_conv3d_set_last_kind(int kind);
 size_t k5_groupnorm_workspace_bytes(int M, int G);
 int k5_launch_groupnorm_bf16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int G, float eps,
                              int silu, int ldx, int ldo, void* workspace, hipStream_t s);

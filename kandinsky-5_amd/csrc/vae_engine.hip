@@ -109,6 +109,10 @@ struct k5_vae {
   // workspaces
   Buf zin, x0, bx, balt, bt1, bt2, bres, gnws, gnq, qk, vt, scores, P, o, yout;
   struct PendStats { const void* ptr = nullptr; int M = 0, C = 0, nblk = 0; } pend;   // GroupNorm partials emitted by the last conv (gnq)
+  // launches per kernel route since the last reset (k5_vae_path_counts): [0] conv 128x128 tiles, [1] conv 4-wave, [2] conv 4-wave +
+  // GroupNorm statistics, [3] conv_out3, [4] GroupNorm from the conv's statistics, [5] GroupNorm with its own statistics pass,
+  // [6] mid attention in one kernel (C = 512), [7] mid attention as GEMM - softmax - GEMM
+  long long path[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -223,6 +227,7 @@ int gn(k5_vae* v, hipStream_t s, const GN& g, const void* x, void* out, int M, b
   const auto pend = v->pend;
   v->pend = {};
   K5CHK(v->gnws.ensure(k5_groupnorm_workspace_bytes(M, v->G)));
+  ++v->path[(pend.ptr == x && pend.M == M && pend.C == g.c && pend.nblk > 0) ? 4 : 5];
   if (pend.ptr == x && pend.M == M && pend.C == g.c && pend.nblk > 0)
     return k5_launch_groupnorm_bf16_quads(x, g.g.as<float>(), g.b.as<float>(), out, M, g.c, v->G, 1e-6f, silu ? 1 : 0, g.c, g.c,
                                           v->gnq.as<float>(), pend.nblk, v->gnws.as<float>(), s);
@@ -237,10 +242,12 @@ int conv(k5_vae* v, hipStream_t s, const Conv& c, const void* x, void* out, int 
     K5CHK(v->gnq.ensure((size_t)nblk * (c.cout / 4) * 2 * sizeof(float)));
     const int r = k5_launch_conv3d_w4(x, c.w.p, c.b.as<float>(), out, T, H, W, c.cin_pad, c.cout, up_t, up_s, c.cout, resid, c.cout,
                                       v->gnq.as<float>(), s);
-    if (r == K5_OK) { v->pend = {out, (int)M, c.cout, nblk}; return K5_OK; }
+    if (r == K5_OK) { v->pend = {out, (int)M, c.cout, nblk}; ++v->path[K5_CONV_KIND_W4_STATS]; return K5_OK; }
     if (r != K5_ERR_UNSUPPORTED) return r;
   }
-  return k5_launch_conv3d_bf16(x, c.w.p, c.b.as<float>(), out, T, H, W, c.cin_pad, c.cout, up_t, up_s, c.cout, resid, c.cout, s);
+  const int r = k5_launch_conv3d_bf16(x, c.w.p, c.b.as<float>(), out, T, H, W, c.cin_pad, c.cout, up_t, up_s, c.cout, resid, c.cout, s);
+  if (r == K5_OK && k5_conv3d_last_kind() >= 0 && k5_conv3d_last_kind() < 4) ++v->path[k5_conv3d_last_kind()];
+  return r;
 }
 
 // x [M][cin] -> out [M][cout] ; uses t1,t2,res as scratch.  vae.py:257-275
@@ -264,6 +271,7 @@ int mid_attention(k5_vae* v, hipStream_t s, const MidAttn& a, void* h, int T, in
   const int C = a.gn.c, S = T * H * W, Sp = (int)rup(S, flash ? 32 : 8);
   K5CHK(v->qk.ensure((size_t)S * 2 * C * 2)); K5CHK(v->vt.ensure((size_t)C * Sp * 2)); K5CHK(v->o.ensure((size_t)S * C * 2));
   if (!flash) { K5CHK(v->scores.ensure((size_t)S * Sp * 4)); K5CHK(v->P.ensure((size_t)S * Sp * 2)); }
+  ++v->path[flash ? 6 : 7];
   K5CHK(gn(v, s, a.gn, h, v->bt1.p, S, false));
   K5CHK(k5_launch_gemm_bf16(v->bt1.p, a.wqk.p, a.bqk.as<float>(), v->qk.p, S, 2 * C, C, C, C, 2 * C, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   HIPCHK(hipMemsetAsync(v->vt.p, 0, (size_t)C * Sp * 2, s));
@@ -491,6 +499,12 @@ extern "C" int k5_vae_encode_tile(k5_vae* v, const float* x, int T, int H, int W
 }
 
 extern "C" int k5_vae_has_encoder(k5_vae* v) { return v && v->has_encoder ? 1 : 0; }
+
+extern "C" int k5_vae_path_counts(k5_vae* v, long long* out8, int reset) {
+  if (!v || !out8) return K5_ERR_ARG;
+  for (int i = 0; i < 8; ++i) { out8[i] = v->path[i]; if (reset) v->path[i] = 0; }
+  return K5_OK;
+}
 
 extern "C" int k5_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, void* stream) {
   return k5_launch_blend_bf16(a, b, outer, len_a, len_b, inner, extent, (hipStream_t)stream);

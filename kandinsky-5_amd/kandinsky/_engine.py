@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("K5_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libk5.so"))
 
 K5_OK = 0
+ABI_VERSION = 3          # include/k5.h K5_ABI_VERSION
 K5_F32, K5_BF16, K5_F16 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_M, EPI_GELU, EPI_GATE = 0, 1, 2, 3
 
@@ -118,6 +119,10 @@ SYMBOLS = {
     "k5_conv3d_strided_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k5_groupnorm_workspace_size": (_I64, [_I, _I]),
     "k5_groupnorm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P]),
+    "k5_conv3d_stats_size": (_I64, [_I, _I]),
+    "k5_conv3d_bf16_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "k5_groupnorm_bf16_quads": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P]),
+    "k5_vae_path_counts": (_I, [_P, C.POINTER(C.c_longlong), _I]),
     "k5_vae_create": (_I, [C.POINTER(VaeConfig), C.POINTER(_P)]),
     "k5_vae_destroy": (None, [_P]),
     "k5_vae_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
@@ -150,6 +155,14 @@ def lib() -> C.CDLL:
         L = C.CDLL(LIB_PATH)
     except OSError as e:
         raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
+    try:
+        L.k5_abi_version.restype = C.c_int
+        have = L.k5_abi_version()
+    except AttributeError as e:
+        raise RuntimeError(f"{LIB_PATH} is not a libk5.so (no k5_abi_version)") from e
+    if have != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has C ABI version {have}, this host binding needs {ABI_VERSION}: rebuild it with "
+                           "`python kandinsky-5_amd/build.py`")
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError => symbol missing: loud
         fn.restype = res

@@ -322,11 +322,16 @@ class DiffusionTransformer3D(nn.Module):
         key blocks while the gather is in flight; default 1),
         "sp_slices" (sequence parallelism: exchange K / V^T in this many slices, attend each as it lands; default 1),
         "sp_pass1_tiles", "emulate_world" (timing only)."""
-        E.check(E.lib().k5_dit_set_option(self._handle, name.encode(), int(value)), f"k5_dit_set_option({name})")
+        if self._handle is not None:     # no engine yet: remembered and applied when it is built (_reapply_settings)
+            E.check(E.lib().k5_dit_set_option(self._handle, name.encode(), int(value)), f"k5_dit_set_option({name})")
         self._settings["options"][name] = int(value)
         return self
 
     def get_option(self, name):
+        if self._handle is None:
+            if name in self._settings["options"]:
+                return self._settings["options"][name]
+            raise RuntimeError("get_option before the engine is built: only options set through set_option are known")
         v = C.c_int()
         E.check(E.lib().k5_dit_get_option(self._handle, name.encode(), C.byref(v)), f"k5_dit_get_option({name})")
         return v.value

@@ -40,8 +40,8 @@ class DiagonalGaussianDistribution:
     moments tensor = [mean | logvar] along the channel axis, logvar clamped to [-30, 20]."""
 
     def __init__(self, parameters):
-        self.parameters = parameters
-        self.mean, logvar = torch.chunk(parameters.float(), 2, dim=1)
+        self.parameters = parameters                         # moments keep the encoder's dtype (bf16 from the engine), as in diffusers
+        self.mean, logvar = torch.chunk(parameters, 2, dim=1)
         self.logvar = logvar.clamp(-30.0, 20.0)
         self.std = torch.exp(0.5 * self.logvar)
         self.var = torch.exp(self.logvar)
@@ -154,7 +154,8 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         names = dict(decoder_manifest(latent_channels, out_channels, block_out_channels, layers_per_block))
         self._encoder_keys = list(encoder_manifest(in_channels, latent_channels, block_out_channels, layers_per_block))
         names.update(encoder_manifest(in_channels, latent_channels, block_out_channels, layers_per_block))
-        self._encoder_loaded = False
+        self._encoder_loaded = None     # None: never went through load_state_dict (parameters filled by the caller) — everything is real;
+        # False: a decode-only checkpoint left the encoder.* / quant_conv.* parameters as placeholders; True: loaded
         for name, shape in names.items():
             node = self
             parts = name.split(".")
@@ -231,7 +232,7 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         with torch.cuda.device(device):
             E.check(E.lib().k5_vae_create(C.byref(cc), C.byref(h)), "k5_vae_create")
             for name, t in self.state_dict().items():
-                if not self._encoder_loaded and name in self._encoder_keys:
+                if self._encoder_loaded is False and name in self._encoder_keys:
                     continue      # placeholders of a decode-only load
                 t = t.detach()
                 if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
@@ -258,7 +259,7 @@ class AutoencoderKLHunyuanVideo(nn.Module):
     def _encode_tile(self, x):
         """x (1,3,T,H,W) -> moments (1, 2*latent, (T-1)/4+1, H/8, W/8) bf16 = quant_conv(encoder(x))."""
         h = self._engine(x.device)
-        if not self._encoder_loaded or not E.lib().k5_vae_has_encoder(h):
+        if self._encoder_loaded is False or not E.lib().k5_vae_has_encoder(h):
             raise RuntimeError("this VAE was loaded without its encoder.* / quant_conv.* tensors: encode() is unavailable")
         xx = x[0].float().contiguous()
         _, t, hh, ww = xx.shape
@@ -466,8 +467,8 @@ class AutoencoderKLHunyuanVideo(nn.Module):
     @torch.no_grad()
     def encode(self, x, opt_tiling=True, return_dict=True):
         """vae.py:813-845: x (B,3,F,H,W) in [-1,1] -> AutoencoderKLOutput(latent_dist=DiagonalGaussianDistribution)."""
-        if x.shape[0] != 1:
-            h = torch.cat([self.encode(x[i:i + 1]).latent_dist.parameters for i in range(x.shape[0])], 0)
+        if x.shape[0] != 1:     # the engine encodes one sample at a time; the caller's tiling choice goes with every sample
+            h = torch.cat([self.encode(x[i:i + 1], opt_tiling=opt_tiling).latent_dist.parameters for i in range(x.shape[0])], 0)
         else:
             if opt_tiling:
                 tile_size, tile_stride = self.get_enc_optimal_tiling(x.shape)

@@ -28,6 +28,27 @@ def _r(x: Tensor, mode: str) -> Tensor:
     return x.to(torch.bfloat16).float() if mode == "bf16" else x
 
 
+def synthetic_decoder_state_dict(manifest: Dict[str, Sequence[int]], seed: int = 0) -> Dict[str, Tensor]:
+    """Synthetic decoder weights laid out like the checkpoint (`manifest`: key -> shape, tests/golden/vae_meta.json
+    "full_manifest").  One torch CPU generator per tensor seeded by (seed, index in the sorted key order), so the golden
+    generator in the build container and the test on the GPU box make the same tensors.  Conv / linear weights ~ N(0, 1.5 /
+    sqrt(fan_in)) rounded to fp16 (the checkpoint's dtype, vae.py:1279), norm weights N(1, 0.2), biases N(0, 0.1)."""
+    sd = {}
+    for idx, k in enumerate(sorted(manifest)):
+        shape = tuple(manifest[k])
+        g = torch.Generator().manual_seed(seed * 1000003 + idx)
+        if "norm" in k and k.endswith("weight"):
+            sd[k] = 1.0 + 0.2 * torch.randn(shape, generator=g)
+        elif k.endswith("bias"):
+            sd[k] = 0.1 * torch.randn(shape, generator=g)
+        else:
+            fan = 1
+            for d in shape[1:]:
+                fan *= d
+            sd[k] = (torch.randn(shape, generator=g) * (1.5 / fan ** 0.5)).half().float()
+    return sd
+
+
 # ------------------------------------------------------------------------------------------ layers
 def causal_conv3d(sd, name: str, x: Tensor, mode: str) -> Tensor:
     """HunyuanVideoCausalConv3d vae.py:125-163: replicate pad (W 1,1 ; H 1,1 ; T k-1,0) then Conv3d (stride 1)."""

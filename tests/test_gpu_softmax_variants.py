@@ -469,5 +469,33 @@ def test_fused_query_norm_across_passes(E):
     T = Sk // 64
     out = run_qnorm(E, qraw.reshape(Sq, -1).cuda().to(BF), wd, cd, sd, kd, vt, H, flags, kmax,
                     passes=[(0, T // 2, 2, 1), (T // 2, T - T // 2, 1, 2)])
-    assert flags.tolist()[:2] == [1, 1] and flags.tolist()[2] in (0, 2), flags
+    assert flags.tolist() == [1, 1, 2], flags       # a flip in a multi-pass schedule is always the LATE flag (recompute from scratch)
     close(out, O.sdpa(qnf, k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="fused query norm across passes")
+
+
+def test_fused_query_norm_flip_from_a_tail_job_across_passes(E):
+    """ADVICE r2 (attn_fwd.hip QN flip): 4 heads x 130 query blocks = 520 jobs = one full round of the 512 resident workgroups + 8
+    TAIL jobs (head 3, the last 8 query blocks), which the balanced launcher runs after BOTH forms' full-round launches.  Head 3's
+    rows sit on non-zero per-row offsets (bound ~ 150) and exactly one row — in the very last query block, i.e. in a tail job — is over
+    the 180 limit: its flip lands after online(full) has skipped the head, while the full jobs of the head left fixed-form state.
+    The flip must be the LATE flag (2) so that pass B's online launch recomputes the head from scratch instead of resuming that
+    state as offset 0."""
+    Sq, Sk, H = 33280, 2048, 4
+    qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([2.0, 2.0, 2.0, 10.0]), 91)
+    w[7] = 3.0
+    qraw[Sq - 3, 3] = 0.01 * qraw[Sq - 3, 3]
+    qraw[Sq - 3, 3, 7] = 30.0
+    qraw = bfr(qraw)
+    qn = normed_queries(E, qraw, w, cos, sin, H)
+    qnf = qn.float().cpu().reshape(Sq, H, 64)
+    b = qnf.norm(dim=-1) * k.norm(dim=-1).amax(0)[None]
+    assert (b[:, 3] > 185).sum() == 1 and b[Sq - 3, 3] > 185 and b[:, :3].max() < 88 and b[:, 3].median() > 95, (b[:, 3].topk(3), b[:, 3].median())
+    wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()
+    kd, vt = k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
+    flags, kmax = kflags(E, k, H)
+    T = Sk // 64
+    out = run_qnorm(E, qraw.reshape(Sq, -1).cuda().to(BF), wd, cd, sd, kd, vt, H, flags, kmax,
+                    passes=[(0, T // 2, 2, 1), (T // 2, T - T // 2, 1, 2)])
+    assert flags.tolist() == [1, 1, 1, 2], flags
+    rows = torch.cat([torch.arange(0, Sq - 2048, 997), torch.arange(Sq - 2048, Sq, 61), torch.tensor([Sq - 3, Sq - 1])])
+    close(out[rows], O.sdpa(qnf[rows], k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="flip from a tail job across passes")

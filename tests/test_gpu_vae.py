@@ -319,3 +319,155 @@ def test_config5_spatial_tiling_at_real_size():
     assert tuple(out.shape) == tuple(ref.shape) == (1, 3, 33, 768, 1280)
     assert torch.isfinite(out.float()).all() and out.float().std().item() > 1e-3
     assert torch.equal(out.float(), ref.float()), rel(out, ref)
+
+
+# ------------------------------------------------------------------------------------------ production width
+def _fused_stats_case(Cin, Cout, dims, up, use_res, seed):
+    from kandinsky import _engine as E
+    g = torch.Generator().manual_seed(seed)
+    Ts, Hs, Ws = dims
+    up_t, up_s = up
+    x = bfr(torch.randn(1, Cin, Ts, Hs, Ws, generator=g))
+    w = bfr(torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.03)
+    b = bfr(torch.randn(Cout, generator=g) * 0.1)
+    xin = x
+    if up_t > 1 or up_s > 1:
+        first = torch.nn.functional.interpolate(x[:, :, 0], scale_factor=(up_s, up_s), mode="nearest").unsqueeze(2)
+        rest = torch.nn.functional.interpolate(x[:, :, 1:], scale_factor=(up_t, up_s, up_s), mode="nearest")
+        xin = torch.cat([first, rest], 2)
+    conv = V.causal_conv3d({"c.conv.weight": w, "c.conv.bias": b}, "c", xin, "bf16")            # oracle, bf16 mode (vae.py:125-163)
+    M = conv.shape[2] * conv.shape[3] * conv.shape[4]
+    want = conv[0].permute(1, 2, 3, 0).reshape(M, Cout)
+    resid = bfr(torch.randn(M, Cout, generator=g)) if use_res else None
+    if use_res:
+        want = bfr(want + resid)                                                             # resnet skip, vae.py:274
+    gamma, beta = 1 + 0.2 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    xd = x[0].permute(1, 2, 3, 0).contiguous().cuda().bfloat16()
+    wd = w.permute(0, 2, 3, 4, 1).reshape(Cout, 27 * Cin).contiguous().cuda().bfloat16()
+    return E, (Ts, Hs, Ws, M), xd, wd, b.cuda(), None if resid is None else resid.cuda().bfloat16(), gamma, beta, want
+
+
+@pytest.mark.parametrize("Cin,Cout,dims,up,use_res", [(128, 128, (5, 112, 128), (1, 1), True), (256, 128, (4, 64, 72), (1, 2), False),
+                                                     (512, 512, (3, 72, 96), (1, 1), True), (256, 256, (3, 50, 68), (2, 2), False),
+                                                     (128, 128, (5, 113, 127), (1, 1), False)])
+def test_conv_statistics_feed_groupnorm_vs_oracle(Cin, Cout, dims, up, use_res):
+    """The decoder's GroupNorm -> SiLU -> conv chain as production runs it (vae.py:230-275, 246-263): the 4-wave conv emits the
+    GroupNorm statistics of the outputs it stores (k5_conv3d_bf16_stats), the next norm normalises from them without a statistics
+    pass (k5_groupnorm_bf16_quads).  Checked against torch.group_norm (+ SiLU) of the ORACLE's conv output (bf16 mode, residual
+    added as the resnet does), and against the two-pass GroupNorm kernel on the very tensor the conv stored.  Shapes: both tile
+    widths (Cout 128 / >= 256), folded upsampling, residual epilogue, M not a multiple of 256 / 128 (ragged last statistics block)."""
+    G = 32
+    E, (Ts, Hs, Ws, M), xd, wd, bd, rd, gamma, beta, want = _fused_stats_case(Cin, Cout, dims, up, use_res, Cin + Cout + dims[1])
+    L = E.lib()
+    out = torch.empty(M, Cout, dtype=torch.bfloat16, device="cuda")
+    qs = torch.full((L.k5_conv3d_stats_size(M, Cout) // 4,), float("nan"), device="cuda")
+    st = L.k5_conv3d_bf16_stats(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), Ts, Hs, Ws, Cin, Cout, up[0], up[1], Cout,
+                                None if rd is None else rd.data_ptr(), Cout, qs.data_ptr(), E.stream_ptr())
+    assert st == 0, (st, E.last_error())                     # really in the 4-wave kernel's range: the statistics exist
+    torch.cuda.synchronize()
+    assert torch.isfinite(qs).all()
+    err = (out.float().cpu() - want).abs()
+    tol = 2.0 ** -6 * want.abs().clamp(min=1.0) + (2.0 ** -7 * want.abs() if use_res else 0)
+    assert not (err > tol).any(), (float(err.max()), int((err > tol).sum()))
+    # the statistics are those of the STORED tensor: fold them on the host and compare with the tensor's own sums
+    q = qs.view(-1, Cout // 4, 2).double().sum(0).cpu()                                       # [Cout / 4][sum, sum of squares]
+    o64 = out.double().cpu().view(M, Cout // 4, 4)
+    assert torch.allclose(q[:, 0], o64.sum((0, 2)), rtol=1e-5, atol=1e-2) and torch.allclose(q[:, 1], (o64 * o64).sum((0, 2)), rtol=1e-5)
+    gd, btd = gamma.cuda(), beta.cuda()
+    ws = torch.empty(L.k5_groupnorm_workspace_size(M, G), dtype=torch.uint8, device="cuda")
+    for silu in (1, 0):
+        y = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+        E.check(L.k5_groupnorm_bf16_quads(out.data_ptr(), gd.data_ptr(), btd.data_ptr(), y.data_ptr(), M, Cout, G, 1e-6, silu, qs.data_ptr(),
+                                          ws.data_ptr(), E.stream_ptr()), "k5_groupnorm_bf16_quads")
+        y2 = torch.empty_like(y)
+        E.check(L.k5_groupnorm_bf16(out.data_ptr(), gd.data_ptr(), btd.data_ptr(), y2.data_ptr(), M, Cout, G, 1e-6, silu, ws.data_ptr(),
+                                    E.stream_ptr()), "k5_groupnorm_bf16")
+        torch.cuda.synchronize()
+        ref = torch.nn.functional.group_norm(want.t()[None], G, gamma, beta, 1e-6)[0].t()        # oracle conv -> GroupNorm
+        if silu:
+            ref = torch.nn.functional.silu(ref)
+        e = (y.float().cpu() - ref).abs()
+        # conv outputs differ from the oracle's by a bf16 ulp here and there (2^-8 relative), amplified by gamma / sigma ~ 1.2
+        t = 2.0 ** -6 * ref.abs().clamp(min=1.0)
+        assert not (e > t).any(), (silu, float(e.max()), int((e > t).sum()))
+        d = (y.float() - y2.float()).abs()
+        assert d.max().item() <= 2.0 ** -7 * max(1.0, y2.float().abs().max().item()) and (d > 0).float().mean().item() < 2e-3, \
+            (float(d.max()), float((d > 0).float().mean()))     # same tensor, statistics summed in another order
+
+
+def test_conv_statistics_outside_the_four_wave_range():
+    """Below 5/8 of a round of tiles (or Cin % 128 != 0) the conv has no statistics epilogue: K5_ERR_UNSUPPORTED and nothing launched."""
+    from kandinsky import _engine as E
+    L = E.lib()
+    x = torch.zeros(2 * 8 * 8, 64, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(128, 27 * 64, dtype=torch.bfloat16, device="cuda")
+    b = torch.zeros(128, device="cuda")
+    out = torch.full((128, 128), 7.0, dtype=torch.bfloat16, device="cuda")
+    qs = torch.zeros(L.k5_conv3d_stats_size(128, 128) // 4, device="cuda")
+    st = L.k5_conv3d_bf16_stats(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), 2, 8, 8, 64, 128, 1, 1, 128, None, 128, qs.data_ptr(),
+                                E.stream_ptr())
+    torch.cuda.synchronize()
+    assert st == 6 and (out == 7.0).all()
+
+
+@pytest.fixture(scope="module")
+def full_vae():
+    """The production decoder (128 / 256 / 512 / 512 channels, 32 groups) with the weights the golden generator used
+    (oracle/gen_golden_vae_fullwidth.py: synthetic_decoder_state_dict(full_manifest, 21))."""
+    from kandinsky.models.vae import AutoencoderKLHunyuanVideo
+    here = os.path.dirname(__file__)
+    meta = json.load(open(os.path.join(here, "golden", "vae_meta.json")))
+    fm = json.load(open(os.path.join(here, "golden", "vae_fullwidth_meta.json")))
+    sd = V.synthetic_decoder_state_dict(meta["full_manifest"], fm["weights_seed"])
+    with torch.device("meta"):
+        m = AutoencoderKLHunyuanVideo()
+    m.load_state_dict(sd, assign=True)
+    return m.to("cuda:0"), fm
+
+
+def _path_counts(m, reset=True):
+    import ctypes as C
+    from kandinsky import _engine as E
+    c = (C.c_longlong * 8)()
+    E.check(E.lib().k5_vae_path_counts(m._handle, c, 1 if reset else 0), "k5_vae_path_counts")
+    return list(c)
+
+
+def test_production_tile_vs_reference_golden(full_vae):
+    """The decode bench.py times is 14 of these: one (5, 64, 96) latent tile through the production-width decoder.  Golden: the
+    REFERENCE decoder itself (vae.py:589-696, fp32, build container) on the same seeded weights and latent, 32768 sampled outputs +
+    whole-tensor sums; plus the same samples from the oracle in bf16-autocast mode (the engine's arithmetic).  The engine must have
+    taken the production kernels — 4-wave conv with the fused GroupNorm statistics, GroupNorm from those statistics, the C = 512
+    one-kernel mid attention, conv_out3 — which its per-route launch counters prove."""
+    from safetensors.torch import load_file
+    m, fm = full_vae
+    g = load_file(os.path.join(os.path.dirname(__file__), "golden", "vae_fullwidth.safetensors"))
+    T, H, W = fm["tile"]
+    z = torch.randn(1, 16, T, H, W, generator=torch.Generator().manual_seed(fm["latent_seed"]))
+    _path_counts(m)
+    out = m._decode_tile(z.cuda())
+    torch.cuda.synchronize()
+    cnt = _path_counts(m)
+    print("VAE kernel routes [tile128, w4, w4+stats, out3, gn quads, gn own pass, attn512, attn gemm]:", cnt)
+    assert list(out.shape) == fm["ref"]["out_shape"] == [1, 3, 4 * (T - 1) + 1, 8 * H, 8 * W]
+    # conv_in (Cin = 16 -> padded 64) is the only conv outside the 4-wave kernel; 31 convs carry statistics; 2 norms (the first one
+    # and the one after the attention) make their own statistics pass
+    assert cnt[2] == 31 and cnt[0] == 1 and cnt[1] == 0 and cnt[3] == 1 and cnt[6] == 1 and cnt[7] == 0 and cnt[4] == 28 and cnt[5] == 2, cnt
+    flat = out.float().reshape(-1)
+    got = flat[g["sample_idx"].cuda()].cpu()
+    ref, ob = g["ref.sample_val"], g["oraclebf16.sample_val"]
+    r_ref, r_bf = ((got - ref).norm() / ref.norm()).item(), ((got - ob).norm() / ob.norm()).item()
+    r_oo = ((ob - ref).norm() / ref.norm()).item()
+    print(f"production tile: engine vs reference fp32 {r_ref:.3e}, vs bf16 oracle {r_bf:.3e}; bf16 oracle vs reference {r_oo:.3e}")
+    assert r_bf <= 2e-2, r_bf
+    assert r_ref <= 4e-2, (r_ref, r_oo)
+    s, ss = flat.double().sum().item(), flat.double().pow(2).sum().item()
+    assert abs(ss - fm["ref"]["out_sumsq"]) <= 4e-2 * fm["ref"]["out_sumsq"], (ss, fm["ref"]["out_sumsq"])
+    assert abs(s - fm["ref"]["out_sum"]) <= 2e-2 * math.sqrt(fm["ref"]["out_sumsq"] * flat.numel()), (s, fm["ref"]["out_sum"])
+    u8 = lambda t: ((t.clamp(-1.0, 1.0) + 1.0) * 127.5).to(torch.uint8).int()                 # generation_utils.py:222
+    diff = (u8(got) - u8(ref.bfloat16().float())).abs()
+    hist = [round((diff == i).float().mean().item(), 5) for i in range(int(diff.max()) + 1)]
+    print("uint8 |engine - reference| on the samples:", hist)
+    assert diff.float().mean().item() < 1.0 and (diff <= 3).float().mean().item() >= 0.99, hist
+    again = m._decode_tile(z.cuda())
+    assert torch.equal(out, again)                                                            # deterministic

@@ -109,8 +109,12 @@ def test_encode_api_and_round_trip(vae):
     x = torch.randn(1, 3, 5, 32, 32, generator=torch.Generator().manual_seed(3)).clamp(-1, 1).cuda()
     post = m.encode(x).latent_dist
     h = m._encode_tile(x)
-    assert torch.equal(post.mean, h[:, :16].float()) and torch.equal(post.mode(), post.mean)
-    assert torch.equal(post.logvar, h[:, 16:].float().clamp(-30, 20))
+    assert post.mean.dtype == h.dtype == torch.bfloat16       # the moments keep the encoder's dtype, as diffusers' class does
+    assert torch.equal(post.mean, h[:, :16]) and torch.equal(post.mode(), post.mean)
+    assert torch.equal(post.logvar, h[:, 16:].clamp(-30, 20))
+    xb = torch.cat([x, x.flip(-1)], 0)                        # batch of 2: per-sample encode, the caller's tiling choice kept
+    pb = m.encode(xb, opt_tiling=False).latent_dist.parameters
+    assert tuple(pb.shape) == (2, 32) + tuple(h.shape[2:]) and torch.equal(pb[:1], m.encode(x, opt_tiling=False).latent_dist.parameters)
     g = torch.Generator(device="cuda").manual_seed(1)
     s1 = post.sample(generator=g)
     assert s1.shape == post.mean.shape and torch.isfinite(s1).all() and not torch.equal(s1, post.mean)

@@ -1,0 +1,61 @@
+"""tools/profile_summarize.py is what turns rocprofv3 output into the evidence files under profiles/ — VERDICT r2 found a derived
+line in a committed summary that was nonsense (the attention kernel's template grew two parameters and the role detection looked at
+the LAST one).  These tests pin the parsing by position, the derived per-block figure on a synthetic trace, and — for the committed
+round-3 summary — that the kernel-trace figure agrees with the HIP-event figure bench.py printed in the very same profiled run."""
+import json
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import profile_summarize as P  # noqa: E402
+
+
+def test_template_arguments_are_read_by_position():
+    a = P.attn_template_args("void (anonymous namespace)::attn_fwd_kernel<true, false, true, true, false, false>(AttnP)")
+    assert a == dict(BOUNDED=True, SPARSE=False, RANGE=True, PRE=True, QN=False, HALF=False)
+    a = P.attn_template_args("void attn_fwd_kernel<false, true, false, true, false, true>(AttnP)")
+    assert a["SPARSE"] and a["PRE"] and a["HALF"] and not a["BOUNDED"] and not a["QN"]
+    assert P.attn_template_args("void attn_fwd_kernel<true, false, true>(AttnP)")["PRE"] is False        # defaults for missing trailing ones
+    assert P.attn_template_args("void gemm_bf16_w4_kernel<3>(GemmP)") is None
+
+
+def _row(name, wgs, t0_us, dur_us):
+    return {"Kernel_Name": name, "Grid_Size_X": str(wgs * 512), "Workgroup_Size_X": "512", "Start_Timestamp": str(int(t0_us * 1000)),
+            "End_Timestamp": str(int((t0_us + dur_us) * 1000))}
+
+
+def test_block_time_from_a_synthetic_trace():
+    fixed = "void (anonymous namespace)::attn_fwd_kernel<true, false, true, true, false, false>(AttnP)"
+    online = "void (anonymous namespace)::attn_fwd_kernel<false, false, true, true, false, false>(AttnP)"
+    cross = "void (anonymous namespace)::attn_fwd_kernel<true, false, true, false, false, false>(AttnP)"
+    merge = "(anonymous namespace)::attn_merge_kernel(float const*, float const*, long long, int)"
+    rows, t = [], 0.0
+    for _ in range(3):   # three blocks: main 12000 us, tail 250, online twice 10, merge 30, one cross-attention launch that must NOT count
+        for n, w, d in ((fixed, 5120, 12000.0), (online, 5120, 10.0), (fixed, 440, 250.0), (online, 440, 10.0), (merge, 88, 30.0), (cross, 5208, 150.0)):
+            rows.append(_row(n, w, t, d)); t += d + 5
+    sm = P.attention_block_summary(rows)
+    assert sm["blocks"] == 3 and abs(sm["block_us"] - 12300.0) < 1e-6
+    assert abs(sm["tflops"] - 4.0 * 47616 ** 2 * 64 * 28 / 12300e-6 / 1e12) < 1e-6
+    roles = {(n, w): r for n, w, _, _, r in sm["table"]}
+    assert roles[(fixed.replace("(anonymous namespace)::", ""), 5120)].startswith("visual self-attention, dense, fixed-offset")
+    assert "cross / text" in roles[(cross.replace("(anonymous namespace)::", ""), 5208)]
+    assert "online-max" in roles[(online.replace("(anonymous namespace)::", ""), 440)]
+
+
+@pytest.mark.parametrize("tag", ["r02", "r03"])
+def test_committed_summary_has_a_sane_derived_line(tag):
+    path = os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.md")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not committed yet")
+    m = re.search(r"DERIVED_TFLOPS = ([0-9.]+) TFLOP/s", open(path).read())
+    assert m, "the summary carries no derived self-attention line"
+    tf = float(m.group(1))
+    assert 800.0 < tf < 2500.0, tf                                   # a dense bf16 MFMA kernel cannot beat the 2.5 PFLOP/s peak
+    under = os.path.join(ROOT, "profiles", f"{tag}_bench_under_rocprof.json")
+    if os.path.exists(under):                                        # the bench line printed BY the profiled run (same box, same launches)
+        d = json.load(open(under))
+        assert abs(tf - d["roofline"]["achieved"]) <= 0.02 * tf, (tf, d["roofline"]["achieved"])

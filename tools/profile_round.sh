@@ -6,6 +6,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT; cd /tmp
 # 1. kernel trace + stats of the bench command (no counters in this pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-breakdown > $OUT/${TAG}_bench_under_rocprof.log 2>&1
+grep "^{" $OUT/${TAG}_bench_under_rocprof.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json   # the line of THIS run: what the kernel-trace figure must agree with
 # 2. HBM traffic counters, one per pass (2 visual blocks are enough: per-launch numbers)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-breakdown --blocks 2 > /dev/null 2>&1
