@@ -289,10 +289,21 @@ int k5_dit_comm_init(k5_dit* dit, const char* rccl_lib_path, int rank, int world
  * Loopback group (tests): `world` handles of ONE process on ONE GPU act as the ranks of a sequence-parallel run.  Every rank
  * must be driven by its own host thread (a collective is a rendezvous of the threads around device-to-device copies), and
  * every rank runs exactly the code path / offsets / launch sequence of a real multi-GPU run.  Not with k5_dit_set_graph. */
+/* CFG-parallel (reference semantics: the two forwards of get_velocity, generation_utils.py:53-76): the handle runs ONE
+ * branch of classifier-free guidance inside k5_sample — branch 0 the conditional forward, 1 the unconditional one — and exchanges the
+ * bf16 velocity with the paired handle (the same token shard of the other rank group) once per step: a 2-rank communicator of its own,
+ * initialised AFTER the sequence-parallel one (both are collective: same order on every rank).  Both handles of a pair then apply the
+ * identical bf16 combine + fp32 Euler update, so all ranks of both groups hold bit-identical latents.  The exchange runs on a side
+ * stream between two events and is part of the captured step under k5_dit_set_graph.  With guidance_weight == 1 the pair is idle.
+ * unique_id_128: from k5_comm_unique_id on branch 0, carried to branch 1 by the host.  k5_dit_cfg_branch: 0 / 1, or -1 without a pair. */
+int k5_dit_cfg_pair_init(k5_dit* dit, const char* rccl_lib_path, int branch, const void* unique_id_128);
+int k5_dit_cfg_branch(k5_dit* dit);
 typedef struct k5_loopback k5_loopback;
 int k5_loopback_create(int world, k5_loopback** out);
 void k5_loopback_destroy(k5_loopback* group);
 int k5_dit_comm_init_loopback(k5_dit* dit, k5_loopback* group, int rank);
+/* the CFG pair as a loopback group of world 2 (tests: 2 x P handles on one GPU = two sequence-parallel groups + P pairs) */
+int k5_dit_cfg_pair_init_loopback(k5_dit* dit, k5_loopback* group, int branch);
 /* Engine options by name (all default 0): "attn_mode" 0 = softmax form per head from the data, 1 = online max everywhere;
  * "sp_pass1_tiles" local key tiles attended before the K / V^T gather has landed (0 = all); "emulate_world" P = TIMING
  * ONLY: rank 0's share of a P-rank run on a world = 1 communicator — collectives move nothing, results are garbage and

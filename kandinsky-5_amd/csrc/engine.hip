@@ -258,6 +258,15 @@ struct k5_dit {
   Comm comm;
   int sp_rank = 0, sp_world = 1;
   DevBuf ws_q, ws_kfull, ws_vtfull, ws_attn_state;
+  // CFG-parallel (reference semantics generation_utils.py:53-76): this handle runs ONE branch of classifier-free
+  // guidance — 0 = conditional, 1 = unconditional — and is paired with the handle that runs the other one (a 2-rank communicator of
+  // its own, next to the sequence-parallel one).  Inside k5_sample the pair exchanges the bf16 velocities (one in-place all-gather of
+  // 2 x T H W 16 x 2 B per step on a side stream) and both apply the identical bf16 combine + fp32 Euler update.
+  Comm pair;
+  int cfg_branch = -1;
+  hipStream_t pair_stream = nullptr;
+  hipEvent_t ev_vel_ready = nullptr, ev_vel_done = nullptr;
+  DevBuf ws_vel_pair;                              // [2][T H W 16] bf16: slot 0 = conditional, 1 = unconditional velocity
   bool use_fp8 = false;                            // visual feed-forward GEMMs in W8A8 e4m3 (k5_dit_set_fp8)
   DevBuf ws_h8, ws_ff8;                            // fp8 activations of that path
   DevBuf ws_sched;                                 // sampler tables on the device: t*1000 [steps] | dt [steps] | step counter
@@ -1174,6 +1183,10 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
   if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
   for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered, d->ev_stats, d->ev_means, d->ev_slice[0], d->ev_slice[1], d->ev_slice[2], d->ev_slice[3]}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
+  if (d->pair_stream) { (void)hipStreamSynchronize(d->pair_stream); (void)hipStreamDestroy(d->pair_stream); }
+  for (hipEvent_t e : {d->ev_vel_ready, d->ev_vel_done}) if (e) (void)hipEventDestroy(e);
+  if (d->pair.comm) (void)d->pair.CommDestroy(d->pair.comm);
+  d->ws_vel_pair.release();
   auto rel_attn = [](AttnW& a) {
     DevBuf* bs[] = {&a.wqk, &a.wq, &a.wk, &a.wv, &a.wo, &a.bqk, &a.bq, &a.bk, &a.bv, &a.bo, &a.norm};
     for (DevBuf* b : bs) b->release();
@@ -1361,9 +1374,15 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
   const k5_dit_config& c = d->cfg;
   const int64_t n = (int64_t)a->fwd.T * a->fwd.H * a->fwd.W * c.out_visual_dim;
   if (c.in_visual_dim != c.out_visual_dim) return K5_ERR_UNSUPPORTED;
-  K5CHK(d->ws_vel_c.ensure(n * 2));
   const bool cfg_on = fabsf(a->guidance_weight - 1.0f) > 1e-6f;  // generation_utils.py:63
-  if (cfg_on) K5CHK(d->ws_vel_u.ensure(n * 2));
+  const bool pair = cfg_on && d->pair.active();                  // CFG-parallel: one branch here, the other on the paired handle
+  if (pair) K5CHK(d->ws_vel_pair.ensure(2 * n * 2));
+  else {
+    K5CHK(d->ws_vel_c.ensure(n * 2));
+    if (cfg_on) K5CHK(d->ws_vel_u.ensure(n * 2));
+  }
+  void* vel_c = pair ? d->ws_vel_pair.p : d->ws_vel_c.p;
+  void* vel_u = pair ? (void*)(d->ws_vel_pair.as<bf16_t>() + n) : d->ws_vel_u.p;
   // hipGraph mode (BASELINE config 5 "hipGraph-captured step"): the per-step scalars live in device tables indexed by a
   // device-side step counter, so ONE captured step (forward(s) + CFG/Euler + counter increment) replays for every step.
   // Step 0 runs eagerly (it sizes every workspace and fills the RoPE / permutation caches), step 1 is captured, steps 1..
@@ -1395,11 +1414,24 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
   d->text_cache[0].valid = d->text_cache[1].valid = false;   // the prompt tensors are constant for THIS call only
   auto one_step = [&](int i) -> int {
     const float t1000 = host_tab[i], dt = host_tab[a->num_steps + i];
-    K5CHK(forward_impl(d, &a->fwd, a->fwd.cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_c.p, s, tvec, step, 0));
-    if (cfg_on) K5CHK(forward_impl(d, &a->fwd, a->null_cond, t1000, a->latent, c.in_visual_dim, d->ws_vel_u.p, s, tvec, step, 1));
+    if (pair) {
+      // my branch only; then the pair's velocities change hands on the side stream (fork / join by events: capturable) and both
+      // handles hold [v_cond | v_uncond] — every rank of both groups applies the same update to the same numbers
+      if (d->cfg_branch == 0) K5CHK(forward_impl(d, &a->fwd, a->fwd.cond, t1000, a->latent, c.in_visual_dim, vel_c, s, tvec, step, 0));
+      else K5CHK(forward_impl(d, &a->fwd, a->null_cond, t1000, a->latent, c.in_visual_dim, vel_u, s, tvec, step, 1));
+      Scope sc(d, s, "comm");
+      HIPCHK(hipEventRecord(d->ev_vel_ready, s));
+      HIPCHK(hipStreamWaitEvent(d->pair_stream, d->ev_vel_ready, 0));
+      K5CHK(d->pair.all_gather_inplace(d->ws_vel_pair.p, (size_t)n, 2, d->pair_stream));
+      HIPCHK(hipEventRecord(d->ev_vel_done, d->pair_stream));
+      HIPCHK(hipStreamWaitEvent(s, d->ev_vel_done, 0));
+    } else {
+      K5CHK(forward_impl(d, &a->fwd, a->fwd.cond, t1000, a->latent, c.in_visual_dim, vel_c, s, tvec, step, 0));
+      if (cfg_on) K5CHK(forward_impl(d, &a->fwd, a->null_cond, t1000, a->latent, c.in_visual_dim, vel_u, s, tvec, step, 1));
+    }
     {
       Scope sc(d, s, "elementwise");
-      K5CHK(k5_launch_cfg_euler(a->latent, d->ws_vel_c.p, cfg_on ? d->ws_vel_u.p : nullptr, a->guidance_weight, dt, n, s, dtvec, step));
+      K5CHK(k5_launch_cfg_euler(a->latent, vel_c, cfg_on ? vel_u : nullptr, a->guidance_weight, dt, n, s, dtvec, step));
     }
     if (step) K5CHK(k5_launch_step_inc(step, s));
     return K5_OK;
@@ -1491,6 +1523,27 @@ extern "C" int k5_dit_comm_init(k5_dit* d, const char* rccl_lib_path, int rank, 
   return comm_common_init(d, rank, world);
 }
 
+// CFG-parallel pair (see k5_dit::pair): a 2-rank communicator of its own; branch = this handle's rank in it (0 = conditional forward,
+// 1 = unconditional).  Collective over the two handles of the pair; independent of (and initialised after) the sequence-parallel one.
+static int pair_common_init(k5_dit* d, int branch) {
+  d->pair.rank = branch; d->pair.world = 2; d->cfg_branch = branch;
+  HIPCHK(hipStreamCreateWithFlags(&d->pair_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&d->ev_vel_ready, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&d->ev_vel_done, hipEventDisableTiming));
+  return K5_OK;
+}
+extern "C" int k5_dit_cfg_pair_init(k5_dit* d, const char* rccl_lib_path, int branch, const void* unique_id128) {
+  g_err[0] = 0;
+  if (!d || !unique_id128 || branch < 0 || branch > 1) return K5_ERR_ARG;
+  if (d->pair.active()) { k5_set_error("CFG pair communicator already initialised"); return K5_ERR_STATE; }
+  K5CHK(d->pair.open(rccl_lib_path));
+  ncclUniqueId id;
+  memcpy(&id, unique_id128, 128);
+  const ncclResult_t r = d->pair.CommInitRank(&d->pair.comm, 2, id, branch);
+  if (r != ncclSuccess) { k5_set_error("ncclCommInitRank (CFG pair): %s", d->pair.GetErrorString(r)); return K5_ERR_HIP; }
+  return pair_common_init(d, branch);
+}
+
 // ---- loopback group: P handles of one process on one GPU as the P ranks of a sequence-parallel run (tests) ----
 struct k5_loopback { LoopGroup g; };
 extern "C" int k5_loopback_create(int world, k5_loopback** out) {
@@ -1524,6 +1577,17 @@ extern "C" int k5_dit_comm_init_loopback(k5_dit* d, k5_loopback* lb, int rank) {
   d->comm.loop = &lb->g;
   return comm_common_init(d, rank, lb->g.world);
 }
+
+extern "C" int k5_dit_cfg_pair_init_loopback(k5_dit* d, k5_loopback* lb, int branch) {
+  g_err[0] = 0;
+  if (!d || !lb || lb->g.world != 2 || branch < 0 || branch > 1) return K5_ERR_ARG;
+  if (d->pair.active()) { k5_set_error("CFG pair communicator already initialised"); return K5_ERR_STATE; }
+  if (lb->g.joined[branch]) { k5_set_error("loopback pair rank %d is already taken", branch); return K5_ERR_STATE; }
+  lb->g.joined[branch] = 1;
+  d->pair.loop = &lb->g;
+  return pair_common_init(d, branch);
+}
+extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->cfg_branch : -1; }
 
 // Engine options (all default 0).
 //   "attn_mode"       0 = softmax form per head from the data (fixed offset where |q||k'| <= 90, online max elsewhere),

@@ -80,6 +80,9 @@ SYMBOLS = {
     "k5_loopback_create": (_I, [_I, C.POINTER(_P)]),
     "k5_loopback_destroy": (None, [_P]),
     "k5_dit_comm_init_loopback": (_I, [_P, _P, _I]),
+    "k5_dit_cfg_pair_init": (_I, [_P, C.c_char_p, _I, _P]),
+    "k5_dit_cfg_pair_init_loopback": (_I, [_P, _P, _I]),
+    "k5_dit_cfg_branch": (_I, [_P]),
     "k5_dit_set_option": (_I, [_P, C.c_char_p, _I]),
     "k5_dit_get_option": (_I, [_P, C.c_char_p, C.POINTER(_I)]),
     "k5_dit_attn_variant_counts": (_I, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _I]),

@@ -84,9 +84,11 @@ def generate(model, device, shape, num_steps, text_embeds, null_text_embeds, vis
     from .models.dit import DiffusionTransformer3D
     cfg_on = abs(guidance_weight - 1.0) > 1e-6
     cfg_parallel = getattr(model, "_cfg_parallel", None)
-    if cfg_parallel is not None and cfg_on:
-        # CFG-parallel: this rank's group runs ONE of the two forwards; the pair exchanges the velocities
-        # (6 MB at 5 s) and every rank applies the identical bf16 combine + Euler update -> identical latents everywhere
+    if cfg_parallel is not None and cfg_on and getattr(model, "_cfg_pair", None) is None:
+        # CFG-parallel for a model WITHOUT the engine-side pair (a wrapped / duck-typed model): this rank's group
+        # runs ONE of the two forwards; the pair exchanges the velocities (6 MB at 5 s) over torch.distributed and every rank applies
+        # the identical bf16 combine + Euler update.  A DiffusionTransformer3D set up by parallelize_dit does the same INSIDE
+        # k5_sample (k5_dit_cfg_pair_init) and takes the fused path below.
         from .models.parallelize import exchange_velocity
         branch, pair_group = cfg_parallel
         mine, mine_pos = (text_embeds, text_rope_pos) if branch == 0 else (null_text_embeds, null_text_rope_pos)

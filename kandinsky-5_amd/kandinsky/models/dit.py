@@ -80,17 +80,18 @@ class DiffusionTransformer3D(nn.Module):
         self._handle_device = None
         self._keepalive = []
         self._sp = None              # (rank, world) once a communicator lives on the handle
+        self._cfg_pair = None        # CFG-parallel branch (0 / 1) once the pair communicator lives on the handle
         self._settings = {"fp8": False, "graph": False, "options": {}}   # re-applied when the engine is rebuilt
 
     # ---------------------------------------------------------------- engine lifetime
     def _destroy_engine(self, force=False):
         if self._handle is not None:
-            if getattr(self, "_sp", None) is not None and not force:
+            if (getattr(self, "_sp", None) is not None or getattr(self, "_cfg_pair", None) is not None) and not force:
                 # a rank that silently rebuilt its engine would run the unsharded forward while its peers wait in a collective
                 raise RuntimeError("this DiffusionTransformer3D holds a live sequence-parallel communicator: replacing its "
                                    "weights or moving it to another device would desynchronise the ranks")
             E.lib().k5_dit_destroy(self._handle)
-        self._handle, self._handle_device, self._sp = None, None, None
+        self._handle, self._handle_device, self._sp, self._cfg_pair = None, None, None, None
 
     def __del__(self):
         try:
@@ -309,6 +310,40 @@ class DiffusionTransformer3D(nn.Module):
         with torch.cuda.device(self._handle_device):
             E.check(E.lib().k5_dit_comm_init_loopback(self._handle, group.handle, int(rank)), "k5_dit_comm_init_loopback")
         self._sp = (rank, group.world)
+        self._keepalive.append(group)
+        return self
+
+    def enable_cfg_pair(self, branch, group=None, src=0, device=None):
+        """CFG-parallel inside the engine (k5_dit_cfg_pair_init): this rank runs ONE branch of classifier-free guidance in `sample`
+        (0 = conditional, 1 = unconditional) and exchanges the velocity with its partner — `group` = the 2-rank torch.distributed
+        group of the pair (it only carries the 128-byte id from `src`, the global rank of branch 0).  Call after
+        enable_sequence_parallel (both are collective)."""
+        import os
+        if self._handle is None:
+            if device is None:
+                raise RuntimeError("build the engine first (forward / init_synthetic) or pass device=")
+            self.engine(device)
+        lib_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = lib_path.encode() if os.path.exists(lib_path) else None
+        payload = [None]
+        if branch == 0:
+            uid = C.create_string_buffer(128)
+            E.check(E.lib().k5_comm_unique_id(path, uid), "k5_comm_unique_id")
+            payload = [uid.raw]
+        import torch.distributed as dist
+        dist.broadcast_object_list(payload, src=src, group=group)
+        with torch.cuda.device(self._handle_device):
+            E.check(E.lib().k5_dit_cfg_pair_init(self._handle, path, int(branch), payload[0]), "k5_dit_cfg_pair_init")
+        self._cfg_pair = int(branch)
+        return self
+
+    def enable_cfg_pair_loopback(self, group, branch):
+        """Tests: the pair as a loopback group of world 2 (`kandinsky._engine.LoopbackGroup(2)`)."""
+        if self._handle is None:
+            raise RuntimeError("build the engine first")
+        with torch.cuda.device(self._handle_device):
+            E.check(E.lib().k5_dit_cfg_pair_init_loopback(self._handle, group.handle, int(branch)), "k5_dit_cfg_pair_init_loopback")
+        self._cfg_pair = int(branch)
         self._keepalive.append(group)
         return self
 

@@ -95,6 +95,10 @@ def parallelize_dit(model, rank: int, world: int, device=None, cfg_parallel: boo
         model.enable_sequence_parallel(layout.sp_rank, layout.sp_world, device=device, group=sp_group, src=layout.sp_ranks[0])
     model._layout = layout
     model._cfg_parallel = (layout.branch, pair_group) if cfg_parallel else None
+    if cfg_parallel and hasattr(model, "enable_cfg_pair"):
+        # the exchange lives in the engine: `generate` stays on the fused k5_sample loop (and its captured step) — the pair's torch
+        # group only carries the 128-byte RCCL id
+        model.enable_cfg_pair(layout.branch, group=pair_group, src=layout.pair_ranks[0], device=device)
     if getattr(model, "mag_ratios", None) is not None:   # MagCache slot bookkeeping depends on the branch
         from ..magcache_utils import _apply
         _apply(model)

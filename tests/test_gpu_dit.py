@@ -378,3 +378,77 @@ def test_fp8_feed_forward_mode():
     print(f"fp8 mode: engine vs fp8 oracle {rel(out8, ref8):.3e}; engine fp8 vs engine bf16 {cost:.3e}; fp8 oracle vs bf16 engine {rel(ref8, plain):.3e}")
     assert rel(out8, ref8) <= 4e-2, rel(out8, ref8)
     assert 1e-3 < cost <= 8e-2, cost                                              # the price of 3 mantissa bits
+
+
+# ------------------------------------------------------------------------------------------ BASELINE configs at their own sizes
+def _two_block_model(gain):
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
+    cfg = O.DitConfig(**c)
+    sd = O.synthetic_state_dict(cfg, seed=3)
+    if gain != 1.0:
+        for k in sd:
+            if k.endswith(("query_norm.weight", "key_norm.weight")):
+                sd[k] = torch.full((64,), gain)
+    dit = DiffusionTransformer3D(**c)
+    dit.load_state_dict(sd, assign=True)
+    return dit.to("cuda:0"), sd, cfg
+
+
+def test_config2_length_forward_vs_reference_golden():
+    """k5_dit_forward at the length bench.py times — BASELINE config 2's (31, 64, 96) latent = 47 616 tokens, 256 text tokens, full
+    width, 2 visual blocks — against the REFERENCE's own forward (dit.py:155-181, fp32; oracle/gen_golden_fullwidth_long.py) on the
+    same seeded weights and inputs: 16384 sampled outputs and the whole-tensor sums.  Tolerance: the bf16-vs-fp32 distance of the
+    short full-width case (3e-2); the balanced dense launch (5208 jobs: full rounds + split tail + merge), the per-head softmax-form
+    choice and every workspace are the ones of the timed configuration."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    G, meta = load_file(os.path.join(here, "dit_fullwidth_long.safetensors")), json.load(open(os.path.join(here, "dit_fullwidth_long_meta.json")))
+    dit, _, _ = _two_block_model(meta["qk_gain"])
+    T, H, W = meta["latent"]
+    L = meta["text_len"]
+    g = torch.Generator().manual_seed(meta["input_seed"])
+    x = torch.randn(T, H, W, 16, generator=g)
+    text, pooled = torch.randn(L, 3584, generator=g), torch.randn(1, 768, generator=g)
+    pos = [torch.arange(T), torch.arange(H // 2), torch.arange(W // 2)]
+    dit.attn_variant_counts(reset=True)
+    out = dit(x.cuda(), text.cuda(), pooled.cuda(), torch.tensor([meta["time"]]), pos, torch.arange(L), scale_factor=(1.0, 2.0, 2.0))
+    torch.cuda.synchronize()
+    assert list(out.shape) == meta["out_shape"]
+    n_fixed, n_online = dit.attn_variant_counts()
+    flat = out.float().reshape(-1)
+    got = flat[G["sample_idx"].cuda()].cpu()
+    r = rel(got, G["sample_val"])
+    s, ss = flat.double().sum().item(), flat.double().pow(2).sum().item()
+    print(f"config-2 length (N = {T * H * W // 4}): engine vs reference fp32 {r:.3e} on {got.numel()} samples; sum {s:.4e} / {meta['out_sum']:.4e}, "
+          f"sumsq {ss:.5e} / {meta['out_sumsq']:.5e}; heads fixed / online {n_fixed} / {n_online}")
+    assert r <= 3e-2, r
+    assert abs(ss - meta["out_sumsq"]) <= 3e-2 * meta["out_sumsq"]
+    assert abs(s - meta["out_sum"]) <= 3e-2 * (meta["out_sumsq"] * flat.numel()) ** 0.5
+    assert n_fixed == 2 * 28 and n_online == 0           # gain 1.5: |q||k'| = 64 * 2.25 * 0.18 = 26 -> offset-0 fixed form on every head
+
+
+def test_config1_plumbing_run_vs_oracle():
+    """BASELINE config 1 (config_5s_distil: 256x256, 2 s -> latent (13, 32, 32) = 3328 tokens, NFE 16, guidance 1 -> one forward per
+    step): the whole 16-step sampler through generate() at full width with 2 visual blocks, against the bf16-island oracle's
+    generate on the host (the oracle is pinned to the reference's trajectories by the G4 goldens).  `generate` is called directly, as
+    SURVEY §8d prescribes — the pipeline itself rejects 256x256 (t2v_pipeline.py:43-45)."""
+    from types import SimpleNamespace as NS
+    from kandinsky.generation_utils import generate
+    dit, sd, cfg = _two_block_model(1.0)
+    T, H, W, L, Ln = 13, 32, 32, 48, 8
+    g = torch.Generator().manual_seed(21)
+    noise = torch.randn(T, H, W, 16, generator=g)
+    te = {"text_embeds": torch.randn(L, 3584, generator=g), "pooled_embed": torch.randn(1, 768, generator=g)}
+    ne = {"text_embeds": torch.randn(Ln, 3584, generator=g), "pooled_embed": torch.randn(1, 768, generator=g)}
+    pos = [torch.arange(T), torch.arange(H // 2), torch.arange(W // 2)]
+    conf = NS(model=NS(dit_params=NS(patch_size=(1, 2, 2)), attention=NS(type="flash")), metrics=NS(scale_factor=(1.0, 2.0, 2.0)))
+    cu = lambda d: {k: v.cuda() for k, v in d.items()}   # noqa: E731
+    lat = generate(dit, "cuda:0", (T, H, W, 16), 16, cu(te), cu(ne), pos, torch.arange(L), torch.arange(Ln), 1.0, 5.0, conf, noise=noise)
+    ref = O.generate(sd, cfg, noise, 16, te, ne, pos, torch.arange(L), torch.arange(Ln), 1.0, 5.0, (1.0, 2.0, 2.0), None, "bf16")
+    r = rel(lat, ref)
+    print(f"config 1 (13,32,32) x 16 steps, w = 1: final latent engine vs bf16-island oracle {r:.3e}; moved {rel(ref, noise):.3f} from the noise")
+    assert r <= 1e-2, r
+    assert rel(ref, noise) > 0.05                         # the sampler really moved the latent (the check is not noise vs noise)

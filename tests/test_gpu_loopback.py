@@ -396,3 +396,131 @@ def test_full_width_forward_sliced_exchange(P, W, gain, S):
         assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
     print(f"sliced exchange P={P} S={S} gain={gain}: sharded vs fused rel-L2 {rel(outs[0], fused):.3e}")
     assert rel(outs[0], fused) <= (6e-3 if gain == 1.0 else 1.5e-2), rel(outs[0], fused)
+
+
+# ------------------------------------------------------------------------------------------ CFG-parallel inside the engine
+def run_cfg_ranks(Psp, make_dit, call, options=None):
+    """2 x Psp handles on one GPU = BASELINE config 5's plan: two sequence-parallel groups of Psp ranks (group 0 runs the conditional
+    forward, group 1 the unconditional one; loopback groups of world Psp, none when Psp = 1) and Psp CFG pairs (rank i of one group
+    with rank i of the other; loopback groups of world 2, k5_dit_cfg_pair_init_loopback).  One host thread per handle.  Returns the
+    results in global-rank order (branch * Psp + sp_rank), as kandinsky/models/parallelize.py ParallelLayout numbers them."""
+    from kandinsky import _engine as E
+    sp_groups = [E.LoopbackGroup(Psp) for _ in range(2)] if Psp > 1 else [None, None]
+    pair_groups = [E.LoopbackGroup(2) for _ in range(Psp)]
+    dits = []
+    for branch in range(2):
+        for r in range(Psp):
+            d = make_dit()
+            d.engine("cuda:0")
+            if Psp > 1:
+                d.enable_loopback(sp_groups[branch], r)
+            d.enable_cfg_pair_loopback(pair_groups[r], branch)
+            for k, v in (options or {}).items():
+                d.set_option(k, v)
+            dits.append(d)
+    torch.cuda.synchronize()
+    n = 2 * Psp
+    out, err = [None] * n, [None] * n
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.default_stream())
+            with torch.cuda.stream(st):
+                out[i] = call(dits[i], i)
+            st.synchronize()
+        except Exception as e:
+            err[i] = e
+
+    ths = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(n)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    assert not any(t.is_alive() for t in ths), f"ranks stuck in a collective (errors so far: {err})"
+    for e in err:
+        if e is not None:
+            raise e
+    for d in dits:
+        d._destroy_engine(force=True)
+    return out
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("Psp,sparse", [(1, False), (2, False), (2, True), (4, False)])
+def test_tiny_cfg_parallel_inside_the_engine(golden_meta, tiny_sd, Psp, sparse):
+    """k5_sample with the CFG pair (generation_utils.py:53-76 split over two rank groups): 4 steps, guidance 5.  Every handle of both
+    groups ends with the SAME latent bit for bit.  Psp = 1 (two GPUs: one forward each, no sequence parallelism): the forwards are the
+    single-handle ones and the combine sees the same bf16 velocities — the latent equals the single-handle CFG run BIT FOR BIT.
+    Psp > 1: within the suite's tolerance on a final latent (the sharded schedule's summation order)."""
+    from types import SimpleNamespace as NS
+    from kandinsky.generation_utils import generate
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = tiny_cfg(golden_meta)
+    g = torch.Generator().manual_seed(6)
+    shape = (8, 16, 16, 16)
+    noise = torch.randn(*shape, generator=g)
+    te = {"text_embeds": torch.randn(9, 96, generator=g).cuda(), "pooled_embed": torch.randn(1, 48, generator=g).cuda()}
+    ne = {"text_embeds": torch.randn(4, 96, generator=g).cuda(), "pooled_embed": torch.randn(1, 48, generator=g).cuda()}
+    pos = [torch.arange(8), torch.arange(8), torch.arange(8)]
+    att = NS(type="nabla", P=0.6, wT=3, wH=1, wW=1, add_sta=True, method="topcdf") if sparse else NS(type="flash")
+    conf = NS(model=NS(dit_params=NS(patch_size=(1, 2, 2)), attention=att), metrics=NS(scale_factor=(1.0, 2.0, 2.0)))
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(tiny_sd, assign=True)
+        return d.to("cuda:0")
+
+    def call(d, i):
+        return generate(d, "cuda:0", shape, 4, te, ne, pos, torch.arange(9), torch.arange(4), 5.0, 5.0, conf, noise=noise)
+
+    fused = call(make(), 0)
+    outs = run_cfg_ranks(Psp, make, call)
+    for i in range(1, 2 * Psp):
+        assert torch.equal(outs[i], outs[0]), f"handle {i} differs from handle 0"
+    if Psp == 1:
+        assert torch.equal(outs[0], fused)
+    assert rel(outs[0], fused) <= 1e-2, rel(outs[0], fused)
+    assert rel(fused, noise.cuda()) > 0.05
+
+
+@pytest.mark.timeout(1800)
+def test_config5_cfg_parallel_2x4_on_one_gpu():
+    """BASELINE config 5 as ONE configuration: 1280x768 10 s latent (61, 96, 160) = 234 240 tokens = 3660 blocks, NABLA (P = 0.9,
+    11 x 3 x 3 window), guidance 5, sequence-parallel x 4 inside each CFG branch + the CFG pair exchange, all inside k5_sample — 8
+    handles on one GPU, full width, one visual block, 2 Euler steps.  All 8 handles hold bit-identical latents; the update they
+    applied (latent - noise) agrees with the single-handle CFG run of the same sampler within the 6e-3 of two valid summation orders
+    (x 2 steps)."""
+    from types import SimpleNamespace as NS
+    from kandinsky.generation_utils import generate
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=1, num_text_blocks=1)
+    sd = O.synthetic_state_dict(O.DitConfig(**c), seed=4)
+    g = torch.Generator().manual_seed(13)
+    shape = (61, 96, 160, 16)
+    noise = torch.randn(*shape, generator=g)
+    te = {"text_embeds": torch.randn(48, 3584, generator=g).cuda(), "pooled_embed": torch.randn(1, 768, generator=g).cuda()}
+    ne = {"text_embeds": torch.randn(8, 3584, generator=g).cuda(), "pooled_embed": torch.randn(1, 768, generator=g).cuda()}
+    pos = [torch.arange(61), torch.arange(48), torch.arange(80)]
+    att = NS(type="nabla", P=0.9, wT=11, wH=3, wW=3, add_sta=True, method="topcdf")
+    conf = NS(model=NS(dit_params=NS(patch_size=(1, 2, 2)), attention=att), metrics=NS(scale_factor=(1.0, 2.0, 2.0)))
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(sd, assign=True)
+        return d.to("cuda:0")
+
+    def call(d, i):
+        return generate(d, "cuda:0", shape, 2, te, ne, pos, torch.arange(48), torch.arange(8), 5.0, 10.0, conf, noise=noise)
+
+    one = make()
+    fused = call(one, 0)
+    one._destroy_engine(force=True)
+    outs = run_cfg_ranks(4, make, call)
+    for i in range(1, 8):
+        assert torch.equal(outs[i], outs[0]), f"handle {i} differs from handle 0"
+    upd, upd_f = outs[0] - noise.cuda(), fused - noise.cuda()
+    print(f"config 5 (SP x 4 + CFG x 2 + NABLA, 3660 blocks): update vs the single-handle CFG run rel-L2 {rel(upd, upd_f):.3e}; "
+          f"|update| / |noise| = {rel(fused, noise.cuda()):.3e}")
+    assert rel(upd, upd_f) <= 1.2e-2, rel(upd, upd_f)

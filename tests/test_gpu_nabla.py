@@ -40,13 +40,39 @@ def _cdf_at_entries(q, k, mode="bf16"):
     import math
     S, H, d = q.shape
     nb = S // 64
-    qa = bfr(q.float().transpose(0, 1).reshape(H, nb, 64, d).mean(-2))
-    ka = bfr(k.float().transpose(0, 1).reshape(H, nb, 64, d).mean(-2))
-    p = torch.softmax(bfr(bfr(qa @ ka.transpose(-2, -1)) / math.sqrt(d)), dim=-1)
+    r = bfr if mode == "bf16" else (lambda t: t)
+    qa = r(q.float().transpose(0, 1).reshape(H, nb, 64, d).mean(-2))
+    ka = r(k.float().transpose(0, 1).reshape(H, nb, 64, d).mean(-2))
+    p = torch.softmax(r(r(qa @ ka.transpose(-2, -1)) / math.sqrt(d)), dim=-1)
     vals, inds = p.sort(-1)
     cdf = torch.zeros_like(p)
     cdf.scatter_(-1, inds, vals.cumsum(-1))
     return cdf, p
+
+
+def _may_differ(q, k, P, tol, mode="bf16"):
+    """(H, nb, nb) bool: entries where two correct implementations of nablaT_v2's cut (utils.py:151-156) may disagree —
+    * the entry's cumulative mass, or the mass just below it, is within `tol` of the threshold 1 - P (fp32 exp / cumsum order; on
+      random data a bf16 logit one ulp off), or
+    * it belongs to a group of EXACTLY tied probabilities whose cumulative span [below the group, top of the group] contains the
+      threshold: which members of such a group are kept depends on the sort's order among equals (the reference's torch.sort is not
+      stable; the kernel ranks ties by index).
+    Vectorised (a 3660-block row set has 13 M entries)."""
+    cdf, p = _cdf_at_entries(q, k, mode)
+    thr = 1.0 - P
+    near = ((cdf - thr).abs() <= tol) | ((cdf - p - thr).abs() <= tol)
+    vals, inds = p.sort(-1)
+    cs = vals.cumsum(-1)
+    new_grp = torch.ones_like(vals, dtype=torch.bool)
+    new_grp[..., 1:] = vals[..., 1:] != vals[..., :-1]
+    gid = new_grp.long().cumsum(-1) - 1                                   # tie-group index along the sorted row
+    lo = torch.full_like(vals, float("inf")).scatter_reduce(-1, gid, cs - vals, "amin", include_self=True)
+    hi = torch.full_like(vals, float("-inf")).scatter_reduce(-1, gid, cs, "amax", include_self=True)
+    cnt = torch.zeros_like(vals).scatter_add(-1, gid, torch.ones_like(vals))
+    g_ok = (cnt > 1) & (lo - tol <= thr) & (thr <= hi + tol)              # per group
+    ok_sorted = g_ok.gather(-1, gid)
+    tie_ok = torch.zeros_like(ok_sorted).scatter(-1, inds, ok_sorted)
+    return near | tie_ok
 
 
 @pytest.mark.parametrize("grid,window,P,H", [((6, 2, 2), (3, 1, 1), 0.7, 2), ((10, 3, 4), (5, 3, 3), 0.9, 3),
@@ -54,7 +80,9 @@ def _cdf_at_entries(q, k, mode="bf16"):
                                              # one case per register-resident instantiation of the select kernel (values per lane x rows
                                              # per wave): 600 blocks <16,4>, 1464 (the 10 s clip) <24,4>, 1600 <32,4>, 2100 <64,2>
                                              ((25, 4, 6), (5, 3, 3), 0.9, 2), ((61, 4, 6), (11, 3, 3), 0.9, 2),
-                                             ((25, 8, 8), (11, 3, 3), 0.9, 1), ((35, 6, 10), (5, 3, 3), 0.8, 1)])
+                                             ((25, 8, 8), (11, 3, 3), 0.9, 1), ((35, 6, 10), (5, 3, 3), 0.8, 1),
+                                             # BASELINE config 5's own row length: (61, 96, 160) latent = 61 x 6 x 10 = 3660 blocks (<64,2>)
+                                             ((61, 6, 10), (11, 3, 3), 0.9, 1)])
 @pytest.mark.parametrize("data", ["exact", "random"])
 def test_nabla_map_matches_oracle(E, grid, window, P, H, data):
     """k5_nabla_select_bf16 vs oracle.nabla_block_mask, entry by entry.
@@ -85,23 +113,12 @@ def test_nabla_map_matches_oracle(E, grid, window, P, H, data):
     got = E.nabla_mask(ws, H, nb).cpu()
     diff = (got != ref)
     if diff.any():
-        cdf, p = _cdf_at_entries(q, k)
-        thr = 1.0 - P
-        # a differing entry sits at the threshold: its cdf, or the cdf just below it, is within tol of 1 - P
-        near = ((cdf - thr).abs() <= tol) | ((cdf - p - thr).abs() <= tol)
-        # exact ties: which of several EQUAL probabilities straddling the cut are kept depends on the sort's order among
-        # them (the reference's torch.sort is not stable; the kernel ranks ties by index) -> a differing entry may also be
-        # one that ties with an entry at the threshold
-        # -> a differing entry may also belong to a tie group whose cumulative span [below the group, top of the group]
-        # contains the threshold
-        for h, i, j in diff.nonzero().tolist():
-            tied = p[h, i] == p[h, i, j]
-            lo = float((cdf[h, i][tied] - p[h, i][tied]).min()) - tol
-            hi = float(cdf[h, i][tied].max()) + tol
-            assert near[h, i, j] or (int(tied.sum()) > 1 and lo <= thr <= hi), (h, i, j, float(cdf[h, i, j]), thr, int(tied.sum()))
+        bad = diff & ~_may_differ(q, k, P, tol)
+        assert not bad.any(), (int(bad.sum()), bad.nonzero()[:5].tolist())
     # how MANY entries may differ: integer logits make large tie groups (every member of a group straddling the cut may flip,
     # checked one by one above), random logits at most a few entries next to the cut per row
     # (the tie groups of integer logits grow with the row length: up to a tenth of a 2100-block row ties at the cut)
+    print(f"nabla map {grid} {data}: {int(diff.sum())} of {diff.numel()} entries differ from the oracle (every one at the cut, checked above)")
     assert diff.float().mean().item() <= ((3e-2 if nb < 1000 else 1e-1) if data == "exact" else 5e-3), (int(diff.sum()), diff.numel())
     assert (got & sta[None]).sum() == sta.sum() * H                     # the STA window is always kept
     assert got.any(-1).all()                                            # every row keeps at least one block
@@ -413,3 +430,31 @@ def test_nabla_graph_captured_step_is_bit_identical(tiny_sd, golden, golden_meta
         del dit
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_reference_nabla_golden_through_the_gpu_kernel(E):
+    """The committed reference vector (oracle/gen_golden.py: nablaT_v2 itself, fp32, on fixed q / k with the (6,2,2) STA mask, P = 0.7)
+    fed to k5_nabla_select_bf16 — entry by entry against the REFERENCE's mask, not the oracle's.  The kernel sees bf16 q / k and
+    bf16 logits (the reference's GPU arithmetic under autocast), the golden is the fp32 evaluation: entries may only differ where
+    the cumulative mass sits within a bf16 logit flip of the cut; the exact count is reported."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    G = load_file(os.path.join(here, "dit_tiny.safetensors"))
+    meta = json.load(open(os.path.join(here, "dit_tiny_meta.json")))
+    at = meta["nabla_attention"]
+    q, k, ref = G["nabla.q"], G["nabla.k"], G["nabla.mask"].bool()       # (N, H, 64) fp32, (H, nb, nb)
+    N, H, _ = q.shape
+    T, Hp, Wp = meta["nabla_patched_shape"]
+    grid, window = (T, Hp // 8, Wp // 8), (at["wT"], at["wH"], at["wW"])
+    nb = N // 64
+    assert tuple(ref.shape) == (H, nb, nb) and torch.equal(G["nabla.sta"].bool(), O.fast_sta(*grid, *window))
+    ws = E.nabla_select(q.reshape(N, -1).cuda().to(BF), k.reshape(N, -1).cuda().to(BF), H, grid, window, at["P"])
+    got = E.nabla_mask(ws, H, nb).cpu()
+    diff = got != ref
+    print(f"reference nabla.mask golden vs k5_nabla_select_bf16: {int(diff.sum())} of {diff.numel()} entries differ "
+          f"(golden density {ref.float().mean():.3f}, kernel {got.float().mean():.3f})")
+    ok = _may_differ(bfr(q), bfr(k), at["P"], 0.05) | _may_differ(q, k, at["P"], 0.05, mode="fp32")
+    assert not (diff & ~ok).any(), (diff & ~ok).nonzero()[:5].tolist()
+    assert int(diff.sum()) <= 12, int(diff.sum())                       # 1152 entries; a handful of rows have an entry within one bf16 flip of the cut

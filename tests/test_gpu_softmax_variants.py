@@ -476,12 +476,12 @@ def test_fused_query_norm_across_passes(E):
 def test_fused_query_norm_flip_from_a_tail_job_across_passes(E):
     """ADVICE r2 (attn_fwd.hip QN flip): 4 heads x 130 query blocks = 520 jobs = one full round of the 512 resident workgroups + 8
     TAIL jobs (head 3, the last 8 query blocks), which the balanced launcher runs after BOTH forms' full-round launches.  Head 3's
-    rows sit on non-zero per-row offsets (bound ~ 150) and exactly one row — in the very last query block, i.e. in a tail job — is over
+    rows sit on non-zero per-row offsets (bound ~ 110) and exactly one row — in the very last query block, i.e. in a tail job — is over
     the 180 limit: its flip lands after online(full) has skipped the head, while the full jobs of the head left fixed-form state.
     The flip must be the LATE flag (2) so that pass B's online launch recomputes the head from scratch instead of resuming that
     state as offset 0."""
     Sq, Sk, H = 33280, 2048, 4
-    qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([2.0, 2.0, 2.0, 10.0]), 91)
+    qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([2.0, 2.0, 2.0, 7.5]), 91)
     w[7] = 3.0
     qraw[Sq - 3, 3] = 0.01 * qraw[Sq - 3, 3]
     qraw[Sq - 3, 3, 7] = 30.0

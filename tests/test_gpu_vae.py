@@ -388,7 +388,8 @@ def test_conv_statistics_feed_groupnorm_vs_oracle(Cin, Cout, dims, up, use_res):
             ref = torch.nn.functional.silu(ref)
         e = (y.float().cpu() - ref).abs()
         # conv outputs differ from the oracle's by a bf16 ulp here and there (2^-8 relative), amplified by gamma / sigma ~ 1.2
-        t = 2.0 ** -6 * ref.abs().clamp(min=1.0)
+        # plus one bf16 ulp of the conv output itself (2^-8 |x| each way) through the norm's gain gamma / sigma (<= 2 here)
+        t = 2.0 ** -6 * ref.abs().clamp(min=1.0) + 2.0 ** -6 * want.abs()
         assert not (e > t).any(), (silu, float(e.max()), int((e > t).sum()))
         d = (y.float() - y2.float()).abs()
         assert d.max().item() <= 2.0 ** -7 * max(1.0, y2.float().abs().max().item()) and (d > 0).float().mean().item() < 2e-3, \
