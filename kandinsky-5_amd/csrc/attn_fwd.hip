@@ -511,6 +511,25 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
       }
     }
     }
+#if defined(K5_ATTN_SGB)   // A/B builds (tools/build_variant.sh): ask the scheduler for an explicit MFMA / VALU interleave of the tile body
+    if (BOUNDED && PRE && !SPARSE) {
+#if K5_ATTN_SGB == 1      // one VALU behind every MFMA
+#pragma unroll
+      for (int i = 0; i < 36; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); }
+#elif K5_ATTN_SGB == 2    // S phase: MFMA + LDS read; then MFMA + 2 VALU
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+      for (int i = 0; i < 28; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+#elif K5_ATTN_SGB == 3    // two MFMAs, then three VALU
+#pragma unroll
+      for (int i = 0; i < 18; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+#elif K5_ATTN_SGB == 4    // LDS reads up front in pairs with MFMAs, transcendental after each MFMA, converts wherever
+#pragma unroll
+      for (int i = 0; i < 36; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x400, 1, 0); }
+#endif
+    }
+#endif
     __syncthreads();   // vmcnt(0) + barrier: tile e+1 has landed for every wave, tile e's buffer is free
   };
   for (int e = E0; e < T; e += 2) {

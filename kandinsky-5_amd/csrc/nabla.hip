@@ -3,7 +3,7 @@
 // Replaces nablaT_v2 (kandinsky/models/utils.py:136-163) + fast_sta_nabla (:108-133):
 //   1. block_mean_kernel   qa, ka = mean over each 64-token block (tokens are in fractal order, so a block is one
 //                          8x8 spatial tile of one frame), rounded to bf16 like the reference's bf16 `.mean(-2)`;
-//   2. nabla_select_kernel per (head, query block): logits = bf16(qa . ka_j) / 8, softmax in fp32, keep the
+//   2. nabla_logits_kernel + nabla_select_row_kernel  per (head, query block): logits = bf16(qa . ka_j) / 8, softmax in fp32, keep the
 //                          smallest set of blocks whose probability mass is >= P  ==  drop the ascending-sorted
 //                          prefix whose cumulative sum stays below 1-P (`cvals >= 1 - thr`), OR the sliding-tile
 //                          window |dt|<=wT/2, |dh|<=wH/2, |dw|<=wW/2.  No sort: the cut value is found by bisection on
@@ -59,13 +59,12 @@ struct SelP {
 };
 
 constexpr int SEL_MAXNB = 4096;
+// values per lane of the row-per-wave selection kernel's instantiations (nabla_select_row_kernel<NV>) for a row of nw 64-block words
+inline int sel_row_nv(int nw) { return nw <= 4 ? 4 : nw <= 8 ? 8 : nw <= 16 ? 16 : nw <= 24 ? 24 : nw <= 32 ? 32 : nw <= 48 ? 48 : 64; }
 
 // sum over the 64 lanes, the same value returned in every lane.  DPP inside the 16-lane rows (quad swaps, half-mirror,
 // mirror), then two readlanes across the rows — no LDS round trips (the bisection below does 30 of these per row).
 K5_DEV float wave_sum_dpp(float v) {
-#ifdef K5_NABLA_SHFL
-  return wave_sum(v);
-#endif
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
@@ -78,9 +77,6 @@ K5_DEV float wave_sum_dpp(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 K5_DEV float wave_max_dpp(float v) {
-#ifdef K5_NABLA_SHFL
-  return wave_max(v);
-#endif
   v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true)));
   v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true)));
   v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));
@@ -92,185 +88,150 @@ K5_DEV float wave_max_dpp(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
-// One wave = R query-block rows of ONE head; lane l owns the key blocks l, l + 64, ... (NV per lane) of each of its rows, all
-// in registers.  Round 1 gave every row its own wave and re-read the head's whole key-mean matrix (187 KB at nb = 1464) from
-// L2 per row — 7.7 GB per layer, the kernel's time; here a key mean is loaded once per R rows, the dot products run on
-// v_dot2c_f32_bf16 (both operands ARE bf16), and the bisection works on registers with DPP reductions, the R rows in
-// lockstep (R independent reduction chains in flight).  1.02 -> 0.69 ms per layer at nb = 1464 (profiles/r02_nabla_kernel_stats.md);
-// with R = 4 the dot products moved to v_mfma_f32_4x4x4_16b_bf16 (below): 0.69 -> 0.63; the bisection without per-row branches and with
-// its compares in SGPR pairs: -> 0.56.
-template <int NV, int R>
-__global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t sq[4 * R * 64];   // the block's 4 R query-block means
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rows_per_block = 4 * R;
-  const int blocks_per_head = (p.nqb + rows_per_block - 1) / rows_per_block;
-  const int h = blockIdx.x / blocks_per_head, il0 = (blockIdx.x % blocks_per_head) * rows_per_block + wave * R;
-  // stage the query means (rows past nqb: clamped, their results are dropped)
-  for (int c = threadIdx.x; c < rows_per_block * 8; c += 256) {
-    const int r = c >> 3, il = min((blockIdx.x % blocks_per_head) * rows_per_block + r, p.nqb - 1);
-    *reinterpret_cast<u32x4*>(sq + r * 64 + 8 * (c & 7)) = *reinterpret_cast<const u32x4*>(p.qa + ((size_t)h * p.nqb + il) * 64 + 8 * (c & 7));
-  }
-  __syncthreads();
-  if (il0 >= p.nqb) return;   // wave-uniform; no barrier follows
-  float pv[R][NV];
-  float mx[R];
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The map in two kernels (round 3).  Rounds 1-2 fused logits and selection: R = 4 / 2 rows per wave in registers so that a key mean was
+// loaded once per R rows — and still every wave walked the head's whole key-mean matrix (468 KB at 3660 blocks: 6 GB of L2 reads per
+// layer on a 4-GPU shard of the 1280x768 clip), at one wave per SIMD for the long rows (256 VGPRs: nothing hid the DPP reductions).
+// Now the logits are what they are in the reference — one bf16 matmul per head (utils.py:145-147) — written once (2 B per entry:
+// 187 MB per layer on that shard), and the selection reads its own row back: one wave per row, NV values per lane, <= 128 VGPRs,
+// 4-8 waves per SIMD.  Map per step: 54.8 -> 18.9 ms on that shard, 23.1 -> 14.7 ms on the 768x512 10 s clip (same box, A/B).
+// ---------------------------------------------------------------------------------------------------------------------------------
+
+// logits[h][il][j] = bf16(qa[h][il] . ka[h][j])  (bf16 matmul output; the exact / 8 happens in the consumer).  MFMA 16x16x32 with the
+// KEY means as the A operand: a lane then holds 4 keys of ONE query row per tile, and with the A rows of tile kt taken from keys
+// 16 (i >> 2) + 4 kt + (i & 3) of a 64-key window its four tiles are 16 CONSECUTIVE keys: two 16-byte stores per lane, 128 contiguous
+// bytes per row and wave.  Workgroup = 4 waves = 16 query rows x 4 windows of 64 keys per step.  K = 64: operands straight from global.
+__global__ __launch_bounds__(256) void nabla_logits_kernel(const bf16_t* __restrict__ qa, const bf16_t* __restrict__ ka, bf16_t* __restrict__ out,
+                                                           int H, int nqb, int nb, int ldl, int qtiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x / qtiles, q0 = (blockIdx.x % qtiles) * 16;
+  const bf16_t* qp = qa + ((size_t)h * nqb + min(q0 + l15, nqb - 1)) * 64 + 8 * g;
+  const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp), qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);   // B: [k = 8 g ..][j = query l15]
+  const bf16_t* kh = ka + (size_t)h * nb * 64;
+  bf16_t* orow = out + ((size_t)h * nqb + q0 + l15) * ldl;
+  const int nwin = ldl / 64;                          // >= ceil(nb / 64): the consumer's row width (64 values per lane x NV)
+  for (int w = blockIdx.y * 4 + wave; w < nwin; w += gridDim.y * 4) {
+    f32x4 acc[4];
 #pragma unroll
-  for (int r = 0; r < R; ++r) mx[r] = -3.0e38f;
-  // logits: bf16(qa . ka_j) / sqrt(64)   (bf16 matmul output, then an exact /8)
+    for (int kt = 0; kt < 4; ++kt) {
+      const int key = min(64 * w + 16 * (l15 >> 2) + 4 * kt + (l15 & 3), nb - 1);      // A row i = l15 of tile kt
+      const bf16_t* kp = kh + (size_t)key * 64 + 8 * g;
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(kp), a1 = *reinterpret_cast<const bf16x8*>(kp + 32);
+      acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf1, acc[kt], 0, 0, 0);
+    }
+    // lane (query l15, g): acc[kt][r] = row 4 g + r of tile kt = key 64 w + 16 g + 4 kt + r
+    if (64 * w + 64 > nb) {                             // last window: -inf into the padded columns (exp -> 0 in the consumer)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (64 * w + 16 * g + 4 * kt + r >= nb) acc[kt][r] = -__builtin_inff();
+    }
+    if (q0 + l15 < nqb) {
+      const u32x4 lo = {pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[0][2], acc[0][3]), pack_bf16x2(acc[1][0], acc[1][1]), pack_bf16x2(acc[1][2], acc[1][3])};
+      const u32x4 hi = {pack_bf16x2(acc[2][0], acc[2][1]), pack_bf16x2(acc[2][2], acc[2][3]), pack_bf16x2(acc[3][0], acc[3][1]), pack_bf16x2(acc[3][2], acc[3][3])};
+      u32x4* dst = reinterpret_cast<u32x4*>(orow + 64 * w + 16 * g);
+      dst[0] = lo; dst[1] = hi;
+    }
+  }
+}
+
+// One wave = one (head, query block) row; lane l owns key blocks l, l + 64, ... (NV per lane), all in registers; reductions by DPP
+// inside the 16-lane rows + readlanes (no LDS).  The bisection starts from the row's own [min p, max p] bit range instead of
+// [0, +inf) (~25 steps instead of 31) after one check that the cut exists at all.
+template <int NV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void nabla_select_row_kernel(SelP p, const bf16_t* __restrict__ logits, int ldl) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows_per_head = (p.nqb + 3) / 4 * 4;
+  const int gr = blockIdx.x * 4 + wave;
+  const int h = gr / rows_per_head, il = gr % rows_per_head;
+  if (il >= p.nqb) return;   // wave-uniform; no barrier in this kernel
+  const bf16_t* lrow = logits + ((size_t)h * p.nqb + il) * ldl;
+  // Padding needs no per-value lane masks (64 SGPR pairs of them spill) and no tests at all: a logits row is 64 NV columns wide and
+  // the logits kernel wrote -inf into the columns nb .. 64 NV, so a padded entry is exp(-inf) = 0 — zero mass on either side of any cut.
+  float pv[NV];
+  float mx = -3.0e38f;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const int j = v * 64 + lane;
-    const bf16_t* kp = p.ka + ((size_t)h * p.nb + min(j, p.nb - 1)) * 64;
-    u32x4 kk[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) kk[c] = *reinterpret_cast<const u32x4*>(kp + 8 * c);
-    if constexpr (R == 4 || R == 2) {
-      // four query rows (R = 2: the two rows twice) x this lane's key on the matrix core: v_mfma_f32_4x4x4_16b_bf16 = 16 independent 4x4x4 blocks, block b = lane >> 2.
-      // A: lane (b, i) holds query row i's k-slice, B: lane (b, j) holds key 4 b + j's k-slice, D: lane (b, j) register i = row i x its
-      // key — exactly the pv[r][v] layout (tools/probes/mfma_4x4x4_layout.hip).  16 k-steps of 4 instead of 4 x 32 quarter-rate
-      // v_dot2c per key (49 k of the kernel's ~145 k cycles per wave).
-      typedef __attribute__((ext_vector_type(4))) short bf16x4s;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const bf16_t* qrow = sq + (wave * R + (lane & (R - 1))) * 64;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const u32x4 qq = *reinterpret_cast<const u32x4*>(qrow + 8 * c);
-        const u32x2 alo = {qq[0], qq[1]}, ahi = {qq[2], qq[3]}, blo = {kk[c][0], kk[c][1]}, bhi = {kk[c][2], kk[c][3]};
-        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bf16x4s, alo), __builtin_bit_cast(bf16x4s, blo), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bf16x4s, ahi), __builtin_bit_cast(bf16x4s, bhi), acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float lg = j < p.nb ? bf_round(acc[r]) * 0.125f : -3.0e38f;
-        pv[r][v] = lg;
-        mx[r] = fmaxf(mx[r], lg);
-      }
-    } else
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float d = 0.f;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const u32x4 qq = *reinterpret_cast<const u32x4*>(sq + (wave * R + r) * 64 + 8 * c);   // same address in every lane: broadcast
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#ifdef K5_NABLA_FMA
-          d = fmaf(__uint_as_float(qq[e] << 16), __uint_as_float(kk[c][e] << 16), d);
-          d = fmaf(__uint_as_float(qq[e] & 0xffff0000u), __uint_as_float(kk[c][e] & 0xffff0000u), d);
-#else
-          // inline asm on purpose: the builtin fed through bit_cast(vector element) was compiled with the element index collapsed
-          // to 0 (four identical v_dot2c per 16-byte chunk, ROCm 7.2 clang) — the map then selects from wrong logits
-          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(qq[e]), "v"(kk[c][e]));
-#endif
-        }
-      }
-      const float lg = j < p.nb ? bf_round(d) * 0.125f : -3.0e38f;
-      pv[r][v] = lg;
-      mx[r] = fmaxf(mx[r], lg);
-    }
+    const float lg = (float)lrow[v * 64 + lane] * 0.125f;          // bf16 matmul output, then the exact / sqrt(64); ldl = 64 NV
+    pv[v] = lg;
+    mx = fmaxf(mx, lg);
   }
-  float target_base[R];
-  unsigned lo[R], hi[R];
+  mx = wave_max_dpp(mx);
+  float sum = 0.f;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    mx[r] = wave_max_dpp(mx[r]);
-    float sum = 0.f;
+  for (int v = 0; v < NV; ++v) { const float e = expf(pv[v] - mx); pv[v] = e; sum += e; }
+  sum = wave_sum_dpp(sum);
+  const float inv = 1.0f / sum;
+  float pmin = 3.0e38f, tot = 0.f;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) { const float e = v * 64 + lane < p.nb ? expf(pv[r][v] - mx[r]) : 0.f; pv[r][v] = e; sum += e; }
-    sum = wave_sum_dpp(sum);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) pv[r][v] = pv[r][v] / sum;   // padding lanes: 0 / sum = 0, below every cut, excluded at emission
-    lo[r] = 0u; hi[r] = 0x7f800000u;                          // invariant: g(lo-1) < target <= g(hi)
-    target_base[r] = 0.f;
+  for (int v = 0; v < NV; ++v) {
+    pv[v] = pv[v] * inv;
+    tot += pv[v];
+    pmin = fminf(pmin, pv[v] > 0.f ? pv[v] : 3.0e38f);              // smallest POSITIVE value: zeros (padding, underflow) carry no mass
   }
-  // smallest value v* with  sum_{p <= v*} p  >= target  (bisection over the bit pattern of non-negative floats), R rows in lockstep
-  // The interval [0, 0x7f800000] halves every step, so every row takes the same 31 steps: no per-row branch — the R rows' compare /
-  // select / add chains and DPP reductions sit in ONE basic block and interleave (with a branch per row every v_cmp -> v_cndmask pair
-  // went through VCC back to back: 29 hazard nops per row and step).  Padding lanes hold exactly 0: they add nothing on either side.
-  bool more = true;
-  while (more) {
-    float g[R];
-    unsigned mid[R];
+  tot = wave_sum_dpp(tot);                            // = g(max p): the invariant's upper end
+  pmin = -wave_max_dpp(-pmin);
+  // smallest value v* with  sum_{p <= v*} p >= target  (bisection over the bit pattern of non-negative floats; invariant
+  // g(lo - 1) < target <= g(hi)).  v* is one of the row's values, so [min p, max p] brackets it — unless even the whole row's mass
+  // stays below the target (P ~ 0 and rounding): then, as with the [0, +inf) bracket, nothing lies above the cut.
+  unsigned lo = __float_as_uint(pmin), hi = __float_as_uint(inv);          // max p = exp(0) * inv exactly
+  if (!(tot >= p.target)) lo = hi = 0x7f800000u;
+  if (!(p.target > 0.f)) hi = lo;                     // g(min p) >= min p > 0 >= target
+  // g(mid) = sum of the values whose bit pattern is <= mid, per lane in index order into ONE accumulator (the order of the one-kernel
+  // form above), by EXEC masking: v_cmpx writes the lanes that take part straight into EXEC and a plain v_add follows — two VALU
+  // instructions per value and no SGPR-pair traffic (compare + select + add through SGPR masks: three, and the masks of an unrolled
+  // 64-value row spill).  EXEC is restored from a saved copy before every compare (v_cmpx overwrites the active lanes' bits).
+  while (lo < hi) {                                   // wave-uniform
+    const unsigned mid = lo + ((hi - lo) >> 1);
+    float gl = 0.f;
 #pragma unroll
-    for (int r = 0; r < R; ++r) { mid[r] = lo[r] + ((hi[r] - lo[r]) >> 1); g[r] = 0.f; }
-    // four compares into four SGPR pairs, then the four selects: through VCC the compiler emits v_cmp / s_nop / v_cndmask one element at
-    // a time (gfx950 wants two wait states between a VALU write of a mask and the VALU that reads it; here three instructions lie between)
-    auto select4 = [](unsigned ma, unsigned mb, unsigned mc, unsigned md, float a, float b, float c, float d, float& ta, float& tb,
-                      float& tc, float& td) __attribute__((always_inline)) {
-      unsigned long long m0, m1, m2, m3;
-      asm("v_cmp_ge_u32_e64 %4, %8, %12\n\t"
-          "v_cmp_ge_u32_e64 %5, %9, %13\n\t"
-          "v_cmp_ge_u32_e64 %6, %10, %14\n\t"
-          "v_cmp_ge_u32_e64 %7, %11, %15\n\t"
-          "v_cndmask_b32_e64 %0, 0, %12, %4\n\t"
-          "v_cndmask_b32_e64 %1, 0, %13, %5\n\t"
-          "v_cndmask_b32_e64 %2, 0, %14, %6\n\t"
-          "v_cndmask_b32_e64 %3, 0, %15, %7"
-          : "=&v"(ta), "=&v"(tb), "=&v"(tc), "=&v"(td), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-          : "s"(ma), "s"(mb), "s"(mc), "s"(md), "v"(a), "v"(b), "v"(c), "v"(d));
-    };
-    if constexpr (R == 4) {
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        float t0, t1, t2, t3;
-        select4(mid[0], mid[1], mid[2], mid[3], pv[0][v], pv[1][v], pv[2][v], pv[3][v], t0, t1, t2, t3);
-        g[0] += t0; g[1] += t1; g[2] += t2; g[3] += t3;
-      }
-    } else if constexpr (R == 2 && NV % 2 == 0) {   // two rows x two consecutive values per batch; two accumulators per row
-      float g2[2] = {0.f, 0.f};
-#pragma unroll
-      for (int v = 0; v < NV; v += 2) {
-        float t0, t1, t2, t3;
-        select4(mid[0], mid[1], mid[0], mid[1], pv[0][v], pv[1][v], pv[0][v + 1], pv[1][v + 1], t0, t1, t2, t3);
-        g[0] += t0; g[1] += t1; g2[0] += t2; g2[1] += t3;
-      }
-      g[0] += g2[0]; g[1] += g2[1];
-    } else {
-#pragma unroll
-      for (int v = 0; v < NV; ++v)      // v outer, r inner: R independent add chains side by side
-#pragma unroll
-        for (int r = 0; r < R; ++r) g[r] += __float_as_uint(pv[r][v]) <= mid[r] ? pv[r][v] : 0.f;
+    for (int v = 0; v < NV; v += 4) {
+      unsigned long long sv;
+      asm volatile("s_mov_b64 %1, exec\n\t"
+                   "v_cmpx_ge_u32_e32 %2, %3\n\t"
+                   "v_add_f32_e32 %0, %0, %3\n\t"
+                   "s_mov_b64 exec, %1\n\t"
+                   "v_cmpx_ge_u32_e32 %2, %4\n\t"
+                   "v_add_f32_e32 %0, %0, %4\n\t"
+                   "s_mov_b64 exec, %1\n\t"
+                   "v_cmpx_ge_u32_e32 %2, %5\n\t"
+                   "v_add_f32_e32 %0, %0, %5\n\t"
+                   "s_mov_b64 exec, %1\n\t"
+                   "v_cmpx_ge_u32_e32 %2, %6\n\t"
+                   "v_add_f32_e32 %0, %0, %6\n\t"
+                   "s_mov_b64 exec, %1"
+                   : "+v"(gl), "=&s"(sv)
+                   : "s"(mid), "v"(pv[v]), "v"(pv[v + 1]), "v"(pv[v + 2]), "v"(pv[v + 3])
+                   : "vcc");
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) g[r] = wave_sum_dpp(g[r]);
-    more = false;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (lo[r] < hi[r]) { if (g[r] >= p.target) hi[r] = mid[r]; else lo[r] = mid[r] + 1; }   // wave-uniform selects
-      more = more || lo[r] < hi[r];
-    }
+    const float gsum = wave_sum_dpp(gl);
+    if (gsum >= p.target) hi = mid; else lo = mid + 1;
   }
+  const int i = p.qb0 + il;
+  const unsigned vbits = lo;
+  const float vstar = __uint_as_float(vbits);
+  float base = 0.f;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int il = il0 + r;
-    if (il < p.nqb) {         // wave-uniform (a guard, not a break: the loop must unroll fully or pv[][] goes to scratch)
-    const int i = p.qb0 + il;
-    const unsigned vbits = lo[r];
-    const float vstar = __uint_as_float(vbits);
-    float base = 0.f;
+  for (int v = 0; v < NV; ++v) base += __float_as_uint(pv[v]) < vbits ? pv[v] : 0.f;
+  base = wave_sum_dpp(base);
+  // ties at v*: a stable ascending sort orders them by index; the m-th tie has cumsum base + m*v*
+  int m0 = 1;
+  if (vstar > 0.f) { const float need = (p.target - base) / vstar; m0 = (int)ceilf(need); if (m0 < 1) m0 = 1; }
+  const int hw_blocks = p.Hb * p.Wb;
+  const int ti = i / hw_blocks, hi_ = (i / p.Wb) % p.Hb, wi = i % p.Wb;
+  int tie_seen = 0, kept = 0;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) base += (__float_as_uint(pv[r][v]) < vbits && v * 64 + lane < p.nb) ? pv[r][v] : 0.f;
-    base = wave_sum_dpp(base);
-    // ties at v*: a stable ascending sort orders them by index; the m-th tie has cumsum base + m*v*
-    int m0 = 1;
-    if (vstar > 0.f) { const float need = (p.target - base) / vstar; m0 = (int)ceilf(need); if (m0 < 1) m0 = 1; }
-    // emit bits, 64 kv blocks per word (word c = this lane's value v = c)
-    const int hw_blocks = p.Hb * p.Wb;
-    const int ti = i / hw_blocks, hi_ = (i / p.Wb) % p.Hb, wi = i % p.Wb;
-    int tie_seen = 0, kept = 0;
-#pragma unroll
-    for (int c = 0; c < NV; ++c) {
-      if (c < p.nw) {
+  for (int c = 0; c < NV; ++c) {
+    if (c < p.nw) {
       const int j = c * 64 + lane;
       bool keep = false, tie = false;
-      if (j < p.nb) {
-        const unsigned vb = __float_as_uint(pv[r][c]);
+      if (c + 1 < p.nw || j < p.nb) {                  // only the last word can hold padding
+        const unsigned vb = __float_as_uint(pv[c]);
         tie = vb == vbits;
         keep = vb > vbits;
-        // block coordinates by multiply-high with host-made reciprocals (exact for j < 2^16, divisors <= 2^12): the three runtime
-        // integer divisions per entry were ~60 instructions of this loop's ~90
-        const int tj = hw_blocks == 1 ? j : (int)__umulhi((unsigned)j, p.magic_hw), rj = j - tj * hw_blocks;   // (a divisor of 1 has no 32-bit magic)
+        const int tj = hw_blocks == 1 ? j : (int)__umulhi((unsigned)j, p.magic_hw), rj = j - tj * hw_blocks;
         const int hj = p.Wb == 1 ? rj : (int)__umulhi((unsigned)rj, p.magic_w), wj = rj - hj * p.Wb;
         keep = keep || (abs(ti - tj) <= p.wT / 2 && abs(hi_ - hj) <= p.wH / 2 && abs(wi - wj) <= p.wW / 2);
       }
@@ -285,11 +246,10 @@ __global__ __launch_bounds__(256) void nabla_select_kernel(SelP p) {
       const unsigned long long w = __ballot(keep);
       kept += __popcll(w);
       if (lane == 0) p.bits[((size_t)h * p.nqb + il) * p.nw + c] = w;
-      }
-    }
-    if (lane == 0 && p.kv_nb) p.kv_nb[h * p.nqb + il] = kept;
+      __builtin_amdgcn_sched_barrier(0);   // one word at a time: left free, the scheduler hoists every word's coordinate math and ballots (218 VGPRs, 86 spilled SGPRs at NV = 64)
     }
   }
+  if (lane == 0 && p.kv_nb) p.kv_nb[h * p.nqb + il] = kept;
 }
 
 // per (h, group of 4 query blocks): list[(h*ng+g)*nb + e] = kv_block | membership << 24 ; cnt[h*ng+g].
@@ -380,7 +340,8 @@ size_t k5_nabla_workspace_bytes(int H, int nb) {
          + (size_t)H * nb * nw * 8         // bits
          + (size_t)H * nb * 4              // kv_nb
          + (size_t)H * ((nb + 1) / 2) * nb * 4         // union lists (sized for lists per 2 rows; per 4 rows uses half)
-         + (size_t)2 * H * ((nb + 1) / 2) * 4 + 256;   // counts, counts of the leading local entries (sequence parallelism)
+         + (size_t)2 * H * ((nb + 1) / 2) * 4 + 256    // counts, counts of the leading local entries (sequence parallelism)
+         + (size_t)H * nb * sel_row_nv((int)nw) * 64 * 2;   // bf16 block logits [H][rows][64 NV] (round 3: one matmul per head, read back per row)
 }
 
 // q: [Nq][ldq] bf16 = the query rows handled here (global 64-token blocks [q_block0, q_block0 + Nq/64)), k: [N][ldk] = all
@@ -422,6 +383,7 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   int* list = (int*)ws; ws += (size_t)H * ngmax * nb * 4;
   int* cnt = (int*)ws;
   int* cnt_local = cnt + (size_t)H * ngmax;
+  bf16_t* logits = (bf16_t*)(((uintptr_t)(cnt_local + (size_t)H * ngmax) + 255) & ~(uintptr_t)255);   // 256-B aligned: inside the + 256 slack
   hipLaunchKernelGGL(block_mean_kernel, dim3(nqb), dim3(256), 0, s, (const bf16_t*)q, qa, H, nqb, ldq);
   if (k) hipLaunchKernelGGL(block_mean_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)k, ka, H, nb, ldk);
   SelP p;
@@ -430,21 +392,27 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   p.nqb = nqb; p.qb0 = q_block0;
   p.magic_hw = (unsigned)(((1ull << 32) + (unsigned long long)(Hb * Wb) - 1) / (unsigned long long)(Hb * Wb));
   p.magic_w = (unsigned)(((1ull << 32) + (unsigned long long)Wb - 1) / (unsigned long long)Wb);
-  // values per lane NV = ceil(nb / 64) rounded up to an instantiated size; rows per wave R = 4 (2 for the largest maps: registers)
+  // values per lane NV = ceil(nb / 64) rounded up to an instantiated size
   const int nv = nw;
-  auto launch = [&](auto NVC, auto RC) {
-    constexpr int NV = decltype(NVC)::value, R = decltype(RC)::value;
-    const int bph = (nqb + 4 * R - 1) / (4 * R);
-    hipLaunchKernelGGL((nabla_select_kernel<NV, R>), dim3(H * bph), dim3(256), 0, s, p);
-  };
-  if (nv <= 4) launch(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
-  else if (nv <= 8) launch(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
-  else if (nv <= 16) launch(std::integral_constant<int, 16>{}, std::integral_constant<int, 4>{});
-  else if (nv <= 24) launch(std::integral_constant<int, 24>{}, std::integral_constant<int, 4>{});
-  // (round 2 until late: <32, 2> and <64, 1>; four / two rows per wave share the key-mean loads and take the MFMA path —
-  // 3660 blocks, a 4-GPU shard of the 1280x768 10 s clip: 82.4 -> 60.2 ms of map per step)
-  else if (nv <= 32) launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 4>{});
-  else launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{});
+  {
+    const int ldl = sel_row_nv(nw) * 64, qtiles = (nqb + 15) / 16;
+    const int ysplit = nw >= 16 ? 4 : 1;                      // long rows: four workgroups share a (head, 16-row) strip
+    hipLaunchKernelGGL(nabla_logits_kernel, dim3(H * qtiles, ysplit), dim3(256), 0, s, qa, ka, logits, H, nqb, nb, ldl, qtiles);
+    const int rows_per_head = (nqb + 3) / 4 * 4;
+    auto launch_rows = [&](auto NVC) {
+      constexpr int NV = decltype(NVC)::value;
+      hipLaunchKernelGGL((nabla_select_row_kernel<NV>), dim3(H * rows_per_head / 4), dim3(256), 0, s, p, logits, ldl);
+    };
+    switch (sel_row_nv(nv)) {
+      case 4: launch_rows(std::integral_constant<int, 4>{}); break;
+      case 8: launch_rows(std::integral_constant<int, 8>{}); break;
+      case 16: launch_rows(std::integral_constant<int, 16>{}); break;
+      case 24: launch_rows(std::integral_constant<int, 24>{}); break;
+      case 32: launch_rows(std::integral_constant<int, 32>{}); break;
+      case 48: launch_rows(std::integral_constant<int, 48>{}); break;
+      default: launch_rows(std::integral_constant<int, 64>{}); break;
+    }
+  }
   hipLaunchKernelGGL(nabla_union_kernel, dim3((H * ng + 3) / 4), dim3(256), 0, s, bits, list, cnt, cnt_local, H, nqb, nb, nw, ng, local_block0,
                      local_blocks, group_rows);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;

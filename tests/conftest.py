@@ -14,6 +14,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle on a many-core host: torch's default of one thread per logical CPU (256 on the GPU box) runs the oracle's
+    # medium-size matmuls ~100x slower than 16 threads do (measured, bench.py cpu_baseline) — cap it for every test
+    import torch
+    if torch.get_num_threads() > 32:
+        torch.set_num_threads(32)
 
 
 @pytest.fixture(scope="session")

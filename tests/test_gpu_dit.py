@@ -413,6 +413,7 @@ def test_config2_length_forward_vs_reference_golden():
     x = torch.randn(T, H, W, 16, generator=g)
     text, pooled = torch.randn(L, 3584, generator=g), torch.randn(1, 768, generator=g)
     pos = [torch.arange(T), torch.arange(H // 2), torch.arange(W // 2)]
+    dit.engine("cuda:0")
     dit.attn_variant_counts(reset=True)
     out = dit(x.cuda(), text.cuda(), pooled.cuda(), torch.tensor([meta["time"]]), pos, torch.arange(L), scale_factor=(1.0, 2.0, 2.0))
     torch.cuda.synchronize()

@@ -420,8 +420,7 @@ def full_vae():
     meta = json.load(open(os.path.join(here, "golden", "vae_meta.json")))
     fm = json.load(open(os.path.join(here, "golden", "vae_fullwidth_meta.json")))
     sd = V.synthetic_decoder_state_dict(meta["full_manifest"], fm["weights_seed"])
-    with torch.device("meta"):
-        m = AutoencoderKLHunyuanVideo()
+    m = AutoencoderKLHunyuanVideo()            # decode-only load: the encoder.* / quant_conv.* parameters stay placeholders
     m.load_state_dict(sd, assign=True)
     return m.to("cuda:0"), fm
 
@@ -430,7 +429,7 @@ def _path_counts(m, reset=True):
     import ctypes as C
     from kandinsky import _engine as E
     c = (C.c_longlong * 8)()
-    E.check(E.lib().k5_vae_path_counts(m._handle, c, 1 if reset else 0), "k5_vae_path_counts")
+    E.check(E.lib().k5_vae_path_counts(m._engine(torch.device("cuda:0")), c, 1 if reset else 0), "k5_vae_path_counts")
     return list(c)
 
 
