@@ -38,6 +38,10 @@ WORKLOADS = {
     "10s_hd_nabla": dict(latent=(61, 96, 160), L=256, Lnull=32, w=1.0, attn="nabla",
                          desc="BASELINE config 5's shape: NABLA on the 1280x768 10 s latent (61,96,160,16), 234240 tokens = 3660 blocks, guidance "
                               "1.0 (meant for --emulate-shard 4 / real ranks: one CFG branch of the SP x 4 + CFG x 2 plan)"),
+    "10s_hd_sft": dict(latent=(61, 96, 160), L=256, Lnull=32, w=5.0, attn="nabla",
+                       desc="BASELINE config 5: config_10s_sft.yaml (NABLA P=0.9, wT=11, wH=wW=3, CFG: cond + uncond forward per step, NFE=100) on the "
+                            "1280x768 10 s latent (61,96,160,16), 234240 tokens = 3660 blocks; with --gpus 8 --cfg-parallel: sequence-parallel x 4 inside "
+                            "each CFG branch + the velocity exchange of the pair, all inside k5_sample"),
     "2s_256": dict(latent=(13, 32, 32), L=256, Lnull=32, w=1.0, attn="flash",
                    desc="config_5s_distil.yaml plumbing case: 256x256 2 s latent (13,32,32,16), 3328 tokens"),
 }
@@ -137,6 +141,10 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true", help="skip the separate per-family timing pass")
     ap.add_argument("--sp-slices", type=int, default=1, help="sequence parallelism: exchange K / V^T of a block in this many slices and attend "
                     "each slice as it lands (engine option sp_slices; 1 = one in-place all-gather per block)")
+    ap.add_argument("--cfg-parallel", action="store_true",
+                    help="N even, a workload with guidance (5s_sft, 10s_hd_sft): ranks [0, N/2) run the conditional forward, [N/2, N) the unconditional "
+                         "one, each group sequence-parallel inside; the pair exchange lives in the engine (k5_dit_cfg_pair_init)")
+    ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured step (k5_dit_set_graph; needs --profile-level 0: events cannot be captured)")
     ap.add_argument("--emulate-shard", type=int, default=0, metavar="P",
                     help="debug only (INVALID as a bench): per-rank compute of a P-GPU run on one GPU, collectives move nothing")
     ap.add_argument("--engine-option", action="append", default=[], metavar="NAME=INT",
@@ -183,8 +191,18 @@ def main():
         set_magcache_params(dit, default_configs()[cname]["magcache"]["mag_ratios"], 50, abs(wl["w"] - 1.0) <= 1e-6)
     if args.fp8:
         dit.set_fp8(True)
-    if world > 1 or args.force_sp or args.emulate_shard > 1:
+    sp_world = world
+    if args.cfg_parallel:
+        if world < 2 or world % 2 or abs(wl["w"] - 1.0) <= 1e-6:
+            raise SystemExit("--cfg-parallel needs an even number of ranks and a workload with guidance (5s_sft, 10s_hd_sft)")
+        from kandinsky.models.parallelize import parallelize_dit
+        dit.engine(dev)
+        parallelize_dit(dit, rank, world, device=dev, cfg_parallel=True)
+        sp_world = world // 2
+    elif world > 1 or args.force_sp or args.emulate_shard > 1:
         dit.enable_sequence_parallel(rank, world)
+    if args.graph:
+        dit.set_graph(True)
     if args.emulate_shard > 1:
         dit.set_option("emulate_world", args.emulate_shard)
     if args.sp_slices > 1:
@@ -272,8 +290,8 @@ def main():
         del vae, img, u8
     attn_ms, attn_n = fam["attn_self"]
     fwd_per_step = 2 if abs(wl["w"] - 1.0) > 1e-6 else 1
-    sp_on = world > 1 or args.force_sp or args.emulate_shard > 1
-    shard = world if world > 1 else max(args.emulate_shard, 1)
+    sp_on = sp_world > 1 or args.force_sp or args.emulate_shard > 1
+    shard = sp_world if world > 1 else max(args.emulate_shard, 1)      # token shards of ONE forward (CFG-parallel: half of the ranks each)
     # algorithmic FLOPs of the self-attention on THIS rank, from the launches actually MADE (MagCache skips whole block
     # stacks; under sequence parallelism a block's attention is two timed launches: local chunk, then the gathered chunks):
     #   dense: 4 * N^2 * 64 * 28 / shard per block;  NABLA: that times the kept fraction of 64x64 blocks, counted on the device
@@ -292,7 +310,7 @@ def main():
         variant = "n/a (no data-derived flags on this path)"
     else:
         variant = (f"fixed-offset softmax on {n_fixed} and online-max on {n_online} of {n_fixed + n_online} (block, head) "
-                   f"launches, chosen per head on the device: max|q|*max|k'| <= 180 keeps the fixed form (per-row offsets |q|*max|k'| - 90, "
+                   f"launches, chosen per head on the device: max|q|*max|k'| <= 300 keeps the fixed form (per-row offsets |q|*max|k'| - 90, "
                    f"all zero when the bound is <= 90)")
     traffic, traffic_source = None, None   # HBM-side bytes per attention launch: NOT measured in this run (PMC counters need their own
     for tf in ("r03_attention_traffic.json", "r02_attention_traffic.json"):   # rocprofv3 --pmc passes) but read from the committed profile,
@@ -339,8 +357,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16+fp8ff (REDUCED PRECISION, not the headline)" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": wl["desc"], "tokens": N, "text_len": L, "forwards_per_step": fwd_per_step,
-                       "parallelism": "single GPU" if world == 1 else (f"sequence-parallel x{world} (token shards, K/V all-gather)" if args.sp_slices < 2 else
-                                       f"sequence-parallel x{world} (token shards, K/V exchange in {args.sp_slices} slices)"),
+                       "parallelism": "single GPU" if world == 1 else (
+                           (f"CFG-parallel x2 (cond / uncond rank groups, velocity exchange inside k5_sample) x " if args.cfg_parallel else "") +
+                           (f"sequence-parallel x{sp_world} (token shards, K/V all-gather)" if args.sp_slices < 2 else
+                            f"sequence-parallel x{sp_world} (token shards, K/V exchange in {args.sp_slices} slices)")),
+                       **({"hipgraph_step": True} if args.graph else {}),
                        "visual_blocks": args.blocks, "magcache": bool(args.magcache),
                        **({"emulated_shard": args.emulate_shard} if args.emulate_shard > 1 else {}),
                        **({"sp_slices": args.sp_slices} if args.sp_slices > 1 or args.emulate_shard > 1 else {}),

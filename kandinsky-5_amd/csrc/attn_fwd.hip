@@ -39,8 +39,13 @@ constexpr int KB = 64;    // keys per tile
 constexpr int TILE = 64 * 128;  // bytes of one [64][64] bf16 tile
 
 constexpr float K5_ATTN_EXP_LIMIT = 90.f;   // |exp2 argument| bound of the fixed-offset form: p <= 2^90, l <= 2^107, O <= 2^114
-constexpr float K5_ATTN_ROW_MIN = 8.6736174e-19f;   // 2^-60: a row sum below this (per-row offsets only) sends the head to the online form
-constexpr float K5_ATTN_ROWOFF_LIMIT = 180.f;   // heads whose bound |q|max |k'|max exceeds this go to the online form right away
+// 2^-100: a row sum below this (per-row offsets only) sends the head to the online form.  The sum is then still 26 octaves above the smallest
+// normal fp32 / bf16 (2^-126): what a flush of smaller terms loses is < 2^-26 of the row's largest term (round 2 had 2^-60 — needlessly early)
+constexpr float K5_ATTN_ROW_MIN = 7.8886091e-31f;
+// heads whose bound |q|max |k'|max exceeds this go to the online form right away.  A row on the offset bound - 90 keeps its sum above 2^-100
+// while its largest score lies within 190 of its Cauchy-Schwarz bound: at a bound of 300 that asks for a best key at cos >= 0.37 — random
+// 64-dim directions over >= 10^4 keys reach ~0.5; a row that does not have one sends its head to the online form late (round 2: 180)
+constexpr float K5_ATTN_ROWOFF_LIMIT = 300.f;
 
 struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
@@ -51,6 +56,12 @@ struct AttnP {
   // partition the heads between them.  null = every head.
   const int* sp_begin;   // SPARSE + RANGE, nullable: per workgroup the list position this launch starts from (sp_cnt = where it ends)
   const int* head_flags; int my_flag;
+  // per-JOB fallback of the per-row-offset form (round 3): job = (head, query block of this launch) = the `lid` of the kernel.  A fixed-form
+  // workgroup that sees a row underflow marks ITS job only — 1: the online launch of the same call redoes the job; 2 (multi-pass
+  // schedules): "late", every later launch skips it and the last pass's online launch recomputes it from scratch — instead of sending
+  // the whole head (186 jobs at 47 616 tokens) to the online form because of one row in 47 616.  null: head-level flags as in round 2.
+  // Lives at the end of the balance workspace (k5_attention_balance_bytes), zeroed by the first pass of a schedule.
+  const int* job_flags;
   // fixed-offset form with PER-ROW offsets (pre-scaled keys): kmax[h] = max |k'_h| (with margin) -> query row q of head h runs with
   // the constant offset max(0, |q| kmax[h] - K5_ATTN_EXP_LIMIT): exp2(s - offset) <= 2^90 whatever the data, and exact unless the
   // row's whole sum underflows (l < 2^-60: the row's true maximum lies > 150 below its Cauchy-Schwarz bound) — a workgroup that
@@ -68,8 +79,8 @@ struct AttnP {
   // visual self-attention (pre-scaled keys): with q_cos / q_sin ([row][32] fp32) the same load also applies the rotary embedding
   // (apply_rotary, nn.py:193-197) — the whole norm_qk + RoPE of the QUERIES happens here, once per workgroup, and the pass over the
   // (N, 1792) query projection is gone.  There is then no max|q_h|^2 statistic before the launch, so the head-level choice
-  // "bound <= 180 -> fixed-offset form" is taken by the fixed-offset workgroups themselves: a workgroup with a row whose bound
-  // |q| max|k'| exceeds 180 sets its head's flag to 0 (the online-max launch that follows owns the head) and exits before any work.
+  // "bound <= 300 -> fixed-offset form" is taken by the fixed-offset workgroups themselves: a workgroup with a row whose bound
+  // |q| max|k'| exceeds 300 sets its head's flag to 0 (the online-max launch that follows owns the head) and exits before any work.
   const float* q_cos; const float* q_sin;
   unsigned long long* variant_counters;   // [fixed, online] heads (diagnostics): moved when a head flips
   // sequence-parallel layout of V^T: keys are split in chunks of vt_chunk_keys (multiple of 64) and chunk c
@@ -153,7 +164,8 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   const int h = lid / p.nqb, qb = lid % p.nqb;
   bool late = false;   // online form, last pass, head flagged late: walk ALL key tiles from a fresh state
   if (p.head_flags) {   // workgroup-uniform: the other variant's launch owns this head
-    const int hf = p.head_flags[h];
+    int hf = p.head_flags[h];
+    if (p.job_flags && hf == 1) { const int jf = p.job_flags[lid]; if (jf) hf = jf == 2 ? 2 : 0; }   // this job alone left the fixed form
     if (BOUNDED) { if (hf != 1) return; }
     else {
       if (hf == 1) return;
@@ -555,7 +567,10 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         st_ml[0] = BOUNDED ? 0.f : (fresh ? -1e30f : -nm[qt][0]);   // no tile seen: weight 0 in a merge, "still fresh" on resume
         st_ml[1] = g == 0 ? lt[qt][0] : 0.f;                    // slot 0 carries the whole row sum
         // per-row offsets: a part whose own sum underflows flags the head (conservative: the row's total is at least this part's)
-        if (BOUNDED && PRE && p.kmax && nm[qt][0] < 0.f && lt[qt][0] < K5_ATTN_ROW_MIN && seen) const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
+        if (BOUNDED && PRE && p.kmax && nm[qt][0] < 0.f && lt[qt][0] < K5_ATTN_ROW_MIN && seen) {
+          if (p.job_flags) const_cast<int*>(p.job_flags)[lid] = p.late_pass ? 2 : 1;
+          else const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
+        }
       }
     return;
   }
@@ -566,7 +581,10 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     const float l_tot = lt[qt][0];   // the ones-MFMA left the whole row sum in every lane of the query's column
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int q = q0 + 16 * qt + l15;
-    if (BOUNDED && PRE && p.kmax && q < p.q_len && nm[qt][0] < 0.f && l_tot < K5_ATTN_ROW_MIN) const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
+    if (BOUNDED && PRE && p.kmax && q < p.q_len && nm[qt][0] < 0.f && l_tot < K5_ATTN_ROW_MIN) {
+      if (p.job_flags) const_cast<int*>(p.job_flags)[lid] = p.late_pass ? 2 : 1;
+      else const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
+    }
     if (q < p.q_len) {
       bf16_t* op = p.O + (size_t)q * p.ldo + h * 64 + 4 * g;
 #pragma unroll
@@ -811,9 +829,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd32_kernel(AttnP p) {
 // sum, m is common to the four.
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, const float* split_state, long long split_stride,
                                                          int splits, int job0, int H, int q_len, int nqb, float c, bf16_t* O, int ldo,
-                                                         int bounded_all, const int* head_flags, float* state_out) {
+                                                         int bounded_all, const int* head_flags, float* state_out, const int* job_flags) {
   const int job = job0 + blockIdx.x, h = job / nqb, qb = job % nqb;
-  const bool bounded = head_flags ? head_flags[h] == 1 : bounded_all != 0;   // fixed offset: every part's weight is 1
+  const bool bounded = head_flags ? (head_flags[h] == 1 && !(job_flags && job_flags[job])) : bounded_all != 0;   // fixed offset: every part's weight is 1
   const int q = qb * QB + threadIdx.x;
   if (q >= q_len) return;
   const size_t ml0 = st_ml_off(q, h, 0, nqb, H), ml1 = st_ml_off(q, h, 1, nqb, H), ml2 = st_ml_off(q, h, 2, nqb, H), ml3 = st_ml_off(q, h, 3, nqb, H);
@@ -856,20 +874,35 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
 // (kstat: nk partial maxima at stride kstride — one per sequence-parallel rank after the gather).  Cauchy-Schwarz:
 // every exp2 argument of head h lies in [-B, B], B = |q|max |k'|max; B <= limit -> flag 1 (fixed offset 0), else 0.
 // The statistics are consumed: reset to 0 for the next producer.  counters[0 / 1] count heads sent each way.
+// prefer_online (nullable, [H]): heads that the per-row-offset form served badly the last time this layer ran (attn_pref_update_kernel).
 __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstride, int H, float limit, int force_online,
-                                  int* flags, unsigned long long* counters, float* kmax_out) {
+                                  int* flags, unsigned long long* counters, float* kmax_out, const int* prefer_online) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
   const float q2 = qstat[h];
   float k2 = 0.f;
   for (int i = 0; i < nk; ++i) { const float v = kstat[(size_t)i * kstride + h]; k2 = v == v ? fmaxf(k2, v) : __uint_as_float(0x7f800000u); }
   const float b = sqrtf(q2) * sqrtf(k2) * 1.002f;   // margin: fp32 rounding of the norms and of the MFMA accumulation
-  const int fast = (!force_online && b <= limit) ? 1 : 0;   // NaN / inf compare false -> online
+  const int fast = (!force_online && b <= limit && !(prefer_online && b > K5_ATTN_EXP_LIMIT && prefer_online[h])) ? 1 : 0;   // NaN / inf compare false -> online
   flags[h] = fast;
   if (kmax_out) kmax_out[h] = sqrtf(k2) * 1.002f;   // per-row offsets of the fixed-offset form: |q_row| * this - 90 (AttnP::kmax)
   if (counters) atomicAdd(counters + (fast ? 0 : 1), 1ull);
   qstat[h] = 0.f;
   for (int i = 0; i < nk; ++i) kstat[(size_t)i * kstride + h] = 0.f;
+}
+
+// The Cauchy-Schwarz bound says where exp2 cannot overflow, not where a row's sum survives the offset built from it: data with a large
+// common component (every score of a head near -0.4 bound) underflows row after row however small the bound.  The per-job fallback
+// keeps that correct at the price of computing such jobs twice; this makes it a one-time price: after a layer's attention, a head
+// more than a quarter of whose jobs fell back is remembered, and k5_launch_attn_flags sends it to the online form directly the next
+// time the layer runs (the next sampler step: the statistics of a layer change slowly along the trajectory).  Never reset within a
+// handle's life: a head that lost the fixed form does not get it back (no evidence would ever arrive).
+__global__ void attn_pref_update_kernel(const int* job_flags, int nqb, int H, int* prefer_online) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  int cnt = 0;
+  for (int j = 0; j < nqb; ++j) cnt += job_flags[h * nqb + j] != 0;
+  if (4 * cnt > nqb) prefer_online[h] = 1;
 }
 
 }  // namespace
@@ -886,7 +919,14 @@ size_t k5_attention_state_bytes(int H, int q_len) { return (size_t)H * ((q_len +
 // Workspace of the balanced launcher below: up to K5_ATTN_MAX_SPLITS - 1 extra states + (when the caller passes no state
 // of its own) one base state.
 constexpr int K5_ATTN_MAX_SPLITS = 6;
-size_t k5_attention_balance_bytes(int H, int q_len) { return (size_t)K5_ATTN_MAX_SPLITS * k5_attention_state_bytes(H, q_len); }
+// + the per-job fallback flags of the per-row-offset form (AttnP::job_flags): one int per (head, 128-query group)
+size_t k5_attention_balance_bytes(int H, int q_len) {
+  return (size_t)K5_ATTN_MAX_SPLITS * k5_attention_state_bytes(H, q_len) + (size_t)H * ((q_len + QB / 2 - 1) / (QB / 2) + 1) * sizeof(int);
+}
+namespace {
+inline int* attn_job_flags(float* ws, int H, int q_len) { return reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (size_t)K5_ATTN_MAX_SPLITS * k5_attention_state_bytes(H, q_len)); }
+inline size_t attn_job_flags_bytes(int H, int q_len) { return (size_t)H * ((q_len + QB / 2 - 1) / (QB / 2) + 1) * sizeof(int); }
+}  // namespace
 
 namespace {
 int g_attn_slots = 0;   // concurrently resident attention workgroups on the device: 2 per CU (128 VGPRs x 8 waves)
@@ -900,12 +940,19 @@ int attn_slots() {
 }
 }  // namespace
 
+int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_rows, int* prefer_online, hipStream_t stream) {
+  if (!balance_ws || !prefer_online || H <= 0 || q_len <= 0) return K5_ERR_ARG;
+  const int nqb = group_rows == 2 ? (q_len + QB / 2 - 1) / (QB / 2) : (q_len + QB - 1) / QB;
+  hipLaunchKernelGGL(attn_pref_update_kernel, dim3((H + 63) / 64), dim3(64), 0, stream, attn_job_flags(balance_ws, H, q_len), nqb, H, prefer_online);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
 int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
-                         unsigned long long* counters, hipStream_t stream, float* kmax_out) {
+                         unsigned long long* counters, hipStream_t stream, float* kmax_out, const int* prefer_online) {
   if (!qstat || !kstat || !flags || H <= 0 || nk <= 0) return K5_ERR_ARG;
   // with kmax_out the attention runs per-row offsets: heads up to K5_ATTN_ROWOFF_LIMIT keep the fixed-offset form
   hipLaunchKernelGGL(attn_flags_kernel, dim3((H + 63) / 64), dim3(64), 0, stream, qstat, kstat, nk, kstride, H,
-                     kmax_out ? K5_ATTN_ROWOFF_LIMIT : K5_ATTN_EXP_LIMIT, force_online, flags, counters, kmax_out);
+                     kmax_out ? K5_ATTN_ROWOFF_LIMIT : K5_ATTN_EXP_LIMIT, force_online, flags, counters, kmax_out, kmax_out ? prefer_online : nullptr);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -934,6 +981,11 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.kmax = kmax;
   if (late_pass < 0 || late_pass > 2 || (late_pass && !kmax)) return K5_ERR_ARG;
   p.late_pass = late_pass; p.late_total = (kv_len + KB - 1) / KB;
+  p.job_flags = nullptr;
+  if (kmax && ws) {   // per-row offsets with a workspace: fallback per job; the first pass of a schedule (it does not resume) clears the flags
+    p.job_flags = attn_job_flags(ws, H, q_len);
+    if (!(flags & 1) && hipMemsetAsync(const_cast<int*>(p.job_flags), 0, attn_job_flags_bytes(H, q_len), stream) != hipSuccess) return K5_ERR_HIP;
+  }
   p.q_norm_w = qn ? qn->w : nullptr; p.q_cos = qn ? qn->cos : nullptr; p.q_sin = qn ? qn->sin : nullptr;
   p.variant_counters = qn ? qn->counters : nullptr;
   if (p.q_norm_w) {
@@ -1008,7 +1060,7 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   // merge weights: 1 for the fixed-offset heads, exp2(m_s - max m) for the online ones (exp2 domain when the keys are pre-scaled)
   hipLaunchKernelGGL(attn_merge_kernel, dim3(rem), dim3(256), 0, stream, base, ws + stride, stride, S, full, H, q_len, p.nqb,
                      k_prescaled ? 1.f : p.c, (bf16_t*)O, ldo, (k_prescaled ? (run_fixed && !run_online) : bounded) ? 1 : 0,
-                     (k_prescaled && run_fixed && run_online) ? head_flags : nullptr, to_state ? state : nullptr);
+                     (k_prescaled && run_fixed && run_online) ? head_flags : nullptr, to_state ? state : nullptr, p.job_flags);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -1026,7 +1078,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled,
                                     const int* head_flags, int variant, const float* kmax, const K5SparsePass* pass, float* ws,
-                                    int group_rows) {
+                                    int group_rows, bool balance) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0 || (q_len % KB) || (kv_len % KB) || !list || !cnt) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -1034,13 +1086,18 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   AttnP p;
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
   p.H = H; p.q_len = q_len; p.kv_len = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
-  if (group_rows != 4 && (group_rows != 2 || !k_prescaled || pass || ws)) return K5_ERR_ARG;   // lists of 2 rows: 128-query workgroups
+  if (group_rows != 4 && (group_rows != 2 || !k_prescaled || pass)) return K5_ERR_ARG;   // lists of 2 rows: 128-query workgroups (ws: job flags only)
   const bool half = group_rows == 2;
   p.nqb = half ? (q_len + QB / 2 - 1) / (QB / 2) : (q_len + QB - 1) / QB;
   p.c = 0.125f * 1.44269504088896340736f;
   p.head_flags = nullptr; p.my_flag = 0;
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;
   p.kmax = kmax; p.late_pass = 0; p.late_total = 0; p.q_norm_w = nullptr; p.q_cos = p.q_sin = nullptr; p.variant_counters = nullptr;
+  p.job_flags = nullptr;
+  if (kmax && ws) {
+    p.job_flags = attn_job_flags(ws, H, q_len);
+    if (!(pass && (pass->flags & 1)) && hipMemsetAsync(const_cast<int*>(p.job_flags), 0, attn_job_flags_bytes(H, q_len), stream) != hipSuccess) return K5_ERR_HIP;
+  }
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride; p.sp_begin = nullptr;
   p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;
@@ -1077,7 +1134,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
     int S = rem > 0 ? slots / rem : 1;
     if (S > K5_ATTN_MAX_SPLITS) S = K5_ATTN_MAX_SPLITS;
     static const bool no_balance = getenv("K5_ATTN_NO_BALANCE") != nullptr;   // A/B switch for benchmarking
-    if (!ws || S < 2 || no_balance) {
+    if (!ws || S < 2 || no_balance || half || !balance) {
       launch(jobs, pass != nullptr);
     } else {
       if (full > 0) launch(full, pass != nullptr);
@@ -1091,7 +1148,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
       launch(rem * S, true);
       hipLaunchKernelGGL(attn_merge_kernel, dim3(rem), dim3(256), 0, stream, base, ws + stride, stride, S, full, H, q_len, p.nqb, 1.f,
                          (bf16_t*)O, ldo, (run_fixed && !run_online) ? 1 : 0, (run_fixed && run_online) ? head_flags : nullptr,
-                         to_state ? state : nullptr);
+                         to_state ? state : nullptr, p.job_flags);
     }
   } else if (bounded) {
     hipLaunchKernelGGL((attn_fwd_kernel<true, true, false>), grid, block, 0, stream, p);

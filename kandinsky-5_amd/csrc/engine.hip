@@ -106,6 +106,7 @@ struct AttnW {  // one attention module, packed
   DevBuf wqk, wq, wk, wv, wo;       // bf16
   DevBuf bqk, bq, bk, bv, bo, norm; // fp32 (bias values bf16-rounded); norm = [q_norm | k_norm]
   float score_bound = 0.f;          // |q.k| <= 64 max|w_q| max|w_k| after norm_qk (RoPE preserves norms)
+  mutable DevBuf pref;              // visual self-attention: heads the per-row-offset softmax served badly the last time (k5_launch_attn_pref_update)
 };
 struct BlockW {
   AttnW self_attn, cross_attn;
@@ -295,7 +296,7 @@ struct k5_dit {
   bool nabla_hint_pending = false;
   int sp_nabla_passes = 1;                         // "sp_nabla_passes" = 2: NABLA under sequence parallelism attends the rank's own key blocks during the gather
   int fuse_qnorm = 0;                              // "attn_fuse_qnorm": norm_qk + RoPE of the visual queries inside the attention kernel
-  bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 180)
+  bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 300)
   int sp_slices = 1;                               // "sp_slices": the K / V^T exchange of a block in this many slices (dense attention)
   hipEvent_t ev_slice[4] = {};                     // slice s of every peer has landed
   bool emulated = false;                           // "emulate_world": timing-only layout, results are garbage
@@ -528,7 +529,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   const bool pre = !strcmp(fam_attn, "attn_self") && rows % 64 == 0;   // visual blocks only (not the text blocks)
   const bool by_data = pre && d->attn_mode == K5_ATTN_AUTO;            // per-head flags from the data
   const int* hflags = nullptr;
-  // per-row softmax offsets: heads with a Cauchy-Schwarz bound up to 180 keep the fixed-offset kernel, each query row on its own
+  // per-row softmax offsets: heads with a Cauchy-Schwarz bound up to 300 keep the fixed-offset kernel, each query row on its own
   // constant offset |q| max|k'| - 90
   const float* kmax = nullptr;
   // dense visual blocks: norm_qk + RoPE of the queries happen in the attention kernel's Q load ("attn_fuse_qnorm")
@@ -551,7 +552,9 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
       hflags = d->ws_attn_flags.as<int>();
       float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
       kmax = kmax_w;
-      K5CHK(k5_launch_attn_flags(stats, stats + H, 1, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w));
+      if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
+      K5CHK(k5_launch_attn_flags(stats, stats + H, 1, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w,
+                                 kmax_w ? a.pref.as<int>() : nullptr));
     }
   }
   const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
@@ -572,11 +575,13 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     K5CHK(nabla_density_hint(d, H, nb, nb, s));
     const int *list, *cnt;
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt);
+    K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));   // here only for the per-job fallback flags of the per-row offsets
     Scope sc(d, s, fam_attn);
     // (no tail balancing here: 10 248 jobs are 20 rounds of unequal lists — measured -0.6 % at density 0.81, +1 % at 0.12, +2.4 % at
     // 0.05; a token shard's 5 rounds are another matter, run_self_attention_sp)
     K5CHK(k5_launch_attention_bf16_sparse(qk, pre ? d->ws_kc.as<bf16_t>() : (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, pre ? D : 2 * D,
-                                          ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant, kmax, nullptr, nullptr, grp));
+                                          ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant, kmax, nullptr,
+                                          pre ? d->ws_attn_bal.as<float>() : nullptr, grp, false));
   } else {
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     Scope sc(d, s, fam_attn);
@@ -584,6 +589,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
                                          0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), pre, hflags, variant, nullptr, kmax, 0,
                                          fuse_q ? &qn : nullptr));
   }
+  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, nabla ? (pre ? d->nabla_grp_now : 4) : 4, a.pref.as<int>(), s));
   {
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(o, a.wo.p, a.bo.as<float>(), resid, rows, D, D, D, D, D, K5_EPI_GATE, resid, D, gate, s));
@@ -707,7 +713,9 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     hflags = d->ws_attn_flags.as<int>();
     float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
     kmax = kmax_w;
-    K5CHK(k5_launch_attn_flags(qstat, kstat, P, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w));
+    if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
+    K5CHK(k5_launch_attn_flags(qstat, kstat, P, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w,
+                               kmax_w ? a.pref.as<int>() : nullptr));
   }
   const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
   if (nabla) {
@@ -739,7 +747,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
-                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, nullptr, 2));
+                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, d->ws_attn_bal.as<float>(), 2));
     } else if (d->sp_nabla_passes > 1 && P > 1) {
       // two passes over every list: the rank's own key blocks (they lead the lists; K' / V^T of them are in place) while the other
       // ranks' keys travel — state out —, then the rest once the gather has landed (resume, normalise); late fallback as in the dense
@@ -814,6 +822,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       }
     }
   }
+  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, (nabla && d->nabla_grp_now == 2 && d->sp_nabla_passes == 1) ? 2 : 4, a.pref.as<int>(), s));
   {
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(o, a.wo.p, a.bo.as<float>(), resid, rows, D, D, D, D, D, K5_EPI_GATE, resid, D, gate, s));
@@ -1593,7 +1602,7 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //   "attn_mode"       0 = softmax form per head from the data (fixed offset where |q||k'| <= 90, online max elsewhere),
 //                     1 = online max everywhere (what a checkpoint with large QK-norm gains gets; bench.py --attn-online)
 //   "sp_pass1_tiles"  local key tiles attended before the K/V^T gather has landed (0 = all of the rank's own tiles)
-//   "attn_row_offsets" 1 (default) / 0: fixed-offset softmax with per-row offsets — heads whose bound max|q| max|k'| lies in (90, 180]
+//   "attn_row_offsets" 1 (default) / 0: fixed-offset softmax with per-row offsets — heads whose bound max|q| max|k'| lies in (90, 300]
 //                     stay on the fast kernel (a row whose sum underflows sends its head to the online form late); 0 = the plain <= 90 rule
 //   "attn_fuse_qnorm" 0 (default): norm_qk + RoPE of the visual queries is a standalone pass; 1 = dense visual self-attention on ONE rank
 //                     applies it inside the attention kernel's Q-fragment load (K5QueryNorm; needs attn_row_offsets or attn_mode 1);

@@ -34,7 +34,7 @@ struct K5SparsePass { const int* begin; float* state; int flags; int late_pass; 
 // norm_qk (+ apply_rotary) of the QUERY rows fused into the attention kernel's Q-fragment load: Q then holds the raw projection.
 // w: 64 RMSNorm weights.  cos / sin null: cross-attention (unscaled keys; K5_ERR_UNSUPPORTED unless score_bound selects the fixed-offset
 // kernel).  cos / sin [row][32] fp32: visual self-attention (pre-scaled keys); with row_offset_kmax the fixed-offset workgroups then
-// decide per head themselves (a row bound above 180 flips the head's flag to the online form; counters [fixed, online] follow).
+// decide per head themselves (a row bound above 300 flips the head's flag to the online form; counters [fixed, online] follow).
 struct K5QueryNorm { const float* w; const float* cos; const float* sin; unsigned long long* counters; };
 int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
@@ -50,10 +50,14 @@ enum { K5_ATTN_AUTO = 0, K5_ATTN_ONLINE = 1 };
 // per-head flags from the |q|^2 / |k'|^2 maxima that k5_launch_rmsnorm_rope(stats) left (consumed: reset to 0); kstat holds
 // nk partial maxima at stride kstride floats; counters (optional, device u64[2]) += heads sent to {fixed, online}
 // kmax_out (nullable, H floats): max |k'_h| with margin for the per-row offsets of the fixed-offset form (row_offset_kmax of the
-// attention launchers); with it heads up to a bound of 180 (instead of 90) keep that form — a row whose sum underflows sends its
+// attention launchers); with it heads up to a bound of 300 (instead of 90) keep that form — a row whose sum underflows sends its
 // head to the online form late (the flag is rewritten by the attention kernel)
+// prefer_online (nullable, H ints, with kmax_out only): heads to send to the online form although their bound is within the per-row-offset
+// window — k5_launch_attn_pref_update sets the entry of a head more than a quarter of whose (head, query block) jobs fell back the
+// last time (job flags at the end of the balance workspace that run's attention launches used; group_rows 2: 128-query jobs)
 int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
-                         unsigned long long* counters, hipStream_t stream, float* kmax_out = nullptr);
+                         unsigned long long* counters, hipStream_t stream, float* kmax_out = nullptr, const int* prefer_online = nullptr);
+int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_rows, int* prefer_online, hipStream_t stream);
 
 // ---- fp8 (e4m3) feed-forward path, opt-in (gemm_fp8.hip) ----
 int k5_launch_gemm_fp8(const void* A8, const void* W8, const float* w_scale, void* C, int M, int N, int K, int lda, int ldw, int ldc,
@@ -82,7 +86,8 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled = false,
                                     const int* head_flags = nullptr, int variant = 0, const float* row_offset_kmax = nullptr,
                                     const K5SparsePass* pass = nullptr, float* balance_ws = nullptr,   // k5_attention_balance_bytes; pre-scaled keys
-                                    int group_rows = 4);   // 2: lists per TWO 64-query rows (k5_launch_nabla_select_rect group_rows = 2), 128-query workgroups
+                                    int group_rows = 4,    // 2: lists per TWO 64-query rows (k5_launch_nabla_select_rect group_rows = 2), 128-query workgroups
+                                    bool balance = true);  // false: balance_ws only carries the per-job fallback flags of the per-row-offset form
 
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,

@@ -108,13 +108,13 @@ def test_tiny_forward_P_ranks_on_one_gpu(golden_meta, tiny_sd, P, T, sparse):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("P,W,gain,qfuse", [(2, 32, 1.0, 0), (4, 32, 1.0, 0), (8, 48, 1.0, 0), (4, 32, 3.0, 0),
-                                            (8, 48, 1.0, 2), (4, 32, 3.0, 2), (2, 32, 5.0, 2)])
+                                            (8, 48, 1.0, 2), (4, 32, 3.0, 2), (2, 32, 6.0, 2)])
 def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain, qfuse):
     """2B-Lite width (28 heads, D = 1792), 2 visual blocks, latent (5,16,W): 10 blocks (P=2: 5+5, P=4: 3+3+3+1) or 15 blocks
     (P=8: 7 x 2 + 1).  gain 3 on the QK-norm weights sends every head to the online-max softmax: the per-head flags come from
     the gathered |k'|^2 maxima of ALL ranks, and both attention passes must take the same form.
     qfuse = 2 ("attn_fuse_qnorm"; the single handle then runs with 1): the queries are normalised inside the attention kernel — every
-    pass of the sharded schedule redoes it from the raw projection, and at gain 5 (bound 288) the fixed-offset workgroups of pass 1
+    pass of the sharded schedule redoes it from the raw projection, and at gain 6 (bound 415 > 300) the fixed-offset workgroups of pass 1
     send every head to the online form."""
     from kandinsky.models.dit import DiffusionTransformer3D
     c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
@@ -158,18 +158,18 @@ def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain, qfuse):
         O.PRESCALE_K = False
     print(f"P={P} gain={gain} qfuse={qfuse}: sharded vs fused rel-L2 {rel(outs[0], fused):.3e}; sharded vs oracle {rel(outs[0], ref):.3e}, fused vs oracle {rel(fused, ref):.3e}")
     # larger gains = peakier softmax = more bf16 noise in the oracle itself (tests/test_gpu_dit.py measures it per case)
-    assert rel(outs[0], fused) <= {1.0: 6e-3, 3.0: 1.5e-2, 5.0: 4e-2}[gain], rel(outs[0], fused)
-    assert rel(outs[0], ref) <= {1.0: 1.5e-2, 3.0: 3e-2, 5.0: 8e-2}[gain], rel(outs[0], ref)
+    assert rel(outs[0], fused) <= {1.0: 6e-3, 3.0: 1.5e-2, 6.0: 6e-2}[gain], rel(outs[0], fused)
+    assert rel(outs[0], ref) <= {1.0: 1.5e-2, 3.0: 3e-2, 6.0: 1.2e-1}[gain], rel(outs[0], ref)
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("P,gain,passes,grp", [(2, 1.0, 2, 4), (4, 3.0, 2, 4), (3, 5.0, 2, 4), (4, 3.0, 1, 4), (8, 1.0, 2, 4),
-                                                (4, 3.0, 1, 2), (3, 5.0, 1, 2), (8, 1.0, 1, 2)])
+@pytest.mark.parametrize("P,gain,passes,grp", [(2, 1.0, 2, 4), (4, 3.0, 2, 4), (3, 6.0, 2, 4), (4, 3.0, 1, 4), (8, 1.0, 2, 4),
+                                                (4, 3.0, 1, 2), (3, 6.0, 1, 2), (8, 1.0, 1, 2)])
 def test_full_width_nabla_P_ranks_on_one_gpu(P, gain, passes, grp):
     """NABLA under sequence parallelism at 2B-Lite width (2 visual blocks, latent (8,16,32) -> 16 blocks of 64 tokens): the ranks
     gather the SCALED keys plus the 64-token block means of their unscaled keys (all the map needs), so the sharded path runs the
     same pre-scaled kernels, per-head flags and per-row offsets as one GPU — at gain 3 (bound 104) every head must stay on the
-    fixed-offset form in BOTH paths, at gain 5 (288) every head must take the online form.  Ranks bit-identical; against the
+    fixed-offset form in BOTH paths, at gain 6 (415) every head must take the online form.  Ranks bit-identical; against the
     single-handle run: same map up to threshold ties, same arithmetic up to summation order.
     passes = 2 ("sp_nabla_passes"; default 1): every list is walked in two passes — the rank's own key blocks first (while the
     gather is in flight), the rest after it, with the fp32 state in between; P = 8 on 16 blocks: two blocks per rank, so most
@@ -209,8 +209,8 @@ def test_full_width_nabla_P_ranks_on_one_gpu(P, gain, passes, grp):
         assert (n_online == 0) if gain <= 3.0 else (n_fixed == 0), (gain, n_fixed, n_online)
     print(f"NABLA P={P} gain={gain}: sharded vs single handle rel-L2 {rel(outs[0], fused):.3e}")
     assert torch.isfinite(outs[0].float()).all()
-    # gain 5: logits 25x those of gain 1 — two valid summation orders of a softmax that peaky differ by the oracle's own bf16 noise
-    assert rel(outs[0], fused) <= {1.0: 6e-3, 3.0: 1.5e-2, 5.0: 6e-2}[gain], rel(outs[0], fused)
+    # gain 6: logits 36x those of gain 1 — two valid summation orders of a softmax that peaky differ by the oracle's own bf16 noise
+    assert rel(outs[0], fused) <= {1.0: 6e-3, 3.0: 1.5e-2, 6.0: 9e-2}[gain], rel(outs[0], fused)
 
 
 @pytest.mark.timeout(600)

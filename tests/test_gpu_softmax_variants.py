@@ -260,7 +260,7 @@ def flags_rows(E, qf, kf, H):
 
 @pytest.mark.parametrize("Sq,Sk,H", [(700 - 700 % 64 + 64, 1088, 4), (33280, 2048, 4)])
 def test_row_offsets_keep_large_norm_heads_on_the_fixed_form(E, Sq, Sk, H):
-    """Gains 1, 2, 3, 3.7 on heads 0..3: bounds 11.5 g^2 = 11.5 / 46 / 104 / 158 — all within 180, so k5_attention_flags_rows keeps
+    """Gains 1, 2, 3, 3.7 on heads 0..3: bounds 11.5 g^2 = 11.5 / 46 / 104 / 158 — all within 300, so k5_attention_flags_rows keeps
     every head on the fixed-offset kernel, the last two on non-zero per-row offsets; parity with the oracle, flags untouched
     afterwards (no row underflowed).  (33 280 x 4 heads = 520 jobs: whole rounds AND split tail jobs.)"""
     g = torch.Generator().manual_seed(Sq)
@@ -282,7 +282,7 @@ def test_row_offsets_keep_large_norm_heads_on_the_fixed_form(E, Sq, Sk, H):
 def test_row_offsets_late_fallback_when_a_row_underflows(E):
     """Head 0: every key points AWAY from every query (scores ~ -|q||k'| = -140 with a little noise), so the row maxima sit ~280
     below the Cauchy-Schwarz bound the per-row offset (bound - 90 = 50) was built from: exp2(s - 50) underflows for every key, the
-    workgroups see l < 2^-60, set head_flags[0] = 0, and the online-max launch of the same call recomputes the head.  Head 1 is an
+    workgroups see l < 2^-100, set head_flags[0] = 0, and the online-max launch of the same call recomputes the head.  Head 1 is an
     ordinary gain-3 head (bound 104) that stays on the fixed form.  Both must match the oracle."""
     Sq, Sk, H = 768, 1024, 2
     g = torch.Generator().manual_seed(9)
@@ -297,12 +297,49 @@ def test_row_offsets_late_fallback_when_a_row_underflows(E):
     q, k = bfr(q), bfr(k)
     v = bfr(torch.randn(Sk, H, 64, generator=g))
     flags, kmax = flags_rows(E, q, k, H)
-    assert flags.tolist() == [1, 1], flags                                 # both bounds are <= 180: the fixed form is tried first
+    assert flags.tolist() == [1, 1], flags                                 # both bounds are <= 300: the fixed form is tried first
     s0 = (q[:, 0] @ k[:, 0].t())
     assert s0.max().item() < -100 and (kmax[0].item() * q[:, 0].norm(dim=-1).min().item()) > 130
+    ref = O.sdpa(q, k, v, "bf16", None, base2=True)
+    # with a workspace the fallback is per JOB (round 3): the underflowing (head, 256-query) jobs are redone by the online launch of the
+    # same call and the head's flag is left alone
     out = run_rows(E, q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v), H, flags, kmax)
+    assert flags.tolist() == [1, 1], flags
+    close(out, ref, ulps=4, atol=5e-3, what="late fallback, per job")
+    # without one (no room for job flags): the whole head, as in round 2
+    out = run_rows(E, q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v), H, flags, kmax, balanced=False)
     assert flags.tolist() == [0, 1], flags                                 # head 0 fell back late, head 1 did not
-    close(out, O.sdpa(q, k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="late fallback")
+    close(out, ref, ulps=4, atol=5e-3, what="late fallback, per head")
+
+
+def test_row_offsets_fallback_is_per_job(E):
+    """What the per-job flags are for: ONE query block of a head underflows (its queries point away from every key: scores ~ -140
+    against an offset of +50) while the head's other 129 blocks are ordinary rows on non-zero offsets.  33 280 rows x 4 heads = 520
+    jobs = whole-round jobs and split tail jobs; the bad block sits once in a whole-round job (block 3 of head 1) and once in a tail job
+    (the last block of head 3).  Only those jobs are redone by the online launch — the head flags stay on the fixed form — and every
+    row matches the oracle."""
+    Sq, Sk, H = 33280, 2048, 4
+    g = torch.Generator().manual_seed(33)
+    def rmsn(x, gain):
+        return gain * x / x.pow(2).mean(-1, keepdim=True).sqrt()
+    q = rmsn(torch.randn(Sq, H, 64, generator=g), 3.3)
+    k = rmsn(torch.randn(Sk, H, 64, generator=g), 3.3) * O.SOFTMAX_C
+    for h, blk in ((1, 3), (3, Sq // 256 - 1)):
+        u = k[:, h].mean(0); u = u / u.norm()
+        kk = k[:, h]
+        k[:, h] = kk + (4.0 - kk @ u)[:, None] * u[None, :]                   # every key of the head gets the same component 4 along u ...
+        q[256 * blk:256 * blk + 256, h] = -26.0 * u + 0.3 * torch.randn(256, 64, generator=g)   # ... and the bad block's queries point against it
+    q, k = bfr(q), bfr(k)
+    v = bfr(torch.randn(Sk, H, 64, generator=g))
+    flags, kmax = flags_rows(E, q, k, H)
+    assert flags.tolist() == [1, 1, 1, 1], flags
+    s_bad = q[256 * 3:256 * 3 + 256, 1] @ k[:, 1].t()
+    off_bad = q[256 * 3:256 * 3 + 256, 1].norm(dim=-1) * kmax[1].item() - 90
+    assert (s_bad.max(-1).values < off_bad - 110).all(), (s_bad.max().item(), off_bad.min().item())     # really below 2^-100 after the offset
+    out = run_rows(E, q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v), H, flags, kmax)
+    assert flags.tolist() == [1, 1, 1, 1], flags
+    rows = torch.cat([torch.arange(0, Sq, 1237), torch.arange(256 * 3, 256 * 4, 17), torch.arange(Sq - 256, Sq, 13), torch.arange(Sq - 2048, Sq - 256, 211)])
+    close(out[rows], O.sdpa(q[rows], k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="per-job fallback")
 
 
 @pytest.mark.parametrize("bad_half", ["first", "both"])
@@ -340,9 +377,9 @@ def test_row_offsets_late_fallback_across_passes(E, bad_half):
                                                         state.data_ptr(), fl, late, ws.data_ptr(), E.stream_ptr()), "rows_pass")
         torch.cuda.synchronize()
     run_pass(0, T // 2, 2, 1)
-    assert flags.tolist() == [2, 1], flags            # head 0 went late in pass A
+    assert flags.tolist() == [1, 1], flags            # per-job flags (in the workspace): head 0's jobs went late in pass A, its head flag stays
     run_pass(T // 2, T - T // 2, 1, 2)
-    assert flags.tolist() == [2, 1], flags
+    assert flags.tolist() == [1, 1], flags
     close(out, O.sdpa(q, k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what=f"late fallback across passes ({bad_half})")
 
 
@@ -403,15 +440,15 @@ def kflags(E, k, H):
 
 @pytest.mark.parametrize("Sq,Sk,H", [(768, 1088, 4), (33280, 2048, 4)])
 def test_fused_query_norm_matches_the_standalone_norm(E, Sq, Sk, H):
-    """Heads with key gains 1, 5, 10, 16 (|q| ~ 9-10.5, |k'| = 1.44 gain: bounds ~ 15 / 76 / 150 / 240): the first three stay on the fixed
-    form (the third on non-zero per-row offsets), and the kernel's own decision sends the last one to the online form.  Reference:
-    the attention on the queries the standalone norm kernel wrote (same arithmetic: equal up to the rounding of a few fp32 sums),
-    and the oracle."""
-    qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([1.0, 5.0, 10.0, 16.0]), Sq)
+    """Heads with key gains 1, 5, 10, 24 (|q| ~ 9-10.5, |k'| = 1.44 gain: bounds ~ 15 / 76 / 150 / 360): the first three stay on the fixed
+    form (the third on non-zero per-row offsets), and the kernel's own decision sends the last one (beyond the limit of 300) to the
+    online form.  Reference: the attention on the queries the standalone norm kernel wrote (same arithmetic: equal up to the rounding
+    of a few fp32 sums), and the oracle."""
+    qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([1.0, 5.0, 10.0, 24.0]), Sq)
     qn = normed_queries(E, qraw, w, cos, sin, H)
     qnf = qn.float().cpu().reshape(Sq, H, 64)
     bound = qnf.norm(dim=-1).amax(0) * k.norm(dim=-1).amax(0)
-    assert bound[2] > 95 and bound[2] < 175 and bound[3] > 190 and bound[1] < 88, bound
+    assert bound[2] > 95 and bound[2] < 175 and bound[3] > 310 and bound[1] < 88, bound
     wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()
     kd, vt = k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
     flags, kmax = kflags(E, k, H)
@@ -433,19 +470,19 @@ def test_fused_query_norm_matches_the_standalone_norm(E, Sq, Sk, H):
 
 def test_fused_query_norm_one_large_row_flips_its_head(E):
     """The decision is per HEAD although it is taken per workgroup: w has one large channel and a single query row (in the last
-    256-row block) has its energy in that channel, so only that row's bound exceeds 180 — its wave flips the flag at the end of its
+    256-row block) has its energy in that channel, so only that row's bound exceeds 300 — its wave flips the flag at the end of its
     tile loop, after most other workgroups of the head have already finished in the fixed form; the online launch then recomputes
     the whole head."""
     Sq, Sk, H = 2048, 1024, 2
     qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([7.0, 7.0]), 5)
-    w[7] = 3.0
+    w[7] = 5.0
     qraw[Sq - 3, 0] = 0.01 * qraw[Sq - 3, 0]
-    qraw[Sq - 3, 0, 7] = 30.0                                           # after the norm: ~ 8 * 3 = 24 in channel 7, |q| |k'| ~ 24 * 10 = 240
+    qraw[Sq - 3, 0, 7] = 30.0                                           # after the norm: ~ 8 * 5 = 40 in channel 7, |q| |k'| ~ 40 * 10 = 400
     qraw = bfr(qraw)
     qn = normed_queries(E, qraw, w, cos, sin, H)
     qnf = qn.float().cpu().reshape(Sq, H, 64)
     b = qnf.norm(dim=-1) * k.norm(dim=-1).amax(0)[None]
-    assert (b[:, 0] > 185).sum() == 1 and b[Sq - 3, 0] > 185 and b[:, 1].max() < 175, (b[:, 0].topk(3), b[:, 1].max())
+    assert (b[:, 0] > 290).sum() == 1 and b[Sq - 3, 0] > 310 and b[:, 1].max() < 290, (b[:, 0].topk(3), b[:, 1].max())
     wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()
     kd, vt = k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
     flags, kmax = kflags(E, k, H)
@@ -460,7 +497,7 @@ def test_fused_query_norm_across_passes(E):
     wave underflowed on its over-large offset first, flag 2 (late: recomputed from scratch by the online launch of pass B); both are
     the online form on all keys."""
     Sq, Sk, H = 1024, 2048, 3
-    qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([2.0, 10.0, 16.0]), 77)
+    qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([2.0, 10.0, 24.0]), 77)
     qn = normed_queries(E, qraw, w, cos, sin, H)
     qnf = qn.float().cpu().reshape(Sq, H, 64)
     wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()
@@ -477,19 +514,19 @@ def test_fused_query_norm_flip_from_a_tail_job_across_passes(E):
     """ADVICE r2 (attn_fwd.hip QN flip): 4 heads x 130 query blocks = 520 jobs = one full round of the 512 resident workgroups + 8
     TAIL jobs (head 3, the last 8 query blocks), which the balanced launcher runs after BOTH forms' full-round launches.  Head 3's
     rows sit on non-zero per-row offsets (bound ~ 110) and exactly one row — in the very last query block, i.e. in a tail job — is over
-    the 180 limit: its flip lands after online(full) has skipped the head, while the full jobs of the head left fixed-form state.
+    the limit of 300: its flip lands after online(full) has skipped the head, while the full jobs of the head left fixed-form state.
     The flip must be the LATE flag (2) so that pass B's online launch recomputes the head from scratch instead of resuming that
     state as offset 0."""
     Sq, Sk, H = 33280, 2048, 4
     qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([2.0, 2.0, 2.0, 7.5]), 91)
-    w[7] = 3.0
+    w[7] = 4.5
     qraw[Sq - 3, 3] = 0.01 * qraw[Sq - 3, 3]
     qraw[Sq - 3, 3, 7] = 30.0
     qraw = bfr(qraw)
     qn = normed_queries(E, qraw, w, cos, sin, H)
     qnf = qn.float().cpu().reshape(Sq, H, 64)
     b = qnf.norm(dim=-1) * k.norm(dim=-1).amax(0)[None]
-    assert (b[:, 3] > 185).sum() == 1 and b[Sq - 3, 3] > 185 and b[:, :3].max() < 88 and b[:, 3].median() > 95, (b[:, 3].topk(3), b[:, 3].median())
+    assert (b[:, 3] > 290).sum() == 1 and b[Sq - 3, 3] > 310 and b[:, :3].max() < 88 and b[:, 3].median() > 95, (b[:, 3].topk(3), b[:, 3].median())
     wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()
     kd, vt = k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
     flags, kmax = kflags(E, k, H)
