@@ -30,8 +30,8 @@ typedef enum { K5_F32 = 0, K5_BF16 = 1, K5_F16 = 2 } k5_dtype;
 typedef enum { K5_EPI_BIAS = 0, K5_EPI_BIAS_M = 1, K5_EPI_GELU = 2, K5_EPI_GATE = 3, K5_EPI_F32 = 4 /* internal */ } k5_epilogue;
 
 /* bumped whenever an entry point is added or changes meaning; the host binding checks it BEFORE binding symbols, so that a stale
- * libk5.so fails with a clear message instead of a missing-symbol lookup (round 3: 3) */
-#define K5_ABI_VERSION 3
+ * libk5.so fails with a clear message instead of a missing-symbol lookup (round 3: 4) */
+#define K5_ABI_VERSION 4
 int k5_abi_version(void);
 const char* k5_last_error(void);
 
@@ -105,6 +105,23 @@ int k5_attention_flags_rows(float* qstat, float* kstat, int nk, int kstride, int
                             void* stream);
 int k5_attention_bf16_prescaled_rows(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                      int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, void* workspace, void* stream);
+/* CENTRED per-row offsets (round 3; what the engine's single-GPU path runs).  The plain offset |q| max|k'| - 90 is built from a bound the
+ * scores may sit far below: keys of a head that share a large mean direction put EVERY score of a row near +-0.4 of that bound, and the
+ * row sums underflow wholesale.  With a centre c_h (any convex combination of the head's keys; k5_rmsnorm_rope_centre_bf16 takes the mean
+ * of a strided sample in the pass that writes the keys) and the radius R_h = max |k' - c_h|:  q.k' <= q.c + |q| R  and  max_j q.k'_j >= q.c,
+ * so a row whose plain bound exceeds 90 runs with the offset q.c + |q| R - 90 — exp2 arguments <= 90 and a row sum >= 2^(90 - |q| R): no
+ * underflow at all while |q| R <= 190.  Same softmax (any offset gives the same softmax); rows with a plain bound <= 90 keep offset 0.
+ * k5_rmsnorm_rope_centre_bf16: as k5_rmsnorm_rope_stats_bf16, plus centre [H - scale_from_head][64] out and H - scale_from_head squared radii
+ * appended to stats.  k5_attention_flags_rows_centred: rstat (consumed) -> krad; a head keeps the fixed form while min(|q|max kmax,
+ * |q|max R) <= 300.  k5_attention_bf16_prescaled_rows_centred: k5_attention_bf16_prescaled_rows with the centred offsets. */
+int k5_rmsnorm_rope_centre_bf16(void* x, const float* weight, const float* cos_tab, const float* sin_tab, int rows, int H, int ld,
+                                int heads_per_weight, int rope_heads, float out_scale, int scale_from_head, float* stats, float* centre,
+                                void* stream);
+int k5_attention_flags_rows_centred(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* head_flags, float* kmax,
+                                    float* rstat, float* krad, void* stream);
+int k5_attention_bf16_prescaled_rows_centred(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                             int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, const float* centre,
+                                             const float* krad, void* workspace, void* stream);
 /* One pass of a multi-pass schedule (sequence parallelism: local keys first, gathered keys later) with per-row offsets: key tiles
  * [tile_off0, tile_off0 + tile_cnt), flags & 1 = resume `state`, & 2 = leave it instead of writing O (k5_attention_state_size
  * bytes).  late_pass 1 = not the last pass, 2 = the last: a row that underflows in any pass writes head_flags[h] = 2, every later

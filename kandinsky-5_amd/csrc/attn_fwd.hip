@@ -68,6 +68,13 @@ struct AttnP {
   // sees that on a row with a non-zero offset sets its head's flag to 0 and the online-max launch that follows redoes the head.
   // null = offset 0 for every row (what the flags then have to guarantee: bound <= K5_ATTN_EXP_LIMIT).
   const float* kmax;
+  // CENTRED form of the same bound (round 3; single-GPU path): kcentre[h][64] = a convex combination c_h of the head's keys (sample mean,
+  // key_centre_kernel), krad[h] = max_j |k'_j - c_h| (with margin).  For every key  q.k' = q.c + q.(k' - c) <= q.c + |q| R, and the row's
+  // largest score is >= q.c (the centred keys' projections on q average to ~0, so their maximum is >= 0).  A row whose plain bound
+  // |q| kmax exceeds 90 therefore runs with the offset q.c + |q| R - 90 (any sign): exp2 arguments <= 90, and the row sum is >= 2^(90 - |q| R)
+  // — no underflow at all while |q| R <= 190, whatever common component the scores carry (keys sharing a large mean direction put every
+  // score of a head near +-0.4 of its plain bound: with the plain offset such rows underflow wholesale).  null: plain offsets.
+  const float* kcentre; const float* krad;
   // multi-pass schedules (sequence parallelism) with per-row offsets: 0 = single launch group (an underflowing row writes flag 0 and
   // the online launch of the same call redoes the head), 1 = a pass that is not the last (the row writes flag 2 = "late": every
   // later fixed-offset launch skips the head, the online launches of non-final passes skip it too), 2 = the last pass (the online
@@ -355,9 +362,19 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   bool over_limit = false;
   if (BOUNDED && PRE && p.kmax) {   // per-row constant offsets from |q_row| * max|k'| (see AttnP::kmax); 0 when the bound is <= 90
     const float km = p.kmax[h];
+    const bool centred = p.kcentre != nullptr;   // kernel-uniform
+    const float kr = centred ? p.krad[h] : 0.f;
+    f32x4 cc[2][2];   // the centre's entries at this lane's 16 query dimensions (32 ks + 8 g .. + 8)
+    if (centred) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        cc[ks][0] = *reinterpret_cast<const f32x4*>(p.kcentre + h * 64 + 32 * ks + 8 * g);
+        cc[ks][1] = *reinterpret_cast<const f32x4*>(p.kcentre + h * 64 + 32 * ks + 8 * g + 4);
+      }
+    }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float ss = 0.f;
+      float ss = 0.f, tc = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const u32x4 w = __builtin_bit_cast(u32x4, qf[qt][ks]);
@@ -365,6 +382,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         for (int j = 0; j < 4; ++j) {
           const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
           ss = fmaf(lo, lo, fmaf(hi, hi, ss));
+          if (centred) tc = fmaf(lo, cc[ks][j >> 1][2 * (j & 1)], fmaf(hi, cc[ks][j >> 1][2 * (j & 1) + 1], tc));
         }
       }
       {   // the query's four lanes (l15 + 16 g) hold 16 of its 64 dimensions each
@@ -373,8 +391,19 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
         ss = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
       }
-      const float bnd = sqrtf(ss) * km;
-      const float off = fmaxf(bnd - K5_ATTN_EXP_LIMIT, 0.f);
+      if (centred) {
+        const auto t16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tc), __float_as_uint(tc), false, false);
+        tc = __uint_as_float(t16[0]) + __uint_as_float(t16[1]);
+        const auto t32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tc), __float_as_uint(tc), false, false);
+        tc = __uint_as_float(t32[0]) + __uint_as_float(t32[1]);
+      }
+      const float nq = sqrtf(ss);
+      float bnd = nq * km;                                        // plain Cauchy-Schwarz bound: <= 90 -> offset 0, as without any of this
+      float off = fmaxf(bnd - K5_ATTN_EXP_LIMIT, 0.f);
+      if (centred && bnd > K5_ATTN_EXP_LIMIT) {
+        bnd = nq * kr;                                            // what the row sum's survival depends on now
+        off = tc * 1.0f + bnd * 1.002f + 0.5f - K5_ATTN_EXP_LIMIT;  // margins: fp32 rounding of q.c and of the MFMA accumulation
+      }
       nm[qt] = f32x4{-off, -off, -off, -off};
       if (QN) over_limit |= (q0 + 16 * qt + l15 < p.q_len) && !(bnd <= K5_ATTN_ROWOFF_LIMIT);   // NaN counts as over
     }
@@ -567,7 +596,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         st_ml[0] = BOUNDED ? 0.f : (fresh ? -1e30f : -nm[qt][0]);   // no tile seen: weight 0 in a merge, "still fresh" on resume
         st_ml[1] = g == 0 ? lt[qt][0] : 0.f;                    // slot 0 carries the whole row sum
         // per-row offsets: a part whose own sum underflows flags the head (conservative: the row's total is at least this part's)
-        if (BOUNDED && PRE && p.kmax && nm[qt][0] < 0.f && lt[qt][0] < K5_ATTN_ROW_MIN && seen) {
+        if (BOUNDED && PRE && p.kmax && nm[qt][0] != 0.f && lt[qt][0] < K5_ATTN_ROW_MIN && seen) {
           if (p.job_flags) const_cast<int*>(p.job_flags)[lid] = p.late_pass ? 2 : 1;
           else const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
         }
@@ -581,7 +610,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     const float l_tot = lt[qt][0];   // the ones-MFMA left the whole row sum in every lane of the query's column
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int q = q0 + 16 * qt + l15;
-    if (BOUNDED && PRE && p.kmax && q < p.q_len && nm[qt][0] < 0.f && l_tot < K5_ATTN_ROW_MIN) {
+    if (BOUNDED && PRE && p.kmax && q < p.q_len && nm[qt][0] != 0.f && l_tot < K5_ATTN_ROW_MIN) {
       if (p.job_flags) const_cast<int*>(p.job_flags)[lid] = p.late_pass ? 2 : 1;
       else const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
     }
@@ -875,14 +904,23 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
 // every exp2 argument of head h lies in [-B, B], B = |q|max |k'|max; B <= limit -> flag 1 (fixed offset 0), else 0.
 // The statistics are consumed: reset to 0 for the next producer.  counters[0 / 1] count heads sent each way.
 // prefer_online (nullable, [H]): heads that the per-row-offset form served badly the last time this layer ran (attn_pref_update_kernel).
+// rstat / krad_out (nullable, [H]): squared radii of the keys around their centres (k5_launch_rmsnorm_rope key_centre) in, radii with margin
+// out; the head-level bound is then the smaller of |q|max kmax and |q|max R (the centred offsets' survival depends on the latter).
 __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstride, int H, float limit, int force_online,
-                                  int* flags, unsigned long long* counters, float* kmax_out, const int* prefer_online) {
+                                  int* flags, unsigned long long* counters, float* kmax_out, const int* prefer_online, float* rstat, float* krad_out) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
   const float q2 = qstat[h];
   float k2 = 0.f;
   for (int i = 0; i < nk; ++i) { const float v = kstat[(size_t)i * kstride + h]; k2 = v == v ? fmaxf(k2, v) : __uint_as_float(0x7f800000u); }
-  const float b = sqrtf(q2) * sqrtf(k2) * 1.002f;   // margin: fp32 rounding of the norms and of the MFMA accumulation
+  float b = sqrtf(q2) * sqrtf(k2) * 1.002f;   // margin: fp32 rounding of the norms and of the MFMA accumulation
+  if (rstat && krad_out) {
+    const float r2 = rstat[h];
+    const float rr = r2 == r2 ? sqrtf(r2) * 1.002f : __uint_as_float(0x7f800000u);
+    krad_out[h] = rr;
+    if (b > K5_ATTN_EXP_LIMIT) b = fminf(b, sqrtf(q2) * rr * 1.002f);   // NaN-safe: fminf keeps the finite operand only when b is finite too
+    rstat[h] = 0.f;
+  }
   const int fast = (!force_online && b <= limit && !(prefer_online && b > K5_ATTN_EXP_LIMIT && prefer_online[h])) ? 1 : 0;   // NaN / inf compare false -> online
   flags[h] = fast;
   if (kmax_out) kmax_out[h] = sqrtf(k2) * 1.002f;   // per-row offsets of the fixed-offset form: |q_row| * this - 90 (AttnP::kmax)
@@ -948,11 +986,13 @@ int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_ro
 }
 
 int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
-                         unsigned long long* counters, hipStream_t stream, float* kmax_out, const int* prefer_online) {
+                         unsigned long long* counters, hipStream_t stream, float* kmax_out, const int* prefer_online, float* rstat, float* krad_out) {
+  if ((rstat == nullptr) != (krad_out == nullptr) || (rstat && !kmax_out)) return K5_ERR_ARG;
   if (!qstat || !kstat || !flags || H <= 0 || nk <= 0) return K5_ERR_ARG;
   // with kmax_out the attention runs per-row offsets: heads up to K5_ATTN_ROWOFF_LIMIT keep the fixed-offset form
   hipLaunchKernelGGL(attn_flags_kernel, dim3((H + 63) / 64), dim3(64), 0, stream, qstat, kstat, nk, kstride, H,
-                     kmax_out ? K5_ATTN_ROWOFF_LIMIT : K5_ATTN_EXP_LIMIT, force_online, flags, counters, kmax_out, kmax_out ? prefer_online : nullptr);
+                     kmax_out ? K5_ATTN_ROWOFF_LIMIT : K5_ATTN_EXP_LIMIT, force_online, flags, counters, kmax_out, kmax_out ? prefer_online : nullptr,
+                     rstat, krad_out);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -967,7 +1007,7 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* ws, bool k_prescaled,
                                    const int* head_flags, int variant, const K5TileSegments* seg, const float* kmax, int late_pass,
-                                   const K5QueryNorm* qn) {
+                                   const K5QueryNorm* qn, const K5KeyCentre* kc) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -979,6 +1019,8 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   p.head_flags = nullptr; p.my_flag = 0;
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;   // per-row offsets need the per-head flags (late fallback)
   p.kmax = kmax;
+  p.kcentre = (kc && kmax) ? kc->centre : nullptr; p.krad = (kc && kmax) ? kc->radius : nullptr;
+  if ((p.kcentre == nullptr) != (p.krad == nullptr)) return K5_ERR_ARG;
   if (late_pass < 0 || late_pass > 2 || (late_pass && !kmax)) return K5_ERR_ARG;
   p.late_pass = late_pass; p.late_total = (kv_len + KB - 1) / KB;
   p.job_flags = nullptr;
@@ -1078,7 +1120,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled,
                                     const int* head_flags, int variant, const float* kmax, const K5SparsePass* pass, float* ws,
-                                    int group_rows, bool balance) {
+                                    int group_rows, bool balance, const K5KeyCentre* kc) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0 || (q_len % KB) || (kv_len % KB) || !list || !cnt) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
@@ -1093,6 +1135,8 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   p.head_flags = nullptr; p.my_flag = 0;
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;
   p.kmax = kmax; p.late_pass = 0; p.late_total = 0; p.q_norm_w = nullptr; p.q_cos = p.q_sin = nullptr; p.variant_counters = nullptr;
+  p.kcentre = (kc && kmax) ? kc->centre : nullptr; p.krad = (kc && kmax) ? kc->radius : nullptr;
+  if ((p.kcentre == nullptr) != (p.krad == nullptr)) return K5_ERR_ARG;
   p.job_flags = nullptr;
   if (kmax && ws) {
     p.job_flags = attn_job_flags(ws, H, q_len);

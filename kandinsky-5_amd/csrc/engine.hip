@@ -490,8 +490,8 @@ int ensure_zeroed(DevBuf& b, size_t n, hipStream_t s) {
 }
 // statistics / flags / counters of the data-derived softmax bound; layout of ws_attn_stats: [q: Hh][k: sp_world x Hh]
 int ensure_attn_flags(k5_dit* d, hipStream_t s) {
-  K5CHK(ensure_zeroed(d->ws_attn_stats, (size_t)d->Hh * (1 + d->sp_world) * 4, s));
-  K5CHK(d->ws_attn_flags.ensure((size_t)d->Hh * 8));   // int flags[H] | float kmax[H] (per-row offsets of the fixed-offset form)
+  K5CHK(ensure_zeroed(d->ws_attn_stats, (size_t)d->Hh * (2 + d->sp_world) * 4, s));   // + [r: Hh] squared key radii (one GPU: centred offsets)
+  K5CHK(d->ws_attn_flags.ensure((size_t)d->Hh * (3 + 64) * 4));   // int flags[H] | float kmax[H] | krad[H] | centre[H][64] (per-row offsets of the fixed-offset form)
   K5CHK(d->ws_attn_part.ensure(k5_rmsnorm_stats_workspace_bytes(2 * d->Hh)));
   K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
   return K5_OK;
@@ -532,6 +532,8 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   // per-row softmax offsets: heads with a Cauchy-Schwarz bound up to 300 keep the fixed-offset kernel, each query row on its own
   // constant offset |q| max|k'| - 90
   const float* kmax = nullptr;
+  K5KeyCentre kcen{nullptr, nullptr};
+  const K5KeyCentre* kcp = nullptr;
   // dense visual blocks: norm_qk + RoPE of the queries happen in the attention kernel's Q load ("attn_fuse_qnorm")
   const bool fuse_q = pre && !nabla && d->fuse_qnorm && ((by_data && d->row_offsets) || d->attn_mode == K5_ATTN_ONLINE);
   if (by_data) K5CHK(ensure_attn_flags(d, s));   // before the counters' address is taken
@@ -542,19 +544,23 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     void* kc = nullptr;   // NABLA: the block map needs the unscaled keys -> the scaled copy goes to its own buffer
     if (pre && nabla) { K5CHK(d->ws_kc.ensure((size_t)rows * D * 2)); kc = d->ws_kc.p; }
     float* stats = nullptr;
-    if (by_data) stats = d->ws_attn_stats.as<float>();   // [q heads | k' heads] = the call's 2H heads
+    if (by_data) stats = d->ws_attn_stats.as<float>();   // [q heads | k' heads] = the call's 2H heads (| squared key radii with the centred offsets)
+    // centred per-row offsets (K5KeyCentre): the keys' sample-mean centre and their radius around it come out of the same pass
+    float* centre = (by_data && d->row_offsets) ? d->ws_attn_flags.as<float>() + 3 * H : nullptr;
     if (fuse_q)   // keys only; the query statistic stays 0 (the fixed-offset workgroups take the head-level decision, K5QueryNorm)
       K5CHK(k5_launch_rmsnorm_rope((bf16_t*)qk + D, a.norm.as<float>() + 64, cosT, sinT, rows, H, 2 * D, nullptr, s, K5_SOFTMAX_C, 0, nullptr, 0,
-                                   stats ? stats + H : nullptr, d->ws_attn_part.as<float>()));
+                                   stats ? stats + H : nullptr, d->ws_attn_part.as<float>(), centre));
     else
-      K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D, stats, d->ws_attn_part.as<float>()));
+      K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D, stats, d->ws_attn_part.as<float>(),
+                                   pre ? centre : nullptr));
     if (by_data) {
       hflags = d->ws_attn_flags.as<int>();
       float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
       kmax = kmax_w;
       if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
       K5CHK(k5_launch_attn_flags(stats, stats + H, 1, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w,
-                                 kmax_w ? a.pref.as<int>() : nullptr));
+                                 kmax_w ? a.pref.as<int>() : nullptr, centre ? stats + 2 * H : nullptr, centre ? kmax_w + H : nullptr));
+      if (centre) { kcen.centre = centre; kcen.radius = kmax_w + H; kcp = &kcen; }
     }
   }
   const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
@@ -581,13 +587,13 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     // 0.05; a token shard's 5 rounds are another matter, run_self_attention_sp)
     K5CHK(k5_launch_attention_bf16_sparse(qk, pre ? d->ws_kc.as<bf16_t>() : (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, pre ? D : 2 * D,
                                           ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant, kmax, nullptr,
-                                          pre ? d->ws_attn_bal.as<float>() : nullptr, grp, false));
+                                          pre ? d->ws_attn_bal.as<float>() : nullptr, grp, false, kcp));
   } else {
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     Scope sc(d, s, fam_attn);
     K5CHK(k5_launch_attention_bf16_range(qk, (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, 2 * D, ldvt, D, pre ? 0.f : a.score_bound, 0, 0, 0, -1,
                                          0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), pre, hflags, variant, nullptr, kmax, 0,
-                                         fuse_q ? &qn : nullptr));
+                                         fuse_q ? &qn : nullptr, kcp));
   }
   if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, nabla ? (pre ? d->nabla_grp_now : 4) : 4, a.pref.as<int>(), s));
   {

@@ -83,6 +83,22 @@ int k5_attention_flags_rows(float* qstat, float* kstat, int nk, int kstride, int
   if (!kmax) return ret(K5_ERR_ARG, "k5_attention_flags_rows");
   return ret(k5_launch_attn_flags(qstat, kstat, nk, kstride, H, force_online, flags, nullptr, (hipStream_t)stream, kmax), "k5_attention_flags_rows");
 }
+// centred per-row offsets (K5KeyCentre): rstat = squared radii of the keys around `centre` (consumed), krad out
+int k5_attention_flags_rows_centred(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags, float* kmax, float* rstat,
+                                    float* krad, void* stream) {
+  if (!kmax || !rstat || !krad) return ret(K5_ERR_ARG, "k5_attention_flags_rows_centred");
+  return ret(k5_launch_attn_flags(qstat, kstat, nk, kstride, H, force_online, flags, nullptr, (hipStream_t)stream, kmax, nullptr, rstat, krad),
+             "k5_attention_flags_rows_centred");
+}
+int k5_attention_bf16_prescaled_rows_centred(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                             int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, const float* centre, const float* krad,
+                                             void* workspace, void* stream) {
+  if (!head_flags || !kmax || !centre || !krad) return ret(K5_ERR_ARG, "k5_attention_bf16_prescaled_rows_centred");
+  const K5KeyCentre kc{centre, krad};
+  return ret(k5_launch_attention_bf16_range(Q, Kc, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, 0.f, 0, 0, 0, -1, 0x7fffffff, 0,
+                                            nullptr, 0, (hipStream_t)stream, (float*)workspace, true, head_flags, K5_ATTN_AUTO, nullptr, kmax, 0, nullptr, &kc),
+             "k5_attention_bf16_prescaled_rows_centred");
+}
 int k5_attention_bf16_prescaled_rows(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                      int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, void* workspace, void* stream) {
   if (!head_flags || !kmax) return ret(K5_ERR_ARG, "k5_attention_bf16_prescaled_rows");
@@ -222,6 +238,23 @@ int k5_rmsnorm_rope_stats_bf16(void* x, const float* weight, const float* cos_ta
   }
   return ret(k5_launch_rmsnorm_rope(x, weight, cos_tab, sin_tab, rows, H, ld, hc, (hipStream_t)stream, out_scale, scale_from_head,
                                     nullptr, 0, stats, ws), "k5_rmsnorm_rope_stats_bf16");
+}
+
+// the same with the centred statistics: centre [H - scale_from_head][64] out, stats = H squared norms then H - scale_from_head squared radii
+int k5_rmsnorm_rope_centre_bf16(void* x, const float* weight, const float* cos_tab, const float* sin_tab, int rows, int H, int ld,
+                                int heads_per_weight, int rope_heads, float out_scale, int scale_from_head, float* stats, float* centre, void* stream) {
+  if (!stats || !centre || scale_from_head < 0 || scale_from_head >= H) return ret(K5_ERR_ARG, "k5_rmsnorm_rope_centre_bf16");
+  const int32_t hc[2] = {heads_per_weight, rope_heads};
+  static float* ws = nullptr; static size_t ws_bytes = 0;
+  const size_t need = k5_rmsnorm_stats_workspace_bytes(H);
+  if (need > ws_bytes) {
+    if (ws) (void)hipFree(ws);
+    ws = nullptr; ws_bytes = 0;
+    if (hipMalloc((void**)&ws, need) != hipSuccess) return ret(K5_ERR_HIP, "k5_rmsnorm_rope_centre_bf16");
+    ws_bytes = need;
+  }
+  return ret(k5_launch_rmsnorm_rope(x, weight, cos_tab, sin_tab, rows, H, ld, hc, (hipStream_t)stream, out_scale, scale_from_head,
+                                    nullptr, 0, stats, ws, centre), "k5_rmsnorm_rope_centre_bf16");
 }
 
 int k5_gate_sum_bf16(const void* x, const void* y, const float* gate, void* out, int rows, int D, void* stream) {

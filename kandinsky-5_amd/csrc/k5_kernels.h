@@ -36,13 +36,18 @@ struct K5SparsePass { const int* begin; float* state; int flags; int late_pass; 
 // kernel).  cos / sin [row][32] fp32: visual self-attention (pre-scaled keys); with row_offset_kmax the fixed-offset workgroups then
 // decide per head themselves (a row bound above 300 flips the head's flag to the online form; counters [fixed, online] follow).
 struct K5QueryNorm { const float* w; const float* cos; const float* sin; unsigned long long* counters; };
+// Centred form of the per-row offsets (AttnP::kcentre): centre [H][64] = a convex combination of each head's keys (k5_launch_rmsnorm_rope
+// key_centre), radius [H] = max |k' - centre| with margin (k5_launch_attn_flags krad_out).  Rows whose plain bound |q| kmax exceeds 90 run
+// with the offset q.c + |q| R - 90: no overflow, and no row-sum underflow while |q| R <= 190 whatever common component the scores carry.
+struct K5KeyCentre { const float* centre; const float* radius; };
 int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
                                    int tile_skip_n, float* state, int flags, hipStream_t stream, float* balance_ws = nullptr, bool k_prescaled = false,
                                    const int* head_flags = nullptr, int variant = 0, const K5TileSegments* segments = nullptr,
                                    const float* row_offset_kmax = nullptr, int late_pass = 0,   // late_pass: AttnP::late_pass (multi-pass + per-row offsets)
-                                   const K5QueryNorm* query_norm = nullptr);   // fused norm_qk (+ RoPE) of the query rows, see K5QueryNorm
+                                   const K5QueryNorm* query_norm = nullptr,   // fused norm_qk (+ RoPE) of the query rows, see K5QueryNorm
+                                   const K5KeyCentre* key_centre = nullptr);   // centred per-row offsets (with row_offset_kmax), see K5KeyCentre
 size_t k5_attention_balance_bytes(int H, int q_len);
 // softmax form of the pre-scaled-key launches: AUTO = fixed offset where the bound (score_bound, or the per-head device
 // flags) allows it and the lazy online max elsewhere; ONLINE = the online max everywhere
@@ -56,7 +61,8 @@ enum { K5_ATTN_AUTO = 0, K5_ATTN_ONLINE = 1 };
 // window — k5_launch_attn_pref_update sets the entry of a head more than a quarter of whose (head, query block) jobs fell back the
 // last time (job flags at the end of the balance workspace that run's attention launches used; group_rows 2: 128-query jobs)
 int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
-                         unsigned long long* counters, hipStream_t stream, float* kmax_out = nullptr, const int* prefer_online = nullptr);
+                         unsigned long long* counters, hipStream_t stream, float* kmax_out = nullptr, const int* prefer_online = nullptr,
+                         float* rstat = nullptr, float* krad_out = nullptr);   // squared radii in (consumed) / radii with margin out: K5KeyCentre::radius
 int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_rows, int* prefer_online, hipStream_t stream);
 
 // ---- fp8 (e4m3) feed-forward path, opt-in (gemm_fp8.hip) ----
@@ -87,7 +93,8 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
                                     const int* head_flags = nullptr, int variant = 0, const float* row_offset_kmax = nullptr,
                                     const K5SparsePass* pass = nullptr, float* balance_ws = nullptr,   // k5_attention_balance_bytes; pre-scaled keys
                                     int group_rows = 4,    // 2: lists per TWO 64-query rows (k5_launch_nabla_select_rect group_rows = 2), 128-query workgroups
-                                    bool balance = true);  // false: balance_ws only carries the per-job fallback flags of the per-row-offset form
+                                    bool balance = true,   // false: balance_ws only carries the per-job fallback flags of the per-row-offset form
+                                    const K5KeyCentre* key_centre = nullptr);
 
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,
@@ -98,7 +105,8 @@ int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift,
 int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cos, const float* sin, int rows,
                            int H, int ld, const int32_t* heads_cfg, hipStream_t stream,
                            float out_scale = 1.f, int scale_from_head = 0x7fffffff, void* scaled_out = nullptr, int ld_scaled = 0,
-                           float* stats = nullptr, float* stats_ws = nullptr);
+                           float* stats = nullptr, float* stats_ws = nullptr,
+                           float* key_centre = nullptr);   // OUT [H - scale_from_head][64]: sample-mean key per scaled head; stats then also gets H - scale_from_head squared radii |k' - c|^2
 size_t k5_rmsnorm_stats_workspace_bytes(int H);   // stats_ws: scratch of this size whenever stats is given
 // heads >= scale_from_head are multiplied by out_scale before the bf16 rounding — in place, or (scaled_out != null) into
 // scaled_out[row][(head - scale_from_head) * 64 ...] while the unscaled values stay in place.

@@ -87,8 +87,10 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
                                                            const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                            int rows, int H, int heads_per_weight, int ld, int rope_heads,
                                                            float out_scale, int scale_from_head, bf16_t* __restrict__ scaled_out,
-                                                           int ld_scaled, float* __restrict__ stats) {
-  __shared__ unsigned int smax[256];   // stats: per-head maxima of this block (H <= 256 heads per row)
+                                                           int ld_scaled, float* __restrict__ stats, const float* __restrict__ centre) {
+  // stats: per-head maxima of this block: |x_h|^2 for the H heads of a row, then (centre given) |k'_h - c_h|^2 for the scaled heads —
+  // the radius of a head's keys around the centre key_centre_kernel estimated; H + (H - scale_from_head) <= 256 entries
+  __shared__ unsigned int smax[256];
   if (stats) { smax[threadIdx.x] = 0u; __syncthreads(); }
   const int64_t total = (int64_t)rows * H * 8;
   const int64_t stride = (int64_t)gridDim.x * 256;        // multiple of H * 8 (launcher)
@@ -101,7 +103,13 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
   for (int j = 0; j < 8; ++j) wv[j] = w[j];
   const bool rope = cosT && head < rope_heads;
   const bool scaled = head >= scale_from_head;
-  float n2max = 0.f;
+  float n2max = 0.f, r2max = 0.f;
+  float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool centred = stats && centre && scaled;
+  if (centred) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cv[j] = centre[(head - scale_from_head) * 64 + 8 * c + j];
+  }
   // every lane of a wave runs the same number of iterations except in the last one (shuffles need the whole 8-lane group:
   // groups never straddle the end because total is a multiple of 8)
   for (int64_t g = g0; g < total; g += stride) {
@@ -148,25 +156,96 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
     *reinterpret_cast<u32x4*>(px) = pk;
     if (stats) {   // |x|^2 of the bf16 values the softmax will consume (the scaled copy where there is one)
       const u32x4 src = (scaled && scaled_out) ? pks : pk;
-      float n2 = 0.f;
+      float n2 = 0.f, r2 = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float lo = __uint_as_float(src[j] << 16), hi = __uint_as_float(src[j] & 0xffff0000u);
         n2 += lo * lo + hi * hi;
+        if (centred) { const float dl = lo - cv[2 * j], dh = hi - cv[2 * j + 1]; r2 += dl * dl + dh * dh; }
       }
       n2 += __shfl_xor(n2, 1, 64);   // the head vector's 8 lanes
       n2 += __shfl_xor(n2, 2, 64);
       n2 += __shfl_xor(n2, 4, 64);
       n2max = n2 == n2 ? fmaxf(n2max, n2) : __uint_as_float(0x7f800000u);   // NaN -> +inf: forces the online-max path
+      if (centred) {
+        r2 += __shfl_xor(r2, 1, 64);
+        r2 += __shfl_xor(r2, 2, 64);
+        r2 += __shfl_xor(r2, 4, 64);
+        r2max = r2 == r2 ? fmaxf(r2max, r2) : __uint_as_float(0x7f800000u);
+      }
     }
   }
   // per-head max over the rows of this call: |q.k'| <= |q| |k'| then bounds every exp2 argument of the head
   // (attn_flags_kernel).  Non-negative floats order like their bit patterns.  No global atomics (a hundred thousand of them on
   // 28 addresses cost more than the kernel): LDS max per block, one partial row per block, reduced by stats_reduce_kernel.
   if (stats) {
-    if (c == 0 && g0 < total) atomicMax(&smax[head], __float_as_uint(n2max));
+    const int Hs = centre ? H + (H - scale_from_head) : H;
+    if (c == 0 && g0 < total) {
+      atomicMax(&smax[head], __float_as_uint(n2max));
+      if (centred) atomicMax(&smax[H + head - scale_from_head], __float_as_uint(r2max));
+    }
     __syncthreads();
-    if ((int)threadIdx.x < H) stats[(size_t)blockIdx.x * H + threadIdx.x] = __uint_as_float(smax[threadIdx.x]);
+    if ((int)threadIdx.x < Hs) stats[(size_t)blockIdx.x * Hs + threadIdx.x] = __uint_as_float(smax[threadIdx.x]);
+  }
+}
+
+// Centre of a head's keys for the centred Cauchy-Schwarz bound of the attention's per-row softmax offsets (attn_fwd.hip, AttnP::kcentre):
+// c_h = mean of k'_j over a strided SAMPLE of the rows — any vector is a valid centre for the upper bound q.k' <= q.c + |q| max|k' - c|, and
+// a convex combination of actual keys also gives the lower bound max_j q.k'_j >= q.c that rules the row-sum underflow out.  Runs BEFORE
+// rmsnorm_rope_kernel on the raw projection, with that kernel's arithmetic (RMSNorm, weight, bf16, RoPE, scale, bf16), so that the main
+// kernel can take max|k' - c|^2 in its one pass.  One block per key head: thread = (sample lane t >> 3, 16-B chunk t & 7); fixed-order sums.
+__global__ __launch_bounds__(256) void key_centre_kernel(const bf16_t* __restrict__ x, const float* __restrict__ weight,
+                                                         const float* __restrict__ cosT, const float* __restrict__ sinT, int rows, int ld,
+                                                         int head0, int heads_per_weight, int rope_heads, float out_scale, int nsample,
+                                                         float* __restrict__ centre) {
+  __shared__ float part[32][64];
+  const int hk = blockIdx.x, head = head0 + hk, c = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const float* w = weight + (head / heads_per_weight) * 64 + 8 * c;
+  float wv[8], acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { wv[j] = w[j]; acc[j] = 0.f; }
+  const bool rope = cosT && head < rope_heads;
+  const int niter = (nsample + 31) / 32;
+  for (int it = 0; it < niter; ++it) {
+    const int i = it * 32 + sl;
+    const bool live = i < nsample;
+    const int row = (int)(((long long)(live ? i : 0) * rows) / nsample);
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)row * ld + head * 64 + 8 * c);
+    float v[8], sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[2 * j] = __uint_as_float(raw[j] << 16);
+      v[2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u);
+      sq += v[2 * j] * v[2 * j] + v[2 * j + 1] * v[2 * j + 1];
+    }
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    sq += __shfl_xor(sq, 4, 64);
+    const float rs = rsqrtf(sq * (1.0f / 64.0f) + 1.1920928955078125e-07f);
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = bf_round(__fmul_rn(__fmul_rn(v[j], rs), wv[j]));
+    if (rope) {
+      const f32x4 cs = *reinterpret_cast<const f32x4*>(cosT + (size_t)row * 32 + 4 * c);
+      const f32x4 sn = *reinterpret_cast<const f32x4*>(sinT + (size_t)row * 32 + 4 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x0 = y[2 * j], x1 = y[2 * j + 1];
+        y[2 * j] = __fadd_rn(__fmul_rn(cs[j], x0), __fmul_rn(-sn[j], x1));
+        y[2 * j + 1] = __fadd_rn(__fmul_rn(sn[j], x0), __fmul_rn(cs[j], x1));
+      }
+    }
+    if (live)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += bf_round(__fmul_rn(y[j], out_scale));
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[sl][8 * c + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+    for (int l = 0; l < 32; ++l) s += part[l][threadIdx.x];
+    centre[hk * 64 + threadIdx.x] = s / (float)nsample;
   }
 }
 
@@ -355,11 +434,11 @@ int k5_launch_ln_affine(const void* x, const float* w, const float* b, void* out
   return done();
 }
 
-size_t k5_rmsnorm_stats_workspace_bytes(int H) { return (size_t)4096 * H * sizeof(float); }
+size_t k5_rmsnorm_stats_workspace_bytes(int H) { return (size_t)4096 * 2 * H * sizeof(float); }   // partial rows of up to 2 H entries (norms + radii)
 
 int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, const float* sinT, int rows, int H,
                            int ld, const int32_t* heads_cfg, hipStream_t s, float out_scale, int scale_from_head, void* scaled_out,
-                           int ld_scaled, float* stats, float* stats_ws) {
+                           int ld_scaled, float* stats, float* stats_ws, float* key_centre) {
   // heads_cfg (host pointer, optional): {heads_per_weight, rope_heads}; default: one weight, rope on all heads
   if (rows <= 0 || H <= 0) return K5_ERR_ARG;
   if (ld & 7) return K5_ERR_ALIGN;
@@ -376,9 +455,18 @@ int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, cons
   int64_t blocks = (total + 255) / 256;
   if (blocks > cap) blocks = cap;
   blocks = (blocks + unit - 1) / unit * unit;           // <= cap: cap is a multiple of unit
+  // key_centre (nullable, with stats and scaled heads only): [H - scale_from_head][64] floats OUT = the centres of the scaled (key) heads;
+  // stats then has H + (H - scale_from_head) entries: the squared norms, then the squared radii around the centres
+  const bool centred = key_centre && stats && scale_from_head < H;
+  if (centred)
+    hipLaunchKernelGGL(key_centre_kernel, dim3(H - scale_from_head), dim3(256), 0, s, (const bf16_t*)x, weight, cosT, sinT, rows, ld, scale_from_head, hpw,
+                       rope_heads, out_scale, rows < 1024 ? rows : 1024, key_centre);
+  const int Hs = centred ? H + (H - scale_from_head) : H;
+  if (Hs > 256) return K5_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)x, weight,
-                     cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled, stats ? stats_ws : nullptr);
-  if (stats) hipLaunchKernelGGL(stats_reduce_kernel, dim3(blocks >= 2048 ? 64 : (blocks >= 512 ? 16 : 1)), dim3(256), 0, s, stats_ws, (int)blocks, H, stats);
+                     cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled, stats ? stats_ws : nullptr,
+                     centred ? key_centre : nullptr);
+  if (stats) hipLaunchKernelGGL(stats_reduce_kernel, dim3(blocks >= 2048 ? 64 : (blocks >= 512 ? 16 : 1)), dim3(256), 0, s, stats_ws, (int)blocks, Hs, stats);
   return done();
 }
 
