@@ -96,7 +96,7 @@ int k5_attention_bf16_prescaled(const void* Q, const void* Kc, const void* Vt, v
  * everywhere.  workspace: NULL or k5_attention_balance_size bytes (balanced launch). */
 int k5_attention_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* head_flags, void* stream);
 /* The same pair with PER-ROW softmax offsets (what the engine's single-GPU path runs): k5_attention_flags_rows also writes
- * kmax[h] = max |k'_h| and keeps heads up to |q|max |k'|max <= 300 on the fixed-offset form; there query row q of head h runs on
+ * kmax[h] = max |k'_h| and keeps heads up to |q|max |k'|max <= 190 on the fixed-offset form; there query row q of head h runs on
  * the constant offset max(0, |q| kmax[h] - 90) — exp2 cannot overflow whatever the data, and the result is exact unless the row's
  * whole sum underflows (< 2^-60: its largest score lies more than 150 below its Cauchy-Schwarz bound).  A workgroup that meets
  * such a row sets head_flags[h] = 0 and the online-max launch that follows in the same call redoes that head: head_flags is
@@ -113,7 +113,7 @@ int k5_attention_bf16_prescaled_rows(const void* Q, const void* Kc, const void* 
  * underflow at all while |q| R <= 190.  Same softmax (any offset gives the same softmax); rows with a plain bound <= 90 keep offset 0.
  * k5_rmsnorm_rope_centre_bf16: as k5_rmsnorm_rope_stats_bf16, plus centre [H - scale_from_head][64] out and H - scale_from_head squared radii
  * appended to stats.  k5_attention_flags_rows_centred: rstat (consumed) -> krad; a head keeps the fixed form while min(|q|max kmax,
- * |q|max R) <= 300.  k5_attention_bf16_prescaled_rows_centred: k5_attention_bf16_prescaled_rows with the centred offsets. */
+ * |q|max R) <= 190.  k5_attention_bf16_prescaled_rows_centred: k5_attention_bf16_prescaled_rows with the centred offsets. */
 int k5_rmsnorm_rope_centre_bf16(void* x, const float* weight, const float* cos_tab, const float* sin_tab, int rows, int H, int ld,
                                 int heads_per_weight, int rope_heads, float out_scale, int scale_from_head, float* stats, float* centre,
                                 void* stream);
@@ -133,7 +133,7 @@ int k5_attention_bf16_prescaled_rows_pass(const void* Q, const void* Kc, const v
 /* The same pass with the reference's norm_qk + apply_rotary of the QUERIES (nn.py:193-197, 239-243) done inside the kernel's Q load:
  * Q holds the raw query projection, q_norm_w the 64 RMSNorm weights, q_cos / q_sin [q_len][32] fp32 the rotary table
  * (k5_rope_table).  There is no max|q|^2 statistic then: call k5_attention_flags_rows with a zero query statistic (every head
- * starts on the fixed form) and the fixed-offset workgroups decide per head — a row whose bound |q| max|k'| exceeds 300 sets
+ * starts on the fixed form) and the fixed-offset workgroups decide per head — a row whose bound |q| max|k'| exceeds 190 sets
  * head_flags[h] = 0 and the online launch of the same call owns the head.  head_flags and kmax both null: online max everywhere.
  * tile_cnt -1 = all key tiles from tile_off0 (single pass: state null, flags 0, late_pass 0). */
 int k5_attention_bf16_prescaled_qnorm_pass(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,

@@ -42,10 +42,13 @@ constexpr float K5_ATTN_EXP_LIMIT = 90.f;   // |exp2 argument| bound of the fixe
 // 2^-100: a row sum below this (per-row offsets only) sends the head to the online form.  The sum is then still 26 octaves above the smallest
 // normal fp32 / bf16 (2^-126): what a flush of smaller terms loses is < 2^-26 of the row's largest term (round 2 had 2^-60 — needlessly early)
 constexpr float K5_ATTN_ROW_MIN = 7.8886091e-31f;
-// heads whose bound |q|max |k'|max exceeds this go to the online form right away.  A row on the offset bound - 90 keeps its sum above 2^-100
-// while its largest score lies within 190 of its Cauchy-Schwarz bound: at a bound of 300 that asks for a best key at cos >= 0.37 — random
-// 64-dim directions over >= 10^4 keys reach ~0.5; a row that does not have one sends its head to the online form late (round 2: 180)
-constexpr float K5_ATTN_ROWOFF_LIMIT = 300.f;
+// heads whose bound exceeds this go to the online form right away.  With the centred offsets (AttnP::kcentre) the bound is |q|max R and
+// 190 is where the guarantee ends: a row's sum is >= 2^(90 - |q| R) >= 2^-100, so a fixed-form head NEVER falls back.  With the plain
+// offsets (sequence-parallel path) the bound is |q|max kmax and the number is empirical (round 2: 180): rows keep their sum while their
+// best score lies within 190 of the bound; the per-job fallback below catches the rest.  Measured on data whose scores carry a large
+// common component (bench.py --qk-gain 5): gambling on bounds up to 300 computed most jobs twice (947 ms per step against 688 for the
+// online form everywhere), the centred bound below 190 never does (gain 4: 553 ms, all heads fixed; plain offsets: 583-613).
+constexpr float K5_ATTN_ROWOFF_LIMIT = 190.f;
 
 struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
@@ -86,8 +89,8 @@ struct AttnP {
   // visual self-attention (pre-scaled keys): with q_cos / q_sin ([row][32] fp32) the same load also applies the rotary embedding
   // (apply_rotary, nn.py:193-197) — the whole norm_qk + RoPE of the QUERIES happens here, once per workgroup, and the pass over the
   // (N, 1792) query projection is gone.  There is then no max|q_h|^2 statistic before the launch, so the head-level choice
-  // "bound <= 300 -> fixed-offset form" is taken by the fixed-offset workgroups themselves: a workgroup with a row whose bound
-  // |q| max|k'| exceeds 300 sets its head's flag to 0 (the online-max launch that follows owns the head) and exits before any work.
+  // "bound <= 190 -> fixed-offset form" is taken by the fixed-offset workgroups themselves: a workgroup with a row whose bound
+  // |q| max|k'| exceeds 190 sets its head's flag to 0 (the online-max launch that follows owns the head) and exits before any work.
   const float* q_cos; const float* q_sin;
   unsigned long long* variant_counters;   // [fixed, online] heads (diagnostics): moved when a head flips
   // sequence-parallel layout of V^T: keys are split in chunks of vt_chunk_keys (multiple of 64) and chunk c
@@ -402,8 +405,12 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
       float off = fmaxf(bnd - K5_ATTN_EXP_LIMIT, 0.f);
       if (centred && bnd > K5_ATTN_EXP_LIMIT) {
         bnd = nq * kr;                                            // what the row sum's survival depends on now
-        off = tc * 1.0f + bnd * 1.002f + 0.5f - K5_ATTN_EXP_LIMIT;  // margins: fp32 rounding of q.c and of the MFMA accumulation
+        off = tc + bnd * 1.002f + 0.5f - K5_ATTN_EXP_LIMIT;       // margins: fp32 rounding of q.c and of the MFMA accumulation
       }
+      // an INTEGER offset: exp2(s - off) then differs between any two offset policies by an exact power of two, so the bf16 rounding of
+      // every probability — and with it the whole result — is the same whichever policy chose the offset (0, plain, centred; one GPU or
+      // the sequence-parallel schedule), as long as nothing under- or overflows
+      off = ceilf(off);
       nm[qt] = f32x4{-off, -off, -off, -off};
       if (QN) over_limit |= (q0 + 16 * qt + l15 < p.q_len) && !(bnd <= K5_ATTN_ROWOFF_LIMIT);   // NaN counts as over
     }

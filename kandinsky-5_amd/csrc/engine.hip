@@ -296,7 +296,7 @@ struct k5_dit {
   bool nabla_hint_pending = false;
   int sp_nabla_passes = 1;                         // "sp_nabla_passes" = 2: NABLA under sequence parallelism attends the rank's own key blocks during the gather
   int fuse_qnorm = 0;                              // "attn_fuse_qnorm": norm_qk + RoPE of the visual queries inside the attention kernel
-  bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 300)
+  bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 190)
   int sp_slices = 1;                               // "sp_slices": the K / V^T exchange of a block in this many slices (dense attention)
   hipEvent_t ev_slice[4] = {};                     // slice s of every peer has landed
   bool emulated = false;                           // "emulate_world": timing-only layout, results are garbage
@@ -529,7 +529,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   const bool pre = !strcmp(fam_attn, "attn_self") && rows % 64 == 0;   // visual blocks only (not the text blocks)
   const bool by_data = pre && d->attn_mode == K5_ATTN_AUTO;            // per-head flags from the data
   const int* hflags = nullptr;
-  // per-row softmax offsets: heads with a Cauchy-Schwarz bound up to 300 keep the fixed-offset kernel, each query row on its own
+  // per-row softmax offsets: heads with a Cauchy-Schwarz bound up to 190 keep the fixed-offset kernel, each query row on its own
   // constant offset |q| max|k'| - 90
   const float* kmax = nullptr;
   K5KeyCentre kcen{nullptr, nullptr};
@@ -1608,7 +1608,7 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //   "attn_mode"       0 = softmax form per head from the data (fixed offset where |q||k'| <= 90, online max elsewhere),
 //                     1 = online max everywhere (what a checkpoint with large QK-norm gains gets; bench.py --attn-online)
 //   "sp_pass1_tiles"  local key tiles attended before the K/V^T gather has landed (0 = all of the rank's own tiles)
-//   "attn_row_offsets" 1 (default) / 0: fixed-offset softmax with per-row offsets — heads whose bound max|q| max|k'| lies in (90, 300]
+//   "attn_row_offsets" 1 (default) / 0: fixed-offset softmax with per-row offsets — heads whose bound max|q| max|k'| lies in (90, 190]
 //                     stay on the fast kernel (a row whose sum underflows sends its head to the online form late); 0 = the plain <= 90 rule
 //   "attn_fuse_qnorm" 0 (default): norm_qk + RoPE of the visual queries is a standalone pass; 1 = dense visual self-attention on ONE rank
 //                     applies it inside the attention kernel's Q-fragment load (K5QueryNorm; needs attn_row_offsets or attn_mode 1);

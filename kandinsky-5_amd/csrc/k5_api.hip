@@ -77,7 +77,7 @@ int k5_attention_flags(float* qstat, float* kstat, int nk, int kstride, int H, i
   return ret(k5_launch_attn_flags(qstat, kstat, nk, kstride, H, force_online, flags, nullptr, (hipStream_t)stream), "k5_attention_flags");
 }
 
-// the same two with per-row offsets: k5_attention_flags_rows also writes kmax[H] and keeps heads up to a bound of 300 on the fixed
+// the same two with per-row offsets: k5_attention_flags_rows also writes kmax[H] and keeps heads up to a bound of 190 on the fixed
 // form; k5_attention_bf16_prescaled_rows runs them with it (head_flags is read AND, on a late fallback, written)
 int k5_attention_flags_rows(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags, float* kmax, void* stream) {
   if (!kmax) return ret(K5_ERR_ARG, "k5_attention_flags_rows");
@@ -120,7 +120,7 @@ int k5_attention_bf16_prescaled_rows_pass(const void* Q, const void* Kc, const v
 
 // the same pass with norm_qk + apply_rotary of the QUERIES fused into the kernel's Q load (K5QueryNorm): Q holds the raw projection.
 // head_flags + kmax (k5_attention_flags_rows with a ZERO query statistic: every head starts on the fixed form) -> the fixed-offset
-// workgroups decide per head (a row bound above 300 flips the flag to 0); both null -> online max everywhere.
+// workgroups decide per head (a row bound above 190 flips the flag to 0); both null -> online max everywhere.
 int k5_attention_bf16_prescaled_qnorm_pass(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                            int ldk, int ldvt, int ldo, const float* q_norm_w, const float* q_cos, const float* q_sin,
                                            int* head_flags, const float* kmax, int tile_off0, int tile_cnt, float* state, int flags,

@@ -34,7 +34,7 @@ struct K5SparsePass { const int* begin; float* state; int flags; int late_pass; 
 // norm_qk (+ apply_rotary) of the QUERY rows fused into the attention kernel's Q-fragment load: Q then holds the raw projection.
 // w: 64 RMSNorm weights.  cos / sin null: cross-attention (unscaled keys; K5_ERR_UNSUPPORTED unless score_bound selects the fixed-offset
 // kernel).  cos / sin [row][32] fp32: visual self-attention (pre-scaled keys); with row_offset_kmax the fixed-offset workgroups then
-// decide per head themselves (a row bound above 300 flips the head's flag to the online form; counters [fixed, online] follow).
+// decide per head themselves (a row bound above 190 flips the head's flag to the online form; counters [fixed, online] follow).
 struct K5QueryNorm { const float* w; const float* cos; const float* sin; unsigned long long* counters; };
 // Centred form of the per-row offsets (AttnP::kcentre): centre [H][64] = a convex combination of each head's keys (k5_launch_rmsnorm_rope
 // key_centre), radius [H] = max |k' - centre| with margin (k5_launch_attn_flags krad_out).  Rows whose plain bound |q| kmax exceeds 90 run
@@ -55,7 +55,7 @@ enum { K5_ATTN_AUTO = 0, K5_ATTN_ONLINE = 1 };
 // per-head flags from the |q|^2 / |k'|^2 maxima that k5_launch_rmsnorm_rope(stats) left (consumed: reset to 0); kstat holds
 // nk partial maxima at stride kstride floats; counters (optional, device u64[2]) += heads sent to {fixed, online}
 // kmax_out (nullable, H floats): max |k'_h| with margin for the per-row offsets of the fixed-offset form (row_offset_kmax of the
-// attention launchers); with it heads up to a bound of 300 (instead of 90) keep that form — a row whose sum underflows sends its
+// attention launchers); with it heads up to a bound of 190 (instead of 90) keep that form — a row whose sum underflows sends its
 // head to the online form late (the flag is rewritten by the attention kernel)
 // prefer_online (nullable, H ints, with kmax_out only): heads to send to the online form although their bound is within the per-row-offset
 // window — k5_launch_attn_pref_update sets the entry of a head more than a quarter of whose (head, query block) jobs fell back the

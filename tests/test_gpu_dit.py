@@ -207,9 +207,8 @@ def _qk_gain_sd(cfg, case):
                                                            ("ch8", "any", 1, 1), ("x3", "fixed", 1, 1), ("x6", "online", 1, 1)])
 def test_full_width_qk_norm_gains_vs_oracle(case, expect, row_offsets, qfuse):
     """The engine on QK-norm gains a trained checkpoint could have: N(1, 0.5), every gain 2 (|q||k'| = 64 * 4 * 0.18 = 46),
-    every gain 3 (104: outside the offset-0 window of 90, inside the per-row-offset one of 300 — fixed form with the engine's
-    default, online max with "attn_row_offsets" = 0), every gain 5 (288: inside the window, but on 320 keys a row's best score need not
-    lie within 190 of its bound — heads may fall back late: either form), every gain 6 (415: online max), one channel at 8 (the bound depends on how
+    every gain 3 (104: outside the offset-0 window of 90, inside the per-row-offset one of 190 — fixed form with the engine's
+    default, online max with "attn_row_offsets" = 0), every gain 5 (288: fixed where the keys' radius around their centre keeps |q| R within 190, online elsewhere: either form), every gain 6 (415: online max), one channel at 8 (the bound depends on how
     much of a row's energy sits in that channel: heads fall on either side).  The softmax form is chosen per head ON THE
     DEVICE from the data; the test states which one must have run and demands oracle parity either way (round 1 derived the
     bound from max|w| and never left the fixed-offset branch in any engine-level test).

@@ -114,7 +114,7 @@ def test_full_width_forward_P_ranks_on_one_gpu(P, W, gain, qfuse):
     (P=8: 7 x 2 + 1).  gain 3 on the QK-norm weights sends every head to the online-max softmax: the per-head flags come from
     the gathered |k'|^2 maxima of ALL ranks, and both attention passes must take the same form.
     qfuse = 2 ("attn_fuse_qnorm"; the single handle then runs with 1): the queries are normalised inside the attention kernel — every
-    pass of the sharded schedule redoes it from the raw projection, and at gain 6 (bound 415 > 300) the fixed-offset workgroups of pass 1
+    pass of the sharded schedule redoes it from the raw projection, and at gain 6 (bound 415 > 190) the fixed-offset workgroups of pass 1
     send every head to the online form."""
     from kandinsky.models.dit import DiffusionTransformer3D
     c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)

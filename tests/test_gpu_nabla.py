@@ -377,7 +377,7 @@ def test_two_pass_list_walk_on_prescaled_keys(E, case):
 def test_lists_per_two_rows_give_the_same_bits(gain):
     """"nabla_group_rows" = 2: key-tile lists per TWO 64-query rows and 128-query attention workgroups instead of four / 256.  A
     64-query row attends its own kept blocks in ascending order either way (the other rows' blocks of the shared list are skipped),
-    so the result must be BIT-identical to the default — at gain 1 (offset 0), gain 3 (per-row offsets) and gain 6 (bound 415 > 300: online form)."""
+    so the result must be BIT-identical to the default — at gain 1 (offset 0), gain 3 (per-row offsets) and gain 6 (bound 415 > 190: online form)."""
     from kandinsky.models.dit import DiffusionTransformer3D
     c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
     sd = O.synthetic_state_dict(O.DitConfig(**c), seed=3)

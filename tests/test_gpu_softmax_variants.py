@@ -260,7 +260,7 @@ def flags_rows(E, qf, kf, H):
 
 @pytest.mark.parametrize("Sq,Sk,H", [(700 - 700 % 64 + 64, 1088, 4), (33280, 2048, 4)])
 def test_row_offsets_keep_large_norm_heads_on_the_fixed_form(E, Sq, Sk, H):
-    """Gains 1, 2, 3, 3.7 on heads 0..3: bounds 11.5 g^2 = 11.5 / 46 / 104 / 158 — all within 300, so k5_attention_flags_rows keeps
+    """Gains 1, 2, 3, 3.7 on heads 0..3: bounds 11.5 g^2 = 11.5 / 46 / 104 / 158 — all within 190, so k5_attention_flags_rows keeps
     every head on the fixed-offset kernel, the last two on non-zero per-row offsets; parity with the oracle, flags untouched
     afterwards (no row underflowed).  (33 280 x 4 heads = 520 jobs: whole rounds AND split tail jobs.)"""
     g = torch.Generator().manual_seed(Sq)
@@ -297,7 +297,7 @@ def test_row_offsets_late_fallback_when_a_row_underflows(E):
     q, k = bfr(q), bfr(k)
     v = bfr(torch.randn(Sk, H, 64, generator=g))
     flags, kmax = flags_rows(E, q, k, H)
-    assert flags.tolist() == [1, 1], flags                                 # both bounds are <= 300: the fixed form is tried first
+    assert flags.tolist() == [1, 1], flags                                 # both bounds are <= 190: the fixed form is tried first
     s0 = (q[:, 0] @ k[:, 0].t())
     assert s0.max().item() < -100 and (kmax[0].item() * q[:, 0].norm(dim=-1).min().item()) > 130
     ref = O.sdpa(q, k, v, "bf16", None, base2=True)
@@ -441,7 +441,7 @@ def kflags(E, k, H):
 @pytest.mark.parametrize("Sq,Sk,H", [(768, 1088, 4), (33280, 2048, 4)])
 def test_fused_query_norm_matches_the_standalone_norm(E, Sq, Sk, H):
     """Heads with key gains 1, 5, 10, 24 (|q| ~ 9-10.5, |k'| = 1.44 gain: bounds ~ 15 / 76 / 150 / 360): the first three stay on the fixed
-    form (the third on non-zero per-row offsets), and the kernel's own decision sends the last one (beyond the limit of 300) to the
+    form (the third on non-zero per-row offsets), and the kernel's own decision sends the last one (beyond the limit of 190) to the
     online form.  Reference: the attention on the queries the standalone norm kernel wrote (same arithmetic: equal up to the rounding
     of a few fp32 sums), and the oracle."""
     qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([1.0, 5.0, 10.0, 24.0]), Sq)
@@ -470,19 +470,19 @@ def test_fused_query_norm_matches_the_standalone_norm(E, Sq, Sk, H):
 
 def test_fused_query_norm_one_large_row_flips_its_head(E):
     """The decision is per HEAD although it is taken per workgroup: w has one large channel and a single query row (in the last
-    256-row block) has its energy in that channel, so only that row's bound exceeds 300 — its wave flips the flag at the end of its
+    256-row block) has its energy in that channel, so only that row's bound exceeds 190 — its wave flips the flag at the end of its
     tile loop, after most other workgroups of the head have already finished in the fixed form; the online launch then recomputes
     the whole head."""
     Sq, Sk, H = 2048, 1024, 2
     qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([7.0, 7.0]), 5)
-    w[7] = 5.0
+    w[7] = 3.0
     qraw[Sq - 3, 0] = 0.01 * qraw[Sq - 3, 0]
-    qraw[Sq - 3, 0, 7] = 30.0                                           # after the norm: ~ 8 * 5 = 40 in channel 7, |q| |k'| ~ 40 * 10 = 400
+    qraw[Sq - 3, 0, 7] = 30.0                                           # after the norm: ~ 8 * 3 = 24 in channel 7, |q| |k'| ~ 24 * 10 = 240
     qraw = bfr(qraw)
     qn = normed_queries(E, qraw, w, cos, sin, H)
     qnf = qn.float().cpu().reshape(Sq, H, 64)
     b = qnf.norm(dim=-1) * k.norm(dim=-1).amax(0)[None]
-    assert (b[:, 0] > 290).sum() == 1 and b[Sq - 3, 0] > 310 and b[:, 1].max() < 290, (b[:, 0].topk(3), b[:, 1].max())
+    assert (b[:, 0] > 190).sum() == 1 and b[Sq - 3, 0] > 200 and b[:, 1].max() < 185, (b[:, 0].topk(3), b[:, 1].max())
     wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()
     kd, vt = k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
     flags, kmax = kflags(E, k, H)
@@ -514,19 +514,19 @@ def test_fused_query_norm_flip_from_a_tail_job_across_passes(E):
     """ADVICE r2 (attn_fwd.hip QN flip): 4 heads x 130 query blocks = 520 jobs = one full round of the 512 resident workgroups + 8
     TAIL jobs (head 3, the last 8 query blocks), which the balanced launcher runs after BOTH forms' full-round launches.  Head 3's
     rows sit on non-zero per-row offsets (bound ~ 110) and exactly one row — in the very last query block, i.e. in a tail job — is over
-    the limit of 300: its flip lands after online(full) has skipped the head, while the full jobs of the head left fixed-form state.
+    the limit of 190: its flip lands after online(full) has skipped the head, while the full jobs of the head left fixed-form state.
     The flip must be the LATE flag (2) so that pass B's online launch recomputes the head from scratch instead of resuming that
     state as offset 0."""
     Sq, Sk, H = 33280, 2048, 4
     qraw, w, cos, sin, k, v = qnorm_case(Sq, Sk, H, torch.tensor([2.0, 2.0, 2.0, 7.5]), 91)
-    w[7] = 4.5
+    w[7] = 3.0
     qraw[Sq - 3, 3] = 0.01 * qraw[Sq - 3, 3]
     qraw[Sq - 3, 3, 7] = 30.0
     qraw = bfr(qraw)
     qn = normed_queries(E, qraw, w, cos, sin, H)
     qnf = qn.float().cpu().reshape(Sq, H, 64)
     b = qnf.norm(dim=-1) * k.norm(dim=-1).amax(0)[None]
-    assert (b[:, 3] > 290).sum() == 1 and b[Sq - 3, 3] > 310 and b[:, :3].max() < 88 and b[:, 3].median() > 95, (b[:, 3].topk(3), b[:, 3].median())
+    assert (b[:, 3] > 190).sum() == 1 and b[Sq - 3, 3] > 200 and b[:, :3].max() < 88 and b[:, 3].median() > 92, (b[:, 3].topk(3), b[:, 3].median())
     wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()
     kd, vt = k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
     flags, kmax = kflags(E, k, H)
@@ -536,3 +536,99 @@ def test_fused_query_norm_flip_from_a_tail_job_across_passes(E):
     assert flags.tolist() == [1, 1, 1, 2], flags
     rows = torch.cat([torch.arange(0, Sq - 2048, 997), torch.arange(Sq - 2048, Sq, 61), torch.tensor([Sq - 3, Sq - 1])])
     close(out[rows], O.sdpa(qnf[rows], k, v, "bf16", None, base2=True), ulps=4, atol=5e-3, what="flip from a tail job across passes")
+
+
+# ------------------------------------------------------------------------------------------ centred per-row offsets (round 3)
+def flags_rows_centred(E, qf, kf, H):
+    """centre = the mean key of each head (a convex combination), radii around it; k5_attention_flags_rows_centred"""
+    c = kf.mean(0)                                                               # (H, 64)
+    r2 = ((kf - c[None]) ** 2).sum(-1).amax(0).contiguous().cuda()
+    qstat, kstat = (qf * qf).sum(-1).amax(0).contiguous().cuda(), (kf * kf).sum(-1).amax(0).contiguous().cuda()
+    flags = torch.zeros(H, dtype=torch.int32, device="cuda")
+    kmax, krad = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    E.check(E.lib().k5_attention_flags_rows_centred(qstat.data_ptr(), kstat.data_ptr(), 1, H, H, 0, flags.data_ptr(), kmax.data_ptr(), r2.data_ptr(),
+                                                    krad.data_ptr(), E.stream_ptr()), "k5_attention_flags_rows_centred")
+    torch.cuda.synchronize()
+    assert (r2 == 0).all()                                                        # consumed
+    return flags, kmax, krad, c.contiguous().cuda()
+
+
+def run_rows_centred(E, q, kc, vt, H, flags, kmax, centre, krad, balanced=True):
+    Sq, Sk = q.shape[0], kc.shape[0]
+    out = torch.full((Sq, H * 64), float("nan"), dtype=BF, device="cuda")
+    L = E.lib()
+    ws = torch.empty(L.k5_attention_balance_size(H, Sq), dtype=torch.uint8, device="cuda") if balanced else None
+    E.check(L.k5_attention_bf16_prescaled_rows_centred(q.data_ptr(), kc.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk, q.stride(0), kc.stride(0),
+                                                       vt.stride(0), out.stride(0), flags.data_ptr(), kmax.data_ptr(), centre.data_ptr(), krad.data_ptr(),
+                                                       None if ws is None else ws.data_ptr(), E.stream_ptr()), "k5_attention_bf16_prescaled_rows_centred")
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("Sq,Sk", [(768, 1088 - 1088 % 64), (33280, 2048)])
+def test_centred_offsets_on_keys_with_a_common_component(E, Sq, Sk):
+    """Keys that share a large mean direction (what the keys of a layer look like when the tokens' activations are correlated): every score
+    of a row sits near q.c — far below the plain Cauchy-Schwarz bound |q| max|k'| when q.c < 0, so the plain offset underflows whole rows
+    (head 0: all scores ~ -315 under a plain bound of 330: beyond the plain window, online form), and far ABOVE 90 when q.c > 0
+    (head 1: scores ~ +315: an offset is indispensable).  Head 2: no common component, plain bound 150, radius ~ the norm (centring buys
+    nothing and costs nothing).  Head 3: small norms (plain bound < 90): offset 0 as ever.  With the centred bound every head has
+    |q| R <= 190: the fixed form on every head, NO fallback possible — run without a workspace, where a single underflowing row would flip
+    its head's flag — and oracle parity."""
+    H = 4
+    g = torch.Generator().manual_seed(Sq + 1)
+    def unit(x):
+        return x / x.norm(dim=-1, keepdim=True)
+    u = unit(torch.randn(H, 64, generator=g))
+    q = torch.empty(Sq, H, 64); k = torch.empty(Sk, H, 64)
+    k[:, 0] = 7.0 * u[0] + 1.6 * unit(torch.randn(Sk, 64, generator=g));  q[:, 0] = -45.0 * u[0] + 10.0 * unit(torch.randn(Sq, 64, generator=g))
+    k[:, 1] = 7.0 * u[1] + 1.6 * unit(torch.randn(Sk, 64, generator=g));  q[:, 1] = +45.0 * u[1] + 10.0 * unit(torch.randn(Sq, 64, generator=g))
+    k[:, 2] = 5.0 * unit(torch.randn(Sk, 64, generator=g));               q[:, 2] = 30.0 * unit(torch.randn(Sq, 64, generator=g))
+    k[:, 3] = 1.5 * unit(torch.randn(Sk, 64, generator=g));               q[:, 3] = 10.0 * unit(torch.randn(Sq, 64, generator=g))
+    q, k = bfr(q), bfr(k)
+    v = bfr(torch.randn(Sk, H, 64, generator=g))
+    s0, s1 = q[:64, 0] @ k[:, 0].t(), q[:64, 1] @ k[:, 1].t()
+    assert s0.max().item() < -150 and s1.min().item() > 150
+    f_plain, kmax_plain = flags_rows(E, q, k, H)
+    assert f_plain.tolist() == [0, 0, 1, 1], f_plain                       # plain bounds ~ 330 / 330 / 150 / 15: heads 0, 1 beyond the window of 190
+    flags, kmax, krad, centre = flags_rows_centred(E, q, k, H)
+    nqR = q.norm(dim=-1).amax(0) * krad.cpu()
+    assert flags.tolist() == [1, 1, 1, 1] and (nqR[:2] < 190).all() and nqR[2] < 190, (flags, nqR)
+    qd, kd, vt = q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
+    rows = torch.arange(Sq) if Sq < 2000 else torch.tensor([0, 5, 255, 256, 4097, 20000, 32767, 32768, 33000, Sq - 1])
+    ref = O.sdpa(q[rows], k, v, "bf16", None, base2=True)
+    for balanced in (False, True):
+        out = run_rows_centred(E, qd, kd, vt, H, flags, kmax, centre, krad, balanced=balanced)
+        assert flags.tolist() == [1, 1, 1, 1], (balanced, flags)           # nothing underflowed: no head was sent to the online form late
+        close(out[rows], ref, ulps=4, atol=5e-3, what=f"centred offsets (balanced={balanced})")
+    # the plain form of the same call: heads 0 and 1 on the online max — the same numbers
+    out_p = run_rows(E, qd, kd, vt, H, f_plain, kmax_plain)
+    close(out_p[rows], ref, ulps=4, atol=5e-3, what="plain offsets / online form")
+
+
+def test_key_centre_and_radius_from_the_norm_pass(E):
+    """k5_rmsnorm_rope_centre_bf16: the centres are the mean of the kernel's own k' over its strided sample of rows (convex combination of
+    actual keys), the appended statistics the squared radii max |k' - c|^2 over ALL rows, the first H entries the squared norms as before."""
+    rows, Hq, D = 3000, 3, 64
+    H = 2 * Hq                                                                 # a q | k projection: heads 0..2 queries, 3..5 keys (scaled, centred)
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(1, H, D, generator=g) * 6.0
+    x = bfr(base + torch.randn(rows, H, D, generator=g))
+    w = torch.randn(2, 64, generator=g).abs() * 0.3 + 0.85
+    ang = torch.randn(rows, 32, generator=g) * 0.05
+    cos, sin = torch.cos(ang), torch.sin(ang)
+    xd = x.reshape(rows, -1).cuda().to(BF).clone()
+    stats = torch.zeros(H + Hq, device="cuda")
+    centre = torch.full((Hq, 64), float("nan"), device="cuda")
+    wd, cd, sd = w.cuda(), cos.cuda(), sin.cuda()                               # (keep them alive: a temporary's memory is reused at once)
+    E.check(E.lib().k5_rmsnorm_rope_centre_bf16(xd.data_ptr(), wd.data_ptr(), cd.data_ptr(), sd.data_ptr(), rows, H, xd.stride(0),
+                                                Hq, H, O.SOFTMAX_C, Hq, stats.data_ptr(), centre.data_ptr(), E.stream_ptr()), "k5_rmsnorm_rope_centre_bf16")
+    torch.cuda.synchronize()
+    kp = xd.float().cpu().reshape(rows, H, D)[:, Hq:]                           # the keys the kernel wrote
+    ns = 1024
+    idx = (torch.arange(ns) * rows) // ns
+    want_c = kp[idx].mean(0)
+    assert (centre.cpu() - want_c).abs().max().item() <= 2e-3 * want_c.abs().max().item() + 1e-4
+    r2 = ((kp - centre.cpu()[None]) ** 2).sum(-1).amax(0)
+    n2 = (xd.float().cpu().reshape(rows, H, D) ** 2).sum(-1).amax(0)
+    assert torch.allclose(stats[:H].cpu(), n2, rtol=1e-5) and torch.allclose(stats[H:].cpu(), r2, rtol=1e-4), (stats, n2, r2)
+    assert (r2 < 0.5 * n2[Hq:]).all()                                          # these keys do share a common component
