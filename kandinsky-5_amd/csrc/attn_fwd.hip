@@ -914,10 +914,12 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
 // rstat / krad_out (nullable, [H]): squared radii of the keys around their centres (k5_launch_rmsnorm_rope key_centre) in, radii with margin
 // out; the head-level bound is then the smaller of |q|max kmax and |q|max R (the centred offsets' survival depends on the latter).
 __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstride, int H, float limit, int force_online,
-                                  int* flags, unsigned long long* counters, float* kmax_out, const int* prefer_online, float* rstat, float* krad_out) {
+                                  int* flags, unsigned long long* counters, float* kmax_out, const int* prefer_online, float* rstat, float* krad_out,
+                                  int nq, int qstride) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
-  const float q2 = qstat[h];
+  float q2 = 0.f;   // nq partial maxima at stride qstride (Ulysses: one per rank that holds rows of this head's queries; otherwise 1)
+  for (int i = 0; i < nq; ++i) { const float v = qstat[(size_t)i * qstride + h]; q2 = v == v ? fmaxf(q2, v) : __uint_as_float(0x7f800000u); }
   float k2 = 0.f;
   for (int i = 0; i < nk; ++i) { const float v = kstat[(size_t)i * kstride + h]; k2 = v == v ? fmaxf(k2, v) : __uint_as_float(0x7f800000u); }
   float b = sqrtf(q2) * sqrtf(k2) * 1.002f;   // margin: fp32 rounding of the norms and of the MFMA accumulation
@@ -932,7 +934,7 @@ __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstrid
   flags[h] = fast;
   if (kmax_out) kmax_out[h] = sqrtf(k2) * 1.002f;   // per-row offsets of the fixed-offset form: |q_row| * this - 90 (AttnP::kmax)
   if (counters) atomicAdd(counters + (fast ? 0 : 1), 1ull);
-  qstat[h] = 0.f;
+  for (int i = 0; i < nq; ++i) qstat[(size_t)i * qstride + h] = 0.f;
   for (int i = 0; i < nk; ++i) kstat[(size_t)i * kstride + h] = 0.f;
 }
 
@@ -993,13 +995,14 @@ int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_ro
 }
 
 int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
-                         unsigned long long* counters, hipStream_t stream, float* kmax_out, const int* prefer_online, float* rstat, float* krad_out) {
-  if ((rstat == nullptr) != (krad_out == nullptr) || (rstat && !kmax_out)) return K5_ERR_ARG;
+                         unsigned long long* counters, hipStream_t stream, float* kmax_out, const int* prefer_online, float* rstat, float* krad_out,
+                         int nq, int qstride) {
+  if ((rstat == nullptr) != (krad_out == nullptr) || (rstat && !kmax_out) || nq < 1) return K5_ERR_ARG;
   if (!qstat || !kstat || !flags || H <= 0 || nk <= 0) return K5_ERR_ARG;
   // with kmax_out the attention runs per-row offsets: heads up to K5_ATTN_ROWOFF_LIMIT keep the fixed-offset form
   hipLaunchKernelGGL(attn_flags_kernel, dim3((H + 63) / 64), dim3(64), 0, stream, qstat, kstat, nk, kstride, H,
                      kmax_out ? K5_ATTN_ROWOFF_LIMIT : K5_ATTN_EXP_LIMIT, force_online, flags, counters, kmax_out, kmax_out ? prefer_online : nullptr,
-                     rstat, krad_out);
+                     rstat, krad_out, nq, qstride);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 

@@ -195,6 +195,39 @@ struct Comm {
     return K5_OK;
   }
   bool can_exchange() const { return loop || (Send && Recv && GroupStart && GroupEnd); }
+  // all-to-all (Ulysses): block p of `send` (block_bytes each) goes to rank p, block p of `recv` comes from rank p; send != recv.
+  // One grouped send/recv per peer (all xGMI links at once); the rank's own block is a device-to-device copy.
+  int all_to_all(const void* send, void* recv, size_t block_bytes, hipStream_t s) {
+    const char* sb = (const char*)send; char* rb = (char*)recv;
+    HIPCHK(hipMemcpyAsync(rb + (size_t)rank * block_bytes, sb + (size_t)rank * block_bytes, block_bytes, hipMemcpyDeviceToDevice, s));
+    if (world == 1) return K5_OK;
+    if (loop) {
+      loop->ptr[rank] = const_cast<void*>(send);
+      HIPCHK(hipEventRecord(loop->ready[rank], s));
+      pthread_barrier_wait(&loop->bar);
+      for (int p = 0; p < world; ++p) {
+        if (p == rank) continue;
+        HIPCHK(hipStreamWaitEvent(s, loop->ready[p], 0));
+        HIPCHK(hipMemcpyAsync(rb + (size_t)p * block_bytes, (const char*)loop->ptr[p] + (size_t)rank * block_bytes, block_bytes, hipMemcpyDeviceToDevice, s));
+      }
+      HIPCHK(hipEventRecord(loop->pulled[rank], s));
+      pthread_barrier_wait(&loop->bar);
+      for (int p = 0; p < world; ++p)
+        if (p != rank) HIPCHK(hipStreamWaitEvent(s, loop->pulled[p], 0));   // the peers have read my send buffer: it may be rewritten
+      return K5_OK;
+    }
+    if (!can_exchange()) { k5_set_error("RCCL library lacks ncclSend / ncclRecv / ncclGroup*"); return K5_ERR_STATE; }
+    ncclResult_t r = GroupStart();
+    for (int p = 0; p < world && r == ncclSuccess; ++p) {
+      if (p == rank) continue;
+      r = Send(sb + (size_t)p * block_bytes, block_bytes, ncclUint8, p, comm, s);
+      if (r == ncclSuccess) r = Recv(rb + (size_t)p * block_bytes, block_bytes, ncclUint8, p, comm, s);
+    }
+    const ncclResult_t e = GroupEnd();
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) { k5_set_error("ncclSend/ncclRecv group (all-to-all): %s", GetErrorString(r)); return K5_ERR_HIP; }
+    return K5_OK;
+  }
   // part of an in-place all-gather: the bytes [off, off + cnt) of every rank's slot (slot_bytes each, rank p's at p * slot_bytes)
   // travel to every peer — one grouped send/recv per peer, i.e. all seven xGMI links of the GPU at once, so the first slice of ALL
   // peers has landed when a fraction cnt / slot_bytes of the gather time has passed (a ring all-gather completes nothing early).
@@ -298,6 +331,9 @@ struct k5_dit {
   int fuse_qnorm = 0;                              // "attn_fuse_qnorm": norm_qk + RoPE of the visual queries inside the attention kernel
   bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 190)
   int sp_slices = 1;                               // "sp_slices": the K / V^T exchange of a block in this many slices (dense attention)
+  int sp_mode = 0;                                 // "sp_mode": 0 = K / V^T all-gather (any rank count), 1 = Ulysses all-to-all (heads % ranks == 0, dense attention)
+  DevBuf ws_u_send, ws_u_recv, ws_u_vsend, ws_u_vrecv, ws_u_o, ws_u_orecv, ws_u_stats;   // Ulysses exchange buffers
+  hipEvent_t ev_u_o = nullptr, ev_u_back = nullptr;
   hipEvent_t ev_slice[4] = {};                     // slice s of every peer has landed
   bool emulated = false;                           // "emulate_world": timing-only layout, results are garbage
   hipStream_t comm_stream = nullptr;              // all-gathers run here, overlapped with pass 1 of the attention
@@ -836,6 +872,102 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   return K5_OK;
 }
 
+// Ulysses-style sequence parallelism (north_star; "sp_mode" = 1): instead of gathering every rank's K / V^T, the ranks trade token rows for
+// HEADS — an all-to-all turns (rows of this rank x all 28 heads) into (all N rows x the 28 / P heads of this rank) for q | k and V^T, the
+// rank runs the ONE-GPU attention (a single balanced pass over all keys: no fp32 state between passes) for its heads, and a second
+// all-to-all brings the outputs back to the token shards.  Per rank and block 4 x (P - 1) / P^2 x N x D x 2 B leave the GPU (3/16 of
+// the 170 MB of a 5 s clip per tensor at P = 4) against 2 x (P - 1) / P x N x D x 2 B of ingress for the gather: half the bytes at
+// P = 2, a quarter at P = 4 — but the attention cannot start before q, k AND V^T have landed, where the gather hides behind pass 1.
+// Needs heads % P == 0 (28 = 2 x 2 x 7: P in 2, 4, 7, 14) and dense attention; anything else keeps the gather.  Replaces the head split
+// of the reference's tensor-parallel plan (parallelize.py:87-91) together with its all-reduces.
+// Layouts: send [P][rows_pad][2 Dp] (block g: q | k' of the heads of rank g, this rank's rows) -> recv [P][rows_pad][2 Dp] = all rows
+// (rank-major = token order: slots are contiguous token ranges) of this rank's heads; V^T [D][rows_pad] is destination-major as the GEMM
+// writes it (block g = rows g Dp ..) -> vrecv [P][Dp][rows_pad] = the chunked V^T layout of the attention kernel; o [P rows_pad][Dp]
+// -> orecv [P][rows_pad][Dp] (block g: the outputs of rank g's heads for this rank's rows) -> unpacked to [rows][D].
+int run_self_attention_ulysses(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, int rows_pad, int N, void* o,
+                               const float* cosT, const float* sinT, void* resid, const float* gate) {
+  const int D = d->D, H = d->Hh, P = d->sp_world, r = d->sp_rank, Hp = H / P, Dp = D / P;
+  const bool by_data = d->attn_mode == K5_ATTN_AUTO;
+  K5CHK(d->ws_qk.ensure((size_t)rows * 2 * D * 2));
+  K5CHK(d->ws_u_send.ensure((size_t)P * rows_pad * 2 * Dp * 2)); K5CHK(d->ws_u_recv.ensure((size_t)P * rows_pad * 2 * Dp * 2));
+  K5CHK(d->ws_u_vsend.ensure((size_t)D * rows_pad * 2)); K5CHK(d->ws_u_vrecv.ensure((size_t)D * rows_pad * 2));
+  K5CHK(d->ws_u_o.ensure((size_t)P * rows_pad * Dp * 2)); K5CHK(d->ws_u_orecv.ensure((size_t)P * rows_pad * Dp * 2));
+  K5CHK(ensure_zeroed(d->ws_u_stats, (size_t)P * 2 * H * 4, s));
+  if (!d->ev_u_o) { HIPCHK(hipEventCreateWithFlags(&d->ev_u_o, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&d->ev_u_back, hipEventDisableTiming)); }
+  if (by_data) K5CHK(ensure_attn_flags(d, s));
+  float* ustats = d->ws_u_stats.as<float>();         // [P][2 H]: rank p's maxima of |q_h|^2 (H) and |k'_h|^2 (H) over ITS rows
+  if (by_data) HIPCHK(hipMemsetAsync(ustats + (size_t)r * 2 * H, 0, (size_t)2 * H * 4, s));   // the norm pass max-accumulates; only my heads' entries were consumed
+  bf16_t* qk = d->ws_qk.as<bf16_t>();
+  {
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_bf16(h, a.wqk.p, a.bqk.as<float>(), qk, rows, 2 * D, D, D, D, 2 * D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+  }
+  {
+    Scope sc(d, s, "elementwise");
+    const int32_t hc[2] = {H, 2 * H};
+    K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, H, nullptr, 0,
+                                 by_data ? ustats + (size_t)r * 2 * H : nullptr, d->ws_attn_part.as<float>()));
+    K5CHK(k5_launch_ulysses_pack_qk(qk, d->ws_u_send.p, rows, rows_pad, D, P, s));
+  }
+  HIPCHK(hipEventRecord(d->ev_k, s));
+  hipStream_t cs = d->comm_stream;
+  HIPCHK(hipStreamWaitEvent(cs, d->ev_k, 0));
+  {
+    Scope sc(d, cs, "comm");
+    if (by_data) { K5CHK(d->comm.all_gather_inplace(ustats, (size_t)2 * H, 4, cs)); HIPCHK(hipEventRecord(d->ev_stats, cs)); }
+    K5CHK(d->comm.all_to_all(d->ws_u_send.p, d->ws_u_recv.p, (size_t)rows_pad * 2 * Dp * 2, cs));
+  }
+  {
+    Scope sc(d, s, "gemm");   // V^T of the rank's rows while q | k travel
+    K5CHK(k5_launch_gemm_bf16(a.wv.p, h, a.bv.as<float>(), d->ws_u_vsend.p, D, rows, D, D, D, rows_pad, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+  }
+  HIPCHK(hipEventRecord(d->ev_v, s));
+  HIPCHK(hipStreamWaitEvent(cs, d->ev_v, 0));
+  {
+    Scope sc(d, cs, "comm");
+    K5CHK(d->comm.all_to_all(d->ws_u_vsend.p, d->ws_u_vrecv.p, (size_t)Dp * rows_pad * 2, cs));
+  }
+  HIPCHK(hipEventRecord(d->ev_gathered, cs));
+  const int* hflags = nullptr;
+  const float* kmax = nullptr;
+  if (by_data) {   // flags of MY heads from every rank's maxima (each rank held some rows of them)
+    HIPCHK(hipStreamWaitEvent(s, d->ev_stats, 0));
+    hflags = d->ws_attn_flags.as<int>();
+    float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
+    kmax = kmax_w;
+    if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
+    K5CHK(k5_launch_attn_flags(ustats + (size_t)r * Hp, ustats + H + (size_t)r * Hp, P, 2 * H, Hp, 0, d->ws_attn_flags.as<int>(),
+                               d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w, kmax_w ? a.pref.as<int>() + (size_t)r * Hp : nullptr, nullptr, nullptr, P, 2 * H));
+  }
+  HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
+  const bf16_t* qall = d->ws_u_recv.as<bf16_t>();
+  K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(Hp, N)));
+  {
+    Scope sc(d, s, "attn_self");
+    K5CHK(k5_launch_attention_bf16_range(qall, qall + Dp, d->ws_u_vrecv.p, d->ws_u_o.p, Hp, N, N, 2 * Dp, 2 * Dp, rows_pad, Dp, 0.f, rows_pad,
+                                         (long long)Dp * rows_pad, 0, -1, 0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), true, hflags,
+                                         d->attn_mode, nullptr, kmax, 0, nullptr, nullptr));
+  }
+  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), Hp, N, 4, a.pref.as<int>() + (size_t)r * Hp, s));
+  HIPCHK(hipEventRecord(d->ev_u_o, s));
+  HIPCHK(hipStreamWaitEvent(cs, d->ev_u_o, 0));
+  {
+    Scope sc(d, cs, "comm");
+    K5CHK(d->comm.all_to_all(d->ws_u_o.p, d->ws_u_orecv.p, (size_t)rows_pad * Dp * 2, cs));
+  }
+  HIPCHK(hipEventRecord(d->ev_u_back, cs));
+  HIPCHK(hipStreamWaitEvent(s, d->ev_u_back, 0));
+  {
+    Scope sc(d, s, "elementwise");
+    K5CHK(k5_launch_ulysses_unpack_o(d->ws_u_orecv.p, o, rows, rows_pad, D, P, s));
+  }
+  {
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_bf16(o, a.wo.p, a.bo.as<float>(), resid, rows, D, D, D, D, D, K5_EPI_GATE, resid, D, gate, s));
+  }
+  return K5_OK;
+}
+
 int run_cross_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, const void* text,
                         int L, void* q, void* ck, void* cvt, void* o, void* resid, const float* gate) {
   const int D = d->D, H = d->Hh;
@@ -1112,7 +1244,9 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     const float* vsin = d->ws_vsin.as<float>() + (size_t)tok0 * 32;
     K5CHK(ln_mod(d, s, d->ws_vis.p, m, d->ws_h.p, n));
     if (d->profiling) ++d->prof_self_blocks;   // bench.py: FLOPs of the roofline kernel = per-block FLOPs x the blocks that RAN
-    if (sp) {
+    if (sp && d->sp_mode == 1 && !nabla && d->sp_world > 1 && d->Hh % d->sp_world == 0 && !d->emulated) {
+      K5CHK(run_self_attention_ulysses(d, s, b.self_attn, d->ws_h.p, n, n_pad, N, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D));
+    } else if (sp) {
       K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, n_pad, N, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D, nabla ? &na : nullptr));
     } else {
       K5CHK(run_self_attention(d, s, b.self_attn, d->ws_h.p, n, d->ws_qk.p, d->ws_vt.p, d->ws_o.p, vcos, vsin, d->ws_vis.p,
@@ -1199,7 +1333,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
   for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered, d->ev_stats, d->ev_means, d->ev_slice[0], d->ev_slice[1], d->ev_slice[2], d->ev_slice[3]}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
   if (d->pair_stream) { (void)hipStreamSynchronize(d->pair_stream); (void)hipStreamDestroy(d->pair_stream); }
-  for (hipEvent_t e : {d->ev_vel_ready, d->ev_vel_done}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {d->ev_vel_ready, d->ev_vel_done, d->ev_u_o, d->ev_u_back}) if (e) (void)hipEventDestroy(e);
   if (d->pair.comm) (void)d->pair.CommDestroy(d->pair.comm);
   d->ws_vel_pair.release();
   auto rel_attn = [](AttnW& a) {
@@ -1619,6 +1753,8 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //   "sp_nabla_passes" 1 (default) / 2: NABLA under sequence parallelism walks every list in one pass after the gather, or in two — the
 //                     rank's own key blocks while the other ranks' keys travel, the rest after the gather (costs 12 % of the attention
 //                     in compute, emulated P = 4; pays when the exposed part of the gather is longer than that — a property of the node)
+//   "sp_mode"         0 (default): every rank gathers all K / V^T (any rank count, dense and NABLA); 1: Ulysses — two all-to-alls trade token rows
+//                     for heads and back (run_self_attention_ulysses; needs heads % ranks == 0 and dense attention, else the gather is used)
 //   "sp_slices"       S in 1..4: exchange K / V^T of a block in S slices (grouped send/recv to every peer at once) and attend each
 //                     slice as it lands — the gather hides behind the attention of the slices before it (dense attention; NABLA and
 //                     S = 1 keep the single in-place all-gather).  Token slots become multiples of 64 S.
@@ -1633,6 +1769,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
     d->attn_mode = value; return K5_OK;
   }
   if (!strcmp(name, "sp_pass1_tiles")) { if (value < 0) return K5_ERR_ARG; d->sp_pass1_tiles = value; return K5_OK; }
+  if (!strcmp(name, "sp_mode")) { if (value < 0 || value > 1) return K5_ERR_ARG; d->sp_mode = value; return K5_OK; }
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
   if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }
   if (!strcmp(name, "sp_nabla_passes")) { if (value < 1 || value > 2) return K5_ERR_ARG; d->sp_nabla_passes = value; return K5_OK; }
@@ -1655,6 +1792,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   if (!d || !name || !value) return K5_ERR_ARG;
   if (!strcmp(name, "attn_mode")) *value = d->attn_mode;
   else if (!strcmp(name, "sp_pass1_tiles")) *value = d->sp_pass1_tiles;
+  else if (!strcmp(name, "sp_mode")) *value = d->sp_mode;
   else if (!strcmp(name, "sp_slices")) *value = d->sp_slices;
   else if (!strcmp(name, "attn_row_offsets")) *value = d->row_offsets ? 1 : 0;
   else if (!strcmp(name, "attn_fuse_qnorm")) *value = d->fuse_qnorm;

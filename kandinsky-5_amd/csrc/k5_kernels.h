@@ -62,7 +62,8 @@ enum { K5_ATTN_AUTO = 0, K5_ATTN_ONLINE = 1 };
 // last time (job flags at the end of the balance workspace that run's attention launches used; group_rows 2: 128-query jobs)
 int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
                          unsigned long long* counters, hipStream_t stream, float* kmax_out = nullptr, const int* prefer_online = nullptr,
-                         float* rstat = nullptr, float* krad_out = nullptr);   // squared radii in (consumed) / radii with margin out: K5KeyCentre::radius
+                         float* rstat = nullptr, float* krad_out = nullptr,   // squared radii in (consumed) / radii with margin out: K5KeyCentre::radius
+                         int nq = 1, int qstride = 0);                         // qstat as nq partial maxima at stride qstride (Ulysses)
 int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_rows, int* prefer_online, hipStream_t stream);
 
 // ---- fp8 (e4m3) feed-forward path, opt-in (gemm_fp8.hip) ----
@@ -107,7 +108,10 @@ int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cos, const
                            float out_scale = 1.f, int scale_from_head = 0x7fffffff, void* scaled_out = nullptr, int ld_scaled = 0,
                            float* stats = nullptr, float* stats_ws = nullptr,
                            float* key_centre = nullptr);   // OUT [H - scale_from_head][64]: sample-mean key per scaled head; stats then also gets H - scale_from_head squared radii |k' - c|^2
-size_t k5_rmsnorm_stats_workspace_bytes(int H);   // stats_ws: scratch of this size whenever stats is given
+size_t k5_rmsnorm_stats_workspace_bytes(int H);
+// Ulysses sequence parallelism: (q | k) rows [rows][2 D] -> per-destination blocks [P][slot_rows][2 D / P]; outputs [P][slot_rows][D / P] -> [rows][D]
+int k5_launch_ulysses_pack_qk(const void* x, void* out, int rows, int slot_rows, int D, int P, hipStream_t s);
+int k5_launch_ulysses_unpack_o(const void* in, void* out, int rows, int slot_rows, int D, int P, hipStream_t s);   // stats_ws: scratch of this size whenever stats is given
 // heads >= scale_from_head are multiplied by out_scale before the bf16 rounding — in place, or (scaled_out != null) into
 // scaled_out[row][(head - scale_from_head) * 64 ...] while the unscaled values stay in place.
 // stats (device, [H] floats, zeroed by the consumer): stats[h] = max(stats[h], |x_row,h|^2) over the rows of the call, of the

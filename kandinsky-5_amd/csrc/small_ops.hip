@@ -434,6 +434,26 @@ int k5_launch_ln_affine(const void* x, const float* w, const float* b, void* out
   return done();
 }
 
+// Ulysses sequence parallelism (engine.hip run_self_attention_ulysses): head-group repacking around the two all-to-alls.
+// pack: x [rows][2 D] = (q heads | k heads) of the rank's token rows -> out [P][slot_rows][2 Dp], block g = (q | k) of the heads rank g attends
+__global__ __launch_bounds__(256) void ulysses_pack_qk_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int rows, int slot_rows, int D, int Dp) {
+  const int cpr = 2 * D / 8;                                   // 16-B chunks per row
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)rows * cpr; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / cpr), col = (int)(i % cpr) * 8;
+    const int part = col >= D ? 1 : 0, cc = col - part * D, g = cc / Dp, within = cc - g * Dp;
+    *reinterpret_cast<u32x4*>(out + ((size_t)g * slot_rows + row) * (2 * Dp) + part * Dp + within) = *reinterpret_cast<const u32x4*>(x + (size_t)row * 2 * D + col);
+  }
+}
+// unpack: in [P][slot_rows][Dp] (block g = the outputs of rank g's heads for this rank's rows) -> out [rows][D]
+__global__ __launch_bounds__(256) void ulysses_unpack_o_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows, int slot_rows, int D, int Dp) {
+  const int cpr = D / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)rows * cpr; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / cpr), col = (int)(i % cpr) * 8;
+    const int g = col / Dp, within = col - g * Dp;
+    *reinterpret_cast<u32x4*>(out + (size_t)row * D + col) = *reinterpret_cast<const u32x4*>(in + ((size_t)g * slot_rows + row) * Dp + within);
+  }
+}
+
 size_t k5_rmsnorm_stats_workspace_bytes(int H) { return (size_t)4096 * 2 * H * sizeof(float); }   // partial rows of up to 2 H entries (norms + radii)
 
 int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, const float* sinT, int rows, int H,
@@ -467,6 +487,17 @@ int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, cons
                      cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled, stats ? stats_ws : nullptr,
                      centred ? key_centre : nullptr);
   if (stats) hipLaunchKernelGGL(stats_reduce_kernel, dim3(blocks >= 2048 ? 64 : (blocks >= 512 ? 16 : 1)), dim3(256), 0, s, stats_ws, (int)blocks, Hs, stats);
+  return done();
+}
+
+int k5_launch_ulysses_pack_qk(const void* x, void* out, int rows, int slot_rows, int D, int P, hipStream_t s) {
+  if (rows <= 0 || slot_rows < rows || P <= 0 || D % P || (D / P) % 8) return K5_ERR_ARG;
+  hipLaunchKernelGGL(ulysses_pack_qk_kernel, dim3(grid_for((int64_t)rows * (2 * D / 8))), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, rows, slot_rows, D, D / P);
+  return done();
+}
+int k5_launch_ulysses_unpack_o(const void* in, void* out, int rows, int slot_rows, int D, int P, hipStream_t s) {
+  if (rows <= 0 || slot_rows < rows || P <= 0 || D % P || (D / P) % 8) return K5_ERR_ARG;
+  hipLaunchKernelGGL(ulysses_unpack_o_kernel, dim3(grid_for((int64_t)rows * (D / 8))), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, rows, slot_rows, D, D / P);
   return done();
 }
 

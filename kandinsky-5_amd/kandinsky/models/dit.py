@@ -356,6 +356,8 @@ class DiffusionTransformer3D(nn.Module):
         kept density (default), 2, 4 — same bits), "sp_nabla_passes" (NABLA under sequence parallelism: 2 = attend the rank's own
         key blocks while the gather is in flight; default 1),
         "sp_slices" (sequence parallelism: exchange K / V^T in this many slices, attend each as it lands; default 1),
+        "sp_mode" (sequence parallelism: 0 = K / V^T all-gather (default), 1 = Ulysses all-to-all — token rows traded for heads and back;
+        needs heads % ranks == 0 and dense attention, otherwise the gather is used),
         "sp_pass1_tiles", "emulate_world" (timing only)."""
         if self._handle is not None:     # no engine yet: remembered and applied when it is built (_reapply_settings)
             E.check(E.lib().k5_dit_set_option(self._handle, name.encode(), int(value)), f"k5_dit_set_option({name})")

@@ -524,3 +524,90 @@ def test_config5_cfg_parallel_2x4_on_one_gpu():
     print(f"config 5 (SP x 4 + CFG x 2 + NABLA, 3660 blocks): update vs the single-handle CFG run rel-L2 {rel(upd, upd_f):.3e}; "
           f"|update| / |noise| = {rel(fused, noise.cuda()):.3e}")
     assert rel(upd, upd_f) <= 1.2e-2, rel(upd, upd_f)
+
+
+# ------------------------------------------------------------------------------------------ Ulysses all-to-all ("sp_mode" = 1)
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("P,T,W,gain", [(2, 5, 32, 1.0), (4, 5, 32, 1.0), (4, 5, 48, 3.0), (7, 7, 48, 1.0), (2, 5, 32, 6.0)])
+def test_full_width_forward_ulysses(P, T, W, gain):
+    """The Ulysses form of sequence parallelism (north_star; k5_dit_set_option("sp_mode", 1)): 28 heads over P = 2 / 4 / 7 ranks, two
+    all-to-alls per block (token rows -> heads, heads -> token rows), the ONE-GPU attention for the rank's heads over all keys in between.
+    2B-Lite width, 2 visual blocks, latent (T,16,W): 10 / 15 / 21 blocks of 64 tokens (P = 4 on 10 or 15 blocks: the LAST rank's slot is short, 3+3+3+1 and 4+4+4+3;
+    P = 7: 21 blocks, 3 each — 4 heads per rank).  Every rank returns the same velocity bit for bit; and since
+    each (head, query row) is attended over all keys in one pass, as on one GPU, the result agrees with the single-handle run far tighter
+    than the gather schedule does (only the shard-size GEMMs may pick other tiles): gain 1 within 3e-3.  gain 3: per-row offsets
+    (flags from every rank's maxima of MY heads); gain 6: online form."""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
+    cfg = O.DitConfig(**c)
+    sd = O.synthetic_state_dict(cfg, seed=3)
+    if gain != 1.0:
+        for k in sd:
+            if k.endswith(("query_norm.weight", "key_norm.weight")):
+                sd[k] = sd[k] * gain
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(T, 16, W, 16, generator=g)
+    text, pooled = torch.randn(37, 3584, generator=g), torch.randn(1, 768, generator=g)
+    pos = [torch.arange(T), torch.arange(8), torch.arange(W // 2)]
+    t = torch.tensor([875.0])
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(sd, assign=True)
+        return d.to("cuda:0")
+
+    def call(d, r):
+        out = d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(37), scale_factor=(1.0, 2.0, 2.0))
+        return out, d.attn_variant_counts(), d.get_option("sp_mode")
+
+    one = make()
+    fused, counts1, _ = call(one, 0)
+    one._destroy_engine(force=True)
+    res = run_ranks(P, make, call, options={"sp_mode": 1})
+    outs = [o for o, _, _ in res]
+    assert all(m == 1 for _, _, m in res)
+    for r in range(1, P):
+        assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
+    Hp = 28 // P
+    for _, (n_fixed, n_online), _ in res:
+        assert n_fixed + n_online == 2 * Hp                       # every rank flagged ITS heads only
+        assert (n_online == 0) if gain <= 3.0 else (n_fixed == 0), (gain, n_fixed, n_online)
+    xin = torch.cat([x, torch.zeros(T, 16, W, 17)], dim=-1)
+    ref = O.dit_forward(sd, cfg, xin, text, pooled, t, pos, torch.arange(37), (1.0, 2.0, 2.0), None, "bf16")
+    print(f"Ulysses P={P} gain={gain}: sharded vs fused rel-L2 {rel(outs[0], fused):.3e}; sharded vs oracle {rel(outs[0], ref):.3e}")
+    assert rel(outs[0], fused) <= {1.0: 3e-3, 3.0: 1.5e-2, 6.0: 6e-2}[gain], rel(outs[0], fused)
+    assert rel(outs[0], ref) <= {1.0: 1.5e-2, 3.0: 3e-2, 6.0: 1.2e-1}[gain], rel(outs[0], ref)
+
+
+@pytest.mark.timeout(900)
+def test_tiny_sampler_ulysses_with_cfg_pair(golden_meta, tiny_sd):
+    """k5_sample, 4 steps, guidance 5, as 2 x 2 handles: Ulysses inside each CFG branch (the tiny model has 2 heads: one per rank) + the
+    engine-side velocity exchange of the pairs — every handle ends with the same latent; NABLA requests keep the gather (sp_mode falls
+    back) and still agree."""
+    from types import SimpleNamespace as NS
+    from kandinsky.generation_utils import generate
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = tiny_cfg(golden_meta)
+    g = torch.Generator().manual_seed(7)
+    shape = (8, 16, 16, 16)
+    noise = torch.randn(*shape, generator=g)
+    te = {"text_embeds": torch.randn(9, 96, generator=g).cuda(), "pooled_embed": torch.randn(1, 48, generator=g).cuda()}
+    ne = {"text_embeds": torch.randn(4, 96, generator=g).cuda(), "pooled_embed": torch.randn(1, 48, generator=g).cuda()}
+    pos = [torch.arange(8), torch.arange(8), torch.arange(8)]
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(tiny_sd, assign=True)
+        return d.to("cuda:0")
+
+    for att in (NS(type="flash"), NS(type="nabla", P=0.6, wT=3, wH=1, wW=1, add_sta=True, method="topcdf")):
+        conf = NS(model=NS(dit_params=NS(patch_size=(1, 2, 2)), attention=att), metrics=NS(scale_factor=(1.0, 2.0, 2.0)))
+
+        def call(d, i):
+            return generate(d, "cuda:0", shape, 4, te, ne, pos, torch.arange(9), torch.arange(4), 5.0, 5.0, conf, noise=noise)
+
+        fused = call(make(), 0)
+        outs = run_cfg_ranks(2, make, call, options={"sp_mode": 1})
+        for i in range(1, 4):
+            assert torch.equal(outs[i], outs[0]), (att.type, i)
+        assert rel(outs[0], fused) <= 1e-2, (att.type, rel(outs[0], fused))

@@ -15,7 +15,16 @@ from oracle import k5_oracle as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _sp_forward(sd, cfg, x, text, pooled, time, vpos, tpos, rank, world):
+def _all_to_all(send, rank, world):
+    """block g of `send` goes to rank g; returns the blocks received (gloo has no alltoall: every rank gathers everybody's send list and
+    keeps the blocks addressed to it — the same data movement as far as the receiver can tell)"""
+    mine = torch.stack(send, 0)
+    everyone = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    return [everyone[p][rank] for p in range(world)]
+
+
+def _sp_forward(sd, cfg, x, text, pooled, time, vpos, tpos, rank, world, ulysses=False):
     """Sequence-parallel restatement of O.dit_forward: mirrors csrc/engine.hip forward_impl + run_self_attention_sp."""
     from kandinsky.models.parallelize import shard_slot, token_shard
     mode = "fp32"
@@ -42,6 +51,30 @@ def _sp_forward(sd, cfg, x, text, pooled, time, vpos, tpos, rank, world):
         q, k, v = O._attn_qkv(sd, f"{p}.self_attention", h, h, mode, H)
         q, k = O.apply_rotary(q, cos, sin, mode), O.apply_rotary(k, cos, sin, mode)
         # every rank's slot holds `slot` rows; only the last rank's may be partly unused (its tail is never read)
+        if ulysses:
+            # run_self_attention_ulysses: all-to-all trades this rank's rows of ALL heads for ALL rows of its H / world heads (blocks of
+            # `slot` rows per rank, the last one short), one full-sequence attention per owned head, all-to-all of the outputs back
+            Hg = H // world                                    # heads per rank (Hp is the patched height here)
+            def to_heads(t):                                   # (n, H, 64) -> (N, Hg, 64)
+                pad = torch.zeros(slot, H, 64)
+                pad[:n] = t
+                send = [pad[:, g * Hg:(g + 1) * Hg].contiguous() for g in range(world)]
+                return torch.cat(_all_to_all(send, rank, world), 0)[:N]
+            qa, ka, va_ = to_heads(q), to_heads(k), to_heads(v.reshape(n, H, 64))
+            oa = O.sdpa(qa, ka, va_, mode).reshape(N, Hg, 64)
+            opad = torch.zeros(world * slot, Hg, 64)
+            opad[:N] = oa
+            send = [opad[s_ * slot:(s_ + 1) * slot].contiguous() for s_ in range(world)]
+            o = torch.cat(_all_to_all(send, rank, world), 1)[:n].reshape(n, D)   # head groups side by side = the original head order
+            o = O._linear(o, sd[f"{p}.self_attention.out_layer.weight"], sd[f"{p}.self_attention.out_layer.bias"], mode)
+            vis = O.gate_sum(vis, o, gate, mode)
+            shift, scale, gate = torch.chunk(ca, 3, dim=-1)
+            vis = O.gate_sum(vis, O.cross_attention(sd, f"{p}.cross_attention", O.scale_shift_norm(vis, scale, shift, mode),
+                                                    txt, cfg, mode), gate, mode)
+            shift, scale, gate = torch.chunk(ff, 3, dim=-1)
+            vis = O.gate_sum(vis, O.feed_forward(sd, f"{p}.feed_forward", O.scale_shift_norm(vis, scale, shift, mode), mode),
+                             gate, mode)
+            continue
         kpad, vtpad = torch.zeros(slot, H, 64), torch.zeros(D, slot)
         kpad[:n], vtpad[:, :n] = k, v.reshape(n, D).t()
         kfull = [torch.empty_like(kpad) for _ in range(world)]
@@ -67,7 +100,7 @@ def _sp_forward(sd, cfg, x, text, pooled, time, vpos, tpos, rank, world):
     return O.unpatchify(torch.cat(yall, 0)[:N].reshape(Tp, Hp, Wp, -1), cfg.patch_size)
 
 
-def _worker(rank, world, port, q, T=2):
+def _worker(rank, world, port, q, T=2, ulysses=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "kandinsky-5_amd"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -82,21 +115,22 @@ def _worker(rank, world, port, q, T=2):
     text, pooled = torch.randn(9, 96, generator=g), torch.randn(1, 48, generator=g)
     t = torch.tensor([432.0])
     vpos = [torch.arange(T), torch.arange(8), torch.arange(8)]
-    out = _sp_forward(sd, cfg, x, text, pooled, t, vpos, torch.arange(9), rank, world)
+    out = _sp_forward(sd, cfg, x, text, pooled, t, vpos, torch.arange(9), rank, world, ulysses)
     ref = O.dit_forward(sd, cfg, x, text, pooled, t, vpos, torch.arange(9), (1.0, 2.0, 2.0), None, "fp32")
     q.put((rank, float((out - ref).abs().max()), float(ref.abs().max())))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("T", [2, 3])
-def test_sequence_parallel_algorithm_two_ranks_gloo(T):
+@pytest.mark.parametrize("T,ulysses", [(2, False), (3, False), (2, True), (3, True)])
+def test_sequence_parallel_algorithm_two_ranks_gloo(T, ulysses):
+    """ulysses: the all-to-all form (engine option "sp_mode" = 1; the tiny model's 2 heads = one per rank), even and uneven shards."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + T
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, T)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + T + (10 if ulysses else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, T, ulysses)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(2)]
+    res = [q.get(timeout=120) for _ in range(2)]
     for p in procs:
         p.join(60)
     assert sorted(r[0] for r in res) == [0, 1]
