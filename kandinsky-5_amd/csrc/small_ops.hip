@@ -194,6 +194,10 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
 // a convex combination of actual keys also gives the lower bound max_j q.k'_j >= q.c that rules the row-sum underflow out.  Runs BEFORE
 // rmsnorm_rope_kernel on the raw projection, with that kernel's arithmetic (RMSNorm, weight, bf16, RoPE, scale, bf16), so that the main
 // kernel can take max|k' - c|^2 in its one pass.  One block per key head: thread = (sample lane t >> 3, 16-B chunk t & 7); fixed-order sums.
+// Sample size: ANY convex combination of keys is a valid centre; what the sample has to catch is a component the head's keys share, and
+// 256 rows spread over the sequence do.  The kernel is one workgroup per head with a serial chain of row loads per thread — 1024 rows
+// measured 56 us per block (+1.8 ms per step, same-box A/B against attn_row_offsets = 0: 544.3 vs 542.0 ms), 8 iterations instead of 32.
+constexpr int K5_CENTRE_SAMPLE = 256;
 __global__ __launch_bounds__(256) void key_centre_kernel(const bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                          const float* __restrict__ cosT, const float* __restrict__ sinT, int rows, int ld,
                                                          int head0, int heads_per_weight, int rope_heads, float out_scale, int nsample,
@@ -480,7 +484,7 @@ int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, cons
   const bool centred = key_centre && stats && scale_from_head < H;
   if (centred)
     hipLaunchKernelGGL(key_centre_kernel, dim3(H - scale_from_head), dim3(256), 0, s, (const bf16_t*)x, weight, cosT, sinT, rows, ld, scale_from_head, hpw,
-                       rope_heads, out_scale, rows < 1024 ? rows : 1024, key_centre);
+                       rope_heads, out_scale, rows < K5_CENTRE_SAMPLE ? rows : K5_CENTRE_SAMPLE, key_centre);
   const int Hs = centred ? H + (H - scale_from_head) : H;
   if (Hs > 256) return K5_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)x, weight,
