@@ -341,7 +341,8 @@ def main():
     if args.fp8:
         invalid.append("reduced precision (fp8 feed-forward)")
     step_flop = fwd_per_step * flops_forward(N, L, blocks=args.blocks)
-    assert torch.isfinite(latent).all(), "latent diverged"
+    if not torch.isfinite(latent).all():
+        invalid.append("the latent holds non-finite values after the timed steps")
     rank_check = None
     if world > 1:   # every rank applies the same Euler update to the same gathered velocity: the latents must be BIT-identical
         cs = torch.stack([latent.double().sum(), latent.double().abs().sum(), latent.view(torch.int32).sum(dtype=torch.int64).double()])
@@ -349,7 +350,9 @@ def main():
         torch.distributed.all_gather(allcs, cs)
         same = all(torch.equal(allcs[0], c) for c in allcs)
         rank_check = {"latent_checksums_identical_on_all_ranks": bool(same), "checksum": [float(v) for v in allcs[0].tolist()]}
-        assert same, f"ranks disagree on the latent: {[c.tolist() for c in allcs]}"
+        if not same:   # a wrong multi-GPU result is not a measurement — but say so in the line instead of dying without one
+            rank_check["per_rank"] = [[float(v) for v in c.tolist()] for c in allcs]
+            invalid.append("the ranks hold DIFFERENT latents after the timed steps (rank_check.per_rank): the sharded run is wrong")
 
     if rank == 0:
         out = {
