@@ -455,3 +455,42 @@ def test_config1_plumbing_run_vs_oracle():
     print(f"config 1 (13,32,32) x 16 steps, w = 1: final latent engine vs bf16-island oracle {r:.3e}; moved {rel(ref, noise):.3f} from the noise")
     assert r <= 1e-2, r
     assert rel(ref, noise) > 0.05                         # the sampler really moved the latent (the check is not noise vs noise)
+
+
+def test_config3_cfg_step_at_full_length_vs_reference_golden():
+    """BASELINE config 3 (config_5s_sft: CFG, two forwards per step) at its own size: ONE Euler step of the reference's own generate()
+    (generation_utils.py:80-129: seeded noise, sigma schedule, get_velocity with guidance 5, Euler update; fp32, oracle/
+    gen_golden_fullwidth_long.py cfg) on the (31, 64, 96) latent = 47 616 tokens, full width, 2 blocks — through k5_sample (cond forward,
+    uncond forward, bf16 combine, fp32 Euler in one C call).  Compared on 16384 samples of the UPDATE the step applied (latent - noise:
+    the velocity's bf16 noise is not hidden behind the unit-variance noise) and of the latent itself."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    from kandinsky.generation_utils import sigma_schedule
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    G, meta = load_file(os.path.join(here, "dit_fullwidth_long_cfg.safetensors")), json.load(open(os.path.join(here, "dit_fullwidth_long_meta.json")))
+    c = meta["cfg"]
+    dit, _, _ = _two_block_model(meta["qk_gain"])
+    T, H, W = meta["latent"]
+    L = meta["text_len"]
+    g = torch.Generator().manual_seed(meta["input_seed"])
+    torch.randn(T, H, W, 16, generator=g)                                    # the forward golden's latent: same generator stream as the generator script
+    text, pooled = torch.randn(L, 3584, generator=g), torch.randn(1, 768, generator=g)
+    g2 = torch.Generator().manual_seed(c["null_seed"])
+    ntext, npooled = torch.randn(c["null_text_len"], 3584, generator=g2), torch.randn(1, 768, generator=g2)
+    noise = torch.randn(T, H, W, 16, generator=torch.Generator().manual_seed(c["seed"]))
+    lat = noise.clone().cuda()
+    sig = sigma_schedule(c["num_steps"], c["scheduler_scale"]).tolist()
+    pos = [torch.arange(T), torch.arange(H // 2), torch.arange(W // 2)]
+    dit.sample(lat, sig[:2], {"text_embeds": text.cuda(), "pooled_embed": pooled.cuda()}, {"text_embeds": ntext.cuda(), "pooled_embed": npooled.cuda()},
+               pos, torch.arange(L), torch.arange(c["null_text_len"]), c["guidance_weight"], scale_factor=(1.0, 2.0, 2.0))
+    torch.cuda.synchronize()
+    idx = G["sample_idx"]
+    got_lat = lat.reshape(-1)[idx.cuda()].cpu()
+    got_upd = got_lat - noise.reshape(-1)[idx]
+    r_upd, r_lat = rel(got_upd, G["update_val"]), rel(got_lat, G["latent_val"])
+    ss = (lat.cpu() - noise).double().pow(2).sum().item()
+    print(f"config 3 (CFG step at N = {T * H * W // 4}): update vs reference fp32 {r_upd:.3e}, latent {r_lat:.3e}; |update|^2 {ss:.5e} / {c['update_sumsq']:.5e}")
+    assert r_upd <= 3e-2, r_upd
+    assert r_lat <= 3e-2, r_lat
+    assert abs(ss - c["update_sumsq"]) <= 5e-2 * c["update_sumsq"]
