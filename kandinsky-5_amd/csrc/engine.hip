@@ -876,8 +876,8 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
 // HEADS — an all-to-all turns (rows of this rank x all 28 heads) into (all N rows x the 28 / P heads of this rank) for q | k and V^T, the
 // rank runs the ONE-GPU attention (a single balanced pass over all keys: no fp32 state between passes) for its heads, and a second
 // all-to-all brings the outputs back to the token shards.  Per rank and block 4 x (P - 1) / P^2 x N x D x 2 B leave the GPU (3/16 of
-// the 170 MB of a 5 s clip per tensor at P = 4) against 2 x (P - 1) / P x N x D x 2 B of ingress for the gather: half the bytes at
-// P = 2, a quarter at P = 4 — but the attention cannot start before q, k AND V^T have landed, where the gather hides behind pass 1.
+// the 170 MB of a 5 s clip per tensor at P = 4) against 2 x (P - 1) / P x N x D x 2 B of ingress for the gather: a ratio of 2 / P —
+// the same bytes at P = 2, half at P = 4, 2/7 at P = 7 — but the attention cannot start before q, k AND V^T have landed, where the gather hides behind pass 1.
 // Needs heads % P == 0 (28 = 2 x 2 x 7: P in 2, 4, 7, 14) and dense attention; anything else keeps the gather.  Replaces the head split
 // of the reference's tensor-parallel plan (parallelize.py:87-91) together with its all-reduces.
 // Layouts: send [P][rows_pad][2 Dp] (block g: q | k' of the heads of rank g, this rank's rows) -> recv [P][rows_pad][2 Dp] = all rows
