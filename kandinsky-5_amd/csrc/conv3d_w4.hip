@@ -334,11 +334,11 @@ int launch_conv_w4(const ConvW4P& p, int num_cu, hipStream_t stream) {
 // blocks are then the same 2 M / 256 as above).
 constexpr int HALO_W = 34, HALO_ROWS = 340, HALO_PIECES = 11 /* per wave */, HALO_BUF = 4 * HALO_PIECES * 1024;
 
-template <int NTW, bool RESID, bool STATS>
+template <int NTW, int S, bool RESID, bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3d_halo_kernel(ConvW4P p) {
   constexpr int BN = 32 * NTW;
   constexpr int WP = BN / 8;
-  constexpr int W_OP = WP * CW_PAD, H0 = 2 * W_OP;             // weight stage; byte offset of halo buffer 0
+  constexpr int W_OP = WP * CW_PAD, H0 = S * W_OP;             // weight stage (S of them); byte offset of halo buffer 0
   static_assert(H0 % 128 == 0 && HALO_BUF % 128 == 0, "halo rows are 128-byte aligned");
   constexpr int HALF = 8 * NTW, TOT = 16 * NTW;
   constexpr int NDW = WP / 4;                                  // weight DMA instructions per wave and K-tile
@@ -431,34 +431,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     h_soff = halo_soff();
   };
 
-  // fragment cursor: the K-tile whose fragments are read next = (slab parity f_sl & 1 -> halo buffer, in-plane tap f_i)
+  // fragment addresses: a lane reads its 16 halo rows per patch row at  hb + 128 R + 16 ((lc + 4 ks) ^ (R & 6)),  R = its row at tap
+  // (0, 0) + 34 dh + dw — recomputed for every K-tile (the key moves with the tap), piecewise BETWEEN the MFMAs of the K-tile before the
+  // reads that use it (left to the end of the K-tile the 28 instructions are exposed: the MFMA stream has drained by then).
   const uint32_t lds0 = (uint32_t)(uintptr_t)(cw_lds_t*)dsm;
-  int f_sl = 0, f_i = 0;
+  uint32_t hb_cur = lds0 + H0, hb_nxt = lds0 + H0 + HALO_BUF;   // halo buffer of the current / the next group
   const int xr0 = (4 * wm) * HALO_W + l15;     // halo row of this lane's position in patch row 4 wm at tap (0, 0)
   uint32_t xa[4][2];                           // [patch row of the wave][k-step]: byte address of the lane's 16-B chunk
-  auto set_xa = [&]() __attribute__((always_inline)) {
-    const int tap = (f_i / 3) * HALO_W + (f_i % 3);
-    const uint32_t hbase = lds0 + H0 + (f_sl & 1) * HALO_BUF;
-#pragma unroll
-    for (int jh = 0; jh < 4; ++jh) {
-      const uint32_t R = (uint32_t)(xr0 + HALO_W * jh + tap);
-      const uint32_t c0 = ((uint32_t)lc << 4) ^ ((R & 6u) << 4);
-      xa[jh][0] = hbase + (R << 7) + c0;
-      xa[jh][1] = hbase + (R << 7) + (c0 ^ 64u);
-    }
-  };
-  auto advance_f = [&]() __attribute__((always_inline)) {
-    if (++f_i == 9) { f_i = 0; if (++f_sl == cpt) f_sl = 0; }
-    set_xa();
+  auto xa_part = [&](int xr, int jh, int ks, int tapi, uint32_t hb) __attribute__((always_inline)) {
+    const uint32_t R = (uint32_t)(xr + HALO_W * jh + (tapi / 3) * HALO_W + (tapi % 3));
+    xa[jh][ks] = hb + (R << 7) + ((((uint32_t)lc << 4) ^ ((R & 6u) << 4)) ^ (ks ? 64u : 0u));
   };
 
-  uint32_t wbs[2];
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const int lcs = lc ^ (((l15 + 4) >> 3) & 1);
-    wbs[st] = lds0 + st * W_OP + ((NTW == 8 ? 16 * wn : 0) + l15) * CW_PAD + lcs * 16 + (NTW == 8 ? 0 : NTW * wn * 128);
-    asm volatile("" : "+v"(wbs[st]));
-  }
+  // weight stages: K-tile t sits in stage t % S; s_fill = the stage refilled during the current K-tile (its own), wrd = the lane's
+  // read base in the stage of the NEXT K-tile
+  uint32_t wb0 = lds0 + ((NTW == 8 ? 16 * wn : 0) + l15) * CW_PAD + (lc ^ (((l15 + 4) >> 3) & 1)) * 16 + (NTW == 8 ? 0 : NTW * wn * 128);
+  asm volatile("" : "+v"(wb0));
+  int s_fill = 0;
+  uint32_t wrd = wb0;
+  auto advance_stage = [&]() __attribute__((always_inline)) {
+    s_fill = s_fill + 1 == S ? 0 : s_fill + 1;
+    wrd = wb0 + (uint32_t)((s_fill + 1 == S ? 0 : s_fill + 1) * W_OP);
+  };
   bf16x8 wf0[NTW], xf0[8], wf1[2][NTW], xf1[2][8];
   f32x4 acc[NTW][8];
 
@@ -471,56 +465,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   set_halo_tile(slot);
   h_soff = halo_soff();
 #pragma unroll
-  for (int d = 0; d < NDW; ++d) dma_w(0, d);
-  advance_w();
+  for (int st = 0; st < S; ++st) {
 #pragma unroll
-  for (int d = 0; d < NDW; ++d) dma_w(1, d);
-  advance_w();
+    for (int d = 0; d < NDW; ++d) dma_w(st, d);
+    advance_w();
+  }
 #pragma unroll
   for (int pi = 0; pi < HALO_PIECES; ++pi) dma_h(pi);
   advance_halo();
-  set_xa();
+#pragma unroll
+  for (int jh = 0; jh < 4; ++jh) { xa_part(xr0, jh, 0, 0, hb_cur); xa_part(xr0, jh, 1, 0, hb_cur); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int i = 0; i < NTW; ++i) { CW_RD(wf0[i], wbs[0], i * 128); CW_RD(wf1[0][i], wbs[0], i * 128 + 64); }
+  for (int i = 0; i < NTW; ++i) { CW_RD(wf0[i], wrd, i * 128); CW_RD(wf1[0][i], wrd, i * 128 + 64); }
 #pragma unroll
   for (int j = 0; j < 8; ++j) { CW_RD(xf0[j], xa[j >> 1][0], (j & 1) * 2048); CW_RD(xf1[0][j], xa[j >> 1][1], (j & 1) * 2048); }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  advance_f();
+  wrd = wb0 + (uint32_t)((S > 1 ? 1 : 0) * W_OP);
+  if (S >= 3) {   // one-barrier schedule: K-tile 0 reads K-tile 1's k-step-1 fragments in its first half
+#pragma unroll
+    for (int jh = 0; jh < 4; ++jh) xa_part(xr0, jh, 1, 1, hb_cur);
+  }
 
-  // One K-tile (weight stage st) = TOT MFMAs, m = 0..TOT-1:
+  // One K-tile = TOT MFMAs, m = 0..TOT-1; PAR = its parity (fragment double buffer), I = its in-plane tap (position in the group):
   //   top: barrier (every wave holds this K-tile's fragments -> its weight stage may be refilled)
-  //   first half, m = DS d: weight DMA d of K-tile t+2;  after m = HALF-1: vmcnt(NDW) + barrier (K-tile t+1's weights, and every halo
-  //     piece issued before this K-tile, have landed)
-  //   second half: the 2 NR fragment reads of K-tile t+1, spread out; in its free slots the NH halo pieces HB.. of the next group
+  //   first half, m = DS d: weight DMA d of K-tile t+S;  after m = HALF-1: vmcnt(VM) + barrier — K-tile t+1's weights have landed:
+  //     VM = everything issued after them = the weights of K-tiles t+2-S .. t and the halo pieces of K-tiles t+1-S .. t-1
+  //   second half: the 2 NR fragment reads of K-tile t+1, spread out; in its free slots the halo pieces of the next group
+  //     (4, 4, 3 pieces in the group's K-tiles 0, 1, 2)
   constexpr int DS = TOT / 16;
+  constexpr bool ONEBAR = S >= 3;
   static_assert(NDW * DS <= HALF, "weight DMAs belong to the first half");
-  auto ktile = [&](auto STC, auto HBC, auto NHC) __attribute__((always_inline)) {
-    constexpr int st = decltype(STC)::value, HB = decltype(HBC)::value, NH = decltype(NHC)::value;
-    asm volatile("s_barrier" ::: "memory");
+  static_assert(!ONEBAR || (NTW == 4 && 2 * NR <= HALF), "the one-barrier schedule is laid out for the 256 x 128 tile");
+  auto ktile = [&](auto PARC, auto IC) __attribute__((always_inline)) {
+    constexpr int par = decltype(PARC)::value, I = decltype(IC)::value;
+    constexpr int NH = I < 2 ? 4 : I == 2 ? 3 : 0, HB = 4 * I;
+    auto nhs = [](int i) constexpr { i = (i + 9) % 9; return i < 2 ? 4 : i == 2 ? 3 : 0; };
+    constexpr int HSUM = (S > 1 ? nhs(I - 1) : 0) + (S > 2 ? nhs(I - 2) : 0) + (S > 3 ? nhs(I - 3) : 0);
+    constexpr int VM = (ONEBAR ? S - 2 : S - 1) * NDW + HSUM;
+    static_assert(S <= 4 && VM < 64, "vmcnt is a 6-bit field");
+    if (ONEBAR) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(VM) : "memory");
+    else asm volatile("s_barrier" ::: "memory");
+    int xr = xr0;
+    asm volatile("" : "+v"(xr));   // derived in this K-tile: hoisted per tap the rows are 36 registers (and spills)
+    const uint32_t hb1 = I + 1 < 9 ? hb_cur : hb_nxt, hb2 = I + 2 < 9 ? hb_cur : hb_nxt;   // halo buffer of K-tile t+1 / t+2
+    auto rd = [&](int r) __attribute__((always_inline)) {   // fragment read r of K-tile t+1: k-step r / NR, weights then positions
+      const int rr = r % NR, j = (rr - NTW) & 7;
+      if (r < NR) { if (rr < NTW) CW_RD(wf0[rr % NTW], wrd, (rr % NTW) * 128); else CW_RD(xf0[j], xa[j >> 1][0], (j & 1) * 2048); }
+      else { if (rr < NTW) CW_RD(wf1[par ^ 1][rr % NTW], wrd, (rr % NTW) * 128 + 64); else CW_RD(xf1[par ^ 1][j], xa[j >> 1][1], (j & 1) * 2048); }
+    };
     auto chunk = [&](auto BASEC) __attribute__((always_inline)) {
 #pragma unroll
       for (int m = decltype(BASEC)::value; m < decltype(BASEC)::value + 16; ++m) {
         if (m < HALF) CW_MF(wf0, xf0, m);
-        else CW_MF(wf1[st], xf1[st], m - HALF);
-        if (m % DS == 0 && m / DS < NDW) dma_w(st, m / DS);
-        if (m == HALF - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NDW) : "memory");
-        {
-          const int sl = m - HALF;
+        else CW_MF(wf1[par], xf1[par], m - HALF);
+        if (m % DS == 0 && m / DS < NDW) dma_w(s_fill, m / DS);
+        const int sl = m - HALF;
+        if (!ONEBAR) {
+          if (m == HALF - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(VM) : "memory");
+          // second half: reads in every second slot (NTW = 8) / three of four (NTW = 4), halo pieces in slots without one
           const bool has = sl >= 0 && (NTW == 8 ? (sl & 1) == 0 : (sl & 3) != 3);
           const int r = NTW == 8 ? sl / 2 : sl - sl / 4;
-          if (has && r < 2 * NR) {
-            const int rr = r % NR, ks = r / NR;
-            if (rr < NTW) {
-              if (ks == 0) CW_RD(wf0[rr % NTW], wbs[st ^ 1], (rr % NTW) * 128); else CW_RD(wf1[st ^ 1][rr % NTW], wbs[st ^ 1], (rr % NTW) * 128 + 64);
-            } else {
-              const int j = (rr - NTW) & 7;
-              if (ks == 0) CW_RD(xf0[j], xa[j >> 1][0], (j & 1) * 2048); else CW_RD(xf1[st ^ 1][j], xa[j >> 1][1], (j & 1) * 2048);
-            }
-          }
-          // halo pieces: the slots of the second half that carry no fragment read
+          if (has && r < 2 * NR) rd(r);
           if (NTW == 8 ? (sl >= 0 && (sl & 15) == 1 && sl / 16 < NH) : (sl >= 0 && (sl & 7) == 3 && sl / 8 < NH)) dma_h(HB + (NTW == 8 ? sl / 16 : sl / 8));
+          // the addresses of K-tile t+1 (both k-steps), in eight slots of the first half
+          if (m < HALF && m % (HALF / 8) == HALF / 16) xa_part(xr, (m / (HALF / 8)) >> 1, (m / (HALF / 8)) & 1, (I + 1) % 9, hb1);
+        } else {
+          // one barrier per K-tile: the weights of K-tile t+1 landed before it, so its fragments are read across the WHOLE K-tile —
+          // k-step 1 (into the idle half of the double buffer) in the odd slots of the first half, k-step 0 (wf0 / xf0 are free once the
+          // first half has issued) in those of the second; the last read is 8 MFMAs before the end
+          const int hs = m < HALF ? m : sl;                    // slot within the half
+          if ((hs & 1) && hs / 2 < NR) rd((m < HALF ? NR : 0) + hs / 2);
+          if (sl >= 0 && (sl & 7) == 2 && sl / 8 < NH) dma_h(HB + sl / 8);
+          // addresses: k-step 0 of K-tile t+1 in the first half (read in the second), k-step 1 of K-tile t+2 in the second half
+          // (read in the next K-tile's first half; this K-tile's k-step-1 reads have been issued by then)
+          if (m < HALF && (m & 3) == 2 && m / 4 < 4) xa_part(xr, m / 4, 0, (I + 1) % 9, hb1);
+          if (sl >= 0 && (sl & 7) == 4) xa_part(xr, sl / 8, 1, (I + 2) % 9, hb2);
         }
       }
     };
@@ -532,10 +553,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     advance_w();
-    advance_f();
+    advance_stage();
+    if (I == 2) advance_halo();
+    if (I == 8) { const uint32_t t = hb_cur; hb_cur = hb_nxt; hb_nxt = t; }
   };
-  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-  using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
+  auto group = [&](auto PARC) __attribute__((always_inline)) {   // nine K-tiles; PARC = the parity of the first one
+    using P0 = decltype(PARC); using P1 = std::integral_constant<int, P0::value ^ 1>;
+    ktile(P0{}, std::integral_constant<int, 0>{}); ktile(P1{}, std::integral_constant<int, 1>{}); ktile(P0{}, std::integral_constant<int, 2>{});
+    ktile(P1{}, std::integral_constant<int, 3>{}); ktile(P0{}, std::integral_constant<int, 4>{}); ktile(P1{}, std::integral_constant<int, 5>{});
+    ktile(P0{}, std::integral_constant<int, 6>{}); ktile(P1{}, std::integral_constant<int, 7>{}); ktile(P0{}, std::integral_constant<int, 8>{});
+  };
 
   // every MFMA accumulates: the accumulators start at zero and the epilogue leaves them at zero (256 v_accvgpr_write per 27 Cin / 64
   // K-tiles; a write-only first K-tile would be a second copy of the group code below)
@@ -547,26 +574,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   zero_acc();
   for (int ti = slot; ti < x_cnt; ti += per_xcd) {
-    for (int gp = 0; gp < 3 * cpt; gp += 2) {
-      // group gp (weight stage 0 first): its first three K-tiles carry the halo of group gp + 1
-      ktile(I0{}, I0{}, I4{});
-      ktile(I1{}, I4{}, I4{});
-      ktile(I0{}, I8{}, I3{});
-      advance_halo();
-      for (int r = 0; r < 3; ++r) { ktile(I1{}, I0{}, I0{}); ktile(I0{}, I0{}, I0{}); }
-      // group gp + 1 (weight stage 1 first)
-      ktile(I1{}, I0{}, I4{});
-      ktile(I0{}, I4{}, I4{});
-      ktile(I1{}, I8{}, I3{});
-      advance_halo();
-      for (int r = 0; r < 3; ++r) { ktile(I0{}, I0{}, I0{}); ktile(I1{}, I0{}, I0{}); }
+    for (int gp = 0; gp < 3 * cpt; gp += 2) {   // the halo of group g + 1 arrives during the first three K-tiles of group g
+      group(std::integral_constant<int, 0>{});
+      group(std::integral_constant<int, 1>{});
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs are invisible to the hazard recogniser
     const int lid = x_first + ti;
     const int mt = lid / p.tiles_n, n0 = (lid % p.tiles_n) * BN;
     const int wbi = mt % p.wb, hbi = (mt / p.wb) % p.hb, tt = mt / (p.wb * p.hb);
     const int morg = (tt * p.Ho + 8 * hbi) * p.Wo + 32 * wbi;
+#ifndef K5_CONV_ABLATE_EPI   // timing ablation (wrong results): no epilogue
     conv_w4_epilogue<NTW, RESID, STATS>(p, acc, n0, mt, [&](int row) __attribute__((always_inline)) { return morg + (row >> 5) * p.Wo + (row & 31); });
+#endif
     zero_acc();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing may still be loading into a VGPR when the asm stream resumes
   }
@@ -578,14 +597,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 template <int NTW, bool RESID, bool STATS>
 int launch_conv_halo(const ConvW4P& p, int num_cu, hipStream_t stream) {
-  constexpr int LDS = 2 * (32 * NTW / 8) * CW_PAD + 2 * HALO_BUF;
+  constexpr int S = NTW == 8 ? 2 : 4;   // weight stages: what fits beside the two halo buffers
+  constexpr int LDS = S * (32 * NTW / 8) * CW_PAD + 2 * HALO_BUF;
+  static_assert(LDS <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3d_halo_kernel<NTW, RESID, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return K5_ERR_HIP;
+    if (hipFuncSetAttribute((const void*)conv3d_halo_kernel<NTW, S, RESID, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return K5_ERR_HIP;
     attr_set = true;
   }
   const int tiles = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((conv3d_halo_kernel<NTW, RESID, STATS>), dim3(min(tiles, num_cu)), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((conv3d_halo_kernel<NTW, S, RESID, STATS>), dim3(min(tiles, num_cu)), dim3(256), LDS, stream, p);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
