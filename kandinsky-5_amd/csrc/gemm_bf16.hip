@@ -742,17 +742,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     d_cnt = 0;
     vw = vw0 + (uint32_t)d_kt * (2 * BK); vx = vx0 + (uint32_t)d_kt * (2 * BK);
   };
+#ifndef W4_AUX
+#define W4_AUX 0   // cache policy of the operand DMAs (A/B macro: sc0 = 1, nt = 2, sc1 = 16 — none of them moved the stream)
+#endif
   auto dma_w = [&](int stage) {
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + stage * W4_STAGE + (dslot + jj) * W4_PAD), 16, vw,
-                                               (uint32_t)(drow + jj) * ldw2, 0, 0);
+                                               (uint32_t)(drow + jj) * ldw2, 0, W4_AUX);
   };
   auto dma_x = [&](int stage) {
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + stage * W4_STAGE + W4_OP + (dslot + jj) * W4_PAD), 16, vx,
-                                               (uint32_t)(drow + jj) * lda2, 0, 0);
+                                               (uint32_t)(drow + jj) * lda2, 0, W4_AUX);
   };
   // after a K-tile's 16 DMAs: move the cursor; past the last tile it wraps onto the same tile (harmless loads that keep
   // the vmcnt arithmetic uniform; nothing reads them)
@@ -797,9 +800,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto dma1 = [&](int stage, int d) {
     if (dbg & 1) return;
     if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + stage * W4_STAGE + (dslot + d) * W4_PAD), 16, vw,
-                                                        (uint32_t)(drow + d) * ldw2, 0, 0);
+                                                        (uint32_t)(drow + d) * ldw2, 0, W4_AUX);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + stage * W4_STAGE + W4_OP + (dslot + d - 8) * W4_PAD), 16, vx,
-                                                  (uint32_t)(drow + d - 8) * lda2, 0, 0);
+                                                  (uint32_t)(drow + d - 8) * lda2, 0, W4_AUX);
   };
 
   set_dma_tile(slot);

@@ -76,10 +76,12 @@ def test_conv3d_kernel_with_upsample_and_residual(vae):
 
 
 @pytest.mark.parametrize("Cin,Cout,up,dims", [(128, 128, (1, 1), (5, 112, 128)), (128, 256, (2, 2), (3, 60, 64)), (256, 128, (1, 2), (4, 64, 72)),
-                                              (512, 512, (2, 2), (3, 36, 48)), (128, 128, (1, 1), (5, 113, 127))])   # the last one: M not a multiple of 256, odd width
+                                              (512, 512, (2, 2), (3, 36, 48)), (128, 128, (1, 1), (5, 113, 127)),   # M not a multiple of 256, odd width
+                                              (256, 128, (1, 2), (4, 64, 64))])   # halo form of the 256 x 128 tile with four slabs (4 weight stages, one barrier per K-tile)
 def test_conv3d_four_wave_kernel(vae, Cin, Cout, up, dims):
-    """Shapes in the range of the 4-wave 256-row kernel (conv3d_w4.hip: Cin % 128 == 0, Cout = 128 or % 256, >= 256 tiles):
-    gather offsets per tap (replicate pad, causal T, folded nearest upsample), both tile shapes, residual epilogue, ragged M."""
+    """Shapes in the range of the 4-wave 256-row kernels (conv3d_w4.hip: Cin % 128 == 0, Cout = 128 or % 256, >= 256 tiles): output
+    frames of whole 8 x 32 patches take the LDS-halo form (cases 1, 2, 4, 6), the others the per-tap gather (cases 3, 5): source
+    offsets (replicate pad, causal T, folded nearest upsample), both tile shapes, residual epilogue, ragged M."""
     from kandinsky import _engine as E
     torch.manual_seed(1)
     Ts, Hs, Ws = dims
