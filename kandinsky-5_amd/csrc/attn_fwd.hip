@@ -49,6 +49,17 @@ constexpr float K5_ATTN_ROW_MIN = 7.8886091e-31f;
 // common component (bench.py --qk-gain 5): gambling on bounds up to 300 computed most jobs twice (947 ms per step against 688 for the
 // online form everywhere), the centred bound below 190 never does (gain 4: 553 ms, all heads fixed; plain offsets: 583-613).
 constexpr float K5_ATTN_ROWOFF_LIMIT = 190.f;
+// ANCHORED offsets (AttnP::row_anchor) for the heads beyond that limit: the offset of a row is an ACHIEVED score — the maximum s over a
+// sample of keys (the row's own 64-token block + a strided sample, attn_row_anchor_kernel) — plus e + K5_ATTN_ANCHOR_ADD, where
+// e = min(K5_ATTN_ANCHOR_EXTRA_MAX, K5_ATTN_ANCHOR_SPREAD (s - sample mean)) places the window where the maximum over ALL keys is
+// expected (for scores that scatter like a Gaussian the maximum of 47 616 lies ~ 1.3 sigma above the maximum of 512, and s - mean ~ 3
+// sigma).  The row's true maximum m satisfies m >= s, so its term is >= 2^-80 and the row sum cannot underflow whatever the norms are
+// (a PART of a split job may: harmless, its terms are < 2^-20 of the row's); the form is exact while m < s + e + 132 (row sum < 2^112).
+// Beyond that the row sum grows past K5_ATTN_ROW_MAX (or turns inf / NaN) and the job falls back to the online form like an
+// underflowing one: below 2^112 the sum bounds every accumulator (|O| <= l max|v|), so nothing overflowed unnoticed.
+constexpr float K5_ATTN_ANCHOR_ADD = 20.f, K5_ATTN_ANCHOR_SPREAD = 0.45f, K5_ATTN_ANCHOR_EXTRA_MAX = 60.f;
+constexpr float K5_ATTN_ROW_MAX = 5.1922969e33f;   // 2^112
+constexpr int K5_ANCHOR_TILES = 32;                // 16-key sample tiles per row: 4 of the row's own block + 28 strided over all keys
 
 struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
@@ -78,6 +89,9 @@ struct AttnP {
   // — no underflow at all while |q| R <= 190, whatever common component the scores carry (keys sharing a large mean direction put every
   // score of a head near +-0.4 of its plain bound: with the plain offset such rows underflow wholesale).  null: plain offsets.
   const float* kcentre; const float* krad;
+  // ANCHORED per-row offsets (K5_ATTN_ANCHOR_ADD above): row_anchor[h * q_len + row], read for the heads whose kmax entry is NEGATIVE
+  // (k5_launch_attn_flags marks a head beyond the Cauchy-Schwarz window that way instead of sending it to the online form)
+  const float* row_anchor;
   // multi-pass schedules (sequence parallelism) with per-row offsets: 0 = single launch group (an underflowing row writes flag 0 and
   // the online launch of the same call redoes the head), 1 = a pass that is not the last (the row writes flag 2 = "late": every
   // later fixed-offset launch skips the head, the online launches of non-final passes skip it too), 2 = the last pass (the online
@@ -363,8 +377,17 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   f32x4 nm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   bool fresh = true;             // !BOUNDED, wave-uniform: no tile processed yet -> the first one SETS the offset
   bool over_limit = false;
+  bool anchored = false;   // workgroup-uniform: the head runs on anchored offsets (a part's sum may underflow harmlessly; the row's cannot)
   if (BOUNDED && PRE && p.kmax) {   // per-row constant offsets from |q_row| * max|k'| (see AttnP::kmax); 0 when the bound is <= 90
     const float km = p.kmax[h];
+    anchored = km < 0.f && p.row_anchor;
+    if (anchored) {   // workgroup-uniform
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const float off = p.row_anchor[(size_t)h * p.q_len + min(q0 + 16 * qt + l15, p.q_len - 1)];
+        nm[qt] = f32x4{-off, -off, -off, -off};
+      }
+    } else {
     const bool centred = p.kcentre != nullptr;   // kernel-uniform
     const float kr = centred ? p.krad[h] : 0.f;
     f32x4 cc[2][2];   // the centre's entries at this lane's 16 query dimensions (32 ks + 8 g .. + 8)
@@ -413,6 +436,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
       off = ceilf(off);
       nm[qt] = f32x4{-off, -off, -off, -off};
       if (QN) over_limit |= (q0 + 16 * qt + l15 < p.q_len) && !(bnd <= K5_ATTN_ROWOFF_LIMIT);   // NaN counts as over
+    }
     }
   }
   // Fused query norm: no max|q|^2 statistic preceded this launch, so the head-level choice is taken here — a wave that holds a row
@@ -603,7 +627,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         st_ml[0] = BOUNDED ? 0.f : (fresh ? -1e30f : -nm[qt][0]);   // no tile seen: weight 0 in a merge, "still fresh" on resume
         st_ml[1] = g == 0 ? lt[qt][0] : 0.f;                    // slot 0 carries the whole row sum
         // per-row offsets: a part whose own sum underflows flags the head (conservative: the row's total is at least this part's)
-        if (BOUNDED && PRE && p.kmax && nm[qt][0] != 0.f && lt[qt][0] < K5_ATTN_ROW_MIN && seen) {
+        if (BOUNDED && PRE && p.kmax && nm[qt][0] != 0.f && !((lt[qt][0] >= K5_ATTN_ROW_MIN || anchored) && lt[qt][0] < K5_ATTN_ROW_MAX) && seen) {
           if (p.job_flags) const_cast<int*>(p.job_flags)[lid] = p.late_pass ? 2 : 1;
           else const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
         }
@@ -617,7 +641,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     const float l_tot = lt[qt][0];   // the ones-MFMA left the whole row sum in every lane of the query's column
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int q = q0 + 16 * qt + l15;
-    if (BOUNDED && PRE && p.kmax && q < p.q_len && nm[qt][0] != 0.f && l_tot < K5_ATTN_ROW_MIN) {
+    if (BOUNDED && PRE && p.kmax && q < p.q_len && nm[qt][0] != 0.f && !(l_tot >= K5_ATTN_ROW_MIN && l_tot < K5_ATTN_ROW_MAX)) {
       if (p.job_flags) const_cast<int*>(p.job_flags)[lid] = p.late_pass ? 2 : 1;
       else const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
     }
@@ -915,7 +939,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
 // out; the head-level bound is then the smaller of |q|max kmax and |q|max R (the centred offsets' survival depends on the latter).
 __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstride, int H, float limit, int force_online,
                                   int* flags, unsigned long long* counters, float* kmax_out, const int* prefer_online, float* rstat, float* krad_out,
-                                  int nq, int qstride) {
+                                  int nq, int qstride, int anchored) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
   float q2 = 0.f;   // nq partial maxima at stride qstride (Ulysses: one per rank that holds rows of this head's queries; otherwise 1)
@@ -930,9 +954,13 @@ __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstrid
     if (b > K5_ATTN_EXP_LIMIT) b = fminf(b, sqrtf(q2) * rr * 1.002f);   // NaN-safe: fminf keeps the finite operand only when b is finite too
     rstat[h] = 0.f;
   }
-  const int fast = (!force_online && b <= limit && !(prefer_online && b > K5_ATTN_EXP_LIMIT && prefer_online[h])) ? 1 : 0;   // NaN / inf compare false -> online
+  const bool pref = prefer_online && b > K5_ATTN_EXP_LIMIT && prefer_online[h];
+  // anchored: a head beyond the window keeps the fixed form on offsets anchored at achieved scores (AttnP::row_anchor; marked by a
+  // negative kmax entry) unless its jobs kept falling back (prefer_online); inf / NaN statistics go to the online form as before
+  const bool anchor = anchored && kmax_out && !force_online && !pref && b > limit && b < 3.0e38f;
+  const int fast = ((!force_online && b <= limit && !pref) || anchor) ? 1 : 0;   // NaN / inf compare false -> online
   flags[h] = fast;
-  if (kmax_out) kmax_out[h] = sqrtf(k2) * 1.002f;   // per-row offsets of the fixed-offset form: |q_row| * this - 90 (AttnP::kmax)
+  if (kmax_out) kmax_out[h] = anchor ? -1.f : sqrtf(k2) * 1.002f;   // per-row offsets of the fixed-offset form: |q_row| * this - 90 (AttnP::kmax)
   if (counters) atomicAdd(counters + (fast ? 0 : 1), 1ull);
   for (int i = 0; i < nq; ++i) qstat[(size_t)i * qstride + h] = 0.f;
   for (int i = 0; i < nk; ++i) kstat[(size_t)i * kstride + h] = 0.f;
@@ -951,6 +979,48 @@ __global__ __launch_bounds__(64) void attn_pref_update_kernel(const int* job_fla
   for (int j = threadIdx.x; j < nqb; j += 64) cnt += job_flags[h * nqb + j] != 0;
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
   if (threadIdx.x == 0 && 4 * cnt > nqb) prefer_online[h] = 1;
+}
+
+// Anchored offsets (K5_ATTN_ANCHOR_ADD): for every query row of a head marked by a negative kmax entry, the maximum score over a sample
+// of K5_ANCHOR_TILES 16-key tiles — the four tiles of the row's own 64-token block (key index = query index + key0: self-attention;
+// with RoPE and a trained model the row's best keys are its neighbours) and a strided sample of the whole key range — rounded up to an
+// integer (the softmax is offset-invariant, and an integer offset keeps every bf16 probability what any other integer offset gives),
+// plus the constant.  One wave per 16 query rows: S^T = K Q^T on MFMA 16x16x32 with both operands straight from global memory
+// (the sample is 32 x 2 KB per head: cache-resident), 64 MFMAs per wave.  Pre-scaled keys: the scores ARE the exp2 arguments.
+__global__ __launch_bounds__(256) void attn_row_anchor_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, int q_len, int kv_len,
+                                                              int ldq, int ldk, int key0, const float* __restrict__ kmax, float* __restrict__ out) {
+  const int h = blockIdx.y;
+  if (!(kmax[h] < 0.f)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+  const int q0 = 64 * blockIdx.x + 16 * wave;
+  if (q0 >= q_len) return;
+  const bf16_t* qp = Q + (size_t)min(q0 + l15, q_len - 1) * ldq + h * 64 + 8 * g;
+  const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp), qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+  const int ntile = kv_len / 16;   // kv_len is a multiple of 64 (pre-scaled keys)
+  float mx = -3.0e38f, sum = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < K5_ANCHOR_TILES; ++i) {
+    const int t = i < 4 ? min(max((64 * (int)blockIdx.x + key0) / 16 + i, 0), ntile - 1)
+                        : (int)(((long long)(i - 4) * ntile) / (K5_ANCHOR_TILES - 4));
+    const bf16_t* kp = K + (size_t)(16 * t + l15) * ldk + h * 64 + 8 * g;
+    const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp), kf1 = *reinterpret_cast<const bf16x8*>(kp + 32);
+    f32x4 st = mfma16(kf0, qf0, f32x4{0.f, 0.f, 0.f, 0.f});
+    st = mfma16(kf1, qf1, st);   // lane (query l15, g): keys 4 g .. 4 g + 3 of the tile
+    mx = fmaxf(mx, fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
+    sum += (st[0] + st[1]) + (st[2] + st[3]);
+  }
+  {   // the query's four lanes (l15 + 16 g)
+    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    mx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    mx = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+    const auto t16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+    sum = __uint_as_float(t16[0]) + __uint_as_float(t16[1]);
+    const auto t32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+    sum = __uint_as_float(t32[0]) + __uint_as_float(t32[1]);
+  }
+  const float extra = fminf(fmaxf(K5_ATTN_ANCHOR_SPREAD * (mx - sum * (1.0f / (16 * K5_ANCHOR_TILES))), 0.f), K5_ATTN_ANCHOR_EXTRA_MAX);
+  if (g == 0 && q0 + l15 < q_len) out[(size_t)h * q_len + q0 + l15] = ceilf(mx + extra) + K5_ATTN_ANCHOR_ADD;
 }
 
 }  // namespace
@@ -997,13 +1067,23 @@ int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_ro
 
 int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
                          unsigned long long* counters, hipStream_t stream, float* kmax_out, const int* prefer_online, float* rstat, float* krad_out,
-                         int nq, int qstride) {
+                         int nq, int qstride, bool anchored) {
   if ((rstat == nullptr) != (krad_out == nullptr) || (rstat && !kmax_out) || nq < 1) return K5_ERR_ARG;
   if (!qstat || !kstat || !flags || H <= 0 || nk <= 0) return K5_ERR_ARG;
   // with kmax_out the attention runs per-row offsets: heads up to K5_ATTN_ROWOFF_LIMIT keep the fixed-offset form
   hipLaunchKernelGGL(attn_flags_kernel, dim3((H + 63) / 64), dim3(64), 0, stream, qstat, kstat, nk, kstride, H,
                      kmax_out ? K5_ATTN_ROWOFF_LIMIT : K5_ATTN_EXP_LIMIT, force_online, flags, counters, kmax_out, kmax_out ? prefer_online : nullptr,
-                     rstat, krad_out, nq, qstride);
+                     rstat, krad_out, nq, qstride, anchored ? 1 : 0);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
+// anchored offsets of the heads k5_launch_attn_flags(anchored) marked (negative kmax entry): out [H][q_len]; key0 = the key index of
+// query row 0 (0 on one GPU; a rank's first token under sequence parallelism).  Other heads' rows are left untouched.
+int k5_launch_attn_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, const float* kmax,
+                              float* out, hipStream_t stream) {
+  if (!Q || !Kc || !kmax || !out || H <= 0 || q_len <= 0 || kv_len < KB || (kv_len % KB) || (ldq & 7) || (ldk & 7)) return K5_ERR_ARG;
+  hipLaunchKernelGGL(attn_row_anchor_kernel, dim3((q_len + 63) / 64, H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)Kc, q_len, kv_len,
+                     ldq, ldk, key0, kmax, out);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -1031,6 +1111,7 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;   // per-row offsets need the per-head flags (late fallback)
   p.kmax = kmax;
   p.kcentre = (kc && kmax) ? kc->centre : nullptr; p.krad = (kc && kmax) ? kc->radius : nullptr;
+  p.row_anchor = (kc && kmax) ? kc->row_anchor : nullptr;
   if ((p.kcentre == nullptr) != (p.krad == nullptr)) return K5_ERR_ARG;
   if (late_pass < 0 || late_pass > 2 || (late_pass && !kmax)) return K5_ERR_ARG;
   p.late_pass = late_pass; p.late_total = (kv_len + KB - 1) / KB;
@@ -1147,6 +1228,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;
   p.kmax = kmax; p.late_pass = 0; p.late_total = 0; p.q_norm_w = nullptr; p.q_cos = p.q_sin = nullptr; p.variant_counters = nullptr;
   p.kcentre = (kc && kmax) ? kc->centre : nullptr; p.krad = (kc && kmax) ? kc->radius : nullptr;
+  p.row_anchor = (kc && kmax) ? kc->row_anchor : nullptr;
   if ((p.kcentre == nullptr) != (p.krad == nullptr)) return K5_ERR_ARG;
   p.job_flags = nullptr;
   if (kmax && ws) {

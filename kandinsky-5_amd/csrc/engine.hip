@@ -330,6 +330,8 @@ struct k5_dit {
   int sp_nabla_passes = 1;                         // "sp_nabla_passes" = 2: NABLA under sequence parallelism attends the rank's own key blocks during the gather
   int fuse_qnorm = 0;                              // "attn_fuse_qnorm": norm_qk + RoPE of the visual queries inside the attention kernel
   bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 190)
+  bool anchor = true;                              // "attn_anchor": heads beyond that window run the fixed form on anchored offsets (one-GPU path)
+  DevBuf ws_attn_anchor;                           // [H][rows] anchored offsets (k5_launch_attn_row_anchor)
   int sp_slices = 1;                               // "sp_slices": the K / V^T exchange of a block in this many slices (dense attention)
   int sp_mode = 0;                                 // "sp_mode": 0 = K / V^T all-gather (any rank count), 1 = Ulysses all-to-all (heads % ranks == 0, dense attention)
   DevBuf ws_u_send, ws_u_recv, ws_u_vsend, ws_u_vrecv, ws_u_o, ws_u_orecv, ws_u_stats;   // Ulysses exchange buffers
@@ -594,9 +596,17 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
       float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
       kmax = kmax_w;
       if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
+      // heads beyond the Cauchy-Schwarz window: anchored offsets (needs the normalised queries in memory: not with the fused query norm)
+      const bool anchored = centre && d->anchor && !fuse_q;
       K5CHK(k5_launch_attn_flags(stats, stats + H, 1, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w,
-                                 kmax_w ? a.pref.as<int>() : nullptr, centre ? stats + 2 * H : nullptr, centre ? kmax_w + H : nullptr));
+                                 kmax_w ? a.pref.as<int>() : nullptr, centre ? stats + 2 * H : nullptr, centre ? kmax_w + H : nullptr, 1, 0, anchored));
       if (centre) { kcen.centre = centre; kcen.radius = kmax_w + H; kcp = &kcen; }
+      if (anchored) {
+        K5CHK(d->ws_attn_anchor.ensure((size_t)H * rows * 4));
+        K5CHK(k5_launch_attn_row_anchor(qk, (pre && nabla) ? (const void*)d->ws_kc.p : (const void*)((const bf16_t*)qk + D), H, rows, rows, 2 * D,
+                                        (pre && nabla) ? D : 2 * D, 0, kmax_w, d->ws_attn_anchor.as<float>(), s));
+        kcen.row_anchor = d->ws_attn_anchor.as<float>();
+      }
     }
   }
   const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
@@ -1744,6 +1754,9 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //   "sp_pass1_tiles"  local key tiles attended before the K/V^T gather has landed (0 = all of the rank's own tiles)
 //   "attn_row_offsets" 1 (default) / 0: fixed-offset softmax with per-row offsets — heads whose bound max|q| max|k'| lies in (90, 190]
 //                     stay on the fast kernel (a row whose sum underflows sends its head to the online form late); 0 = the plain <= 90 rule
+//   "attn_anchor"     1 (default) / 0: heads beyond that window keep the fixed form on offsets anchored at achieved scores (the row's maximum
+//                     over a sample of keys + 20; attn_row_anchor_kernel) — no underflow whatever the norms, a job whose row sum
+//                     overflows falls back to the online form like an underflowing one; 0 = such heads take the online form (one-GPU path)
 //   "attn_fuse_qnorm" 0 (default): norm_qk + RoPE of the visual queries is a standalone pass; 1 = dense visual self-attention on ONE rank
 //                     applies it inside the attention kernel's Q-fragment load (K5QueryNorm; needs attn_row_offsets or attn_mode 1);
 //                     2 = under sequence parallelism too.  Measured neutral (elementwise -2.0 ms, attention +0.6 .. +3.4 ms per step
@@ -1771,6 +1784,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   if (!strcmp(name, "sp_pass1_tiles")) { if (value < 0) return K5_ERR_ARG; d->sp_pass1_tiles = value; return K5_OK; }
   if (!strcmp(name, "sp_mode")) { if (value < 0 || value > 1) return K5_ERR_ARG; d->sp_mode = value; return K5_OK; }
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
+  if (!strcmp(name, "attn_anchor")) { d->anchor = value != 0; return K5_OK; }
   if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }
   if (!strcmp(name, "sp_nabla_passes")) { if (value < 1 || value > 2) return K5_ERR_ARG; d->sp_nabla_passes = value; return K5_OK; }
   if (!strcmp(name, "attn_fuse_qnorm")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->fuse_qnorm = value; return K5_OK; }
@@ -1795,6 +1809,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "sp_mode")) *value = d->sp_mode;
   else if (!strcmp(name, "sp_slices")) *value = d->sp_slices;
   else if (!strcmp(name, "attn_row_offsets")) *value = d->row_offsets ? 1 : 0;
+  else if (!strcmp(name, "attn_anchor")) *value = d->anchor ? 1 : 0;
   else if (!strcmp(name, "attn_fuse_qnorm")) *value = d->fuse_qnorm;
   else if (!strcmp(name, "sp_nabla_passes")) *value = d->sp_nabla_passes;
   else if (!strcmp(name, "nabla_group_rows")) *value = d->nabla_group_rows;

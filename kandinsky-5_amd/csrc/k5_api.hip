@@ -99,6 +99,26 @@ int k5_attention_bf16_prescaled_rows_centred(const void* Q, const void* Kc, cons
                                             nullptr, 0, (hipStream_t)stream, (float*)workspace, true, head_flags, K5_ATTN_AUTO, nullptr, kmax, 0, nullptr, &kc),
              "k5_attention_bf16_prescaled_rows_centred");
 }
+// anchored offsets for the heads beyond the window (include/k5.h): flags with the marker, the offsets, the attention that reads them
+int k5_attention_flags_rows_anchored(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags, float* kmax, float* rstat,
+                                     float* krad, const int* prefer_online, void* stream) {
+  if (!kmax || !rstat || !krad) return ret(K5_ERR_ARG, "k5_attention_flags_rows_anchored");
+  return ret(k5_launch_attn_flags(qstat, kstat, nk, kstride, H, force_online, flags, nullptr, (hipStream_t)stream, kmax, prefer_online, rstat, krad, 1, 0, true),
+             "k5_attention_flags_rows_anchored");
+}
+int k5_attention_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, const float* kmax, float* anchor,
+                            void* stream) {
+  return ret(k5_launch_attn_row_anchor(Q, Kc, H, q_len, kv_len, ldq, ldk, key0, kmax, anchor, (hipStream_t)stream), "k5_attention_row_anchor");
+}
+int k5_attention_bf16_prescaled_rows_anchored(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
+                                              int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, const float* centre, const float* krad,
+                                              const float* anchor, void* workspace, void* stream) {
+  if (!head_flags || !kmax || !centre || !krad || !anchor) return ret(K5_ERR_ARG, "k5_attention_bf16_prescaled_rows_anchored");
+  const K5KeyCentre kc{centre, krad, anchor};
+  return ret(k5_launch_attention_bf16_range(Q, Kc, Vt, O, H, q_len, kv_len, ldq, ldk, ldvt, ldo, 0.f, 0, 0, 0, -1, 0x7fffffff, 0,
+                                            nullptr, 0, (hipStream_t)stream, (float*)workspace, true, head_flags, K5_ATTN_AUTO, nullptr, kmax, 0, nullptr, &kc),
+             "k5_attention_bf16_prescaled_rows_anchored");
+}
 int k5_attention_bf16_prescaled_rows(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                      int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, void* workspace, void* stream) {
   if (!head_flags || !kmax) return ret(K5_ERR_ARG, "k5_attention_bf16_prescaled_rows");

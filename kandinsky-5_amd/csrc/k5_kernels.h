@@ -39,7 +39,9 @@ struct K5QueryNorm { const float* w; const float* cos; const float* sin; unsigne
 // Centred form of the per-row offsets (AttnP::kcentre): centre [H][64] = a convex combination of each head's keys (k5_launch_rmsnorm_rope
 // key_centre), radius [H] = max |k' - centre| with margin (k5_launch_attn_flags krad_out).  Rows whose plain bound |q| kmax exceeds 90 run
 // with the offset q.c + |q| R - 90: no overflow, and no row-sum underflow while |q| R <= 190 whatever common component the scores carry.
-struct K5KeyCentre { const float* centre; const float* radius; };
+// row_anchor (nullable, [H][q_len]): anchored offsets of the heads k5_launch_attn_flags(anchored) marked with a negative kmax entry
+// (k5_launch_attn_row_anchor) — AttnP::row_anchor
+struct K5KeyCentre { const float* centre; const float* radius; const float* row_anchor = nullptr; };
 int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len,
                                    int kv_len, int ldq, int ldk, int ldvt, int ldo, float score_bound,
                                    int vt_chunk_keys, long long vt_chunk_stride, int tile_off0, int tile_cnt, int tile_skip_at,
@@ -63,7 +65,10 @@ enum { K5_ATTN_AUTO = 0, K5_ATTN_ONLINE = 1 };
 int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
                          unsigned long long* counters, hipStream_t stream, float* kmax_out = nullptr, const int* prefer_online = nullptr,
                          float* rstat = nullptr, float* krad_out = nullptr,   // squared radii in (consumed) / radii with margin out: K5KeyCentre::radius
-                         int nq = 1, int qstride = 0);                         // qstat as nq partial maxima at stride qstride (Ulysses)
+                         int nq = 1, int qstride = 0,                          // qstat as nq partial maxima at stride qstride (Ulysses)
+                         bool anchored = false);   // heads beyond the window: fixed form on anchored offsets (kmax_out entry < 0) instead of the online form
+int k5_launch_attn_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, const float* kmax,
+                              float* out, hipStream_t stream);
 int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_rows, int* prefer_online, hipStream_t stream);
 
 // ---- fp8 (e4m3) feed-forward path, opt-in (gemm_fp8.hip) ----

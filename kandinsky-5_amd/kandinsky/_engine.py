@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("K5_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libk5.so"))
 
 K5_OK = 0
-ABI_VERSION = 4          # include/k5.h K5_ABI_VERSION
+ABI_VERSION = 5          # include/k5.h K5_ABI_VERSION
 K5_F32, K5_BF16, K5_F16 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_M, EPI_GELU, EPI_GATE = 0, 1, 2, 3
 
@@ -79,6 +79,9 @@ SYMBOLS = {
     "k5_rmsnorm_rope_centre_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P]),
     "k5_attention_flags_rows_centred": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "k5_attention_bf16_prescaled_rows_centred": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "k5_attention_flags_rows_anchored": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "k5_attention_row_anchor": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "k5_attention_bf16_prescaled_rows_anchored": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "k5_rmsnorm_rope_stats_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "k5_loopback_create": (_I, [_I, C.POINTER(_P)]),
     "k5_loopback_destroy": (None, [_P]),

@@ -350,6 +350,7 @@ class DiffusionTransformer3D(nn.Module):
     def set_option(self, name, value):
         """k5_dit_set_option: "attn_mode" (0 = softmax form per head from the data, 1 = online max everywhere),
         "attn_row_offsets" (1 = per-row offsets keep heads with a bound up to 190 on the fixed-offset kernel; default),
+        "attn_anchor" (1 = heads beyond that bound keep it too, on offsets anchored at achieved scores; default),
         "attn_fuse_qnorm" (1 = norm_qk + RoPE of the visual queries inside the attention kernel, 2 = under sequence parallelism too;
         default 0, measured neutral),
         "nabla_group_rows" (NABLA on one GPU: 64-query rows per key-tile list / attention workgroup; 0 = by the previous forward's

@@ -202,14 +202,16 @@ def _qk_gain_sd(cfg, case):
     return sd
 
 
-@pytest.mark.parametrize("case,expect,row_offsets,qfuse", [("n05", "fixed", 1, 0), ("x2", "fixed", 1, 0), ("ch8", "any", 1, 0), ("x3", "fixed", 1, 0),
-                                                           ("x3", "online", 0, 0), ("x5", "any", 1, 0), ("x6", "online", 1, 0),
-                                                           ("ch8", "any", 1, 1), ("x3", "fixed", 1, 1), ("x6", "online", 1, 1)])
-def test_full_width_qk_norm_gains_vs_oracle(case, expect, row_offsets, qfuse):
+@pytest.mark.parametrize("case,expect,row_offsets,qfuse,anchor", [("n05", "fixed", 1, 0, 1), ("x2", "fixed", 1, 0, 1), ("ch8", "fixed", 1, 0, 1),
+                                                                  ("x3", "fixed", 1, 0, 1), ("x3", "online", 0, 0, 1), ("x5", "fixed", 1, 0, 1),
+                                                                  ("x5", "any", 1, 0, 0), ("x6", "fixed", 1, 0, 1), ("x6", "online", 1, 0, 0),
+                                                                  ("ch8", "any", 1, 1, 1), ("x3", "fixed", 1, 1, 1), ("x6", "online", 1, 1, 1)])
+def test_full_width_qk_norm_gains_vs_oracle(case, expect, row_offsets, qfuse, anchor):
     """The engine on QK-norm gains a trained checkpoint could have: N(1, 0.5), every gain 2 (|q||k'| = 64 * 4 * 0.18 = 46),
     every gain 3 (104: outside the offset-0 window of 90, inside the per-row-offset one of 190 — fixed form with the engine's
-    default, online max with "attn_row_offsets" = 0), every gain 5 (288: fixed where the keys' radius around their centre keeps |q| R within 190, online elsewhere: either form), every gain 6 (415: online max), one channel at 8 (the bound depends on how
-    much of a row's energy sits in that channel: heads fall on either side).  The softmax form is chosen per head ON THE
+    default, online max with "attn_row_offsets" = 0), every gain 5 (288) / 6 (415) / one channel at 8 (the bound depends on how much of a
+    row's energy sits in that channel) — beyond the Cauchy-Schwarz window: the fixed form on ANCHORED offsets with the engine's default
+    ("attn_anchor"; with the fused query norm there are no normalised queries to anchor on), the online max / either form without.  The softmax form is chosen per head ON THE
     DEVICE from the data; the test states which one must have run and demands oracle parity either way (round 1 derived the
     bound from max|w| and never left the fixed-offset branch in any engine-level test).
     qfuse = 1 ("attn_fuse_qnorm"): the queries are normalised inside the attention kernel and the fixed-offset workgroups take the
@@ -229,6 +231,7 @@ def test_full_width_qk_norm_gains_vs_oracle(case, expect, row_offsets, qfuse):
     dit.engine("cuda:0")
     dit.set_option("attn_row_offsets", row_offsets)
     dit.set_option("attn_fuse_qnorm", qfuse)
+    dit.set_option("attn_anchor", anchor)
     args = (x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(37))
     out = dit(*args, scale_factor=(1.0, 2.0, 2.0))
     n_fixed, n_online = dit.attn_variant_counts(reset=True)

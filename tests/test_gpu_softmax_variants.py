@@ -632,3 +632,132 @@ def test_key_centre_and_radius_from_the_norm_pass(E):
     n2 = (xd.float().cpu().reshape(rows, H, D) ** 2).sum(-1).amax(0)
     assert torch.allclose(stats[:H].cpu(), n2, rtol=1e-5) and torch.allclose(stats[H:].cpu(), r2, rtol=1e-4), (stats, n2, r2)
     assert (r2 < 0.5 * n2[Hq:]).all()                                          # these keys do share a common component
+
+
+# ------------------------------------------------------------------------------------------ anchored offsets beyond the window (round 3)
+def flags_rows_anchored(E, qf, kf, H, prefer=None):
+    c = kf.mean(0)
+    r2 = ((kf - c[None]) ** 2).sum(-1).amax(0).contiguous().cuda()
+    qstat, kstat = (qf * qf).sum(-1).amax(0).contiguous().cuda(), (kf * kf).sum(-1).amax(0).contiguous().cuda()
+    flags = torch.zeros(H, dtype=torch.int32, device="cuda")
+    kmax, krad = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    E.check(E.lib().k5_attention_flags_rows_anchored(qstat.data_ptr(), kstat.data_ptr(), 1, H, H, 0, flags.data_ptr(), kmax.data_ptr(), r2.data_ptr(),
+                                                     krad.data_ptr(), None if prefer is None else prefer.data_ptr(), E.stream_ptr()),
+            "k5_attention_flags_rows_anchored")
+    torch.cuda.synchronize()
+    return flags, kmax, krad, c.contiguous().cuda()
+
+
+def run_rows_anchored(E, q, kc, vt, H, flags, kmax, centre, krad, balanced=True, key0=0):
+    Sq, Sk = q.shape[0], kc.shape[0]
+    L = E.lib()
+    anchor = torch.full((H, Sq), float("nan"), device="cuda")
+    E.check(L.k5_attention_row_anchor(q.data_ptr(), kc.data_ptr(), H, Sq, Sk, q.stride(0), kc.stride(0), key0, kmax.data_ptr(), anchor.data_ptr(),
+                                      E.stream_ptr()), "k5_attention_row_anchor")
+    out = torch.full((Sq, H * 64), float("nan"), dtype=BF, device="cuda")
+    ws = torch.empty(L.k5_attention_balance_size(H, Sq), dtype=torch.uint8, device="cuda") if balanced else None
+    E.check(L.k5_attention_bf16_prescaled_rows_anchored(q.data_ptr(), kc.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk, q.stride(0), kc.stride(0),
+                                                        vt.stride(0), out.stride(0), flags.data_ptr(), kmax.data_ptr(), centre.data_ptr(), krad.data_ptr(),
+                                                        anchor.data_ptr(), None if ws is None else ws.data_ptr(), E.stream_ptr()),
+            "k5_attention_bf16_prescaled_rows_anchored")
+    torch.cuda.synchronize()
+    return out, anchor
+
+
+def _anchor_offsets(q, k, key0=0):
+    """host restatement of attn_row_anchor_kernel: sample = own 64-token block (4 tiles of 16) + 28 strided 16-key tiles; returns the
+    sample maximum and ceil(max + min(60, 0.45 (max - mean))) + 20"""
+    Sq, Sk = q.shape[0], k.shape[0]
+    nt = Sk // 16
+    strided = [((i - 4) * nt) // 28 for i in range(4, 32)]
+    out, mean = torch.empty(Sq), torch.empty(Sq)
+    for b in range((Sq + 63) // 64):
+        own = [min(max((64 * b + key0) // 16 + i, 0), nt - 1) for i in range(4)]
+        idx = torch.cat([torch.arange(16 * t, 16 * t + 16) for t in own + strided])
+        rows = slice(64 * b, min(64 * b + 64, Sq))
+        sc = q[rows] @ k[idx].t()
+        out[rows], mean[rows] = sc.amax(-1), sc.mean(-1)
+    return out, torch.ceil(out + (0.45 * (out - mean)).clamp(0.0, 60.0)) + 20.0
+
+
+@pytest.mark.parametrize("Sq,Sk", [(768, 1024), (33280, 2048)])
+def test_anchored_offsets_beyond_the_window(E, Sq, Sk):
+    """Heads whose Cauchy-Schwarz bound (plain AND centred) lies far beyond 190 used to take the online form.  With anchored offsets they
+    keep the fixed form: head 0 — large norms, random directions (scores ~ N(0, 75^2), bound 600); head 1 — a large common component AND a
+    large radius (centred bound ~ 400); head 2 — inside the centred window (untouched: its kmax stays positive); head 3 — small norms
+    (offset 0).  The anchors are the host restatement's; with a workspace no HEAD leaves the fixed form (a job may: the maximum of
+    iid scores over all keys occasionally lies beyond the exact range — rows counted below) and everything matches the oracle."""
+    H = 4
+    g = torch.Generator().manual_seed(Sq + 7)
+    def unit(x):
+        return x / x.norm(dim=-1, keepdim=True)
+    u = unit(torch.randn(H, 64, generator=g))
+    q = torch.empty(Sq, H, 64); k = torch.empty(Sk, H, 64)
+    k[:, 0] = 10.0 * unit(torch.randn(Sk, 64, generator=g));              q[:, 0] = 60.0 * unit(torch.randn(Sq, 64, generator=g))
+    k[:, 1] = 6.0 * u[1] + 8.0 * unit(torch.randn(Sk, 64, generator=g));  q[:, 1] = 30.0 * u[1] + 40.0 * unit(torch.randn(Sq, 64, generator=g))
+    k[:, 2] = 5.0 * unit(torch.randn(Sk, 64, generator=g));               q[:, 2] = 30.0 * unit(torch.randn(Sq, 64, generator=g))
+    k[:, 3] = 1.5 * unit(torch.randn(Sk, 64, generator=g));               q[:, 3] = 10.0 * unit(torch.randn(Sq, 64, generator=g))
+    q, k = bfr(q), bfr(k)
+    v = bfr(torch.randn(Sk, H, 64, generator=g))
+    f_c, _, krad_c, _ = flags_rows_centred(E, q, k, H)
+    assert f_c.tolist() == [0, 0, 1, 1], f_c                                # without anchoring: heads 0, 1 on the online form
+    flags, kmax, krad, centre = flags_rows_anchored(E, q, k, H)
+    assert flags.tolist() == [1, 1, 1, 1] and (kmax[:2] == -1).all() and (kmax[2:] > 0).all(), (flags, kmax)
+    qd, kd, vt = q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
+    rows = torch.arange(Sq) if Sq < 2000 else torch.tensor([0, 5, 255, 256, 4097, 20000, 32767, 32768, 33000, Sq - 1])
+    ref = O.sdpa(q[rows], k, v, "bf16", None, base2=True)
+    out, anchor = run_rows_anchored(E, qd, kd, vt, H, flags, kmax, centre, krad, balanced=True)
+    assert flags.tolist() == [1, 1, 1, 1], flags
+    close(out[rows], ref, ulps=4, atol=5e-3, what="anchored offsets")
+    beyond = 0
+    for h in (0, 1):
+        smax, want = _anchor_offsets(q[:, h], k[:, h])
+        got = anchor[h].cpu()
+        assert ((got - want).abs() <= 1.0).all() and ((got - want) != 0).float().mean() < 0.01, (h, (got - want).abs().max())   # ceil at an MFMA-rounding edge
+        true_max = torch.cat([(q[i:i + 4096, h] @ k[:, h].t()).amax(-1) for i in range(0, Sq, 4096)])
+        assert (true_max >= smax - 1e-3).all() and (true_max - got > -81.0).all()   # the row's own maximum term is >= 2^-81: no underflow
+        beyond += int((true_max - got >= 112.0).sum())                      # rows whose sum passes 2^112: their jobs fell back
+    assert beyond <= Sq // 1000, beyond
+    assert torch.isnan(anchor[2:]).all()                                    # rows of unmarked heads are not touched
+    if beyond == 0:   # then nothing may have fallen back at all: without a workspace a single overflowing row would flip its head
+        flags2, kmax2, krad2, centre2 = flags_rows_anchored(E, q, k, H)
+        out2, _ = run_rows_anchored(E, qd, kd, vt, H, flags2, kmax2, centre2, krad2, balanced=False)
+        assert flags2.tolist() == [1, 1, 1, 1], flags2
+        close(out2[rows], ref, ulps=4, atol=5e-3, what="anchored offsets (no workspace)")
+
+
+def test_anchored_offsets_overflow_falls_back_per_job(E):
+    """A key OUTSIDE every row's sample (index 20: not in a strided tile, not in the rows' own block) that a few query rows hit with a score
+    ~ 500 above everything else: their anchors sit ~ 500 too low, exp2 overflows, the row sum is inf — the job (head 0, query block 1)
+    falls back to the online form, every other job of the head stays on the fixed form, the head's flag stays 1, the output is the oracle's."""
+    H, Sq, Sk = 2, 768, 1024
+    g = torch.Generator().manual_seed(11)
+    def unit(x):
+        return x / x.norm(dim=-1, keepdim=True)
+    d = unit(torch.randn(64, generator=g))
+    k = 4.0 * unit(torch.randn(Sk, H, 64, generator=g))
+    k[:, 0] -= (k[:, 0] @ d)[:, None] * d                                   # head 0: no key has a component along d ...
+    k[20, 0] = 12.0 * d                                                     # ... except key 20
+    q = 30.0 * unit(torch.randn(Sq, H, 64, generator=g))
+    q[300:311, 0] += 45.0 * d                                               # rows 300..310 (query block 1) see key 20 at ~ +540
+    q, k = bfr(q), bfr(k)
+    v = bfr(torch.randn(Sk, H, 64, generator=g))
+    s = q[300:311, 0] @ k[:, 0].t()
+    assert (s[:, 20] - s[:, torch.arange(Sk) != 20].amax(-1) > 300).all()
+    flags, kmax, krad, centre = flags_rows_anchored(E, q, k, H)
+    assert flags.tolist() == [1, 1] and kmax[0].item() == -1, (flags, kmax)
+    qd, kd, vt = q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
+    out, anchor = run_rows_anchored(E, qd, kd, vt, H, flags, kmax, centre, krad, balanced=True)
+    assert flags.tolist() == [1, 1], flags                                  # a job fell back, not the head
+    assert ((q[300:311, 0] @ k[:, 0].t()).amax(-1) - anchor[0, 300:311].cpu() > 300).all()   # the anchors really were too low
+    ref = O.sdpa(q, k, v, "bf16", None, base2=True)
+    close(out, ref, ulps=4, atol=5e-3, what="anchored offsets with one overflowing job")
+    # without a workspace there are no job flags: the head itself is sent to the online form late (flag 0), same numbers
+    flags2, kmax2, krad2, centre2 = flags_rows_anchored(E, q, k, H)
+    out2, _ = run_rows_anchored(E, qd, kd, vt, H, flags2, kmax2, centre2, krad2, balanced=False)
+    assert flags2.tolist() == [0, 1], flags2
+    close(out2, ref, ulps=4, atol=5e-3, what="anchored offsets, head-level fallback")
+    # a head whose jobs kept falling back is not anchored again
+    prefer = torch.tensor([1, 0], dtype=torch.int32, device="cuda")
+    flags3, kmax3, _, _ = flags_rows_anchored(E, q, k, H, prefer=prefer)
+    assert flags3.tolist() == [0, 1] and kmax3[0].item() > 0, (flags3, kmax3)
