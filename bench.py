@@ -311,7 +311,8 @@ def main():
     else:
         variant = (f"fixed-offset softmax on {n_fixed} and online-max on {n_online} of {n_fixed + n_online} (block, head) "
                    f"launches, chosen per head on the device: max|q|*max|k'| <= 190 (centred: max|q|*R) keeps the fixed form (per-row offsets |q|*max|k'| - 90, "
-                   f"all zero when the bound is <= 90)")
+                   f"all zero when the bound is <= 90); beyond 190 the fixed form runs on offsets anchored at sampled scores (one-GPU path) "
+                   f"unless the layer's jobs kept falling back")
     traffic, traffic_source = None, None   # HBM-side bytes per attention launch: NOT measured in this run (PMC counters need their own
     for tf in ("r03_attention_traffic.json", "r02_attention_traffic.json"):   # rocprofv3 --pmc passes) but read from the committed profile,
         try:                                                                  # and only quoted for the exact workload it was measured on

@@ -761,3 +761,31 @@ def test_anchored_offsets_overflow_falls_back_per_job(E):
     prefer = torch.tensor([1, 0], dtype=torch.int32, device="cuda")
     flags3, kmax3, _, _ = flags_rows_anchored(E, q, k, H, prefer=prefer)
     assert flags3.tolist() == [0, 1] and kmax3[0].item() > 0, (flags3, kmax3)
+
+
+def test_config2_size_anchored_offsets_sampled_rows_vs_oracle(E):
+    """BASELINE config-2 attention shape (47 616 tokens x 28 heads) at QK-norm gains beyond the Cauchy-Schwarz window — RMS-normalised q / k
+    like the engine's, heads 0..13 at gain 6 (bound 415), 14..27 at gain 7 (565): what `bench.py --qk-gain 6 / 7` runs.  Every head is
+    marked for anchored offsets, stays on the fixed form through the balanced launch (a job may fall back: counted through the
+    constant-V check — an output row is exactly the constant either way) and sampled rows match the oracle."""
+    N, H = 47616, 28
+    g = torch.Generator(device="cuda").manual_seed(0)
+    gains = torch.cat([torch.full((14,), 6.0), torch.full((14,), 7.0)]).cuda()
+    def rmsn(x):
+        return gains[None, :, None] * x / x.pow(2).mean(-1, keepdim=True).sqrt()
+    q = rmsn(torch.randn(N, H, 64, device="cuda", generator=g)).reshape(N, -1).to(BF)
+    kc = (rmsn(torch.randn(N, H, 64, device="cuda", generator=g)) * O.SOFTMAX_C).reshape(N, -1).to(BF)
+    v = torch.randn(N, H * 64, device="cuda", generator=g).to(BF)
+    vt = v.t().contiguous()
+    qf, kf = q.float().reshape(N, H, 64), kc.float().reshape(N, H, 64)
+    flags, kmax, krad, centre = flags_rows_anchored(E, qf.cpu(), kf.cpu(), H)
+    assert flags.tolist() == [1] * H and (kmax == -1).all(), (flags, kmax)
+    out, anchor = run_rows_anchored(E, q, kc, vt, H, flags, kmax, centre, krad, balanced=True)
+    assert flags.tolist() == [1] * H, flags                                     # no head left the fixed form
+    rows = torch.tensor([0, 1, 31, 255, 256, 4097, 23808, 40000, 47104, 47615 - 64, 47615])   # incl. rows of the split tail jobs
+    ref = O.sdpa(qf[rows].cpu(), kf.cpu(), v.float().cpu().reshape(N, H, 64), "bf16", None, base2=True)
+    close(out[rows], ref, ulps=4, atol=5e-3, what="config-2 sampled rows, anchored offsets")
+    smax = torch.stack([(qf[rows, h] @ kf[:, h].t()).amax(-1) for h in range(H)]).cpu()   # the rows' true maxima: inside the exact range
+    assert (smax - anchor[:, rows].cpu() < 112).all() and (smax - anchor[:, rows].cpu() > -81).all()
+    oc, _ = run_rows_anchored(E, q, kc, torch.full_like(vt, 0.75), H, flags, kmax, centre, krad, balanced=True)
+    assert (oc.float() - 0.75).abs().max().item() <= 2 ** -8
