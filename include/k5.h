@@ -125,18 +125,20 @@ int k5_attention_bf16_prescaled_rows_centred(const void* Q, const void* Kc, cons
 /* ANCHORED offsets for the heads BEYOND that window (ABI 5; the engine's one-GPU path, option "attn_anchor").  The Cauchy-Schwarz offsets
  * end where min(|q| kmax, |q| R) exceeds 190 and the online-max form (0.39-0.41 of peak instead of 0.52) used to take over.  Instead the offset
  * of a row is anchored at a score the row ACHIEVES: the maximum s over a sample of keys (the four 16-key tiles of the row's own 64-token
- * block and 28 tiles strided over all keys), plus e = min(60, 0.45 (s - sample mean)) — where the maximum over ALL keys is expected when
- * the scores scatter — rounded up, + 20.  The row's true maximum is >= s, so its term is >= 2^-80 and the row sum cannot underflow
- * whatever the norms; the form is exact while the true maximum lies below s + e + 132.  Beyond that the row sum exceeds 2^112 (or is
+ * block and 28 tiles strided over the kv_len keys given), plus e = min(60, spread (s - sample mean)) — where the maximum over ALL
+ * kv_total keys is expected when the scores scatter: spread = 0.4 (sqrt(2 ln kv_total) - sqrt(2 ln 512)), 0.44 at 47 616 keys — rounded
+ * up, + 20.  Dense attention: the row's true maximum is >= s, so its term is >= 2^-80 and the row sum cannot underflow whatever the
+ * norms; the form is exact while the true maximum lies below s + e + 132.  (NABLA: the largest KEPT score may lie below s — no
+ * guarantee, the job flags are the net in both directions.)  Beyond that the row sum exceeds 2^112 (or is
  * inf / NaN): the job falls back to the online form exactly like an underflowing one, and below 2^112 the sum bounds every accumulator,
  * so nothing overflows unnoticed.
  * k5_attention_flags_rows_anchored: as _centred, but a head beyond the window keeps flag 1 and gets kmax[h] = -1 (the marker) unless
  * prefer_online[h] (nullable) is set.  k5_attention_row_anchor: anchor [H][q_len] for the marked heads (other rows untouched); key0 = the
- * key index of query row 0.  k5_attention_bf16_prescaled_rows_anchored: _rows_centred reading the anchors of the marked heads. */
+ * index among the given keys of query row 0's token, kv_total >= kv_len (a rank of a sharded schedule samples its own keys).  k5_attention_bf16_prescaled_rows_anchored: _rows_centred reading the anchors of the marked heads. */
 int k5_attention_flags_rows_anchored(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* head_flags, float* kmax,
                                      float* rstat, float* krad, const int* prefer_online, void* stream);
-int k5_attention_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, const float* kmax,
-                            float* anchor, void* stream);
+int k5_attention_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, int kv_total,
+                            const float* kmax, float* anchor, void* stream);
 int k5_attention_bf16_prescaled_rows_anchored(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                               int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, const float* centre,
                                               const float* krad, const float* anchor, void* workspace, void* stream);

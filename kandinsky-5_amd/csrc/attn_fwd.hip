@@ -51,13 +51,21 @@ constexpr float K5_ATTN_ROW_MIN = 7.8886091e-31f;
 constexpr float K5_ATTN_ROWOFF_LIMIT = 190.f;
 // ANCHORED offsets (AttnP::row_anchor) for the heads beyond that limit: the offset of a row is an ACHIEVED score — the maximum s over a
 // sample of keys (the row's own 64-token block + a strided sample, attn_row_anchor_kernel) — plus e + K5_ATTN_ANCHOR_ADD, where
-// e = min(K5_ATTN_ANCHOR_EXTRA_MAX, K5_ATTN_ANCHOR_SPREAD (s - sample mean)) places the window where the maximum over ALL keys is
-// expected (for scores that scatter like a Gaussian the maximum of 47 616 lies ~ 1.3 sigma above the maximum of 512, and s - mean ~ 3
-// sigma).  The row's true maximum m satisfies m >= s, so its term is >= 2^-80 and the row sum cannot underflow whatever the norms are
-// (a PART of a split job may: harmless, its terms are < 2^-20 of the row's); the form is exact while m < s + e + 132 (row sum < 2^112).
-// Beyond that the row sum grows past K5_ATTN_ROW_MAX (or turns inf / NaN) and the job falls back to the online form like an
-// underflowing one: below 2^112 the sum bounds every accumulator (|O| <= l max|v|), so nothing overflowed unnoticed.
-constexpr float K5_ATTN_ANCHOR_ADD = 20.f, K5_ATTN_ANCHOR_SPREAD = 0.45f, K5_ATTN_ANCHOR_EXTRA_MAX = 60.f;
+// e = min(K5_ATTN_ANCHOR_EXTRA_MAX, spread (s - sample mean)) places the window where the maximum over ALL keys is expected: for scores
+// that scatter like a Gaussian, s - mean ~ sqrt(2 ln 512) sigma and the maximum of N keys lies (sqrt(2 ln N) - sqrt(2 ln 512)) sigma above
+// s (1.1 sigma at N = 47 616: spread 0.44; 0.2 sigma at N = 1024), so spread = K5_ATTN_ANCHOR_SPREAD x that difference (anchor_spread).
+// DENSE attention: the row's true maximum m satisfies m >= s, so its term is >= 2^-80 and the row sum cannot underflow whatever the
+// norms are (a PART of a split job or one PASS of a schedule may: harmless, its terms are < 2^-20 of the row's — exempt from the
+// check); the form is exact while m < s + e + 132 (row sum < 2^112).  Beyond that the row sum grows past K5_ATTN_ROW_MAX (or turns
+// inf / NaN) and the job falls back to the online form like an underflowing one: below 2^112 the sum bounds every accumulator
+// (|O| <= l max|v|), so nothing overflowed unnoticed.  SPARSE (NABLA): a row attends its kept blocks only (its own block is always
+// among them, most of the sample is not), so its largest KEPT score may lie below s: no guarantee, the underflow check stays as it is
+// for every part, and the job flags are the net in both directions.
+constexpr float K5_ATTN_ANCHOR_ADD = 20.f, K5_ATTN_ANCHOR_SPREAD = 0.4f, K5_ATTN_ANCHOR_EXTRA_MAX = 60.f;
+inline float anchor_spread(int kv_total) {
+  const float d = sqrtf(2.f * logf((float)(kv_total > 512 ? kv_total : 512))) - sqrtf(2.f * logf(512.f));
+  return K5_ATTN_ANCHOR_SPREAD * d;
+}
 constexpr float K5_ATTN_ROW_MAX = 5.1922969e33f;   // 2^112
 constexpr int K5_ANCHOR_TILES = 32;                // 16-key sample tiles per row: 4 of the row's own block + 28 strided over all keys
 
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   f32x4 nm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   bool fresh = true;             // !BOUNDED, wave-uniform: no tile processed yet -> the first one SETS the offset
   bool over_limit = false;
-  bool anchored = false;   // workgroup-uniform: the head runs on anchored offsets (a part's sum may underflow harmlessly; the row's cannot)
+  bool anchored = false;   // workgroup-uniform: the head runs on anchored offsets (dense: a part's sum may underflow harmlessly; the row's cannot)
   if (BOUNDED && PRE && p.kmax) {   // per-row constant offsets from |q_row| * max|k'| (see AttnP::kmax); 0 when the bound is <= 90
     const float km = p.kmax[h];
     anchored = km < 0.f && p.row_anchor;
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         st_ml[0] = BOUNDED ? 0.f : (fresh ? -1e30f : -nm[qt][0]);   // no tile seen: weight 0 in a merge, "still fresh" on resume
         st_ml[1] = g == 0 ? lt[qt][0] : 0.f;                    // slot 0 carries the whole row sum
         // per-row offsets: a part whose own sum underflows flags the head (conservative: the row's total is at least this part's)
-        if (BOUNDED && PRE && p.kmax && nm[qt][0] != 0.f && !((lt[qt][0] >= K5_ATTN_ROW_MIN || anchored) && lt[qt][0] < K5_ATTN_ROW_MAX) && seen) {
+        if (BOUNDED && PRE && p.kmax && nm[qt][0] != 0.f && !((lt[qt][0] >= K5_ATTN_ROW_MIN || (anchored && !SPARSE)) && lt[qt][0] < K5_ATTN_ROW_MAX) && seen) {
           if (p.job_flags) const_cast<int*>(p.job_flags)[lid] = p.late_pass ? 2 : 1;
           else const_cast<int*>(p.head_flags)[h] = p.late_pass ? 2 : 0;
         }
@@ -988,7 +996,8 @@ __global__ __launch_bounds__(64) void attn_pref_update_kernel(const int* job_fla
 // plus the constant.  One wave per 16 query rows: S^T = K Q^T on MFMA 16x16x32 with both operands straight from global memory
 // (the sample is 32 x 2 KB per head: cache-resident), 64 MFMAs per wave.  Pre-scaled keys: the scores ARE the exp2 arguments.
 __global__ __launch_bounds__(256) void attn_row_anchor_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, int q_len, int kv_len,
-                                                              int ldq, int ldk, int key0, const float* __restrict__ kmax, float* __restrict__ out) {
+                                                              int ldq, int ldk, int key0, float spread, const float* __restrict__ kmax,
+                                                              float* __restrict__ out) {
   const int h = blockIdx.y;
   if (!(kmax[h] < 0.f)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
@@ -1019,7 +1028,7 @@ __global__ __launch_bounds__(256) void attn_row_anchor_kernel(const bf16_t* __re
     const auto t32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
     sum = __uint_as_float(t32[0]) + __uint_as_float(t32[1]);
   }
-  const float extra = fminf(fmaxf(K5_ATTN_ANCHOR_SPREAD * (mx - sum * (1.0f / (16 * K5_ANCHOR_TILES))), 0.f), K5_ATTN_ANCHOR_EXTRA_MAX);
+  const float extra = fminf(fmaxf(spread * (mx - sum * (1.0f / (16 * K5_ANCHOR_TILES))), 0.f), K5_ATTN_ANCHOR_EXTRA_MAX);
   if (g == 0 && q0 + l15 < q_len) out[(size_t)h * q_len + q0 + l15] = ceilf(mx + extra) + K5_ATTN_ANCHOR_ADD;
 }
 
@@ -1077,13 +1086,14 @@ int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H,
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
-// anchored offsets of the heads k5_launch_attn_flags(anchored) marked (negative kmax entry): out [H][q_len]; key0 = the key index of
-// query row 0 (0 on one GPU; a rank's first token under sequence parallelism).  Other heads' rows are left untouched.
-int k5_launch_attn_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, const float* kmax,
-                              float* out, hipStream_t stream) {
+// anchored offsets of the heads k5_launch_attn_flags(anchored) marked (negative kmax entry): out [H][q_len]; Kc = the keys to sample
+// (kv_len of them), key0 = the index among them of query row 0's token, kv_total = the number of keys the attention will see (>= kv_len:
+// a rank samples its own shard).  Other heads' rows are left untouched.
+int k5_launch_attn_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, int kv_total,
+                              const float* kmax, float* out, hipStream_t stream) {
   if (!Q || !Kc || !kmax || !out || H <= 0 || q_len <= 0 || kv_len < KB || (kv_len % KB) || (ldq & 7) || (ldk & 7)) return K5_ERR_ARG;
   hipLaunchKernelGGL(attn_row_anchor_kernel, dim3((q_len + 63) / 64, H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)Kc, q_len, kv_len,
-                     ldq, ldk, key0, kmax, out);
+                     ldq, ldk, key0, anchor_spread(kv_total > kv_len ? kv_total : kv_len), kmax, out);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 

@@ -604,7 +604,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
       if (anchored) {
         K5CHK(d->ws_attn_anchor.ensure((size_t)H * rows * 4));
         K5CHK(k5_launch_attn_row_anchor(qk, (pre && nabla) ? (const void*)d->ws_kc.p : (const void*)((const bf16_t*)qk + D), H, rows, rows, 2 * D,
-                                        (pre && nabla) ? D : 2 * D, 0, kmax_w, d->ws_attn_anchor.as<float>(), s));
+                                        (pre && nabla) ? D : 2 * D, 0, rows, kmax_w, d->ws_attn_anchor.as<float>(), s));
         kcen.row_anchor = d->ws_attn_anchor.as<float>();
       }
     }
@@ -760,14 +760,25 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   // per-row softmax offsets (§4.1) across the passes: a row that underflows in ANY pass marks its head late (flag 2), the fixed
   // form then skips the head and the online form of the LAST pass recomputes it from scratch over all keys (late_pass 1 / 2)
   const float* kmax = nullptr;
+  K5KeyCentre kcen{nullptr, nullptr, nullptr};
+  const K5KeyCentre* kcp = nullptr;
   if (by_data) {
     HIPCHK(hipStreamWaitEvent(s, d->ev_stats, 0));
     hflags = d->ws_attn_flags.as<int>();
     float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
     kmax = kmax_w;
     if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
+    // heads beyond the window of the plain offsets: anchored offsets, sampled from the rank's OWN keys (the row's own block is among them;
+    // they are in place before the gather) — every pass of the schedule then runs the head on them
+    const bool anchored = kmax_w && d->anchor && !fuse_q;
     K5CHK(k5_launch_attn_flags(qstat, kstat, P, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w,
-                               kmax_w ? a.pref.as<int>() : nullptr));
+                               kmax_w ? a.pref.as<int>() : nullptr, nullptr, nullptr, 1, 0, anchored));
+    if (anchored) {
+      K5CHK(d->ws_attn_anchor.ensure((size_t)H * rows * 4));
+      K5CHK(k5_launch_attn_row_anchor(q, kloc, H, rows, rows, D, D, 0, N, kmax_w, d->ws_attn_anchor.as<float>(), s));
+      kcen.row_anchor = d->ws_attn_anchor.as<float>();
+      kcp = &kcen;
+    }
   }
   const int variant = pre ? d->attn_mode : K5_ATTN_AUTO;
   if (nabla) {
@@ -799,7 +810,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
-                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, d->ws_attn_bal.as<float>(), 2));
+                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, d->ws_attn_bal.as<float>(), 2, true, kcp));
     } else if (d->sp_nabla_passes > 1 && P > 1) {
       // two passes over every list: the rank's own key blocks (they lead the lists; K' / V^T of them are in place) while the other
       // ranks' keys travel — state out —, then the rest once the gather has landed (resume, normalise); late fallback as in the dense
@@ -809,18 +820,18 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
         const K5SparsePass p1{nullptr, d->ws_attn_state.as<float>(), 2, kmax ? 1 : 0};
         Scope sc(d, s, "attn_self");
         K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt_local, nb, rows_pad,
-                                              (long long)D * ldv, s, true, hflags, variant, kmax, &p1, d->ws_attn_bal.as<float>()));
+                                              (long long)D * ldv, s, true, hflags, variant, kmax, &p1, d->ws_attn_bal.as<float>(), 4, true, kcp));
       }
       HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
       const K5SparsePass p2{cnt_local, d->ws_attn_state.as<float>(), 1, kmax ? 2 : 0};
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
-                                            (long long)D * ldv, s, true, hflags, variant, kmax, &p2, d->ws_attn_bal.as<float>()));
+                                            (long long)D * ldv, s, true, hflags, variant, kmax, &p2, d->ws_attn_bal.as<float>(), 4, true, kcp));
     } else {
       HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
-                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, d->ws_attn_bal.as<float>()));
+                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, d->ws_attn_bal.as<float>(), 4, true, kcp));
     }
   } else {
     // ... while the main stream attends the local query rows to the LOCAL key chunk (pass 1, leaves the fp32 state),
@@ -841,14 +852,14 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, S > 1 ? cols : ldv, D, 0.f, S > 1 ? cols : rows_pad,
                                            S > 1 ? (long long)D * cols : (long long)D * ldv,
                                            r * tpc_pad, k1, 0x7fffffff, 0, d->ws_attn_state.as<float>(), 2, s, d->ws_attn_bal.as<float>(), true, hflags, variant,
-                                           nullptr, kmax, kmax ? 1 : 0, qnp));
+                                           nullptr, kmax, kmax ? 1 : 0, qnp, kcp));
     }
     if (S == 1) {
       HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, rows_pad, (long long)D * ldv,
                                            0, total - k1, r * tpc_pad, k1, d->ws_attn_state.as<float>(), 1, s, d->ws_attn_bal.as<float>(),
-                                           true, hflags, variant, nullptr, kmax, kmax ? 2 : 0, qnp));
+                                           true, hflags, variant, nullptr, kmax, kmax ? 2 : 0, qnp, kcp));
     } else {
       // one pass per slice, as soon as that slice of every peer has landed: slice sl of rank p = key tiles [p tpc_pad + sl tps, + tps)
       // (P - 1 segments: mine was pass 1; the last rank's slot may end early — it is the last segment, so the count is cut short).
@@ -870,7 +881,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
         Scope sc(d, s, "attn_self");
         K5CHK(k5_launch_attention_bf16_range(q, kfull, vtfull, o, H, rows, N, D, D, cols, D, 0.f, cols, (long long)D * cols,
                                              sl * tps, cnt, 0x7fffffff, 0, d->ws_attn_state.as<float>(), fin ? 1 : 3, s,
-                                             d->ws_attn_bal.as<float>(), true, hflags, variant, &seg, kmax, kmax ? (fin ? 2 : 1) : 0, qnp));
+                                             d->ws_attn_bal.as<float>(), true, hflags, variant, &seg, kmax, kmax ? (fin ? 2 : 1) : 0, qnp, kcp));
       }
     }
   }
@@ -947,16 +958,24 @@ int run_self_attention_ulysses(k5_dit* d, hipStream_t s, const AttnW& a, const v
     kmax = kmax_w;
     if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
     K5CHK(k5_launch_attn_flags(ustats + (size_t)r * Hp, ustats + H + (size_t)r * Hp, P, 2 * H, Hp, 0, d->ws_attn_flags.as<int>(),
-                               d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w, kmax_w ? a.pref.as<int>() + (size_t)r * Hp : nullptr, nullptr, nullptr, P, 2 * H));
+                               d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w, kmax_w ? a.pref.as<int>() + (size_t)r * Hp : nullptr, nullptr, nullptr, P, 2 * H,
+                               kmax_w && d->anchor));
   }
   HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
   const bf16_t* qall = d->ws_u_recv.as<bf16_t>();
   K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(Hp, N)));
+  K5KeyCentre kcen{nullptr, nullptr, nullptr};
+  if (kmax && d->anchor) {   // anchored offsets of the heads beyond the window: this rank holds all rows of its heads
+    K5CHK(d->ws_attn_anchor.ensure((size_t)Hp * N * 4));
+    Scope sc(d, s, "elementwise");
+    K5CHK(k5_launch_attn_row_anchor(qall, qall + Dp, Hp, N, N, 2 * Dp, 2 * Dp, 0, N, kmax, d->ws_attn_anchor.as<float>(), s));
+    kcen.row_anchor = d->ws_attn_anchor.as<float>();
+  }
   {
     Scope sc(d, s, "attn_self");
     K5CHK(k5_launch_attention_bf16_range(qall, qall + Dp, d->ws_u_vrecv.p, d->ws_u_o.p, Hp, N, N, 2 * Dp, 2 * Dp, rows_pad, Dp, 0.f, rows_pad,
                                          (long long)Dp * rows_pad, 0, -1, 0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), true, hflags,
-                                         d->attn_mode, nullptr, kmax, 0, nullptr, nullptr));
+                                         d->attn_mode, nullptr, kmax, 0, nullptr, kcen.row_anchor ? &kcen : nullptr));
   }
   if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), Hp, N, 4, a.pref.as<int>() + (size_t)r * Hp, s));
   HIPCHK(hipEventRecord(d->ev_u_o, s));

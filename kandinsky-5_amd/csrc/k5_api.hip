@@ -106,9 +106,9 @@ int k5_attention_flags_rows_anchored(float* qstat, float* kstat, int nk, int kst
   return ret(k5_launch_attn_flags(qstat, kstat, nk, kstride, H, force_online, flags, nullptr, (hipStream_t)stream, kmax, prefer_online, rstat, krad, 1, 0, true),
              "k5_attention_flags_rows_anchored");
 }
-int k5_attention_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, const float* kmax, float* anchor,
-                            void* stream) {
-  return ret(k5_launch_attn_row_anchor(Q, Kc, H, q_len, kv_len, ldq, ldk, key0, kmax, anchor, (hipStream_t)stream), "k5_attention_row_anchor");
+int k5_attention_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, int kv_total, const float* kmax,
+                            float* anchor, void* stream) {
+  return ret(k5_launch_attn_row_anchor(Q, Kc, H, q_len, kv_len, ldq, ldk, key0, kv_total, kmax, anchor, (hipStream_t)stream), "k5_attention_row_anchor");
 }
 int k5_attention_bf16_prescaled_rows_anchored(const void* Q, const void* Kc, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                               int ldk, int ldvt, int ldo, int* head_flags, const float* kmax, const float* centre, const float* krad,

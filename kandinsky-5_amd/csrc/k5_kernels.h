@@ -67,8 +67,8 @@ int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H,
                          float* rstat = nullptr, float* krad_out = nullptr,   // squared radii in (consumed) / radii with margin out: K5KeyCentre::radius
                          int nq = 1, int qstride = 0,                          // qstat as nq partial maxima at stride qstride (Ulysses)
                          bool anchored = false);   // heads beyond the window: fixed form on anchored offsets (kmax_out entry < 0) instead of the online form
-int k5_launch_attn_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, const float* kmax,
-                              float* out, hipStream_t stream);
+int k5_launch_attn_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, int kv_total,
+                              const float* kmax, float* out, hipStream_t stream);
 int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_rows, int* prefer_online, hipStream_t stream);
 
 // ---- fp8 (e4m3) feed-forward path, opt-in (gemm_fp8.hip) ----

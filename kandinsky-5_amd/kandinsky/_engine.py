@@ -80,7 +80,7 @@ SYMBOLS = {
     "k5_attention_flags_rows_centred": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "k5_attention_bf16_prescaled_rows_centred": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "k5_attention_flags_rows_anchored": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "k5_attention_row_anchor": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "k5_attention_row_anchor": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "k5_attention_bf16_prescaled_rows_anchored": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "k5_rmsnorm_rope_stats_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "k5_loopback_create": (_I, [_I, C.POINTER(_P)]),

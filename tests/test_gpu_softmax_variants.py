@@ -652,7 +652,7 @@ def run_rows_anchored(E, q, kc, vt, H, flags, kmax, centre, krad, balanced=True,
     Sq, Sk = q.shape[0], kc.shape[0]
     L = E.lib()
     anchor = torch.full((H, Sq), float("nan"), device="cuda")
-    E.check(L.k5_attention_row_anchor(q.data_ptr(), kc.data_ptr(), H, Sq, Sk, q.stride(0), kc.stride(0), key0, kmax.data_ptr(), anchor.data_ptr(),
+    E.check(L.k5_attention_row_anchor(q.data_ptr(), kc.data_ptr(), H, Sq, Sk, q.stride(0), kc.stride(0), key0, Sk, kmax.data_ptr(), anchor.data_ptr(),
                                       E.stream_ptr()), "k5_attention_row_anchor")
     out = torch.full((Sq, H * 64), float("nan"), dtype=BF, device="cuda")
     ws = torch.empty(L.k5_attention_balance_size(H, Sq), dtype=torch.uint8, device="cuda") if balanced else None
@@ -666,7 +666,9 @@ def run_rows_anchored(E, q, kc, vt, H, flags, kmax, centre, krad, balanced=True,
 
 def _anchor_offsets(q, k, key0=0):
     """host restatement of attn_row_anchor_kernel: sample = own 64-token block (4 tiles of 16) + 28 strided 16-key tiles; returns the
-    sample maximum and ceil(max + min(60, 0.45 (max - mean))) + 20"""
+    sample maximum and ceil(max + min(60, spread (max - mean))) + 20, spread = 0.4 (sqrt(2 ln Sk) - sqrt(2 ln 512))"""
+    import math
+    spread = 0.4 * (math.sqrt(2 * math.log(max(k.shape[0], 512))) - math.sqrt(2 * math.log(512)))
     Sq, Sk = q.shape[0], k.shape[0]
     nt = Sk // 16
     strided = [((i - 4) * nt) // 28 for i in range(4, 32)]
@@ -677,7 +679,7 @@ def _anchor_offsets(q, k, key0=0):
         rows = slice(64 * b, min(64 * b + 64, Sq))
         sc = q[rows] @ k[idx].t()
         out[rows], mean[rows] = sc.amax(-1), sc.mean(-1)
-    return out, torch.ceil(out + (0.45 * (out - mean)).clamp(0.0, 60.0)) + 20.0
+    return out, torch.ceil(out + (spread * (out - mean)).clamp(0.0, 60.0)) + 20.0
 
 
 @pytest.mark.parametrize("Sq,Sk", [(768, 1024), (33280, 2048)])
