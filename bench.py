@@ -369,7 +369,8 @@ def main():
                        "visual_blocks": args.blocks, "magcache": bool(args.magcache),
                        **({"emulated_shard": args.emulate_shard} if args.emulate_shard > 1 else {}),
                        **({"sp_slices": args.sp_slices} if args.sp_slices > 1 or args.emulate_shard > 1 else {}),
-                       **({"engine_options": args.engine_option} if args.engine_option else {})},
+                       **({"engine_options": args.engine_option} if args.engine_option else {}),
+                       **({"qk_gain": args.qk_gain} if args.qk_gain != 1.0 else {})},
             "nfe_per_s": fwd_per_step * args.steps / dt,
             "step_tflop": step_flop / 1e12,
             "model_tflops_per_gpu": step_flop * args.steps / dt / 1e12 / world,

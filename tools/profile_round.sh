@@ -25,6 +25,8 @@ python tools/profile_summarize.py $TAG
 : > $OUT/${TAG}_workloads.jsonl; : > $OUT/${TAG}_shards.jsonl
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --attn-online 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --qk-gain 3 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --qk-gain 6 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl   # beyond the window: anchored offsets
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --qk-gain 6 --engine-option attn_anchor=0 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl   # ... the online form
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --workload 5s_sft 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vae --workload 2s_256 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
 python bench.py --steps 45 --warmup 5 --no-cpu-baseline --no-vae --magcache 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
