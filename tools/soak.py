@@ -54,6 +54,17 @@ for i in range(3):
 nd = sum(0 if torch.equal(o, outs[0]) else 1 for o in outs[1:])
 print(f"2-step sample, QK-norm gain 3 (per-row offsets): {nd} of {len(outs) - 1} repeats differ; variants {dit.attn_variant_counts()}")
 bad += nd
+# round 3: beyond the Cauchy-Schwarz window — anchored offsets (gain 7: every head marked, none falls back; a head that did would take
+# the online form from its second run on and legitimately change the bits)
+dit.init_synthetic(dev, seed=0, qk_gain=7.0)
+outs = []
+for i in range(3):
+    lat = lat0.clone()
+    dit.sample(lat, [1.0, 0.9, 0.8], te, te, vpos, torch.arange(256), torch.arange(256), 1.0, scale_factor=(1.0, 2.0, 2.0), sparse_params=None)
+    outs.append(lat.clone())
+nd = sum(0 if torch.equal(o, outs[0]) else 1 for o in outs[1:])
+print(f"2-step sample, QK-norm gain 7 (anchored offsets): {nd} of {len(outs) - 1} repeats differ; variants {dit.attn_variant_counts()}")
+bad += nd
 dit.init_synthetic(dev, seed=0)
 sp = {"P": 0.15, "wT": 11, "wH": 3, "wW": 3, "to_fractal": True}
 outs = []
