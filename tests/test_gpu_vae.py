@@ -77,10 +77,12 @@ def test_conv3d_kernel_with_upsample_and_residual(vae):
 
 @pytest.mark.parametrize("Cin,Cout,up,dims", [(128, 128, (1, 1), (5, 112, 128)), (128, 256, (2, 2), (3, 60, 64)), (256, 128, (1, 2), (4, 64, 72)),
                                               (512, 512, (2, 2), (3, 36, 48)), (128, 128, (1, 1), (5, 113, 127)),   # M not a multiple of 256, odd width
-                                              (256, 128, (1, 2), (4, 64, 64))])   # halo form of the 256 x 128 tile with four slabs (4 weight stages, one barrier per K-tile)
+                                              (256, 128, (1, 2), (4, 64, 64)),    # halo form of the 256 x 128 tile with four slabs (4 weight stages, one barrier per K-tile)
+                                              (128, 128, (1, 1), (2, 104, 672)),  # halo form on the 1280 x 768 clips' full-resolution tile width: 13 x 21 patches per frame
+                                              (256, 256, (2, 2), (2, 52, 112))])  # ... and an upsampling conv onto 13 x 7 patches (odd counts in both directions)
 def test_conv3d_four_wave_kernel(vae, Cin, Cout, up, dims):
     """Shapes in the range of the 4-wave 256-row kernels (conv3d_w4.hip: Cin % 128 == 0, Cout = 128 or % 256, >= 256 tiles): output
-    frames of whole 8 x 32 patches take the LDS-halo form (cases 1, 2, 4, 6), the others the per-tap gather (cases 3, 5): source
+    frames of whole 8 x 32 patches take the LDS-halo form (cases 1, 2, 4, 6, 7, 8), the others the per-tap gather (cases 3, 5): source
     offsets (replicate pad, causal T, folded nearest upsample), both tile shapes, residual epilogue, ragged M."""
     from kandinsky import _engine as E
     torch.manual_seed(1)
