@@ -458,7 +458,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 #define CW_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define CW_MF(WF, XF, Q) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(Q) % NTW][(Q) / NTW]) : "v"(WF[(Q) % NTW]), "v"(XF[(Q) / NTW]))
-#define CW_MF0(WF, XF, Q) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[(Q) % NTW][(Q) / NTW]) : "v"(WF[(Q) % NTW]), "v"(XF[(Q) / NTW]))
 
   // prologue: weights of K-tiles 0 and 1, the halo of group 0, the fragments of K-tile 0
   set_w_tile(slot);
@@ -590,7 +589,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing may still be loading into a VGPR when the asm stream resumes
   }
 #undef CW_MF
-#undef CW_MF0
 #undef CW_RD
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wrapped DMAs still write this workgroup's LDS
 }
