@@ -67,7 +67,10 @@ inline float anchor_spread(int kv_total) {
   return K5_ATTN_ANCHOR_SPREAD * d;
 }
 constexpr float K5_ATTN_ROW_MAX = 5.1922969e33f;   // 2^112
-constexpr int K5_ANCHOR_TILES = 32;                // 16-key sample tiles per row: 4 of the row's own block + 28 strided over all keys
+constexpr int K5_ANCHOR_TILES = 32;
+#ifndef K5_ATTN_PAIR
+#define K5_ATTN_PAIR 1   // A/B switch (tools/build_variant.sh -DK5_ATTN_PAIR=0): one key tile per barrier
+#endif                // 16-key sample tiles per row: 4 of the row's own block + 28 strided over all keys
 
 struct AttnP {
   const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
@@ -186,9 +189,13 @@ template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false, bool QN = fal
 __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_kernel(AttnP p) {
   static_assert(BOUNDED || PRE, "the online-max form of this kernel takes pre-scaled keys (attn_fwd32_kernel serves the rest)");
   static_assert(!HALF || (SPARSE && PRE && !RANGE && !QN), "128-query workgroups: the list-driven single-launch form only");
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
+  // K5_ATTN_PAIR: two key tiles per barrier (four LDS slots per operand instead of two) for the 256-query workgroups — same arithmetic in
+  // the same order, half the barriers; the 128-query form keeps one tile per barrier (four workgroups per CU: 32 KB each)
+  constexpr bool PAIR = K5_ATTN_PAIR && !HALF;
+  constexpr int NBUF = PAIR ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * NBUF * TILE];
   char* sK = smem;
-  char* sV = smem + 2 * TILE;
+  char* sV = smem + NBUF * TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int gid = xcd_remap(blockIdx.x, gridDim.x);
   const int part = RANGE ? gid % p.splits : 0;
@@ -482,12 +489,17 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
 
   bool seen = !SPARSE && T > E0;   // wave-uniform: this wave's queries saw at least one key tile in this launch
   if (T > E0) load_tile(E0, 0);
-  __syncthreads();   // drains the DMA (vmcnt) and publishes the tile
-  // one key tile; BUF (LDS double-buffer half) is a compile-time constant so that every ds_read address is
-  // lane_base + immediate (the loop below is unrolled by two): no per-tile address arithmetic on the VALU
+  if (PAIR && T > E0 + 1) load_tile(E0 + 1, 1);
+  __syncthreads();   // drains the DMA (vmcnt) and publishes the tile(s)
+  // one key tile; BUF (LDS slot) is a compile-time constant so that every ds_read address is
+  // lane_base + immediate (the loop below is unrolled over the slots): no per-tile address arithmetic on the VALU
   auto tile_step = [&](auto BUFC, int e) {
     constexpr int buf = decltype(BUFC)::value;
-    if (e + 1 < T) load_tile(e + 1, buf ^ 1);   // buffer buf^1 was last read before the barrier that ended tile e-1
+    if (!PAIR) { if (e + 1 < T) load_tile(e + 1, buf ^ 1); }   // buffer buf^1 was last read before the barrier that ended tile e-1
+    else if ((buf & 1) == 0) {   // first tile of a pair: the NEXT pair goes into the other two slots (last read before the previous barrier)
+      if (e + 2 < T) load_tile(e + 2, buf ^ 2);
+      if (e + 3 < T) load_tile(e + 3, (buf ^ 2) + 1);
+    }
     const int t = tile_of(e);
     const char* cK = sK + buf * TILE;
     const char* cV = sV + buf * TILE;
@@ -610,12 +622,24 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
 #endif
     }
 #endif
-    __syncthreads();   // vmcnt(0) + barrier: tile e+1 has landed for every wave, tile e's buffer is free
+    if (!PAIR) __syncthreads();   // vmcnt(0) + barrier: tile e+1 has landed for every wave, tile e's buffer is free
   };
-  for (int e = E0; e < T; e += 2) {
-    tile_step(std::integral_constant<int, 0>{}, e);
-    if (e + 1 >= T) break;
-    tile_step(std::integral_constant<int, 1>{}, e + 1);
+  if (!PAIR) {
+    for (int e = E0; e < T; e += 2) {
+      tile_step(std::integral_constant<int, 0>{}, e);
+      if (e + 1 >= T) break;
+      tile_step(std::integral_constant<int, 1>{}, e + 1);
+    }
+  } else {
+    for (int e = E0; e < T; e += 4) {
+      tile_step(std::integral_constant<int, 0>{}, e);
+      if (e + 1 < T) tile_step(std::integral_constant<int, 1>{}, e + 1);
+      __syncthreads();   // vmcnt(0) + barrier: the next pair has landed for every wave, this pair's slots are free
+      if (e + 2 >= T) break;
+      tile_step(std::integral_constant<int, NBUF - 2>{}, e + 2);
+      if (e + 3 < T) tile_step(std::integral_constant<int, NBUF - 1>{}, e + 3);
+      __syncthreads();
+    }
   }
   // In a multi-pass schedule (late_pass != 0) the flip writes the LATE flag: the launches of a pass are balanced as fixed(full),
   // online(full), fixed(tail), online(tail), so a flip that comes from a tail job lands after online(full) has skipped the head —
