@@ -1023,37 +1023,40 @@ __global__ __launch_bounds__(256) void attn_row_anchor_kernel(const bf16_t* __re
                                                               int ldq, int ldk, int key0, float spread, const float* __restrict__ kmax,
                                                               float* __restrict__ out) {
   const int h = blockIdx.y;
-  if (!(kmax[h] < 0.f)) return;
+  if (!(kmax[h] < 0.f)) return;   // (256 rows per workgroup: at 47 616 tokens the launch that finds no marked head is 5208 workgroups that leave at once)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
-  const int q0 = 64 * blockIdx.x + 16 * wave;
-  if (q0 >= q_len) return;
-  const bf16_t* qp = Q + (size_t)min(q0 + l15, q_len - 1) * ldq + h * 64 + 8 * g;
-  const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp), qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
   const int ntile = kv_len / 16;   // kv_len is a multiple of 64 (pre-scaled keys)
-  float mx = -3.0e38f, sum = 0.f;
+  for (int it = 0; it < 4; ++it) {
+    const int blk = 4 * blockIdx.x + it;   // 64-token block of this wave's rows
+    const int q0 = 64 * blk + 16 * wave;
+    if (q0 >= q_len) return;
+    const bf16_t* qp = Q + (size_t)min(q0 + l15, q_len - 1) * ldq + h * 64 + 8 * g;
+    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp), qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+    float mx = -3.0e38f, sum = 0.f;
 #pragma unroll 4
-  for (int i = 0; i < K5_ANCHOR_TILES; ++i) {
-    const int t = i < 4 ? min(max((64 * (int)blockIdx.x + key0) / 16 + i, 0), ntile - 1)
-                        : (int)(((long long)(i - 4) * ntile) / (K5_ANCHOR_TILES - 4));
-    const bf16_t* kp = K + (size_t)(16 * t + l15) * ldk + h * 64 + 8 * g;
-    const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp), kf1 = *reinterpret_cast<const bf16x8*>(kp + 32);
-    f32x4 st = mfma16(kf0, qf0, f32x4{0.f, 0.f, 0.f, 0.f});
-    st = mfma16(kf1, qf1, st);   // lane (query l15, g): keys 4 g .. 4 g + 3 of the tile
-    mx = fmaxf(mx, fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
-    sum += (st[0] + st[1]) + (st[2] + st[3]);
+    for (int i = 0; i < K5_ANCHOR_TILES; ++i) {
+      const int t = i < 4 ? min(max((64 * blk + key0) / 16 + i, 0), ntile - 1)
+                          : (int)(((long long)(i - 4) * ntile) / (K5_ANCHOR_TILES - 4));
+      const bf16_t* kp = K + (size_t)(16 * t + l15) * ldk + h * 64 + 8 * g;
+      const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp), kf1 = *reinterpret_cast<const bf16x8*>(kp + 32);
+      f32x4 st = mfma16(kf0, qf0, f32x4{0.f, 0.f, 0.f, 0.f});
+      st = mfma16(kf1, qf1, st);   // lane (query l15, g): keys 4 g .. 4 g + 3 of the tile
+      mx = fmaxf(mx, fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
+      sum += (st[0] + st[1]) + (st[2] + st[3]);
+    }
+    {   // the query's four lanes (l15 + 16 g)
+      const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+      const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+      const auto t16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+      sum = __uint_as_float(t16[0]) + __uint_as_float(t16[1]);
+      const auto t32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+      sum = __uint_as_float(t32[0]) + __uint_as_float(t32[1]);
+    }
+    const float extra = fminf(fmaxf(spread * (mx - sum * (1.0f / (16 * K5_ANCHOR_TILES))), 0.f), K5_ATTN_ANCHOR_EXTRA_MAX);
+    if (g == 0 && q0 + l15 < q_len) out[(size_t)h * q_len + q0 + l15] = ceilf(mx + extra) + K5_ATTN_ANCHOR_ADD;
   }
-  {   // the query's four lanes (l15 + 16 g)
-    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-    mx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
-    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-    mx = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
-    const auto t16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
-    sum = __uint_as_float(t16[0]) + __uint_as_float(t16[1]);
-    const auto t32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
-    sum = __uint_as_float(t32[0]) + __uint_as_float(t32[1]);
-  }
-  const float extra = fminf(fmaxf(spread * (mx - sum * (1.0f / (16 * K5_ANCHOR_TILES))), 0.f), K5_ATTN_ANCHOR_EXTRA_MAX);
-  if (g == 0 && q0 + l15 < q_len) out[(size_t)h * q_len + q0 + l15] = ceilf(mx + extra) + K5_ATTN_ANCHOR_ADD;
 }
 
 }  // namespace
@@ -1116,7 +1119,7 @@ int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H,
 int k5_launch_attn_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, int kv_total,
                               const float* kmax, float* out, hipStream_t stream) {
   if (!Q || !Kc || !kmax || !out || H <= 0 || q_len <= 0 || kv_len < KB || (kv_len % KB) || (ldq & 7) || (ldk & 7)) return K5_ERR_ARG;
-  hipLaunchKernelGGL(attn_row_anchor_kernel, dim3((q_len + 63) / 64, H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)Kc, q_len, kv_len,
+  hipLaunchKernelGGL(attn_row_anchor_kernel, dim3((q_len + 255) / 256, H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)Kc, q_len, kv_len,
                      ldq, ldk, key0, anchor_spread(kv_total > kv_len ? kv_total : kv_len), kmax, out);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
