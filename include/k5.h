@@ -126,10 +126,10 @@ int k5_attention_bf16_prescaled_rows_centred(const void* Q, const void* Kc, cons
  * end where min(|q| kmax, |q| R) exceeds 190 and the online-max form (0.39-0.41 of peak instead of 0.52) used to take over.  Instead the offset
  * of a row is anchored at a score the row ACHIEVES: the maximum s over a sample of keys (the four 16-key tiles of the row's own 64-token
  * block and 28 tiles strided over the kv_len keys given), plus e = min(60, spread (s - sample mean)) — where the maximum over ALL
- * kv_total keys is expected when the scores scatter: spread = 0.4 (sqrt(2 ln kv_total) - sqrt(2 ln 512)), 0.44 at 47 616 keys — rounded
+ * kv_total keys is expected when the scores scatter: spread = 1.4 (sqrt(2 ln kv_total) - c) / c, c = sqrt(2 ln 512): 0.44 at 47 616 keys — rounded
  * up, + 20.  Dense attention: the row's true maximum is >= s, so its term is >= 2^-80 and the row sum cannot underflow whatever the
- * norms; the form is exact while the true maximum lies below s + e + 132.  (NABLA: the largest KEPT score may lie below s — no
- * guarantee, the job flags are the net in both directions.)  Beyond that the row sum exceeds 2^112 (or is
+ * norms; the form is exact while the true maximum lies below s + e + 132.  (Dense attention only: under NABLA the largest KEPT score
+ * may lie far below a sample of all keys — the engine leaves such heads on the online form there.)  Beyond that the row sum exceeds 2^112 (or is
  * inf / NaN): the job falls back to the online form exactly like an underflowing one, and below 2^112 the sum bounds every accumulator,
  * so nothing overflows unnoticed.
  * k5_attention_flags_rows_anchored: as _centred, but a head beyond the window keeps flag 1 and gets kmax[h] = -1 (the marker) unless

@@ -52,8 +52,8 @@ constexpr float K5_ATTN_ROWOFF_LIMIT = 190.f;
 // ANCHORED offsets (AttnP::row_anchor) for the heads beyond that limit: the offset of a row is an ACHIEVED score — the maximum s over a
 // sample of keys (the row's own 64-token block + a strided sample, attn_row_anchor_kernel) — plus e + K5_ATTN_ANCHOR_ADD, where
 // e = min(K5_ATTN_ANCHOR_EXTRA_MAX, spread (s - sample mean)) places the window where the maximum over ALL keys is expected: for scores
-// that scatter like a Gaussian, s - mean ~ sqrt(2 ln 512) sigma and the maximum of N keys lies (sqrt(2 ln N) - sqrt(2 ln 512)) sigma above
-// s (1.1 sigma at N = 47 616: spread 0.44; 0.2 sigma at N = 1024), so spread = K5_ATTN_ANCHOR_SPREAD x that difference (anchor_spread).
+// that scatter like a Gaussian, s - mean ~ c sigma with c = sqrt(2 ln 512) and the maximum of N keys lies (sqrt(2 ln N) - c) sigma above
+// s (1.1 sigma at N = 47 616; 0.2 sigma at N = 1024), so spread = K5_ATTN_ANCHOR_SPREAD (sqrt(2 ln N) - c) / c: 0.44 at 47 616 keys.
 // DENSE attention: the row's true maximum m satisfies m >= s, so its term is >= 2^-80 and the row sum cannot underflow whatever the
 // norms are (a PART of a split job or one PASS of a schedule may: harmless, its terms are < 2^-20 of the row's — exempt from the
 // check); the form is exact while m < s + e + 132 (row sum < 2^112).  Beyond that the row sum grows past K5_ATTN_ROW_MAX (or turns
@@ -61,10 +61,11 @@ constexpr float K5_ATTN_ROWOFF_LIMIT = 190.f;
 // (|O| <= l max|v|), so nothing overflowed unnoticed.  SPARSE (NABLA): a row attends its kept blocks only (its own block is always
 // among them, most of the sample is not), so its largest KEPT score may lie below s: no guarantee, the underflow check stays as it is
 // for every part, and the job flags are the net in both directions.
-constexpr float K5_ATTN_ANCHOR_ADD = 20.f, K5_ATTN_ANCHOR_SPREAD = 0.4f, K5_ATTN_ANCHOR_EXTRA_MAX = 60.f;
+constexpr float K5_ATTN_ANCHOR_ADD = 20.f, K5_ATTN_ANCHOR_SPREAD = 1.4f, K5_ATTN_ANCHOR_EXTRA_MAX = 60.f;
+// s - mean ~ c sigma with c = sqrt(2 ln 512); the maximum of kv_total keys lies (sqrt(2 ln kv_total) - c) sigma above the sample's
 inline float anchor_spread(int kv_total) {
-  const float d = sqrtf(2.f * logf((float)(kv_total > 512 ? kv_total : 512))) - sqrtf(2.f * logf(512.f));
-  return K5_ATTN_ANCHOR_SPREAD * d;
+  const float c = sqrtf(2.f * logf(512.f));
+  return K5_ATTN_ANCHOR_SPREAD * (sqrtf(2.f * logf((float)(kv_total > 512 ? kv_total : 512))) - c) / c;
 }
 constexpr float K5_ATTN_ROW_MAX = 5.1922969e33f;   // 2^112
 constexpr int K5_ANCHOR_TILES = 32;
@@ -1019,43 +1020,72 @@ __global__ __launch_bounds__(64) void attn_pref_update_kernel(const int* job_fla
 // integer (the softmax is offset-invariant, and an integer offset keeps every bf16 probability what any other integer offset gives),
 // plus the constant.  One wave per 16 query rows: S^T = K Q^T on MFMA 16x16x32 with both operands straight from global memory
 // (the sample is 32 x 2 KB per head: cache-resident), 64 MFMAs per wave.  Pre-scaled keys: the scores ARE the exp2 arguments.
-__global__ __launch_bounds__(256) void attn_row_anchor_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, int q_len, int kv_len,
+__global__ __launch_bounds__(512) void attn_row_anchor_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, int q_len, int kv_len,
                                                               int ldq, int ldk, int key0, float spread, const float* __restrict__ kmax,
                                                               float* __restrict__ out) {
+  // the strided part of the sample is the same for every row of a head: staged once per workgroup (28 tiles x 16 keys x 128 B = 56 KB)
+  __shared__ __attribute__((aligned(16))) char sk[(K5_ANCHOR_TILES - 4) * 16 * 128];
   const int h = blockIdx.y;
-  if (!(kmax[h] < 0.f)) return;   // (256 rows per workgroup: at 47 616 tokens the launch that finds no marked head is 5208 workgroups that leave at once)
+  if (!(kmax[h] < 0.f)) return;   // (1024 rows per workgroup: at 47 616 tokens the launch that finds no marked head is 1316 workgroups that leave at once)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   const int ntile = kv_len / 16;   // kv_len is a multiple of 64 (pre-scaled keys)
-  for (int it = 0; it < 4; ++it) {
-    const int blk = 4 * blockIdx.x + it;   // 64-token block of this wave's rows
-    const int q0 = 64 * blk + 16 * wave;
-    if (q0 >= q_len) return;
-    const bf16_t* qp = Q + (size_t)min(q0 + l15, q_len - 1) * ldq + h * 64 + 8 * g;
-    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp), qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
-    float mx = -3.0e38f, sum = 0.f;
+  for (int c = threadIdx.x; c < (K5_ANCHOR_TILES - 4) * 16 * 8; c += 512) {   // 16-B chunk c of row r of tile i: row-major, chunk XOR row (conflict-free fragment reads)
+    const int i = c >> 7, r = (c >> 3) & 15, ch = c & 7;
+    const int t = (int)(((long long)i * ntile) / (K5_ANCHOR_TILES - 4));
+    *reinterpret_cast<u32x4*>(sk + (i * 16 + r) * 128 + ((ch ^ (r & 7)) << 4)) =
+        *reinterpret_cast<const u32x4*>(K + (size_t)(16 * t + r) * ldk + h * 64 + 8 * ch);
+  }
+  __syncthreads();
+  for (int it = 0; it < 2; ++it) {   // eight waves (the 56 KB of LDS allow two workgroups per CU: four waves per SIMD hide the loads' latency)
+    const int blk = 16 * blockIdx.x + 8 * it + wave;   // one wave per 64-token block: its four 16-row tiles share every key fragment
+    if (64 * blk >= q_len) return;                       // (no barrier below)
+    bf16x8 qf[4][2];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const bf16_t* qp = Q + (size_t)min(64 * blk + 16 * qt + l15, q_len - 1) * ldq + h * 64 + 8 * g;
+      qf[qt][0] = *reinterpret_cast<const bf16x8*>(qp); qf[qt][1] = *reinterpret_cast<const bf16x8*>(qp + 32);
+    }
+    const int own = min(max((64 * blk + key0) / 64, 0), ntile / 4 - 1);
+    float mx[4], sum[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) { mx[qt] = -3.0e38f; sum[qt] = 0.f; }
+    auto fold = [&](bf16x8 kf0, bf16x8 kf1) __attribute__((always_inline)) {
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        f32x4 st = mfma16(kf0, qf[qt][0], f32x4{0.f, 0.f, 0.f, 0.f});
+        st = mfma16(kf1, qf[qt][1], st);   // lane (query l15 of tile qt, g): keys 4 g .. 4 g + 3 of the tile
+        mx[qt] = fmaxf(mx[qt], fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
+        sum[qt] += (st[0] + st[1]) + (st[2] + st[3]);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // the block's own four tiles, from global memory
+      const bf16_t* kp = K + (size_t)(16 * (4 * own + i) + l15) * ldk + h * 64 + 8 * g;
+      fold(*reinterpret_cast<const bf16x8*>(kp), *reinterpret_cast<const bf16x8*>(kp + 32));
+    }
 #pragma unroll 4
-    for (int i = 0; i < K5_ANCHOR_TILES; ++i) {
-      const int t = i < 4 ? min(max((64 * blk + key0) / 16 + i, 0), ntile - 1)
-                          : (int)(((long long)(i - 4) * ntile) / (K5_ANCHOR_TILES - 4));
-      const bf16_t* kp = K + (size_t)(16 * t + l15) * ldk + h * 64 + 8 * g;
-      const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp), kf1 = *reinterpret_cast<const bf16x8*>(kp + 32);
-      f32x4 st = mfma16(kf0, qf0, f32x4{0.f, 0.f, 0.f, 0.f});
-      st = mfma16(kf1, qf1, st);   // lane (query l15, g): keys 4 g .. 4 g + 3 of the tile
-      mx = fmaxf(mx, fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
-      sum += (st[0] + st[1]) + (st[2] + st[3]);
+    for (int i = 0; i < K5_ANCHOR_TILES - 4; ++i) {   // the head's strided tiles, from LDS
+      const char* kp = sk + (i * 16 + l15) * 128;
+      fold(*reinterpret_cast<const bf16x8*>(kp + ((g ^ (l15 & 7)) << 4)), *reinterpret_cast<const bf16x8*>(kp + (((4 + g) ^ (l15 & 7)) << 4)));
     }
-    {   // the query's four lanes (l15 + 16 g)
-      const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
-      const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
-      const auto t16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
-      sum = __uint_as_float(t16[0]) + __uint_as_float(t16[1]);
-      const auto t32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
-      sum = __uint_as_float(t32[0]) + __uint_as_float(t32[1]);
+    const float inv_n = 1.0f / (float)(16 * K5_ANCHOR_TILES);
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      float m = mx[qt], sm = sum[qt];
+      {   // the query's four lanes (l15 + 16 g)
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        m = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        m = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+        const auto t16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
+        sm = __uint_as_float(t16[0]) + __uint_as_float(t16[1]);
+        const auto t32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
+        sm = __uint_as_float(t32[0]) + __uint_as_float(t32[1]);
+      }
+      const float extra = fminf(fmaxf(spread * (m - sm * inv_n), 0.f), K5_ATTN_ANCHOR_EXTRA_MAX);
+      const int row = 64 * blk + 16 * qt + l15;
+      if (g == 0 && row < q_len) out[(size_t)h * q_len + row] = ceilf(m + extra) + K5_ATTN_ANCHOR_ADD;
     }
-    const float extra = fminf(fmaxf(spread * (mx - sum * (1.0f / (16 * K5_ANCHOR_TILES))), 0.f), K5_ATTN_ANCHOR_EXTRA_MAX);
-    if (g == 0 && q0 + l15 < q_len) out[(size_t)h * q_len + q0 + l15] = ceilf(mx + extra) + K5_ATTN_ANCHOR_ADD;
   }
 }
 
@@ -1115,11 +1145,15 @@ int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H,
 
 // anchored offsets of the heads k5_launch_attn_flags(anchored) marked (negative kmax entry): out [H][q_len]; Kc = the keys to sample
 // (kv_len of them), key0 = the index among them of query row 0's token, kv_total = the number of keys the attention will see (>= kv_len:
-// a rank samples its own shard).  Other heads' rows are left untouched.
+// a rank samples its own shard).  Dense attention only: under NABLA a row attends its kept blocks, among which a strided sample of ALL
+// keys (or of the spatial-window blocks that make up most of a kept set) says little about the few top-scoring blocks the map keeps —
+// measured at QK-norm gain 6 on the 10 s clip: anchors from the own block + two kept blocks sent half the heads to the online form
+// and computed most jobs twice (985 ms per step against 384 for the online form) — so NABLA heads beyond the window keep the online form.
+// Other heads' rows are left untouched.
 int k5_launch_attn_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, int kv_total,
                               const float* kmax, float* out, hipStream_t stream) {
   if (!Q || !Kc || !kmax || !out || H <= 0 || q_len <= 0 || kv_len < KB || (kv_len % KB) || (ldq & 7) || (ldk & 7)) return K5_ERR_ARG;
-  hipLaunchKernelGGL(attn_row_anchor_kernel, dim3((q_len + 255) / 256, H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)Kc, q_len, kv_len,
+  hipLaunchKernelGGL(attn_row_anchor_kernel, dim3((q_len + 1023) / 1024, H), dim3(512), 0, stream, (const bf16_t*)Q, (const bf16_t*)Kc, q_len, kv_len,
                      ldq, ldk, key0, anchor_spread(kv_total > kv_len ? kv_total : kv_len), kmax, out);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }

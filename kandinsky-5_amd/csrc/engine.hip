@@ -597,14 +597,13 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
       kmax = kmax_w;
       if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
       // heads beyond the Cauchy-Schwarz window: anchored offsets (needs the normalised queries in memory: not with the fused query norm)
-      const bool anchored = centre && d->anchor && !fuse_q;
+      const bool anchored = centre && d->anchor && !fuse_q && !nabla;   // dense attention only (k5_launch_attn_row_anchor)
       K5CHK(k5_launch_attn_flags(stats, stats + H, 1, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w,
                                  kmax_w ? a.pref.as<int>() : nullptr, centre ? stats + 2 * H : nullptr, centre ? kmax_w + H : nullptr, 1, 0, anchored));
       if (centre) { kcen.centre = centre; kcen.radius = kmax_w + H; kcp = &kcen; }
       if (anchored) {
         K5CHK(d->ws_attn_anchor.ensure((size_t)H * rows * 4));
-        K5CHK(k5_launch_attn_row_anchor(qk, (pre && nabla) ? (const void*)d->ws_kc.p : (const void*)((const bf16_t*)qk + D), H, rows, rows, 2 * D,
-                                        (pre && nabla) ? D : 2 * D, 0, rows, kmax_w, d->ws_attn_anchor.as<float>(), s));
+        K5CHK(k5_launch_attn_row_anchor(qk, (const bf16_t*)qk + D, H, rows, rows, 2 * D, 2 * D, 0, rows, kmax_w, d->ws_attn_anchor.as<float>(), s));
         kcen.row_anchor = d->ws_attn_anchor.as<float>();
       }
     }
@@ -770,7 +769,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
     // heads beyond the window of the plain offsets: anchored offsets, sampled from the rank's OWN keys (the row's own block is among them;
     // they are in place before the gather) — every pass of the schedule then runs the head on them
-    const bool anchored = kmax_w && d->anchor && !fuse_q;
+    const bool anchored = kmax_w && d->anchor && !fuse_q && !nabla;   // dense attention only
     K5CHK(k5_launch_attn_flags(qstat, kstat, P, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w,
                                kmax_w ? a.pref.as<int>() : nullptr, nullptr, nullptr, 1, 0, anchored));
     if (anchored) {

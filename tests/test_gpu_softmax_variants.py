@@ -666,15 +666,16 @@ def run_rows_anchored(E, q, kc, vt, H, flags, kmax, centre, krad, balanced=True,
 
 def _anchor_offsets(q, k, key0=0):
     """host restatement of attn_row_anchor_kernel: sample = own 64-token block (4 tiles of 16) + 28 strided 16-key tiles; returns the
-    sample maximum and ceil(max + min(60, spread (max - mean))) + 20, spread = 0.4 (sqrt(2 ln Sk) - sqrt(2 ln 512))"""
+    sample maximum and ceil(max + min(60, spread (max - mean))) + 20, spread = 1.4 (sqrt(2 ln Sk) - c) / c, c = sqrt(2 ln 512)"""
     import math
-    spread = 0.4 * (math.sqrt(2 * math.log(max(k.shape[0], 512))) - math.sqrt(2 * math.log(512)))
+    c = math.sqrt(2 * math.log(512))
+    spread = 1.4 * (math.sqrt(2 * math.log(max(k.shape[0], 512))) - c) / c
     Sq, Sk = q.shape[0], k.shape[0]
     nt = Sk // 16
     strided = [((i - 4) * nt) // 28 for i in range(4, 32)]
     out, mean = torch.empty(Sq), torch.empty(Sq)
     for b in range((Sq + 63) // 64):
-        own = [min(max((64 * b + key0) // 16 + i, 0), nt - 1) for i in range(4)]
+        own = [4 * min(max((64 * b + key0) // 64, 0), nt // 4 - 1) + i for i in range(4)]
         idx = torch.cat([torch.arange(16 * t, 16 * t + 16) for t in own + strided])
         rows = slice(64 * b, min(64 * b + 64, Sq))
         sc = q[rows] @ k[idx].t()
