@@ -1146,9 +1146,9 @@ int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H,
 // anchored offsets of the heads k5_launch_attn_flags(anchored) marked (negative kmax entry): out [H][q_len]; Kc = the keys to sample
 // (kv_len of them), key0 = the index among them of query row 0's token, kv_total = the number of keys the attention will see (>= kv_len:
 // a rank samples its own shard).  Dense attention only: under NABLA a row attends its kept blocks, among which a strided sample of ALL
-// keys (or of the spatial-window blocks that make up most of a kept set) says little about the few top-scoring blocks the map keeps —
-// measured at QK-norm gain 6 on the 10 s clip: anchors from the own block + two kept blocks sent half the heads to the online form
-// and computed most jobs twice (985 ms per step against 384 for the online form) — so NABLA heads beyond the window keep the online form.
+// keys says little about the kept ones, and the one attempt at sampling the kept set (own block + two kept blocks; QK-norm gain 6 on the
+// 10 s clip) sent half the heads to the online form with most jobs computed twice (985 ms per step against 384 for the online form;
+// not root-caused) — so NABLA heads beyond the window keep the online form.
 // Other heads' rows are left untouched.
 int k5_launch_attn_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, int kv_total,
                               const float* kmax, float* out, hipStream_t stream) {
