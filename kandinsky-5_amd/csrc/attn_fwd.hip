@@ -39,9 +39,11 @@ constexpr int KB = 64;    // keys per tile
 constexpr int TILE = 64 * 128;  // bytes of one [64][64] bf16 tile
 
 constexpr float K5_ATTN_EXP_LIMIT = 90.f;   // |exp2 argument| bound of the fixed-offset form: p <= 2^90, l <= 2^107, O <= 2^114
-// 2^-100: a row sum below this (per-row offsets only) sends the head to the online form.  The sum is then still 26 octaves above the smallest
-// normal fp32 / bf16 (2^-126): what a flush of smaller terms loses is < 2^-26 of the row's largest term (round 2 had 2^-60 — needlessly early)
-constexpr float K5_ATTN_ROW_MIN = 7.8886091e-31f;
+// 2^-88: a row sum below this (per-row offsets only) sends the job to the online form.  bf16 / fp32 flush below 2^-126, so a flushed term is
+// < 2^-38 of such a sum and ALL N <= 2^18 of them together < 2^-20 of it — far below bf16 resolution (round 3 had 2^-100: N 2^-126 against
+// 2^-100 is 2^-10.5 at 47 616 keys, next to bf16's 2^-9 — ADVICE r3; round 2 had 2^-60, needlessly early).  The centred offsets guarantee
+// a row sum >= 2^(90 - |q| R) >= 2^-100 only; rows between 2^-100 and 2^-88 now take the (exact) fallback instead of a 1e-3 error.
+constexpr float K5_ATTN_ROW_MIN = 3.2311743e-27f;
 // heads whose bound exceeds this go to the online form right away.  With the centred offsets (AttnP::kcentre) the bound is |q|max R and
 // 190 is where the guarantee ends: a row's sum is >= 2^(90 - |q| R) >= 2^-100, so a fixed-form head NEVER falls back.  With the plain
 // offsets (sequence-parallel path) the bound is |q|max kmax and the number is empirical (round 2: 180): rows keep their sum while their
@@ -395,8 +397,12 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   bool over_limit = false;
   bool anchored = false;   // workgroup-uniform: the head runs on anchored offsets (dense: a part's sum may underflow harmlessly; the row's cannot)
   if (BOUNDED && PRE && p.kmax) {   // per-row constant offsets from |q_row| * max|k'| (see AttnP::kmax); 0 when the bound is <= 90
-    const float km = p.kmax[h];
-    anchored = km < 0.f && p.row_anchor;
+    // a NEGATIVE entry marks a head beyond the Cauchy-Schwarz window (k5_launch_attn_flags, anchored offsets) and still carries the
+    // magnitude: a caller of the public ABI that marks heads (k5_attention_flags_rows_anchored) and then attends WITHOUT row anchors gets
+    // the plain per-row offsets of |entry| — exp2 arguments <= 90 whatever the data, and the underflow check + per-job fallback as the net
+    const float km_raw = p.kmax[h];
+    const float km = fabsf(km_raw);
+    anchored = km_raw < 0.f && p.row_anchor;
     if (anchored) {   // workgroup-uniform
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
@@ -443,8 +449,11 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
       float bnd = nq * km;                                        // plain Cauchy-Schwarz bound: <= 90 -> offset 0, as without any of this
       float off = fmaxf(bnd - K5_ATTN_EXP_LIMIT, 0.f);
       if (centred && bnd > K5_ATTN_EXP_LIMIT) {
-        bnd = nq * kr;                                            // what the row sum's survival depends on now
-        off = tc + bnd * 1.002f + 0.5f - K5_ATTN_EXP_LIMIT;       // margins: fp32 rounding of q.c and of the MFMA accumulation
+        // both are upper bounds of the row's scores: take the TIGHTER one (R may reach 2 kmax when the keys do not share a direction);
+        // the row sum's survival depends on the distance between the offset and the row's largest score, which the smaller offset shortens
+        const float bc = nq * kr;
+        const float offc = tc + bc * 1.002f + 0.5f - K5_ATTN_EXP_LIMIT;   // margins: fp32 rounding of q.c and of the MFMA accumulation
+        if (offc < off) { off = offc; bnd = bc; } else bnd = fminf(bnd, bc);
       }
       // an INTEGER offset: exp2(s - off) then differs between any two offset policies by an exact power of two, so the bf16 rounding of
       // every probability — and with it the whole result — is the same whichever policy chose the offset (0, plain, centred; one GPU or
@@ -993,7 +1002,7 @@ __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstrid
   const bool anchor = anchored && kmax_out && !force_online && !pref && b > limit && b < 3.0e38f;
   const int fast = ((!force_online && b <= limit && !pref) || anchor) ? 1 : 0;   // NaN / inf compare false -> online
   flags[h] = fast;
-  if (kmax_out) kmax_out[h] = anchor ? -1.f : sqrtf(k2) * 1.002f;   // per-row offsets of the fixed-offset form: |q_row| * this - 90 (AttnP::kmax)
+  if (kmax_out) kmax_out[h] = (anchor ? -1.f : 1.f) * sqrtf(k2) * 1.002f;   // negative = anchored head (the magnitude stays usable)   // per-row offsets of the fixed-offset form: |q_row| * this - 90 (AttnP::kmax)
   if (counters) atomicAdd(counters + (fast ? 0 : 1), 1ull);
   for (int i = 0; i < nq; ++i) qstat[(size_t)i * qstride + h] = 0.f;
   for (int i = 0; i < nk; ++i) kstat[(size_t)i * kstride + h] = 0.f;

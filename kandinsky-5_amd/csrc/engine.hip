@@ -106,7 +106,9 @@ struct AttnW {  // one attention module, packed
   DevBuf wqk, wq, wk, wv, wo;       // bf16
   DevBuf bqk, bq, bk, bv, bo, norm; // fp32 (bias values bf16-rounded); norm = [q_norm | k_norm]
   float score_bound = 0.f;          // |q.k| <= 64 max|w_q| max|w_k| after norm_qk (RoPE preserves norms)
-  mutable DevBuf pref;              // visual self-attention: heads the per-row-offset softmax served badly the last time (k5_launch_attn_pref_update)
+  mutable DevBuf pref;              // visual self-attention: [2][H] heads the per-row-offset softmax served badly the last time this layer ran for
+                                    // the cond (0) / uncond (1) branch (k5_launch_attn_pref_update); zeroed at the start of every k5_sample and
+                                    // by k5_dit_set_option("attn_pref_reset") — never carried from one sampling run, prompt or shape to the next
 };
 struct BlockW {
   AttnW self_attn, cross_attn;
@@ -556,7 +558,7 @@ int nabla_density_hint(k5_dit* d, int H, int nqb, int nb, hipStream_t s) {
 
 int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, void* qk, void* vt,
                        void* o, const float* cosT, const float* sinT, void* resid, const float* gate,
-                       const char* fam_attn, const NablaArgs* nabla = nullptr) {
+                       const char* fam_attn, const NablaArgs* nabla = nullptr, int pref_slot = 0) {
   const int D = d->D, H = d->Hh;
   const int ldvt = (int)rup(rows, 8);
   {
@@ -595,11 +597,11 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
       hflags = d->ws_attn_flags.as<int>();
       float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
       kmax = kmax_w;
-      if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
+      if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)2 * H * 4, s));
       // heads beyond the Cauchy-Schwarz window: anchored offsets (needs the normalised queries in memory: not with the fused query norm)
       const bool anchored = centre && d->anchor && !fuse_q && !nabla;   // dense attention only (k5_launch_attn_row_anchor)
       K5CHK(k5_launch_attn_flags(stats, stats + H, 1, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w,
-                                 kmax_w ? a.pref.as<int>() : nullptr, centre ? stats + 2 * H : nullptr, centre ? kmax_w + H : nullptr, 1, 0, anchored));
+                                 kmax_w ? (a.pref.as<int>() + (size_t)pref_slot * H) : nullptr, centre ? stats + 2 * H : nullptr, centre ? kmax_w + H : nullptr, 1, 0, anchored));
       if (centre) { kcen.centre = centre; kcen.radius = kmax_w + H; kcp = &kcen; }
       if (anchored) {
         K5CHK(d->ws_attn_anchor.ensure((size_t)H * rows * 4));
@@ -640,7 +642,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
                                          0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), pre, hflags, variant, nullptr, kmax, 0,
                                          fuse_q ? &qn : nullptr, kcp));
   }
-  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, nabla ? (pre ? d->nabla_grp_now : 4) : 4, a.pref.as<int>(), s));
+  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, nabla ? (pre ? d->nabla_grp_now : 4) : 4, (a.pref.as<int>() + (size_t)pref_slot * H), s));
   {
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(o, a.wo.p, a.bo.as<float>(), resid, rows, D, D, D, D, D, K5_EPI_GATE, resid, D, gate, s));
@@ -656,7 +658,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
 // own fewer (rows < rows_pad), so the padded row index of every real key equals its global index and the unused tail of the
 // last slot is never read (the key-tile ranges stop at N).
 int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, int rows_pad, int N, void* o,
-                          const float* cosT, const float* sinT, void* resid, const float* gate, const NablaArgs* nabla = nullptr) {
+                          const float* cosT, const float* sinT, void* resid, const float* gate, const NablaArgs* nabla = nullptr, int pref_slot = 0) {
   const int D = d->D, H = d->Hh, P = d->sp_world, r = d->sp_rank;
   const int ldv = rows_pad;  // rows, rows_pad, N are multiples of 64 (checked by the caller)
   bf16_t* q = d->ws_q.as<bf16_t>();
@@ -766,12 +768,12 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     hflags = d->ws_attn_flags.as<int>();
     float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
     kmax = kmax_w;
-    if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
+    if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)2 * H * 4, s));
     // heads beyond the window of the plain offsets: anchored offsets, sampled from the rank's OWN keys (the row's own block is among them;
     // they are in place before the gather) — every pass of the schedule then runs the head on them
     const bool anchored = kmax_w && d->anchor && !fuse_q && !nabla;   // dense attention only
     K5CHK(k5_launch_attn_flags(qstat, kstat, P, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w,
-                               kmax_w ? a.pref.as<int>() : nullptr, nullptr, nullptr, 1, 0, anchored));
+                               kmax_w ? (a.pref.as<int>() + (size_t)pref_slot * H) : nullptr, nullptr, nullptr, 1, 0, anchored));
     if (anchored) {
       K5CHK(d->ws_attn_anchor.ensure((size_t)H * rows * 4));
       K5CHK(k5_launch_attn_row_anchor(q, kloc, H, rows, rows, D, D, 0, N, kmax_w, d->ws_attn_anchor.as<float>(), s));
@@ -789,7 +791,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     // sparse maps: 128-query workgroups (lists per two rows, see nabla_group_rows) — without the split-job / two-pass machinery, which
     // lives on the 256-query form; dense maps: that form, balanced
     const int grp = (d->nabla_grp_now == 2 && d->sp_nabla_passes == 1) ? 2 : 4;
-    K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
+    K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb, rows / 64)));   // the logits region by the rank's own query-block rows
     {
       Scope sc(d, s, "nabla_map");
       K5CHK(k5_launch_nabla_key_means_from_slots(kmeans, H, nb, slot_blocks, d->ws_nabla.p, s));
@@ -884,7 +886,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       }
     }
   }
-  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, (nabla && d->nabla_grp_now == 2 && d->sp_nabla_passes == 1) ? 2 : 4, a.pref.as<int>(), s));
+  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, (nabla && d->nabla_grp_now == 2 && d->sp_nabla_passes == 1) ? 2 : 4, (a.pref.as<int>() + (size_t)pref_slot * H), s));
   {
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(o, a.wo.p, a.bo.as<float>(), resid, rows, D, D, D, D, D, K5_EPI_GATE, resid, D, gate, s));
@@ -905,7 +907,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
 // writes it (block g = rows g Dp ..) -> vrecv [P][Dp][rows_pad] = the chunked V^T layout of the attention kernel; o [P rows_pad][Dp]
 // -> orecv [P][rows_pad][Dp] (block g: the outputs of rank g's heads for this rank's rows) -> unpacked to [rows][D].
 int run_self_attention_ulysses(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, int rows_pad, int N, void* o,
-                               const float* cosT, const float* sinT, void* resid, const float* gate) {
+                               const float* cosT, const float* sinT, void* resid, const float* gate, int pref_slot = 0) {
   const int D = d->D, H = d->Hh, P = d->sp_world, r = d->sp_rank, Hp = H / P, Dp = D / P;
   const bool by_data = d->attn_mode == K5_ATTN_AUTO;
   K5CHK(d->ws_qk.ensure((size_t)rows * 2 * D * 2));
@@ -955,9 +957,9 @@ int run_self_attention_ulysses(k5_dit* d, hipStream_t s, const AttnW& a, const v
     hflags = d->ws_attn_flags.as<int>();
     float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
     kmax = kmax_w;
-    if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)H * 4, s));
+    if (kmax_w) K5CHK(ensure_zeroed(a.pref, (size_t)2 * H * 4, s));
     K5CHK(k5_launch_attn_flags(ustats + (size_t)r * Hp, ustats + H + (size_t)r * Hp, P, 2 * H, Hp, 0, d->ws_attn_flags.as<int>(),
-                               d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w, kmax_w ? a.pref.as<int>() + (size_t)r * Hp : nullptr, nullptr, nullptr, P, 2 * H,
+                               d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w, kmax_w ? (a.pref.as<int>() + (size_t)pref_slot * H) + (size_t)r * Hp : nullptr, nullptr, nullptr, P, 2 * H,
                                kmax_w && d->anchor));
   }
   HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
@@ -976,7 +978,7 @@ int run_self_attention_ulysses(k5_dit* d, hipStream_t s, const AttnW& a, const v
                                          (long long)Dp * rows_pad, 0, -1, 0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), true, hflags,
                                          d->attn_mode, nullptr, kmax, 0, nullptr, kcen.row_anchor ? &kcen : nullptr));
   }
-  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), Hp, N, 4, a.pref.as<int>() + (size_t)r * Hp, s));
+  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), Hp, N, 4, (a.pref.as<int>() + (size_t)pref_slot * H) + (size_t)r * Hp, s));
   HIPCHK(hipEventRecord(d->ev_u_o, s));
   HIPCHK(hipStreamWaitEvent(cs, d->ev_u_o, 0));
   {
@@ -1048,6 +1050,16 @@ int run_ff(k5_dit* d, hipStream_t s, const BlockW& b, const void* h, int rows, v
   Scope sc(d, s, "gemm");
   K5CHK(k5_launch_gemm_bf16(h, b.w1.p, nullptr, ff, rows, FF, D, D, D, FF, K5_EPI_GELU, nullptr, 0, nullptr, s));
   K5CHK(k5_launch_gemm_bf16(ff, b.w2.p, nullptr, resid, rows, D, FF, FF, FF, D, K5_EPI_GATE, resid, D, gate, s));
+  return K5_OK;
+}
+
+// forget which heads the per-row-offset softmax served badly (AttnW::pref): the memory is a speed hint for the NEXT step of the SAME sampling
+// run; carried across runs it made results depend on what the handle had computed before
+int reset_attn_pref(k5_dit* d, hipStream_t s, bool sync = false) {
+  if (sync) HIPCHK(hipDeviceSynchronize());   // called outside any stream order (k5_dit_set_option): nothing may still be reading the flags
+  for (auto& b : d->vblocks)
+    if (b.self_attn.pref.p) HIPCHK(hipMemsetAsync(b.self_attn.pref.p, 0, b.self_attn.pref.bytes, s));
+  if (sync) HIPCHK(hipDeviceSynchronize());
   return K5_OK;
 }
 
@@ -1273,12 +1285,12 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     K5CHK(ln_mod(d, s, d->ws_vis.p, m, d->ws_h.p, n));
     if (d->profiling) ++d->prof_self_blocks;   // bench.py: FLOPs of the roofline kernel = per-block FLOPs x the blocks that RAN
     if (sp && d->sp_mode == 1 && !nabla && d->sp_world > 1 && d->Hh % d->sp_world == 0 && !d->emulated) {
-      K5CHK(run_self_attention_ulysses(d, s, b.self_attn, d->ws_h.p, n, n_pad, N, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D));
+      K5CHK(run_self_attention_ulysses(d, s, b.self_attn, d->ws_h.p, n, n_pad, N, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D, text_slot > 0 ? 1 : 0));
     } else if (sp) {
-      K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, n_pad, N, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D, nabla ? &na : nullptr));
+      K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, n_pad, N, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D, nabla ? &na : nullptr, text_slot > 0 ? 1 : 0));
     } else {
       K5CHK(run_self_attention(d, s, b.self_attn, d->ws_h.p, n, d->ws_qk.p, d->ws_vt.p, d->ws_o.p, vcos, vsin, d->ws_vis.p,
-                               m + 2 * D, "attn_self", nabla ? &na : nullptr));
+                               m + 2 * D, "attn_self", nabla ? &na : nullptr, text_slot > 0 ? 1 : 0));
     }
     K5CHK(ln_mod(d, s, d->ws_vis.p, m + 3 * D, d->ws_h.p, n));
     K5CHK(run_cross_attention(d, s, b.cross_attn, d->ws_h.p, n, d->ws_text.p, L, d->ws_qk.p, d->ws_ck.p, d->ws_cvt.p,
@@ -1589,6 +1601,7 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
     tvec = d->ws_sched.as<float>(); dtvec = tvec + a->num_steps;
   }
   d->text_cache[0].valid = d->text_cache[1].valid = false;   // the prompt tensors are constant for THIS call only
+  K5CHK(reset_attn_pref(d, s));                              // ... and so is what the softmax-form memory of the layers is worth
   auto one_step = [&](int i) -> int {
     const float t1000 = host_tab[i], dt = host_tab[a->num_steps + i];
     if (pair) {
@@ -1775,6 +1788,8 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //   "attn_anchor"     1 (default) / 0: heads beyond that window keep the fixed form on offsets anchored at achieved scores (the row's maximum
 //                     over a sample of keys + 20; attn_row_anchor_kernel) — no underflow whatever the norms, a job whose row sum
 //                     overflows falls back to the online form like an underflowing one; 0 = such heads take the online form (one-GPU path)
+//   "attn_pref_reset" (write-only action) forget which heads kept falling back from the per-row-offset form (k5_sample does it at the start of
+//                     every call; a caller stepping k5_dit_forward itself does it at the start of a sampling run)
 //   "attn_fuse_qnorm" 0 (default): norm_qk + RoPE of the visual queries is a standalone pass; 1 = dense visual self-attention on ONE rank
 //                     applies it inside the attention kernel's Q-fragment load (K5QueryNorm; needs attn_row_offsets or attn_mode 1);
 //                     2 = under sequence parallelism too.  Measured neutral (elementwise -2.0 ms, attention +0.6 .. +3.4 ms per step
@@ -1803,6 +1818,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   if (!strcmp(name, "sp_mode")) { if (value < 0 || value > 1) return K5_ERR_ARG; d->sp_mode = value; return K5_OK; }
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_anchor")) { d->anchor = value != 0; return K5_OK; }
+  if (!strcmp(name, "attn_pref_reset")) return reset_attn_pref(d, nullptr, true);   // an action, not a state: the per-step path (k5_dit_forward) calls it per run
   if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }
   if (!strcmp(name, "sp_nabla_passes")) { if (value < 1 || value > 2) return K5_ERR_ARG; d->sp_nabla_passes = value; return K5_OK; }
   if (!strcmp(name, "attn_fuse_qnorm")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->fuse_qnorm = value; return K5_OK; }

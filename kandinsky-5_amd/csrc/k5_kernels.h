@@ -77,7 +77,7 @@ int k5_launch_gemm_fp8(const void* A8, const void* W8, const float* w_scale, voi
 int k5_launch_quant_rows_fp8(const void* x, void* out, float* scale, int rows, int K, int ldx, int ldo, hipStream_t stream);
 
 // ---- NABLA (block-sparse) ----
-size_t k5_nabla_workspace_bytes(int H, int nb);
+size_t k5_nabla_workspace_bytes(int H, int nb, int nqb = 0);   // nqb: query-block rows selected here (0 = all nb)
 int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,
                            int wW, float P, void* workspace, hipStream_t s);
 void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned long long** bits, const int** kv_nb, const int** list,

@@ -334,14 +334,17 @@ int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void*
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
-size_t k5_nabla_workspace_bytes(int H, int nb) {
+// nqb = query-block rows the selection will handle (a sequence-parallel rank selects nb / P of the nb rows): only the bf16 logits matrix —
+// by far the largest region, 840 MB at 3660 blocks — scales with it; every other region keeps its nb-row size (the views index by nb)
+size_t k5_nabla_workspace_bytes(int H, int nb, int nqb) {
   const size_t nw = (nb + 63) / 64;
+  if (nqb <= 0 || nqb > nb) nqb = nb;
   return (size_t)2 * H * nb * 64 * 2      // qa, ka
          + (size_t)H * nb * nw * 8         // bits
          + (size_t)H * nb * 4              // kv_nb
          + (size_t)H * ((nb + 1) / 2) * nb * 4         // union lists (sized for lists per 2 rows; per 4 rows uses half)
          + (size_t)2 * H * ((nb + 1) / 2) * 4 + 256    // counts, counts of the leading local entries (sequence parallelism)
-         + (size_t)H * nb * sel_row_nv((int)nw) * 64 * 2;   // bf16 block logits [H][rows][64 NV] (round 3: one matmul per head, read back per row)
+         + (size_t)H * (nqb + 4) * sel_row_nv((int)nw) * 64 * 2;   // bf16 block logits [H][nqb rows][64 NV] (round 3: one matmul per head, read back per row)
 }
 
 // q: [Nq][ldq] bf16 = the query rows handled here (global 64-token blocks [q_block0, q_block0 + Nq/64)), k: [N][ldk] = all

@@ -82,6 +82,10 @@ def generate(model, device, shape, num_steps, text_embeds, null_text_embeds, vis
     timesteps = sigma_schedule(num_steps, scheduler_scale, device=device).cpu()  # one sync, before the loop
 
     from .models.dit import DiffusionTransformer3D
+    if isinstance(model, torch.nn.Module):      # per-step paths below: a new sampling run starts with no softmax-form memory (k5_sample resets its own)
+        for m in model.modules():
+            if isinstance(m, DiffusionTransformer3D):
+                m.reset_softmax_memory()
     cfg_on = abs(guidance_weight - 1.0) > 1e-6
     cfg_parallel = getattr(model, "_cfg_parallel", None)
     if cfg_parallel is not None and cfg_on and getattr(model, "_cfg_pair", None) is None:

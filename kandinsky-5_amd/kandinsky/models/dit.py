@@ -365,6 +365,14 @@ class DiffusionTransformer3D(nn.Module):
         self._settings["options"][name] = int(value)
         return self
 
+    def reset_softmax_memory(self):
+        """Forget which heads the per-row-offset softmax served badly ("attn_pref_reset"): a speed hint that is valid from one step to
+        the next of ONE sampling run.  `sample` (k5_sample) does it by itself; a caller stepping `forward` itself calls this per run,
+        so that the same seed on the same handle gives the same bits whatever the handle computed before."""
+        if self._handle is not None:
+            E.check(E.lib().k5_dit_set_option(self._handle, b"attn_pref_reset", 1), "k5_dit_set_option(attn_pref_reset)")
+        return self
+
     def get_option(self, name):
         if self._handle is None:
             if name in self._settings["options"]:

@@ -264,7 +264,7 @@ def test_full_width_qk_norm_gains_vs_oracle(case, expect, row_offsets, qfuse, an
 
 
 # ------------------------------------------------------------------------------------------ MagCache
-@pytest.mark.parametrize("tag", ["sft_12", "nocfg_9", "hand_10"])
+@pytest.mark.parametrize("tag", ["sft_12", "nocfg_9", "hand_10", "sft_50", "nocfg_50"])   # the 50-step cases: the configs' own schedules and ratio tables
 def test_magcache_generate(tiny_dit, tiny_sd, cfg, golden, tag):
     """`set_magcache_params` + generate: the engine's skip pattern is the reference's, the final latent matches the
     bf16-island oracle running the same state machine and the reference's own fp32 result."""

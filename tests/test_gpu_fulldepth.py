@@ -1,0 +1,156 @@
+"""GPU parity at FULL DEPTH and over the FULL SCHEDULE (VERDICT r3 "missing #1"): the whole 2B-Lite network — 32 visual blocks, 2 text
+blocks, D = 1792 — through k5_sample / k5_dit_forward against goldens made by the REFERENCE's own generate() and forward
+(oracle/gen_golden_fulldepth.py; reference dit.py:155-181 loops over all 32 visual_transformer_blocks, generation_utils.py:80-129).
+
+Stated tolerances — MEASURED at depth, not inherited from the 2-block tests (bf16 error compounds through 32 gated residual blocks and
+16 Euler steps; the numbers and the argument are in DESIGN.md §2):
+  the yardstick is the distance of the bf16-island ORACLE (same rounding points as the engine, CPU) from the reference's fp32 result on
+  the same weights, recorded by the generator in dit_fulldepth_meta.json: that is what bf16 autocast costs the reference itself on a GPU.
+  * engine vs reference fp32                <= 1.5 x that yardstick  (and <= the absolute caps below)
+  * engine vs bf16-island oracle            <= 1.5 x that yardstick  (two bf16 evaluations with different fp32 summation orders sit
+                                               ~sqrt(2) x one evaluation's distance apart when their roundings are independent)
+Weights: oracle.synthetic_state_dict(LITE_2B, seed 7), QK-norm gains 1.5; 2.0 B parameters regenerated here from the seed."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import k5_oracle as O  # noqa: E402
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture(scope="module")
+def meta():
+    return json.load(open(os.path.join(HERE, "dit_fulldepth_meta.json")))
+
+
+@pytest.fixture(scope="module")
+def full_dit(meta):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B)
+    assert c["num_visual_blocks"] == 32 and c["num_text_blocks"] == 2
+    sd = O.synthetic_state_dict(O.DitConfig(**c), seed=meta["weights_seed"])
+    for k in sd:
+        if k.endswith(("query_norm.weight", "key_norm.weight")):
+            sd[k] = torch.full((64,), float(meta["qk_gain"]))
+    dit = DiffusionTransformer3D(**c)
+    dit.load_state_dict(sd, assign=True)
+    dit.engine("cuda:0")            # parameters stay on the host: one H2D of the raw bytes, packed on the device
+    del sd
+    yield dit
+    del dit
+    torch.cuda.empty_cache()
+
+
+def test_config1_in_full_vs_the_reference_generate(full_dit, meta):
+    """BASELINE config 1 IN FULL: latent (13, 32, 32, 16) = 3328 tokens, NFE 16, guidance 1, scheduler scale 5, 256 text tokens, all 32
+    visual blocks — the final latent of k5_sample against the final latent of the reference's generate() (fp32) and of the bf16-island
+    oracle, 16384 samples + whole-tensor sums; and step by step (one k5_sample call per step: bit-identical to the fused loop) against
+    2048 samples of the reference's latent after every step, to show how the error grows along the schedule."""
+    from safetensors.torch import load_file
+    from kandinsky.generation_utils import sigma_schedule
+    c = meta["c1"]
+    G = load_file(os.path.join(HERE, "dit_fulldepth_c1.safetensors"))
+    T, H, W = c["latent"]
+    g = torch.Generator().manual_seed(c["xseed"])
+    te = {"text_embeds": torch.randn(c["L"], 3584, generator=g).cuda(), "pooled_embed": torch.randn(1, 768, generator=g).cuda()}
+    ne = {"text_embeds": torch.randn(c["Lnull"], 3584, generator=g).cuda(), "pooled_embed": torch.randn(1, 768, generator=g).cuda()}
+    pos = [torch.arange(T), torch.arange(H // 2), torch.arange(W // 2)]
+    noise = torch.randn(T, H, W, 16, generator=torch.Generator().manual_seed(c["seed"]))
+    sig = sigma_schedule(c["steps"], c["s"]).tolist()
+    args = (te, ne, pos, torch.arange(c["L"]), torch.arange(c["Lnull"]), c["w"])
+    # fused: the whole schedule in one k5_sample call
+    lat = noise.clone().cuda()
+    full_dit.attn_variant_counts(reset=True)
+    full_dit.sample(lat, sig, *args, scale_factor=(1.0, 2.0, 2.0))
+    torch.cuda.synchronize()
+    n_fixed, n_online = full_dit.attn_variant_counts()
+    # step by step
+    lat_s = noise.clone().cuda()
+    per_step = []
+    for i in range(c["steps"]):
+        full_dit.sample(lat_s, sig[i:i + 2], *args, scale_factor=(1.0, 2.0, 2.0))
+        got = lat_s.reshape(-1)[G["step_idx"].cuda()].cpu()
+        per_step.append((rel(got, G["steps_ref"][i]), rel(got, G["steps_bf16_oracle"][i])))
+    torch.cuda.synchronize()
+    assert torch.equal(lat, lat_s), "k5_sample step by step differs from the fused loop"
+    idx = G["sample_idx"]
+    got = lat.reshape(-1)[idx.cuda()].cpu()
+    nz = noise.reshape(-1)[idx]
+    r_ref, r_16 = rel(got, G["final_ref"]), rel(got, G["final_bf16_oracle"])
+    u_ref, u_16 = rel(got - nz, G["final_ref"] - nz), rel(got - nz, G["final_bf16_oracle"] - nz)
+    yard, yard_u = c["bf16_oracle_vs_ref_final"], c["update_bf16_oracle_vs_ref"]
+    ss = lat.double().pow(2).sum().item()
+    print(f"config 1 in full (32 blocks x 16 steps, N = {c['tokens']}): final latent engine vs reference fp32 {r_ref:.3e}, vs bf16-island oracle {r_16:.3e} "
+          f"(bf16 oracle vs reference: {yard:.3e}); on the applied update (latent - noise): {u_ref:.3e} / {u_16:.3e} (oracle: {yard_u:.3e}); "
+          f"sumsq {ss:.6e} / {c['final_sumsq']:.6e}; heads fixed / online {n_fixed} / {n_online}")
+    print("  per step, engine vs reference | vs bf16 oracle | bf16 oracle vs reference:")
+    for i, (a, b) in enumerate(per_step):
+        print(f"   step {i:2d}: {a:.3e} | {b:.3e} | {c['bf16_oracle_vs_ref_per_step'][i]:.3e}")
+    assert c["moved_from_noise"] > 0.05                       # the sampler really moved the latent (the check is not noise vs noise)
+    assert r_ref <= max(1.5 * yard, 1e-2) and r_ref <= 6e-2, (r_ref, yard)
+    assert r_16 <= max(1.5 * yard, 1e-2) and r_16 <= 6e-2, (r_16, yard)
+    assert u_ref <= max(1.5 * yard_u, 2e-2), (u_ref, yard_u)
+    assert abs(ss - c["final_sumsq"]) <= 2 * max(yard, 1e-2) * c["final_sumsq"]
+    assert n_fixed == 16 * 32 * 28 and n_online == 0          # gain 1.5: every head of every block of every step on the fixed-offset form
+
+
+def test_full_depth_forward_320_tokens_vs_reference(full_dit, meta):
+    """One forward through all 32 blocks on a (5, 16, 16) latent (320 tokens, ragged against every tile size; 37 text tokens): the whole
+    velocity against the reference's fp32 forward and the bf16-island oracle."""
+    from safetensors.torch import load_file
+    c = meta["f32"]
+    G = load_file(os.path.join(HERE, "dit_fulldepth_f32.safetensors"))
+    T, H, W = c["latent"]
+    g = torch.Generator().manual_seed(c["xseed"])
+    x = torch.randn(T, H, W, 16, generator=g)
+    text, pooled = torch.randn(c["L"], 3584, generator=g), torch.randn(1, 768, generator=g)
+    pos = [torch.arange(T), torch.arange(H // 2), torch.arange(W // 2)]
+    out = full_dit(x.cuda(), text.cuda(), pooled.cuda(), torch.tensor([c["time"]]), pos, torch.arange(c["L"]), scale_factor=(1.0, 2.0, 2.0))
+    torch.cuda.synchronize()
+    r_ref, r_16, yard = rel(out, G["out_ref"]), rel(out, G["out_bf16_oracle"]), c["bf16_oracle_vs_ref"]
+    print(f"32-block forward at 320 tokens: engine vs reference fp32 {r_ref:.3e}, vs bf16-island oracle {r_16:.3e}; bf16 oracle vs reference {yard:.3e}; "
+          f"residual-stream RMS block 0 / 15 / 31: {c['resid_rms_per_block'][0]:.2f} / {c['resid_rms_per_block'][15]:.2f} / {c['resid_rms_per_block'][31]:.2f}")
+    assert r_ref <= 1.5 * yard, (r_ref, yard)
+    assert r_16 <= 1.5 * yard, (r_16, yard)
+
+
+@pytest.mark.parametrize("w", [1.0, 5.0])
+def test_tiny_50_step_schedule_vs_reference(w):
+    """NFE 50 (config_5s_nocfg / sft: generation_utils.py:80-129 runs all num_steps) on the tiny model: the final latent of one k5_sample
+    call against the reference's generate() (fp32, dit_tiny_50steps.safetensors) and the bf16-island oracle run here."""
+    from types import SimpleNamespace as NS
+    from safetensors.torch import load_file
+    from kandinsky.generation_utils import generate
+    from kandinsky.models.dit import DiffusionTransformer3D
+    g = load_file(os.path.join(HERE, "dit_tiny.safetensors"))
+    m = json.load(open(os.path.join(HERE, "dit_tiny_meta.json")))
+    cfg = dict(m["tiny_config"]); cfg["patch_size"], cfg["axes_dims"] = tuple(cfg["patch_size"]), tuple(cfg["axes_dims"])
+    sd = {k[2:]: v for k, v in g.items() if k.startswith("w.")}
+    dit = DiffusionTransformer3D(**cfg)
+    dit.load_state_dict(sd, assign=True)
+    dit = dit.to("cuda:0")
+    G = load_file(os.path.join(HERE, "dit_tiny_50steps.safetensors"))
+    pos = [torch.arange(3), torch.arange(4), torch.arange(6)]
+    conf = NS(model=NS(dit_params=NS(patch_size=(1, 2, 2)), attention=NS(type="flash")), metrics=NS(scale_factor=(1.0, 2.0, 2.0)))
+    te = {"text_embeds": g["fwd.text"].cuda(), "pooled_embed": g["fwd.pooled"].cuda()}
+    ne = {"text_embeds": g["gen.null_text"].cuda(), "pooled_embed": g["gen.null_pooled"].cuda()}
+    noise = torch.randn(3, 8, 12, 16, generator=torch.Generator().manual_seed(6554))   # what the reference's generate(seed=6554) drew (CPU generator under the patch)
+    out = generate(dit, "cuda:0", (3, 8, 12, 16), 50, te, ne, pos, torch.arange(7), torch.arange(4), w, 5.0, conf, noise=noise)
+    ref16 = O.generate(sd, O.DitConfig(**cfg), noise, 50, {k: v.cpu() for k, v in te.items()}, {k: v.cpu() for k, v in ne.items()}, pos,
+                       torch.arange(7), torch.arange(4), w, 5.0, (1.0, 2.0, 2.0), None, "bf16")
+    r_ref, r_16, yard = rel(out, G[f"gen50.{w}"]), rel(out, ref16), rel(ref16, G[f"gen50.{w}"])
+    print(f"tiny, 50 steps, w = {w}: engine vs reference fp32 {r_ref:.3e}, vs bf16-island oracle {r_16:.3e}; bf16 oracle vs reference {yard:.3e}")
+    assert r_16 <= 1e-2, r_16
+    assert r_ref <= 3e-2, r_ref

@@ -705,7 +705,8 @@ def test_anchored_offsets_beyond_the_window(E, Sq, Sk):
     f_c, _, krad_c, _ = flags_rows_centred(E, q, k, H)
     assert f_c.tolist() == [0, 0, 1, 1], f_c                                # without anchoring: heads 0, 1 on the online form
     flags, kmax, krad, centre = flags_rows_anchored(E, q, k, H)
-    assert flags.tolist() == [1, 1, 1, 1] and (kmax[:2] == -1).all() and (kmax[2:] > 0).all(), (flags, kmax)
+    assert flags.tolist() == [1, 1, 1, 1] and (kmax[:2] < 0).all() and (kmax[2:] > 0).all(), (flags, kmax)   # marked = negative, |entry| = max|k'| (still a bound)
+    assert torch.allclose(-kmax[:2].cpu(), k.norm(dim=-1).amax(0)[:2] * 1.002, rtol=1e-3), kmax
     qd, kd, vt = q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
     rows = torch.arange(Sq) if Sq < 2000 else torch.tensor([0, 5, 255, 256, 4097, 20000, 32767, 32768, 33000, Sq - 1])
     ref = O.sdpa(q[rows], k, v, "bf16", None, base2=True)
@@ -729,6 +730,37 @@ def test_anchored_offsets_beyond_the_window(E, Sq, Sk):
         close(out2[rows], ref, ulps=4, atol=5e-3, what="anchored offsets (no workspace)")
 
 
+def test_marked_heads_attended_without_anchors_fall_back_safely(E):
+    """k5_attention_flags_rows_anchored marks a head beyond the window by a NEGATIVE kmax entry; a caller of the public ABI that
+    then attends through k5_attention_bf16_prescaled_rows / _rows_centred (no row anchors) used to run such a head on offset 0 with the
+    underflow / overflow check skipped — exp2 unguarded at bounds of 400-600.  The entry now keeps its magnitude, the kernel uses |entry| as
+    the plain per-row bound (exp2 arguments <= 90 whatever the data) and rows that underflow send their job (workspace) or head (none) to
+    the online form: the result is the oracle's either way."""
+    H, Sq, Sk = 4, 768, 1024
+    g = torch.Generator().manual_seed(Sq + 7)
+    def unit(x):
+        return x / x.norm(dim=-1, keepdim=True)
+    u = unit(torch.randn(H, 64, generator=g))
+    q = torch.empty(Sq, H, 64); k = torch.empty(Sk, H, 64)
+    k[:, 0] = 10.0 * unit(torch.randn(Sk, 64, generator=g));              q[:, 0] = 60.0 * unit(torch.randn(Sq, 64, generator=g))
+    k[:, 1] = 6.0 * u[1] + 8.0 * unit(torch.randn(Sk, 64, generator=g));  q[:, 1] = 30.0 * u[1] + 40.0 * unit(torch.randn(Sq, 64, generator=g))
+    k[:, 2] = 5.0 * unit(torch.randn(Sk, 64, generator=g));               q[:, 2] = 30.0 * unit(torch.randn(Sq, 64, generator=g))
+    k[:, 3] = 1.5 * unit(torch.randn(Sk, 64, generator=g));               q[:, 3] = 10.0 * unit(torch.randn(Sq, 64, generator=g))
+    q, k = bfr(q), bfr(k)
+    v = bfr(torch.randn(Sk, H, 64, generator=g))
+    qd, kd, vt = q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
+    ref = O.sdpa(q, k, v, "bf16", None, base2=True)
+    for balanced in (True, False):
+        flags, kmax, krad, centre = flags_rows_anchored(E, q, k, H)
+        assert flags.tolist() == [1, 1, 1, 1] and (kmax[:2] < 0).all()
+        out = run_rows_centred(E, qd, kd, vt, H, flags, kmax, centre, krad, balanced=balanced)       # marked heads, NO anchors
+        assert torch.isfinite(out.float()).all()
+        close(out, ref, ulps=4, atol=5e-3, what=f"marked heads without anchors (balanced={balanced})")
+        flags, kmax, _, _ = flags_rows_anchored(E, q, k, H)
+        out_p = run_rows(E, qd, kd, vt, H, flags, kmax)                                             # the plain per-row-offset entry point
+        close(out_p, ref, ulps=4, atol=5e-3, what="marked heads through k5_attention_bf16_prescaled_rows")
+
+
 def test_anchored_offsets_overflow_falls_back_per_job(E):
     """A key OUTSIDE every row's sample (index 20: not in a strided tile, not in the rows' own block) that a few query rows hit with a score
     ~ 500 above everything else: their anchors sit ~ 500 too low, exp2 overflows, the row sum is inf — the job (head 0, query block 1)
@@ -748,7 +780,7 @@ def test_anchored_offsets_overflow_falls_back_per_job(E):
     s = q[300:311, 0] @ k[:, 0].t()
     assert (s[:, 20] - s[:, torch.arange(Sk) != 20].amax(-1) > 300).all()
     flags, kmax, krad, centre = flags_rows_anchored(E, q, k, H)
-    assert flags.tolist() == [1, 1] and kmax[0].item() == -1, (flags, kmax)
+    assert flags.tolist() == [1, 1] and kmax[0].item() < 0, (flags, kmax)
     qd, kd, vt = q.reshape(Sq, -1).cuda().to(BF), k.reshape(Sk, -1).cuda().to(BF), vt_of(v)
     out, anchor = run_rows_anchored(E, qd, kd, vt, H, flags, kmax, centre, krad, balanced=True)
     assert flags.tolist() == [1, 1], flags                                  # a job fell back, not the head
@@ -782,7 +814,7 @@ def test_config2_size_anchored_offsets_sampled_rows_vs_oracle(E):
     vt = v.t().contiguous()
     qf, kf = q.float().reshape(N, H, 64), kc.float().reshape(N, H, 64)
     flags, kmax, krad, centre = flags_rows_anchored(E, qf.cpu(), kf.cpu(), H)
-    assert flags.tolist() == [1] * H and (kmax == -1).all(), (flags, kmax)
+    assert flags.tolist() == [1] * H and (kmax < 0).all(), (flags, kmax)
     out, anchor = run_rows_anchored(E, q, kc, vt, H, flags, kmax, centre, krad, balanced=True)
     assert flags.tolist() == [1] * H, flags                                     # no head left the fixed form
     rows = torch.tensor([0, 1, 31, 255, 256, 4097, 23808, 40000, 47104, 47615 - 64, 47615])   # incl. rows of the split tail jobs
