@@ -679,6 +679,12 @@ int launch_k8(GemmP p, hipStream_t stream) {
 // fetch the next tile, whose first fragments are read while the current tile's last MFMAs run; the epilogue sits between.
 // ---------------------------------------------------------------------------------------------
 constexpr int W4_PAD = 1040, W4_OP = 32 * W4_PAD, W4_STAGE = 2 * W4_OP, W4_LDS = 2 * W4_STAGE;
+#ifdef W4_TRACE
+constexpr int W4_TRACE_N = 192, W4_TRACE_BYTES = W4_TRACE_N * 8;   // 64 tiles x 3 stamps per workgroup
+#else
+constexpr int W4_TRACE_BYTES = 0;
+#endif
+constexpr int W4_PF_BYTES = 4 * 1024;   // EPI_GATE: per-wave bias | gate vectors of the epilogue
 typedef __attribute__((address_space(3))) void w4_lds_t;
 
 template <int EPI>
@@ -934,7 +940,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_KT ktile
 #endif
 
+#ifdef W4_TRACE   // tools/gemm_w4_trace.py: wall-clock (100 MHz) stamps per workgroup and tile: tile start | K loop done | epilogue done
+  unsigned long long* tr_lds = reinterpret_cast<unsigned long long*>(dsm + W4_LDS);
+  int tr_i = 0;
+#define W4_STAMP() do { if (tid == 0 && tr_i < W4_TRACE_N) tr_lds[tr_i] = __builtin_amdgcn_s_memrealtime(); ++tr_i; } while (0)
+#else
+#define W4_STAMP() do {} while (0)
+#endif
   for (int ti = slot; ti < x_cnt; ti += per_xcd) {
+    W4_STAMP();
     W4_KT(std::integral_constant<int, 0>{}, std::true_type{});
     W4_KT(std::integral_constant<int, 1>{}, std::false_type{});
     for (int t = 2; t < nk; t += 2) {
@@ -942,6 +956,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       W4_KT(std::integral_constant<int, 1>{}, std::false_type{});
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs are invisible to the hazard recogniser: let the last ones retire
+    W4_STAMP();
     int m0, n0;
     tile_origin(x_first + ti, m0, n0);
     int tid2 = threadIdx.x;
@@ -971,66 +986,119 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         return;
       }
-      f32x4 bvec[8], gvec[8];
+      // per-column vectors of the wave's 128 columns.  Plain / GELU / per-row bias: 8 x 4 values per lane in registers.  Gated residual:
+      // bias AND gate would be 64 VGPRs next to two register sets of residual rows and the next tile's 128 fragment registers — they live
+      // in this wave's 1-KB LDS slot instead (ds_read_b128 per use: the LDS is idle in the epilogue, and DS reads are not in the vmcnt queue)
+      f32x4 bvec[8];
+      float* vslot = reinterpret_cast<float*>(dsm + W4_LDS + W4_TRACE_BYTES + 1024 * e_wave);   // [bias 128 | gate 128]
+      if constexpr (EPI == K5_EPI_GATE) {
+        const int l = tid2 & 63;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int nc = min(nb + 16 * i, p.N - 4);          // clamped: out-of-range quads are never stored
-        if (EPI != K5_EPI_BIAS_M && has_bias) bvec[i] = *reinterpret_cast<const f32x4*>(p.bias + nc);
-        if (EPI == K5_EPI_GATE) gvec[i] = *reinterpret_cast<const f32x4*>(p.gate + nc);
+        for (int h = 0; h < 2; ++h) {
+          const int c = min(n0 + 128 * e_wn + 2 * l + h, p.N - 1);   // columns 2 l, 2 l + 1 of the wave's 128
+          vslot[2 * l + h] = has_bias ? p.bias[c] : 0.f;
+          vslot[128 + 2 * l + h] = p.gate[c];
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int nc = min(nb + 16 * i, p.N - 4);          // clamped: out-of-range quads are never stored
+          if (EPI != K5_EPI_BIAS_M && has_bias) bvec[i] = *reinterpret_cast<const f32x4*>(p.bias + nc);
+        }
       }
-      constexpr int G = EPI == K5_EPI_GATE ? 1 : 4;        // token tiles per load / store phase (register budget: 2 spills 37 VGPRs, 1 is +1.5-2 %)
+      // one token tile (16 rows) of the wave's 128 x 128 quadrant: accumulators -> bias / GELU / gated residual -> bf16 -> two n-tiles paired
+      // by v_permlane16_swap so that every lane stores 16 B
+      // (gated residual) bias / gate quads of n-tiles 2 iq, 2 iq + 1 from the wave's LDS slot: asm reads with counted lgkmcnt waits — a plain
+      // LDS load would make the compiler wait for every LDS-DMA (the next tile's K-tiles) and store in flight first — fetched one pair ahead
+      const uint32_t vaddr = (uint32_t)(uintptr_t)(w4_lds_t*)(dsm + W4_LDS + W4_TRACE_BYTES) + 1024u * (uint32_t)e_wave + 16u * (uint32_t)e_lc;
+      f32x4 bq[2][2], gq[2][2];
+#define W4_VEC_FETCH(IQ, B) do { W4_RD(bq[B][0], vaddr, 128 * (IQ)); W4_RD(bq[B][1], vaddr, 128 * (IQ) + 64); \
+                                W4_RD(gq[B][0], vaddr, 512 + 128 * (IQ)); W4_RD(gq[B][1], vaddr, 512 + 128 * (IQ) + 64); } while (0)
+      auto finish_rows = [&](int j, float bm, const u32x2 (&rr)[8]) {
+        const int m = m0 + 128 * e_wm + 16 * j + e_l15;
+        if constexpr (EPI == K5_EPI_GATE) W4_VEC_FETCH(0, 0);
 #pragma unroll
-      for (int jh = 0; jh < 8 / G; ++jh) {
-        u32x2 rr[G][8];
-        float bias_m[G];
-#pragma unroll
-        for (int jj = 0; jj < G; ++jj) {
-          const int m = min(m0 + 128 * e_wm + 16 * (G * jh + jj) + e_l15, p.M - 1);
-          bias_m[jj] = (EPI == K5_EPI_BIAS_M && has_bias) ? p.bias[m] : 0.f;
-          if (EPI == K5_EPI_GATE) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-              rr[jj][i] = *reinterpret_cast<const u32x2*>(p.resid + (size_t)m * p.ldr + min(nb + 16 * i, p.N - 4));
+        for (int iq = 0; iq < 4; ++iq) {     // n-tiles 2 iq and 2 iq + 1 together
+          if constexpr (EPI == K5_EPI_GATE) {
+            if (iq == 0) W4_VEC_FETCH(1, 1);
+            if (iq == 1) W4_VEC_FETCH(2, 0);
+            if (iq == 2) W4_VEC_FETCH(3, 1);
+            if (iq < 3) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
           }
-        }
+          u32x2 o[2];
 #pragma unroll
-        for (int jj = 0; jj < G; ++jj) {
-          const int j = G * jh + jj;
-          const int m = m0 + 128 * e_wm + 16 * j + e_l15;
+          for (int h = 0; h < 2; ++h) {
+            const int i = 2 * iq + h;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, gv = bv;
+            if constexpr (EPI == K5_EPI_GATE) { bv = bq[iq & 1][h]; gv = gq[iq & 1][h]; }
+            else if (EPI != K5_EPI_BIAS_M && has_bias) bv = bvec[i];
 #pragma unroll
-          for (int iq = 0; iq < 4; ++iq) {     // n-tiles 2 iq and 2 iq + 1 together
-            u32x2 o[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int i = 2 * iq + h;
-              float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                if (EPI == K5_EPI_BIAS_M) v[e] += bias_m[jj];
-                else if (has_bias) v[e] += bvec[i][e];
-                if (EPI == K5_EPI_GELU) v[e] = gelu_erf(bf_round(v[e]));
-              }
-              if (EPI == K5_EPI_GATE) {
-                v[0] = __uint_as_float(rr[jj][i][0] << 16) + gvec[i][0] * bf_round(v[0]);
-                v[1] = __uint_as_float(rr[jj][i][0] & 0xffff0000u) + gvec[i][1] * bf_round(v[1]);
-                v[2] = __uint_as_float(rr[jj][i][1] << 16) + gvec[i][2] * bf_round(v[2]);
-                v[3] = __uint_as_float(rr[jj][i][1] & 0xffff0000u) + gvec[i][3] * bf_round(v[3]);
-              }
-              o[h] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            for (int e = 0; e < 4; ++e) {
+              if (EPI == K5_EPI_BIAS_M) v[e] += bm;
+              else if (has_bias) v[e] += bv[e];
+              if (EPI == K5_EPI_GELU) v[e] = bf_round(v[e]);
             }
-            // lanes l and l + 16 hold columns 4 c .. 4 c + 3 and the next four of BOTH tiles: trade (tile 2 iq + 1 of the lower
-            // row) for (tile 2 iq of the upper row) and each lane owns 8 consecutive columns of ONE tile -> 16-B stores, half
-            // as many (the epilogue is store-issue bound)
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-              const auto sw = __builtin_amdgcn_permlane16_swap(o[0][d], o[1][d], false, false);
-              o[0][d] = sw[0]; o[1][d] = sw[1];
+            if (EPI == K5_EPI_GELU) { gelu_erf_x2(v[0], v[1]); gelu_erf_x2(v[2], v[3]); }   // same bits as gelu_erf, packed fp32 math
+            if (EPI == K5_EPI_GATE) {
+              v[0] = __uint_as_float(rr[i][0] << 16) + gv[0] * bf_round(v[0]);
+              v[1] = __uint_as_float(rr[i][0] & 0xffff0000u) + gv[1] * bf_round(v[1]);
+              v[2] = __uint_as_float(rr[i][1] << 16) + gv[2] * bf_round(v[2]);
+              v[3] = __uint_as_float(rr[i][1] & 0xffff0000u) + gv[3] * bf_round(v[3]);
             }
-            const int n = n0 + 128 * e_wn + 16 * (2 * iq + (e_lc & 1)) + 8 * (e_lc >> 1);
-            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(p.C + (size_t)m * p.ldc + n) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+            o[h] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
           }
+          // lanes l and l + 16 hold columns 4 c .. 4 c + 3 and the next four of BOTH tiles: trade (tile 2 iq + 1 of the lower
+          // row) for (tile 2 iq of the upper row) and each lane owns 8 consecutive columns of ONE tile -> 16-B stores, half
+          // as many (the epilogue is store-issue bound)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(o[0][d], o[1][d], false, false);
+            o[0][d] = sw[0]; o[1][d] = sw[1];
+          }
+          const int n = n0 + 128 * e_wn + 16 * (2 * iq + (e_lc & 1)) + 8 * (e_lc >> 1);
+          if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(p.C + (size_t)m * p.ldc + n) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
         }
-        asm volatile("" ::: "memory");
+      };
+      if constexpr (EPI == K5_EPI_GATE) {
+        // The residual rows of token tile j + 1 are requested BEFORE token tile j is stored (two register sets, 32 VGPRs): a load issued
+        // behind stores can only be awaited together with them, i.e. after every store has been acknowledged by L2 — with one register set
+        // each of the 8 token tiles paid a store acknowledgement plus a load round trip: 16.5 us of a K = 1792 tile's 57 -> 12.1 (tools/gemm_w4_trace.py;
+        // a plain-store epilogue takes 5.2).  Touching the residual tile's lines ~5 us ahead, from inside the K loop (four 4-B-per-lane LDS-DMA
+        // loads per wave in K-tile nk - 4), was built and measured neutral with either epilogue (out + gate 313.8 / 314.3 / 321.1 us with,
+        // 309.0 / 312.2 / 315.0 without, interleaved): every workgroup of a round reaches its epilogue within a few us of the others, the
+        // 67 MB of residual reads + output writes of a round then move at ~5.6 TB/s — the epilogues are HBM-bandwidth-bound BECAUSE they
+        // are in lockstep, not latency-bound.
+        u32x2 rr[2][8];
+        auto load_rows = [&](int j, u32x2 (&dst)[8]) {
+          const int m = min(m0 + 128 * e_wm + 16 * j + e_l15, p.M - 1);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const u32x2*>(p.resid + (size_t)m * p.ldr + min(nb + 16 * i, p.N - 4));
+        };
+        load_rows(0, rr[0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (j + 1 < 8) load_rows(j + 1, rr[(j + 1) & 1]);
+          asm volatile("" ::: "memory");
+          finish_rows(j, 0.f, rr[j & 1]);
+          asm volatile("" ::: "memory");
+        }
+      } else {
+        constexpr int G = 4;        // token tiles per phase
+#pragma unroll
+        for (int jh = 0; jh < 8 / G; ++jh) {
+          float bias_m[G];
+#pragma unroll
+          for (int jj = 0; jj < G; ++jj)
+            bias_m[jj] = (EPI == K5_EPI_BIAS_M && has_bias) ? p.bias[min(m0 + 128 * e_wm + 16 * (G * jh + jj) + e_l15, p.M - 1)] : 0.f;
+          const u32x2 none[8] = {};
+#pragma unroll
+          for (int jj = 0; jj < G; ++jj) finish_rows(G * jh + jj, bias_m[jj], none);
+          asm volatile("" ::: "memory");
+        }
       }
     };
     if (p.bias) epilogue(std::true_type{}); else epilogue(std::false_type{});
@@ -1038,7 +1106,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // vmcnt waits INSIDE the loop).  Draining the stores as well measured within noise of not draining them (the next tile's
     // first K-tiles have had the whole epilogue to land either way).
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    W4_STAMP();
   }
+#ifdef W4_TRACE
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (p.trace && tid < 64)
+    for (int i = tid; i < W4_TRACE_N; i += 64) p.trace[(size_t)blockIdx.x * W4_TRACE_N + i] = i < tr_i ? tr_lds[i] : 0ull;
+#endif
+#undef W4_VEC_FETCH
+#undef W4_STAMP
 #undef W4_KT
 #undef W4_MF
 #undef W4_MF0
@@ -1046,27 +1122,151 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wrapped DMAs still write this workgroup's LDS
 }
 
+// ---------------------------------------------------------------------------------------------
+// The last, partly filled round of 256x256 tiles as 128x128 QUADRANTS with a deep prefetch (round 4).  The persistent kernels hand the
+// tiles of a round that would leave more than half of the CUs idle to a small kernel, one workgroup per quadrant; until round 4 that was
+// gemm_bf16_glds_kernel — one K-tile of prefetch behind a vmcnt(0) + barrier — and with at most one such workgroup per CU nothing hid
+// the L2 / HBM round trip: tools/gemm_w4_trace.py measured 36 / 70 / 92 / 154 us for the tails of the out, q|k, FF1 and FF2 projections
+// (22 / 44 / 88 / 22 tiles; K = 1792, 1792, 1792, 7168) = 2.5 us per K-tile, 11-15 % of those GEMMs.  Here: the w4 kernel's LDS image
+// (1040-B pieces: fragment reads at immediate offsets, conflict-free) in FOUR stages of 128 + 128 rows (133 120 B), three K-tiles in
+// flight under counted vmcnt waits and one raw s_barrier per K-tile; four waves, one per SIMD, each 64 x 64 = 4 x 4 MFMA 16x16x32 tiles;
+// the fragment reads of k-step 1 fly under the MFMAs of k-step 0.  Same accumulation order over K as the persistent kernels' tiles
+// (K-tile after K-tile, k-step 0 then 1), so a tile's numbers do not depend on which kernel computed it.
+// ---------------------------------------------------------------------------------------------
+constexpr int Q4_OP = 16 * W4_PAD, Q4_STAGE = 2 * Q4_OP, Q4_NST = 4, Q4_LDS = Q4_NST * Q4_STAGE;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1, l15 = lane & 15, lc = lane >> 4;
+  // quadrant b & 3 of the 256x256 logical tile tail_base + b / 4 (the tile walk of the persistent kernels: groups of 4 m-tiles)
+  const int plid = p.tail_base + (int)(blockIdx.x >> 2), q = blockIdx.x & 3;
+  const int pg = plid / (4 * p.tiles256_n), pfirst = pg * 4, pgsz = min(p.tiles256_m - pfirst, 4);
+  const int m0 = (pfirst + (plid % (4 * p.tiles256_n)) % pgsz) * 256 + 128 * (q >> 1);
+  const int n0 = ((plid % (4 * p.tiles256_n)) / pgsz) * 256 + 128 * (q & 1);
+  if (m0 >= p.M || n0 >= p.N) return;
+
+  const int nk = p.K / BK;
+  const uint32_t ldw2 = (uint32_t)p.ldw * 2u, lda2 = (uint32_t)p.lda * 2u;
+  // one DMA instruction = one piece r (rows 16 i + r, i = lane >> 3, 16-B chunk lane & 7); wave w issues pieces 4 w .. 4 w + 3 of both operands
+  uint32_t vw = (uint32_t)(16 * (lane >> 3)) * ldw2 + (uint32_t)(lane & 7) * 16u;
+  uint32_t vx = (uint32_t)(16 * (lane >> 3)) * lda2 + (uint32_t)(lane & 7) * 16u;
+  const int rows_w = min(p.N - n0, 128), rows_x = min(p.M - m0, 128);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.W) + (size_t)n0 * ldw2), 0,
+                                                                       (int)(((uint32_t)(rows_w - 1) * (uint32_t)p.ldw + (uint32_t)p.K) * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.A) + (size_t)m0 * lda2), 0,
+                                                                       (int)(((uint32_t)(rows_x - 1) * (uint32_t)p.lda + (uint32_t)p.K) * 2u), 0x00020000);
+  auto dma = [&](int stage) {   // the next K-tile of both operands into `stage` (8 instructions per wave), then advance the cursor
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + stage * Q4_STAGE + (4 * wave + jj) * W4_PAD), 16, vw, (uint32_t)(4 * wave + jj) * ldw2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + stage * Q4_STAGE + Q4_OP + (4 * wave + jj) * W4_PAD), 16, vx, (uint32_t)(4 * wave + jj) * lda2, 0, 0);
+    }
+    vw += 2 * BK; vx += 2 * BK;
+  };
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(w4_lds_t*)dsm;
+  const uint32_t wb0 = lds0 + (uint32_t)l15 * W4_PAD + (uint32_t)lc * 16u + 512u * (uint32_t)wn;            // + 128 i + 64 s (+ stage)
+  const uint32_t xb0 = lds0 + Q4_OP + (uint32_t)l15 * W4_PAD + (uint32_t)lc * 16u + 512u * (uint32_t)wm;    // + 128 j + 64 s (+ stage)
+#define Q4_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+  f32x4 acc[4][4];   // [n-tile][m-tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 wf[2][4], xf[2][4];
+
+  // three K-tiles in flight
+#pragma unroll
+  for (int st = 0; st < Q4_NST - 1; ++st)
+    if (st < nk) dma(st);
+  int st = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = nk - 1 - kt;                    // K-tiles behind this one that have been issued may stay in flight: min(2, ahead)
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");           // every wave's pieces of K-tile kt have landed; stage (kt - 1) % 4 is no longer read
+    if (kt + Q4_NST - 1 < nk) dma(st == 0 ? Q4_NST - 1 : st - 1);
+    const uint32_t wb = wb0 + (uint32_t)st * Q4_STAGE, xb = xb0 + (uint32_t)st * Q4_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { Q4_RD(wf[0][i], wb, i * 128); Q4_RD(xf[0][i], xb, i * 128); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { Q4_RD(wf[1][i], wb, i * 128 + 64); Q4_RD(xf[1][i], xb, i * 128 + 64); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xf[0][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], xf[1][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    st = st == Q4_NST - 1 ? 0 : st + 1;
+  }
+#undef Q4_RD
+  // accumulator (n-tile i, m-tile j): lane (l15, lc) holds token row m0 + 64 wm + 16 j + l15, columns n0 + 64 wn + 16 i + 4 lc .. + 3
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + 64 * wm + 16 * j + l15;
+    if (m >= p.M) continue;
+    const float bias_m = (EPI == K5_EPI_BIAS_M && p.bias) ? p.bias[m] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      gemm_epilogue_quad<EPI>(p, v, m, n0 + 64 * wn + 16 * i + 4 * lc, bias_m);
+    }
+  }
+}
+
+// the tail launch shared by the persistent kernels: `rem` logical 256x256 tiles from `full` on, as quadrants
+template <int EPI>
+int launch_tail(GemmP p, hipStream_t stream, int full, int rem) {
+  p.tail_base = full;
+  static const bool old_tail = getenv("K5_GEMM_TAIL_V1") != nullptr;   // A/B: the one-K-tile-of-prefetch kernel of rounds 1-3
+  // more quadrants than CUs (FF1: 88 tiles = 352 quadrants): the 64-KB kernel runs two of them per CU at once, 38.5 us against 52.7 for two
+  // rounds of this one (133 KB); up to one round this one wins (rocprofv3, K = 1792 / 7168: 26-35 / 92 us against 28-38 / 115)
+  if (old_tail || (p.K % (2 * BK)) != 0 || p.K < 4 * BK || 4 * rem > 256) {
+    p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL(gemm_bf16_glds_kernel<EPI>, dim3(4 * rem), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_bf16_q4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS) != hipSuccess) return K5_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_q4_kernel<EPI>, dim3(4 * rem), dim3(256), Q4_LDS, stream, p);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
 template <int EPI>
 int launch_w4(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS + W4_TRACE_BYTES + W4_PF_BYTES) != hipSuccess)
       return K5_ERR_HIP;
     attr_set = true;
   }
+#ifdef W4_TRACE
+  p.trace = getenv("K5_GEMM_TRACE") ? (unsigned long long*)strtoull(getenv("K5_GEMM_TRACE"), nullptr, 16) : nullptr;
+#endif
   p.tiles_m = (p.M + K8_BM - 1) / K8_BM; p.tiles_n = (p.N + K8_BN - 1) / K8_BN;
   const int tiles = p.tiles_m * p.tiles_n;
   const int full = tiles / num_cu * num_cu, rem = tiles - full;
   const bool split_tail = !no_tail && full > 0 && rem > 0 && 2 * rem < num_cu;   // see launch_k8_mt
   p.lid_limit = split_tail ? full : tiles;
   p.tiles256_m = p.tiles_m; p.tiles256_n = p.tiles_n;
-  hipLaunchKernelGGL((gemm_bf16_w4_kernel<EPI>), dim3(min(p.lid_limit, num_cu)), dim3(256), W4_LDS, stream, p);
-  if (split_tail) {
-    p.tail_base = full;
-    p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(gemm_bf16_glds_kernel<EPI>, dim3(4 * rem), dim3(256), 0, stream, p);
-  }
-  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+  hipLaunchKernelGGL((gemm_bf16_w4_kernel<EPI>), dim3(min(p.lid_limit, num_cu)), dim3(256), W4_LDS + W4_TRACE_BYTES + W4_PF_BYTES, stream, p);
+  if (hipGetLastError() != hipSuccess) return K5_ERR_HIP;
+  if (split_tail) return launch_tail<EPI>(p, stream, full, rem);
+  return K5_OK;
 }
 
 }  // namespace

@@ -67,6 +67,27 @@ K5_DEV float erf_as(float x) {
   return copysignf(fmaf(-p * t, e, 1.0f), x);
 }
 K5_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// two values at once on the packed fp32 pipe (v_pk_mul / v_pk_fma_f32; rcp and exp2 stay scalar): the SAME operations in the same order as
+// gelu_erf, so the bits are the same — 21 VALU instructions per pair instead of 36.  For epilogues with no MFMA beside them (beside MFMAs
+// packed math is an anti-lever, which is why the build runs with -fno-slp-vectorize).
+typedef float k5_f32x2 __attribute__((ext_vector_type(2)));
+K5_DEV void gelu_erf_x2(float& a, float& b) {
+  const k5_f32x2 x0 = {a, b};
+  const k5_f32x2 x = x0 * k5_f32x2{0.70710678118654752440f, 0.70710678118654752440f};
+  const k5_f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const k5_f32x2 d = __builtin_elementwise_fma(k5_f32x2{0.3275911f, 0.3275911f}, ax, k5_f32x2{1.0f, 1.0f});
+  const k5_f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  k5_f32x2 p = __builtin_elementwise_fma(k5_f32x2{1.061405429f, 1.061405429f}, t, k5_f32x2{-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(p, t, k5_f32x2{1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(p, t, k5_f32x2{-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(p, t, k5_f32x2{0.254829592f, 0.254829592f});
+  const k5_f32x2 a2 = (k5_f32x2{-1.44269504088896340736f, -1.44269504088896340736f} * ax) * ax;
+  const k5_f32x2 e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+  const k5_f32x2 r = __builtin_elementwise_fma(-(p * t), e, k5_f32x2{1.0f, 1.0f});
+  const k5_f32x2 er = {copysignf(r[0], x[0]), copysignf(r[1], x[1])};
+  const k5_f32x2 o = (k5_f32x2{0.5f, 0.5f} * x0) * (k5_f32x2{1.0f, 1.0f} + er);
+  a = o[0]; b = o[1];
+}
 K5_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 // bijective XCD-aware block remap (guide T1): physical block b runs on XCD b%8; give each XCD a

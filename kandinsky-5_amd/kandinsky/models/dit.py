@@ -150,24 +150,29 @@ class DiffusionTransformer3D(nn.Module):
             from ..magcache_utils import _apply
             _apply(self)
 
-    def init_synthetic(self, device, seed=0, std=0.02, qk_gain=1.0):
-        """Random-init weights of this architecture generated ON DEVICE tensor by tensor and handed straight
-        to the engine (no 8 GB host copy).  Linear ~ N(0,std^2) incl. Modulation (reference zero-inits it,
-        nn.py:158-159, which would make every block an identity), norm weights 1, biases N(0,std^2)."""
+    def init_synthetic(self, device, seed=0, std=0.02, qk_gain=1.0, host_rng=False):
+        """Random-init weights of this architecture generated tensor by tensor and handed straight to the engine (no 8 GB host
+        copy).  Linear ~ N(0,std^2) incl. Modulation (reference zero-inits it, nn.py:158-159, which would make every block an
+        identity), norm weights 1, biases N(0,std^2).  Drawn ON DEVICE by default; `host_rng=True` draws every tensor from its own
+        CPU generator seeded (seed * 1000003 + index in state_dict order) — the streams a CPU process can reproduce, so that a
+        reference run on the host sees the very same weights (bench.py's parity check against tests/golden/dit_fulldepth_c2.*)."""
         device = torch.device(device)
         self._destroy_engine()
         with torch.cuda.device(device):
             h = self._create_handle()
-            g = torch.Generator(device=device)
+            g = torch.Generator(device="cpu" if host_rng else device)
             for idx, (name, p) in enumerate(self.state_dict().items()):
                 g.manual_seed(seed * 1000003 + idx)
-                if name.endswith("norm.weight"):
+                if name.endswith("norm.weight") and len(p.shape) == 1:
                     t = torch.ones(p.shape, device=device)
                     if name.endswith(("query_norm.weight", "key_norm.weight")):
                         t = t * float(qk_gain)   # QK-norm gains of a trained checkpoint are not 1: bench.py --qk-gain
                 else:
                     s = std * (2.5 if "modulation" in name else 1.0)
-                    t = torch.randn(p.shape, device=device, generator=g) * s
+                    if host_rng:
+                        t = (torch.randn(p.shape, generator=g) * s).to(device)
+                    else:
+                        t = torch.randn(p.shape, device=device, generator=g) * s
                 self._load_one(h, name, t)
             torch.cuda.synchronize(device)
             E.check(E.lib().k5_dit_finalize(h), "k5_dit_finalize")
