@@ -475,6 +475,8 @@ def main():
             invalid.append("the latent after the timed steps differs from the committed pin of this (workload, steps) beyond the stated tolerance (latent_pin)")
         if parity is not None and parity.get("status") == "FAILED":
             invalid.append("the first two steps of this configuration differ from the reference golden beyond the stated tolerance (parity_check)")
+        if world > 1:
+            out["sp_schedule"] = dit.sp_schedule()     # which exchange the engine's self-tuning picked on this node, and what it measured
         if rank_check is not None:
             out["rank_check"] = rank_check
         if invalid:

@@ -31,7 +31,7 @@ typedef enum { K5_EPI_BIAS = 0, K5_EPI_BIAS_M = 1, K5_EPI_GELU = 2, K5_EPI_GATE 
 
 /* bumped whenever an entry point is added or changes meaning; the host binding checks it BEFORE binding symbols, so that a stale
  * libk5.so fails with a clear message instead of a missing-symbol lookup (round 3: 4) */
-#define K5_ABI_VERSION 5
+#define K5_ABI_VERSION 6
 int k5_abi_version(void);
 const char* k5_last_error(void);
 
@@ -347,6 +347,19 @@ int k5_dit_cfg_pair_init_loopback(k5_dit* dit, k5_loopback* group, int branch);
  * k5_dit_get_option("emulated") reads 1 so that a bench can refuse the number. */
 int k5_dit_set_option(k5_dit* dit, const char* name, int value);
 int k5_dit_get_option(k5_dit* dit, const char* name, int* value);
+/* Self-tuning sequence-parallel schedule (replaces the fixed plan of parallelize_dit, kandinsky/models/parallelize.py:11-102, and the
+ * launcher's world-size bookkeeping, kandinsky/utils.py:40-55).  Which exchange is fastest — one in-place K / V^T all-gather per block,
+ * the same exchange in 2 slices, the Ulysses all-to-all (heads % ranks == 0); for NABLA one or two passes over the lists — depends on
+ * the node.  The first sharded forward of a handle with more than one rank therefore times one block's self-attention section under
+ * every admissible candidate on its own shapes; the ranks exchange their times, each candidate costs its slowest rank, the cheapest is
+ * kept for the life of the handle (every rank decides alike from the same table).  Options set explicitly through k5_dit_set_option
+ * ("sp_mode", "sp_slices", "sp_nabla_passes") are left alone; "sp_autotune" 0 switches the tuner off (the default for loopback groups),
+ * 2 makes the next sharded forward tune again.  k5_dit_sp_schedule: JSON text of what was measured and chosen, incl. the bare gather's
+ * bytes and GB/s ("{}" before the first tuning run); returns the text length, copies at most len - 1 characters + NUL (buf may be null).
+ * k5_sp_pick_schedule: the selection rule alone (host arithmetic, no GPU): times[rank * ncand + cand] in ms, <= 0 / non-finite = did not
+ * run on that rank; valid (nullable) masks candidates; returns the chosen candidate or -1, max-over-ranks per candidate in cost_out. */
+int k5_dit_sp_schedule(k5_dit* dit, char* buf, int len);
+int k5_sp_pick_schedule(const float* times, int ncand, int world, const int* valid, float* cost_out);
 /* (block, head) self-attention launches that took the fixed-offset / the online-max softmax since the last reset. */
 int k5_dit_attn_variant_counts(k5_dit* dit, long long* fixed_heads, long long* online_heads, int reset);
 /* kept / possible 64x64 blocks of the NABLA maps computed while profiling was on, since that reset (realised density). */

@@ -340,6 +340,15 @@ struct k5_dit {
   hipEvent_t ev_u_o = nullptr, ev_u_back = nullptr;
   hipEvent_t ev_slice[4] = {};                     // slice s of every peer has landed
   bool emulated = false;                           // "emulate_world": timing-only layout, results are garbage
+  // Self-tuning sequence-parallel schedule (round 4): which exchange wins — one in-place all-gather per block, the sliced exchange, Ulysses
+  // all-to-all; for NABLA one or two passes over the lists — is a property of the NODE (xGMI link rates, how RCCL drives them) that no
+  // single-GPU box can measure.  So the first sharded forward of a handle (world > 1) times one block's self-attention section under
+  // every admissible candidate on its own shapes, the ranks agree on max-over-ranks per candidate, and the fastest is kept for the life
+  // of the handle.  Knobs the caller set explicitly are left alone; "sp_autotune" = 0 switches it off.
+  bool sp_autotune = true, sp_tuned = false;
+  int sp_user_set = 0;                             // bit 0: sp_mode, 1: sp_slices, 2: sp_nabla_passes were set through k5_dit_set_option
+  std::string sp_report;                           // JSON text of the last tuning run (k5_dit_sp_schedule)
+  DevBuf ws_tune;
   hipStream_t comm_stream = nullptr;              // all-gathers run here, overlapped with pass 1 of the attention
   hipEvent_t ev_k = nullptr, ev_v = nullptr, ev_gathered = nullptr, ev_stats = nullptr, ev_means = nullptr;
   // NABLA: fractal token permutation (cached per shape) and the selection workspace
@@ -1143,6 +1152,121 @@ int to_bf16(k5_dit* d, hipStream_t s, const void* src, int dtype, size_t n, DevB
   return K5_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// self-tuning sequence-parallel schedule (see k5_dit::sp_autotune)
+// ---------------------------------------------------------------------------------------------
+struct SpCand { int mode, slices, passes; const char* name; };
+
+// pure host logic, exported for a CPU test (k5_sp_pick_schedule): candidate c costs max over ranks of times[r * ncand + c] (a collective
+// schedule is as slow as its slowest rank); the cheapest valid one wins, ties to the lowest index (= the more conservative schedule);
+// a non-finite or non-positive time disqualifies the candidate on every rank alike (all ranks see the same gathered table)
+int sp_pick(const float* times, int ncand, int world, const int* valid, float* cost_out) {
+  int best = -1; float best_t = 0.f;
+  for (int c = 0; c < ncand; ++c) {
+    float t = 0.f; bool ok = !valid || valid[c];
+    for (int r = 0; r < world && ok; ++r) {
+      const float v = times[(size_t)r * ncand + c];
+      if (!(v > 0.f) || !(v < 3.0e38f)) ok = false; else t = v > t ? v : t;
+    }
+    if (cost_out) cost_out[c] = ok ? t : -1.f;
+    if (ok && (best < 0 || t < best_t)) { best = c; best_t = t; }
+  }
+  return best;
+}
+
+int sp_autotune_run(k5_dit* d, hipStream_t s, int N, int L, const NablaArgs* nabla) {
+  const int P = d->sp_world, H = d->Hh, D = d->D;
+  d->sp_tuned = true;                                  // whatever happens below: once per handle
+  std::vector<SpCand> cands;
+  if (!nabla) {
+    cands.push_back({0, 1, 1, "K / V^T all-gather"});
+    if (!(d->sp_user_set & 3) && d->comm.can_exchange() && N / 64 >= 4 * P) cands.push_back({0, 2, 1, "K / V^T exchange in 2 slices"});
+    if (!(d->sp_user_set & 3) && H % P == 0 && d->comm.can_exchange()) cands.push_back({1, 1, 1, "Ulysses all-to-all"});
+  } else {
+    cands.push_back({0, 1, 1, "all-gather, one pass over the lists"});
+    if (!(d->sp_user_set & 4)) cands.push_back({0, 1, 2, "all-gather, own key blocks first (two passes)"});
+  }
+  const int nc = (int)cands.size();
+  if (nc < 2) { d->sp_report = "{\"tuned\": false, \"reason\": \"one admissible schedule\"}"; return K5_OK; }
+  const int save_mode = d->sp_mode, save_slices = d->sp_slices, save_passes = d->sp_nabla_passes, save_prof = d->profiling;
+  d->profiling = 0;
+  unsigned long long cnt_save[4] = {0, 0, 0, 0};       // the trial launches must not show up in the softmax-form counters (k5_dit_attn_variant_counts)
+  K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
+  HIPCHK(hipMemcpyAsync(cnt_save, d->ws_attn_cnt.p, 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  std::vector<float> mine(nc, -1.f);
+  double comm_ms = -1.0, comm_bytes = 0.0;
+  const AttnW& a = d->vblocks[0].self_attn;
+  for (int c = 0; c < nc; ++c) {
+    d->sp_mode = cands[c].mode; d->sp_slices = cands[c].slices; d->sp_nabla_passes = cands[c].passes;
+    const int S = d->sp_slices > 1 ? d->sp_slices : 1;
+    const int n_pad = ((N / 64 + P * S - 1) / (P * S)) * S * 64, tok0 = d->sp_rank * n_pad;
+    const int n = N - tok0 < n_pad ? N - tok0 : n_pad;
+    if ((long long)(P - 1) * n_pad >= N || n <= 0) continue;       // this slot size leaves a rank without rows: not a candidate (time stays -1 everywhere)
+    K5CHK(ensure_workspaces(d, P * n_pad, L));
+    K5CHK(d->ws_q.ensure((size_t)n_pad * D * 2)); K5CHK(d->ws_kfull.ensure((size_t)P * n_pad * D * 2)); K5CHK(d->ws_vtfull.ensure((size_t)P * n_pad * D * 2));
+    // finite, harmless operands: activations 0.1 (bf16 0x3dcd), rotary tables and gates zero (the out projection then adds nothing)
+    HIPCHK(hipMemsetD16Async((hipDeviceptr_t)d->ws_h.p, 0x3dcd, (size_t)n_pad * D, s));
+    HIPCHK(hipMemsetD16Async((hipDeviceptr_t)d->ws_vis.p, 0x3dcd, (size_t)n_pad * D, s));
+    HIPCHK(hipMemsetAsync(d->ws_vcos.p, 0, (size_t)N * 32 * 4, s)); HIPCHK(hipMemsetAsync(d->ws_vsin.p, 0, (size_t)N * 32 * 4, s));
+    HIPCHK(hipMemsetAsync(d->ws_mod.p, 0, d->mod_rows * 4, s));
+    const float* cosT = d->ws_vcos.as<float>() + (size_t)tok0 * 32; const float* sinT = d->ws_vsin.as<float>() + (size_t)tok0 * 32;
+    const bool uly = d->sp_mode == 1;
+    for (int it = 0; it < 3; ++it) {
+      if (it == 1) HIPCHK(hipEventRecord(e0, s));
+      if (uly) K5CHK(run_self_attention_ulysses(d, s, a, d->ws_h.p, n, n_pad, N, d->ws_o.p, cosT, sinT, d->ws_vis.p, d->ws_mod.as<float>()));
+      else K5CHK(run_self_attention_sp(d, s, a, d->ws_h.p, n, n_pad, N, d->ws_o.p, cosT, sinT, d->ws_vis.p, d->ws_mod.as<float>(), nabla));
+    }
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    mine[c] = ms / 2.f;
+    if (c == 0) {   // the bare exchange of candidate 0 (both all-gathers back to back, nothing else running): achieved ingress bandwidth
+      HIPCHK(hipEventRecord(e0, s));
+      for (int it = 0; it < 2; ++it) {
+        K5CHK(d->comm.all_gather_inplace(d->ws_kfull.p, (size_t)n_pad * D, 2, s));
+        K5CHK(d->comm.all_gather_inplace(d->ws_vtfull.p, (size_t)D * n_pad, 2, s));
+      }
+      HIPCHK(hipEventRecord(e1, s)); HIPCHK(hipEventSynchronize(e1));
+      HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      comm_ms = ms / 2.0; comm_bytes = 2.0 * (double)(P - 1) * n_pad * D * 2.0;
+    }
+  }
+  // every rank's table to every rank, then the same decision everywhere
+  K5CHK(d->ws_tune.ensure((size_t)P * nc * 4));
+  HIPCHK(hipMemcpyAsync(d->ws_tune.as<float>() + (size_t)d->sp_rank * nc, mine.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s));
+  K5CHK(d->comm.all_gather_inplace(d->ws_tune.p, (size_t)nc, 4, s));
+  std::vector<float> all((size_t)P * nc), cost(nc);
+  HIPCHK(hipMemcpyAsync(all.data(), d->ws_tune.p, all.size() * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  const int best = sp_pick(all.data(), nc, P, nullptr, cost.data());
+  d->profiling = save_prof;
+  // the trial runs used the handle's workspaces with made-up operands: put back what outlives a forward
+  HIPCHK(hipMemcpyAsync(d->ws_attn_cnt.p, cnt_save, 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));                     // cnt_save is a local
+  K5CHK(reset_attn_pref(d, s));
+  d->key_vpos.clear(); d->key_shape[0] = d->key_shape[1] = d->key_shape[2] = 0;   // the RoPE tables were zeroed: rebuild them
+  d->nabla_hint_pending = false;
+  if (best < 0) { d->sp_mode = save_mode; d->sp_slices = save_slices; d->sp_nabla_passes = save_passes; d->sp_report = "{\"tuned\": false, \"reason\": \"no candidate ran\"}"; return K5_OK; }
+  d->sp_mode = cands[best].mode; d->sp_slices = cands[best].slices; d->sp_nabla_passes = cands[best].passes;
+  char buf[256];
+  std::string rep = "{\"tuned\": true, \"world\": " + std::to_string(P) + ", \"tokens\": " + std::to_string(N) + ", \"attention\": \"" + (nabla ? "nabla" : "dense") +
+                    "\", \"chosen\": \"" + cands[best].name + "\", \"unit\": \"ms per block's self-attention section, max over ranks\", \"candidates\": [";
+  for (int c = 0; c < nc; ++c) {
+    snprintf(buf, sizeof(buf), "%s{\"name\": \"%s\", \"ms\": %.4f, \"ms_this_rank\": %.4f}", c ? ", " : "", cands[c].name, cost[c], mine[c]);
+    rep += buf;
+  }
+  snprintf(buf, sizeof(buf), "], \"gather_bytes_in_per_block\": %.0f, \"gather_ms_alone\": %.4f, \"gather_GBps_in\": %.1f}", comm_bytes, comm_ms,
+           comm_ms > 0 ? comm_bytes / comm_ms * 1e-6 : 0.0);
+  rep += buf;
+  d->sp_report = rep;
+  if (d->sp_rank == 0) fprintf(stderr, "libk5: sequence-parallel schedule: %s\n", rep.c_str());
+  return K5_OK;
+}
+
 int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, float time, const float* x,
                  int x_channels, void* out_velocity, hipStream_t s, const float* tvec = nullptr, const int* step = nullptr,
                  int text_slot = -1) {
@@ -1165,6 +1289,12 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
   if (x_channels != Cin && x_channels != c.in_visual_dim) { k5_set_error("x_channels must be %d or %d", Cin, c.in_visual_dim); return K5_ERR_ARG; }
   const int P = d->sp_world;
   const bool sp = d->comm.active();  // a communicator (even of size 1) selects the sharded code path
+  if (sp && P > 1 && !d->emulated && d->sp_autotune && !d->sp_tuned && !d->vblocks.empty() && N % 64 == 0) {
+    NablaArgs tna{};
+    const bool tn = a->attention_type == 1 && !(Hp % 8) && !(Wp % 8);
+    if (tn) tna = NablaArgs{Tp, Hp / 8, Wp / 8, a->nabla_wT, a->nabla_wH, a->nabla_wW, a->nabla_P};
+    if (a->attention_type == 0 || tn) K5CHK(sp_autotune_run(d, s, N, L, tn ? &tna : nullptr));
+  }
   // token shards: whole 64-token blocks, ceil(blocks / P) per rank; the last rank takes what is left (3660 blocks over 8
   // ranks: 7 x 458 + 454).  n_pad = slot size in the gather buffers, n = rows this rank really owns.
   int n = N, n_pad = N, tok0 = 0;
@@ -1690,6 +1820,7 @@ extern "C" int k5_comm_unique_id(const char* rccl_lib_path, void* out128) {
 
 static int comm_common_init(k5_dit* d, int rank, int world) {
   d->comm.rank = rank; d->comm.world = world;
+  if (d->comm.loop) d->sp_autotune = false;   // loopback ranks (tests of specific schedules on one GPU) tune only when asked to ("sp_autotune" = 1)
   d->sp_rank = rank; d->sp_world = world;
   HIPCHK(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&d->ev_k, hipEventDisableTiming));
@@ -1801,6 +1932,10 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //                     in compute, emulated P = 4; pays when the exposed part of the gather is longer than that — a property of the node)
 //   "sp_mode"         0 (default): every rank gathers all K / V^T (any rank count, dense and NABLA); 1: Ulysses — two all-to-alls trade token rows
 //                     for heads and back (run_self_attention_ulysses; needs heads % ranks == 0 and dense attention, else the gather is used)
+//   "sp_autotune"     1 (default) / 0: the first sharded forward of a handle with more than one rank times one block's self-attention section under
+//                     every admissible schedule (all-gather; 2 slices; Ulysses — NABLA: one / two passes) and keeps the fastest (max over ranks; every
+//                     rank takes the same decision from the gathered table).  A knob set explicitly through this call is left alone.  2 = tune again.
+//                     k5_dit_sp_schedule returns what was measured and chosen.
 //   "sp_slices"       S in 1..4: exchange K / V^T of a block in S slices (grouped send/recv to every peer at once) and attend each
 //                     slice as it lands — the gather hides behind the attention of the slices before it (dense attention; NABLA and
 //                     S = 1 keep the single in-place all-gather).  Token slots become multiples of 64 S.
@@ -1815,17 +1950,18 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
     d->attn_mode = value; return K5_OK;
   }
   if (!strcmp(name, "sp_pass1_tiles")) { if (value < 0) return K5_ERR_ARG; d->sp_pass1_tiles = value; return K5_OK; }
-  if (!strcmp(name, "sp_mode")) { if (value < 0 || value > 1) return K5_ERR_ARG; d->sp_mode = value; return K5_OK; }
+  if (!strcmp(name, "sp_mode")) { if (value < 0 || value > 1) return K5_ERR_ARG; d->sp_mode = value; d->sp_user_set |= 1; return K5_OK; }
+  if (!strcmp(name, "sp_autotune")) { d->sp_autotune = value != 0; if (value > 1) d->sp_tuned = false; return K5_OK; }   // 2 = tune again at the next sharded forward
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_anchor")) { d->anchor = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_pref_reset")) return reset_attn_pref(d, nullptr, true);   // an action, not a state: the per-step path (k5_dit_forward) calls it per run
   if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }
-  if (!strcmp(name, "sp_nabla_passes")) { if (value < 1 || value > 2) return K5_ERR_ARG; d->sp_nabla_passes = value; return K5_OK; }
+  if (!strcmp(name, "sp_nabla_passes")) { if (value < 1 || value > 2) return K5_ERR_ARG; d->sp_nabla_passes = value; d->sp_user_set |= 4; return K5_OK; }
   if (!strcmp(name, "attn_fuse_qnorm")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->fuse_qnorm = value; return K5_OK; }
   if (!strcmp(name, "sp_slices")) {
     if (value < 1 || value > 4) return K5_ERR_ARG;
     if (value > 1 && d->comm.comm && !d->comm.can_exchange()) { k5_set_error("sp_slices > 1 needs ncclSend / ncclRecv / ncclGroup* in the RCCL library"); return K5_ERR_STATE; }
-    d->sp_slices = value; return K5_OK;
+    d->sp_slices = value; d->sp_user_set |= 2; return K5_OK;
   }
   if (!strcmp(name, "emulate_world")) {
     if (!d->comm.active() || d->comm.world != 1 || value < 1) { k5_set_error("emulate_world needs a world = 1 communicator"); return K5_ERR_STATE; }
@@ -1846,6 +1982,8 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "attn_anchor")) *value = d->anchor ? 1 : 0;
   else if (!strcmp(name, "attn_fuse_qnorm")) *value = d->fuse_qnorm;
   else if (!strcmp(name, "sp_nabla_passes")) *value = d->sp_nabla_passes;
+  else if (!strcmp(name, "sp_autotune")) *value = d->sp_autotune ? 1 : 0;
+  else if (!strcmp(name, "sp_tuned")) *value = d->sp_tuned ? 1 : 0;
   else if (!strcmp(name, "nabla_group_rows")) *value = d->nabla_group_rows;
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
@@ -1878,6 +2016,21 @@ extern "C" int k5_dit_nabla_block_counts(k5_dit* d, long long* kept, long long* 
   if (kept) *kept = (long long)c[2];
   if (possible) *possible = d->nabla_possible;
   return K5_OK;
+}
+
+// What the self-tuning sequence-parallel schedule measured and chose (JSON text; "{}" before the first sharded forward of a multi-rank handle).
+// Returns the length of the text; copies at most len - 1 characters + NUL into buf (buf may be null to query the length).
+extern "C" int k5_dit_sp_schedule(k5_dit* d, char* buf, int len) {
+  if (!d) return K5_ERR_ARG;
+  const std::string& r = d->sp_report.empty() ? std::string("{}") : d->sp_report;
+  if (buf && len > 0) { const int n = (int)r.size() < len - 1 ? (int)r.size() : len - 1; memcpy(buf, r.data(), (size_t)n); buf[n] = 0; }
+  return (int)(d->sp_report.empty() ? 2 : d->sp_report.size());
+}
+// The selection rule of that tuner as a plain function (tests): times[rank * ncand + cand] in ms (<= 0 or non-finite = did not run), valid
+// (nullable) = admissible candidates; returns the chosen candidate or -1, and max-over-ranks per candidate in cost_out (nullable, -1 = out).
+extern "C" int k5_sp_pick_schedule(const float* times, int ncand, int world, const int* valid, float* cost_out) {
+  if (!times || ncand <= 0 || world <= 0) return -1;
+  return sp_pick(times, ncand, world, valid, cost_out);
 }
 
 extern "C" int k5_dit_set_profiling(k5_dit* d, int level) { if (!d || level < 0 || level > 2) return K5_ERR_ARG; d->profiling = level; return K5_OK; }

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("K5_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libk5.so"))
 
 K5_OK = 0
-ABI_VERSION = 5          # include/k5.h K5_ABI_VERSION
+ABI_VERSION = 6          # include/k5.h K5_ABI_VERSION
 K5_F32, K5_BF16, K5_F16 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_M, EPI_GELU, EPI_GATE = 0, 1, 2, 3
 
@@ -91,6 +91,8 @@ SYMBOLS = {
     "k5_dit_cfg_branch": (_I, [_P]),
     "k5_dit_set_option": (_I, [_P, C.c_char_p, _I]),
     "k5_dit_get_option": (_I, [_P, C.c_char_p, C.POINTER(_I)]),
+    "k5_dit_sp_schedule": (_I, [_P, C.c_char_p, _I]),
+    "k5_sp_pick_schedule": (_I, [C.POINTER(C.c_float), _I, _I, C.POINTER(_I), C.POINTER(C.c_float)]),
     "k5_dit_attn_variant_counts": (_I, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _I]),
     "k5_dit_nabla_block_counts": (_I, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "k5_attention_balance_size": (_I64, [_I, _I]),

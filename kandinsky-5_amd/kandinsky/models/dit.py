@@ -307,6 +307,16 @@ class DiffusionTransformer3D(nn.Module):
         self._sp = (rank, world)
         return self
 
+    def sp_schedule(self):
+        """What the self-tuning sequence-parallel schedule measured and chose on this handle (dict; {} before the first sharded forward
+        of a multi-rank handle): k5_dit_sp_schedule."""
+        import json
+        if self._handle is None:
+            return {}
+        buf = C.create_string_buffer(8192)
+        E.lib().k5_dit_sp_schedule(self._handle, buf, 8192)
+        return json.loads(buf.value.decode() or "{}")
+
     def enable_loopback(self, group, rank):
         """Tests: this handle becomes rank `rank` of a loopback group (`kandinsky._engine.LoopbackGroup`) — several handles of
         one process on one GPU run the sequence-parallel code path of a multi-GPU job, one host thread per rank."""

@@ -46,6 +46,34 @@ def test_ctypes_table_matches_header(built_lib):
     assert L.k5_abi_version() == E.ABI_VERSION == int(re.search(r'#define K5_ABI_VERSION (\d+)', open(os.path.join(ROOT, 'include', 'k5.h')).read()).group(1))
 
 
+def test_sp_schedule_selection_rule(built_lib):
+    """k5_sp_pick_schedule: the rule by which the self-tuning sequence-parallel schedule decides (pure host arithmetic, shared by all ranks):
+    a candidate costs its SLOWEST rank, the cheapest wins, ties go to the lower index (the more conservative schedule), a candidate that did
+    not run on some rank (<= 0, inf, NaN) or is masked out is not eligible, nothing eligible -> -1."""
+    import ctypes as C
+    import math
+    from kandinsky import _engine as E
+    L = E.lib()
+
+    def pick(table, valid=None):
+        world, nc = len(table), len(table[0])
+        t = (C.c_float * (world * nc))(*[v for row in table for v in row])
+        cost = (C.c_float * nc)()
+        va = None if valid is None else (C.c_int * nc)(*valid)
+        return L.k5_sp_pick_schedule(t, nc, world, va, cost), list(cost)
+
+    # 4 ranks, 3 candidates: candidate 1 is fastest on three ranks but one rank is slow on it -> candidate 2 wins on the max
+    best, cost = pick([[2.0, 1.0, 1.5], [2.0, 1.0, 1.4], [2.1, 3.0, 1.6], [2.0, 1.0, 1.5]])
+    assert best == 2 and cost == pytest.approx([2.1, 3.0, 1.6])
+    assert pick([[1.0, 1.0], [1.0, 1.0]])[0] == 0                                   # tie: the lower index
+    assert pick([[2.0, -1.0], [2.0, 0.5]])[0] == 0                                  # candidate 1 did not run on rank 0
+    assert pick([[2.0, float("nan")], [2.0, 0.5]])[0] == 0 and pick([[2.0, math.inf], [2.0, 0.5]])[0] == 0
+    assert pick([[2.0, 0.5], [2.0, 0.5]], valid=[1, 0])[0] == 0                     # masked
+    best, cost = pick([[-1.0, 0.0]])
+    assert best == -1 and cost == [-1.0, -1.0]
+    assert L.k5_sp_pick_schedule(None, 2, 2, None, None) == -1
+
+
 def test_engine_rejects_bad_config_without_gpu(built_lib):
     """k5_dit_create validates on the host (no GPU work): head_dim must be 64."""
     import ctypes as C

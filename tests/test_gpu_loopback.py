@@ -611,3 +611,55 @@ def test_tiny_sampler_ulysses_with_cfg_pair(golden_meta, tiny_sd):
         for i in range(1, 4):
             assert torch.equal(outs[i], outs[0]), (att.type, i)
         assert rel(outs[0], fused) <= 1e-2, (att.type, rel(outs[0], fused))
+
+
+# ------------------------------------------------------------------------------------------ self-tuning schedule (round 4)
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("P,sparse", [(2, False), (4, False), (4, True)])
+def test_self_tuning_schedule_on_loopback_ranks(P, sparse):
+    """"sp_autotune" on P loopback ranks at full width: the first sharded forward times every admissible exchange (dense: all-gather, 2
+    slices, Ulysses where 28 % P == 0; NABLA: one / two passes), all ranks report the SAME choice from the same gathered table, the forward
+    that follows is bit-identical across ranks and within the sharded-vs-fused tolerance, the trial runs leave no trace in the softmax-form
+    counters, and a second forward does not tune again.  (On one GPU the 'exchange' is device-to-device copies: WHICH candidate wins here says
+    nothing about a node — that it is chosen consistently and used correctly is what is tested.)"""
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
+    sd = O.synthetic_state_dict(O.DitConfig(**c), seed=3)
+    g = torch.Generator().manual_seed(5)
+    T, H, W = 4, 32, 32                                          # 1024 tokens = 16 blocks (>= 4 per rank and slice at P = 4); H, W divisible by 16 for NABLA
+    x = torch.randn(T, H, W, 16, generator=g)
+    text, pooled = torch.randn(24, 3584, generator=g), torch.randn(1, 768, generator=g)
+    pos = [torch.arange(T), torch.arange(H // 2), torch.arange(W // 2)]
+    t = torch.tensor([700.0])
+    sp = {"P": 0.7, "wT": 3, "wH": 3, "wW": 3, "to_fractal": True} if sparse else None
+
+    def make():
+        d = DiffusionTransformer3D(**c)
+        d.load_state_dict(sd, assign=True)
+        return d.to("cuda:0")
+
+    def call(d, r):
+        a = d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(24), scale_factor=(1.0, 2.0, 2.0), sparse_params=sp)
+        cnt = d.attn_variant_counts()
+        rep = d.sp_schedule()
+        b = d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(24), scale_factor=(1.0, 2.0, 2.0), sparse_params=sp)
+        return a, b, cnt, rep, d.get_option("sp_mode"), d.get_option("sp_slices"), d.get_option("sp_nabla_passes")
+
+    one = make()
+    fused = one(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(24), scale_factor=(1.0, 2.0, 2.0), sparse_params=sp)
+    one._destroy_engine(force=True)
+    res = run_ranks(P, make, call, options={"sp_autotune": 1})
+    reps = [r[3] for r in res]
+    assert all(rp.get("tuned") is True for rp in reps), reps
+    assert len({rp["chosen"] for rp in reps}) == 1 and len({(r[4], r[5], r[6]) for r in res}) == 1          # one decision on every rank
+    names = [cd["name"] for cd in reps[0]["candidates"]]
+    assert len(names) == (2 if sparse else (3 if 28 % P == 0 else 2)), names
+    costs = [cd["ms"] for cd in reps[0]["candidates"]]
+    assert all(cs > 0 for cs in costs) and reps[0]["chosen"] == names[costs.index(min(costs))]
+    assert all([cd["ms"] for cd in rp["candidates"]] == costs for rp in reps)                               # the same table everywhere
+    assert reps[0]["gather_GBps_in"] > 0
+    for r in range(P):
+        assert torch.equal(res[r][0], res[0][0]) and torch.equal(res[r][1], res[r][0])                        # ranks identical; second forward identical
+        assert res[r][2] == (2 * 28, 0), res[r][2]                                                            # 2 blocks x 28 heads of ONE forward: no trial launches counted
+    print(f"self-tuned schedule, P={P} sparse={sparse}: {reps[0]['chosen']} of {list(zip(names, [round(v, 3) for v in costs]))}; sharded vs fused {rel(res[0][0], fused):.3e}")
+    assert rel(res[0][0], fused) <= 6e-3, rel(res[0][0], fused)
