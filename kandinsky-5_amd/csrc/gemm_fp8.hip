@@ -251,6 +251,234 @@ __global__ __launch_bounds__(512) void gemm_fp8_k8_kernel(Gemm8P p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: the FOUR-wave structure of gemm_bf16_w4_kernel (gemm_bf16.hip) for e4m3 operands.  A row of a 128-element K-tile is 128 B — the
+// bytes of the bf16 kernel's 64-element K-tile — so the LDS image (1040-B pieces, 2 stages x 2 operands x 33 280 B), the LDS-DMA stream
+// (16 `buffer_load_dwordx4 ... lds` per wave and K-tile, SGPR row offsets, range-checked rows) and the persistent tile walk are THE SAME;
+// what changes is the matrix work: one v_mfma_scale_f32_16x16x128_f8f6f4 consumes a whole K-tile of a 16 x 16 tile pair (32 B per lane and
+// operand = two ds_read_b128 into one 8-register tuple), 64 of them per wave and K-tile at 32 cycles each = the bf16 kernel's matrix time for
+// twice the K.  Fragment registers: W double-buffered (2 x 64), X single (64) = the bf16 kernel's 192.  Schedule of K-tile t (MFMA q = 0..63
+// walks m-tile j = q >> 3 outer, n-tile i = q & 7 inner, so X[j] is dead after q = 8 j + 7):
+//     q = 7            lgkmcnt(0) + barrier: every wave holds all of K-tile t's fragments -> stage t & 1 is free
+//     q = 8, 11, .. 53 the 16 DMAs of K-tile t + 2 into that stage
+//     q = 31           vmcnt(8) + barrier: K-tile t + 1 has landed (its 16 DMAs are older than this K-tile's first 8)
+//     q = 32 .. 47     the 16 reads of W(t + 1) into the idle W buffer;  q = 48 .. 55: X(t + 1)[0..3] into the slots X[0..3] left at q <= 31
+//     q = 56 .. 61     X(t + 1)[4], [5], [6] (slots free since q = 39 / 47 / 55);  after q = 63: X(t + 1)[7] — it lands under the next K-tile's
+//                      first eight MFMAs (m-tile 0), which is why the top-of-K-tile barrier sits at q = 7 and not at q = 0
+// Measured / parity: tests/test_gpu_kernels.py::test_gemm_fp8_* (the 256-tile shapes take this kernel), DESIGN.md §4.2.
+// ---------------------------------------------------------------------------------------------
+constexpr int F4_PAD = 1040, F4_OP = 32 * F4_PAD, F4_STAGE = 2 * F4_OP, F4_LDS = 2 * F4_STAGE;
+typedef __attribute__((address_space(3))) void f4_lds_t;
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_fp8_w4_kernel(Gemm8P p) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;
+  const int l15 = lane & 15, lc = lane >> 4;
+
+  const int nblk = p.lid_limit;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7 - xcd) >> 3;
+  const int q8 = nblk >> 3, r8 = nblk & 7;
+  const int x_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, x_cnt = q8 + (xcd < r8 ? 1 : 0);
+  constexpr int GM = 4;
+  const int per_group = GM * p.tiles_n;
+  auto tile_origin = [&](int lid, int& m0, int& n0) {
+    const int g = lid / per_group, first_m = g * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    m0 = (first_m + (lid % per_group) % gsz) * F8_BM;
+    n0 = ((lid % per_group) / gsz) * F8_BN;
+  };
+  if (slot >= x_cnt) return;
+
+  const int nk = p.K / F8_BK;                  // even, >= 4 (launcher)
+  const uint32_t ldw1 = (uint32_t)p.ldw, lda1 = (uint32_t)p.lda;   // bytes per row
+  const uint32_t vw0 = (uint32_t)(16 * (lane >> 3)) * ldw1 + (uint32_t)(lane & 7) * 16u;
+  const uint32_t vx0 = (uint32_t)(16 * (lane >> 3)) * lda1 + (uint32_t)(lane & 7) * 16u;
+  const int drow = 128 * (wave >> 1) + 8 * (wave & 1);
+  const int dslot = 8 * wave;
+  uint32_t vw = vw0, vx = vx0;
+  __amdgpu_buffer_rsrc_t rW, rX;
+  int d_ti = slot, d_kt = 0;
+  auto set_dma_tile = [&](int ti) {
+    int m0, n0;
+    tile_origin(x_first + ti, m0, n0);
+    const int rows_w = min(p.N - n0, F8_BN), rows_x = min(p.M - m0, F8_BM);
+    rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * ldw1), 0, (int)((uint32_t)(rows_w - 1) * ldw1 + (uint32_t)p.K), 0x00020000);
+    rX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * lda1), 0, (int)((uint32_t)(rows_x - 1) * lda1 + (uint32_t)p.K), 0x00020000);
+    d_kt = 0; vw = vw0; vx = vx0;
+  };
+  auto dma1 = [&](int stage, int d) {
+    if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (f4_lds_t*)(dsm + stage * F4_STAGE + (dslot + d) * F4_PAD), 16, vw, (uint32_t)(drow + d) * ldw1, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (f4_lds_t*)(dsm + stage * F4_STAGE + F4_OP + (dslot + d - 8) * F4_PAD), 16, vx, (uint32_t)(drow + d - 8) * lda1, 0, 0);
+  };
+  auto dma_advance = [&]() {   // after a K-tile's 16 DMAs; past the last tile the cursor wraps onto the same tile (harmless loads keep the vmcnt arithmetic uniform)
+    vw += F8_BK; vx += F8_BK;
+    if (++d_kt == nk) {
+      if (d_ti + per_xcd < x_cnt) d_ti += per_xcd;
+      set_dma_tile(d_ti);
+    }
+  };
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(f4_lds_t*)dsm;
+  uint32_t wbs[2], xbs[2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    wbs[st] = lds0 + st * F4_STAGE + (16 * wn + l15) * F4_PAD + lc * 32;           // + 128 i (+ 16: upper half of the lane's 32 bytes)
+    xbs[st] = lds0 + st * F4_STAGE + F4_OP + (16 * wm + l15) * F4_PAD + lc * 32;
+    asm volatile("" : "+v"(wbs[st]), "+v"(xbs[st]));
+  }
+  v4i wl[2][8], wh[2][8], xl[8], xh[8];
+  f32x4 acc[8][8];   // [n-tile][m-tile]
+  const int one = 0x7f7f7f7f;   // E8M0 block scales 2^0
+#define F4_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define F4_OPA(B, I) __builtin_shufflevector(wl[B][I], wh[B][I], 0, 1, 2, 3, 4, 5, 6, 7)
+#define F4_OPB(J) __builtin_shufflevector(xl[J], xh[J], 0, 1, 2, 3, 4, 5, 6, 7)
+#define F4_MF(B, Q) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[(Q) & 7][(Q) >> 3]) : "v"(F4_OPA(B, (Q) & 7)), "v"(F4_OPB((Q) >> 3)), "v"(one))
+#define F4_MF0(B, Q) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]" : "=a"(acc[(Q) & 7][(Q) >> 3]) : "v"(F4_OPA(B, (Q) & 7)), "v"(F4_OPB((Q) >> 3)), "v"(one))
+
+  set_dma_tile(slot);
+#pragma unroll
+  for (int d = 0; d < 16; ++d) dma1(0, d);
+  dma_advance();
+#pragma unroll
+  for (int d = 0; d < 16; ++d) dma1(1, d);
+  dma_advance();
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { F4_RD(wl[0][i], wbs[0], i * 128); F4_RD(wh[0][i], wbs[0], i * 128 + 16); }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { F4_RD(xl[j], xbs[0], j * 128); F4_RD(xh[j], xbs[0], j * 128 + 16); }
+
+  auto ktile = [&](auto STC, auto FIRSTC) {
+    constexpr int st = decltype(STC)::value;        // K-tile parity: its stage, and the W buffer its fragments sit in
+    constexpr bool first = decltype(FIRSTC)::value;
+    const uint32_t wb_n = wbs[st ^ 1], xb_n = xbs[st ^ 1];   // the stage K-tile t + 1 lands in
+    // (one flat loop: a nested generic lambda per 16 MFMAs, as in the bf16 kernel, trips a clang capture bug on the asm operands here)
+#pragma unroll
+    for (int q = 0; q < 64; ++q) {
+      if (first) F4_MF0(st, q); else F4_MF(st, q);
+      if (q == 7) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (q >= 8 && (q - 8) % 3 == 0 && (q - 8) / 3 < 16) dma1(st, (q - 8) / 3);
+      if (q == 31) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      if (q >= 32 && q < 48) {
+        const int r = q - 32;
+        if (r & 1) F4_RD(wh[st ^ 1][r >> 1], wb_n, (r >> 1) * 128 + 16); else F4_RD(wl[st ^ 1][r >> 1], wb_n, (r >> 1) * 128);
+      }
+      if (q >= 48 && q < 62) {                     // X(t+1)[0..3] at q = 48..55, [4] [5] [6] at 56..61
+        const int r = q - 48;
+        if (r & 1) F4_RD(xh[r >> 1], xb_n, (r >> 1) * 128 + 16); else F4_RD(xl[r >> 1], xb_n, (r >> 1) * 128);
+      }
+    }
+    F4_RD(xl[7], xb_n, 7 * 128); F4_RD(xh[7], xb_n, 7 * 128 + 16);
+    dma_advance();
+  };
+
+  for (int ti = slot; ti < x_cnt; ti += per_xcd) {
+    ktile(std::integral_constant<int, 0>{}, std::true_type{});
+    ktile(std::integral_constant<int, 1>{}, std::false_type{});
+    for (int t = 2; t < nk; t += 2) {
+      ktile(std::integral_constant<int, 0>{}, std::false_type{});
+      ktile(std::integral_constant<int, 1>{}, std::false_type{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the next tile's X[7] fragments + let the last asm MFMAs retire
+    int m0, n0;
+    tile_origin(x_first + ti, m0, n0);
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int e_l15 = tid2 & 15, e_lc = (tid2 >> 4) & 3, e_wave = tid2 >> 6;
+    const int e_wn = e_wave & 1, e_wm = e_wave >> 1;
+    const int nb = n0 + 128 * e_wn + 4 * e_lc;          // + 16 i: this lane's four columns of n-tile i
+    f32x4 svec[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) svec[i] = *reinterpret_cast<const f32x4*>(p.w_scale + min(nb + 16 * i, p.N - 4));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = m0 + 128 * e_wm + 16 * j + e_l15;
+      const int mc = min(m, p.M - 1);
+      if constexpr (EPI == K5_EPI_GELU) {
+        // e4m3(GELU(bf16(acc * s))): four values per n-tile = one dword; a 4 x 4 dword transpose over the lanes that share the row (16 apart)
+        // gives every lane 16 consecutive bytes -> 2 stores of 16 B per token tile
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+          uint32_t dw[4];
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * ih + ii;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = bf_round(acc[i][j][e] * svec[i][e]);
+            gelu_erf_x2(v[0], v[1]); gelu_erf_x2(v[2], v[3]);
+            dw[ii] = pack_fp8x4(v[0], v[1], v[2], v[3]);
+          }
+          // lane (row, lc) holds columns 16 ii + 4 lc .. + 3 in dw[ii]  ->  after the transpose dw[ii] = columns 16 lc + 4 ii .. + 3
+          { const auto s0 = __builtin_amdgcn_permlane16_swap(dw[0], dw[1], false, false); dw[0] = s0[0]; dw[1] = s0[1];
+            const auto s1 = __builtin_amdgcn_permlane16_swap(dw[2], dw[3], false, false); dw[2] = s1[0]; dw[3] = s1[1];
+            const auto s2 = __builtin_amdgcn_permlane32_swap(dw[0], dw[2], false, false); dw[0] = s2[0]; dw[2] = s2[1];
+            const auto s3 = __builtin_amdgcn_permlane32_swap(dw[1], dw[3], false, false); dw[1] = s3[0]; dw[3] = s3[1]; }
+          const int n = n0 + 128 * e_wn + 64 * ih + 16 * e_lc;
+          if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(p.C) + (size_t)m * p.ldc + n) = u32x4{dw[0], dw[1], dw[2], dw[3]};
+        }
+      } else {
+        u32x2 rr[8];
+        if constexpr (EPI == K5_EPI_GATE) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) rr[i] = *reinterpret_cast<const u32x2*>(p.resid + (size_t)mc * p.ldr + min(nb + 16 * i, p.N - 4));
+        }
+#pragma unroll
+        for (int iq = 0; iq < 4; ++iq) {
+          u32x2 o[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int i = 2 * iq + h;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * svec[i][e];
+            if constexpr (EPI == K5_EPI_GATE) {
+              const f32x4 gv = *reinterpret_cast<const f32x4*>(p.gate + min(nb + 16 * i, p.N - 4));
+              v[0] = __uint_as_float(rr[i][0] << 16) + gv[0] * bf_round(v[0]);
+              v[1] = __uint_as_float(rr[i][0] & 0xffff0000u) + gv[1] * bf_round(v[1]);
+              v[2] = __uint_as_float(rr[i][1] << 16) + gv[2] * bf_round(v[2]);
+              v[3] = __uint_as_float(rr[i][1] & 0xffff0000u) + gv[3] * bf_round(v[3]);
+            }
+            o[h] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          }
+#pragma unroll
+          for (int dd = 0; dd < 2; ++dd) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(o[0][dd], o[1][dd], false, false);
+            o[0][dd] = sw[0]; o[1][dd] = sw[1];
+          }
+          const int n = n0 + 128 * e_wn + 16 * (2 * iq + (e_lc & 1)) + 8 * (e_lc >> 1);
+          if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+        }
+        asm volatile("" ::: "memory");
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing may still be loading into a VGPR when the asm stream resumes
+  }
+#undef F4_MF
+#undef F4_MF0
+#undef F4_OPA
+#undef F4_OPB
+#undef F4_RD
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI>
+int launch_f8_w4(Gemm8P p, hipStream_t stream, int num_cu) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_fp8_w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F4_LDS) != hipSuccess) return K5_ERR_HIP;
+    attr_set = true;
+  }
+  p.tiles_m = (p.M + F8_BM - 1) / F8_BM; p.tiles_n = (p.N + F8_BN - 1) / F8_BN;
+  p.lid_limit = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL(gemm_fp8_w4_kernel<EPI>, dim3(min(p.lid_limit, num_cu)), dim3(256), F4_LDS, stream, p);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
 // one wave per row: scale[r] = max|x| / 448 (or 1 when `scale` is null: static scale), out = e4m3(x / scale)
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ out, float* __restrict__ scale,
                                                              int rows, int K, int ldx, int ldo) {
@@ -287,6 +515,11 @@ int launch_f8(Gemm8P p, hipStream_t stream) {
   }
   p.tiles_m = (p.M + F8_BM - 1) / F8_BM; p.tiles_n = (p.N + F8_BN - 1) / F8_BN;
   p.lid_limit = p.tiles_m * p.tiles_n;
+  // the four-wave kernel from one full round of tiles up (K in whole pairs of K-tiles; 16-B stores need N % 16 == 0 and aligned rows)
+  static const int force = getenv("K5_GEMM_FP8_V") ? atoi(getenv("K5_GEMM_FP8_V")) : 0;   // A/B: 8 = the 8-wave kernel, 4 = this one
+  const bool w4_ok = (p.K % (2 * F8_BK)) == 0 && p.K >= 4 * F8_BK && p.M >= 512 && p.N >= 256 && !(p.N & 15) && !(p.ldc & 15) &&
+                     (EPI != K5_EPI_GATE || !(p.ldr & 3));
+  if (w4_ok && (force == 4 || (force == 0 && p.lid_limit >= num_cu))) return launch_f8_w4<EPI>(p, stream, num_cu);
   hipLaunchKernelGGL(gemm_fp8_k8_kernel<EPI>, dim3(min(p.lid_limit, num_cu)), dim3(512), F8_LDS, stream, p);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
