@@ -198,7 +198,9 @@ def main():
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-for-`value`) VAE decode leg")
     ap.add_argument("--force-sp", action="store_true", help="debug: drive the sharded code path through a world=1 RCCL communicator")
     ap.add_argument("--magcache", action="store_true", help="MagCache with the config's ratio table (changes the work per step: not the headline metric)")
-    ap.add_argument("--fp8", action="store_true", help="opt-in lossy mode (feed-forward GEMMs in W8A8 e4m3): NOT the headline number, reported as dtype bf16+fp8ff")
+    ap.add_argument("--fp8", type=int, nargs="?", const=1, default=0, metavar="MASK",
+                    help="opt-in lossy mode, W8A8 e4m3 linear layers (k5_dit_set_fp8 mask: 1 feed-forward (default when given without a value), 2 q|k|v "
+                         "projections, 4 out projection; 7 = all): NOT the headline number, reported as dtype bf16+fp8")
     ap.add_argument("--profile-level", type=int, default=2, choices=(0, 1, 2),
                     help="HIP events inside the timed region: 2 = around the roofline kernel only (default), 1 = every kernel family, 0 = none")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the separate per-family timing pass")
@@ -255,7 +257,7 @@ def main():
         dit.engine(dev)
         set_magcache_params(dit, default_configs()[cname]["magcache"]["mag_ratios"], 50, abs(wl["w"] - 1.0) <= 1e-6)
     if args.fp8:
-        dit.set_fp8(True)
+        dit.set_fp8(int(args.fp8))
     sp_world = world
     if args.cfg_parallel:
         if world < 2 or world % 2 or abs(wl["w"] - 1.0) <= 1e-6:
@@ -419,7 +421,7 @@ def main():
     if args.blocks != 32:
         invalid.append("fewer visual blocks than the model")
     if args.fp8:
-        invalid.append("reduced precision (fp8 feed-forward)")
+        invalid.append(f"reduced precision (fp8 linear layers, mask {args.fp8})")
     step_flop = fwd_per_step * flops_forward(N, L, blocks=args.blocks)
     if not torch.isfinite(latent).all():
         invalid.append("the latent holds non-finite values after the timed steps")
@@ -438,7 +440,7 @@ def main():
         out = {
             "metric": "DiT denoising steps/sec (2B Lite, 5s 768x512 latent)", "value": args.steps / dt, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16+fp8ff (REDUCED PRECISION, not the headline)" if args.fp8 else "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": f"bf16+fp8 mask {args.fp8} (REDUCED PRECISION, not the headline)" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": wl["desc"], "tokens": N, "text_len": L, "forwards_per_step": fwd_per_step,
                        "parallelism": "single GPU" if world == 1 else (
                            (f"CFG-parallel x2 (cond / uncond rank groups, velocity exchange inside k5_sample) x " if args.cfg_parallel else "") +

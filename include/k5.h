@@ -438,9 +438,11 @@ int k5_gemm_fp8(const void* A8, const void* W8, const float* w_scale, void* C, i
                 int epi, const void* resid, int ldr, const float* gate, void* stream);
 int k5_quant_rows_fp8(const void* x_bf16, void* out_fp8, float* scale, int rows, int K, int ldx, int ldo, void* stream);
 
-/* Run the feed-forward GEMMs of the visual blocks in W8A8 e4m3 (weights quantised per output channel on first enable,
- * activations with the static scale 1).  LOSSY and off by default: ~3e-2 relative L2 on a velocity against the bf16 path
- * (stated with the parity test tests/test_gpu_dit.py::test_fp8_feed_forward_mode); +30 % on those GEMMs. */
+/* Run linear layers of the visual blocks in W8A8 e4m3 (weights quantised per output channel on first enable, activations with the
+ * static scale 1).  `enabled` is a bit mask: 1 = the feed-forward GEMMs (nn.py:352-361), 2 = the q | k | V^T projections and 4 = the out
+ * projection of the visual self-attention (nn.py:233-244, 282-284); 0 = off.  LOSSY and off by default: the distance to the bf16 path per
+ * layer class is stated with the parity test tests/test_gpu_dit.py::test_fp8_feed_forward_mode and in DESIGN.md §4.2; from 256 tiles up the
+ * GEMMs run on the four-wave e4m3 kernel (gemm_fp8.hip, round 4). */
 int k5_dit_set_fp8(k5_dit* dit, int enabled);
 
 /* k5_sample replays ONE hipGraph-captured sampler step (forwards + CFG/Euler, per-step scalars read from device tables at a

@@ -105,6 +105,7 @@ float bf16_round_host(float f) { uint32_t u = (uint32_t)f32_to_bf16_rne(f) << 16
 struct AttnW {  // one attention module, packed
   DevBuf wqk, wq, wk, wv, wo;       // bf16
   DevBuf bqk, bq, bk, bv, bo, norm; // fp32 (bias values bf16-rounded); norm = [q_norm | k_norm]
+  DevBuf wqk8, wv8, wo8, sqk, sv, so;   // opt-in e4m3 copies (k5_dit_set_fp8 bits 1 / 2): weights + per-output-channel scales
   float score_bound = 0.f;          // |q.k| <= 64 max|w_q| max|w_k| after norm_qk (RoPE preserves norms)
   mutable DevBuf pref;              // visual self-attention: [2][H] heads the per-row-offset softmax served badly the last time this layer ran for
                                     // the cond (0) / uncond (1) branch (k5_launch_attn_pref_update); zeroed at the start of every k5_sample and
@@ -303,7 +304,8 @@ struct k5_dit {
   hipStream_t pair_stream = nullptr;
   hipEvent_t ev_vel_ready = nullptr, ev_vel_done = nullptr;
   DevBuf ws_vel_pair;                              // [2][T H W 16] bf16: slot 0 = conditional, 1 = unconditional velocity
-  bool use_fp8 = false;                            // visual feed-forward GEMMs in W8A8 e4m3 (k5_dit_set_fp8)
+  bool use_fp8 = false;                            // visual feed-forward GEMMs in W8A8 e4m3 (k5_dit_set_fp8 bit 0)
+  int fp8_mask = 0;                                // k5_dit_set_fp8: bit 0 feed-forward, bit 1 q | k | V^T projections, bit 2 out projection of the visual self-attention
   DevBuf ws_h8, ws_ff8;                            // fp8 activations of that path
   DevBuf ws_sched;                                 // sampler tables on the device: t*1000 [steps] | dt [steps] | step counter
   bool use_graph = false;                          // k5_sample replays one captured step (k5_dit_set_graph)
@@ -570,12 +572,24 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
                        const char* fam_attn, const NablaArgs* nabla = nullptr, int pref_slot = 0) {
   const int D = d->D, H = d->Hh;
   const int ldvt = (int)rup(rows, 8);
-  {
+  const bool vis = !strcmp(fam_attn, "attn_self");
+  const bool f8_in = vis && (d->fp8_mask & 2) && a.wqk8.p && rows >= 256 && !(ldvt & 15);   // opt-in lossy mode: e4m3 projections (gemm_fp8.hip)
+  const bool f8_out = vis && (d->fp8_mask & 4) && a.wo8.p && rows >= 256;
+  if (f8_in) {
+    K5CHK(d->ws_h8.ensure((size_t)rows * D));
+    {
+      Scope sc(d, s, "elementwise");
+      K5CHK(k5_launch_quant_rows_fp8(h, d->ws_h8.p, nullptr, rows, D, D, D, s));
+    }
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_fp8(d->ws_h8.p, a.wqk8.p, a.sqk.as<float>(), qk, rows, 2 * D, D, D, D, 2 * D, K5_EPI_BIAS, nullptr, 0, nullptr, s, a.bqk.as<float>(), 0));
+    K5CHK(k5_launch_gemm_fp8(a.wv8.p, d->ws_h8.p, a.sv.as<float>(), vt, D, rows, D, D, D, ldvt, K5_EPI_BIAS, nullptr, 0, nullptr, s, a.bv.as<float>(), 1));
+  } else {
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(h, a.wqk.p, a.bqk.as<float>(), qk, rows, 2 * D, D, D, D, 2 * D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
     K5CHK(k5_launch_gemm_bf16(a.wv.p, h, a.bv.as<float>(), vt, D, rows, D, D, D, ldvt, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
   }
-  const bool pre = !strcmp(fam_attn, "attn_self") && rows % 64 == 0;   // visual blocks only (not the text blocks)
+  const bool pre = vis && rows % 64 == 0;   // visual blocks only (not the text blocks)
   const bool by_data = pre && d->attn_mode == K5_ATTN_AUTO;            // per-head flags from the data
   const int* hflags = nullptr;
   // per-row softmax offsets: heads with a Cauchy-Schwarz bound up to 190 keep the fixed-offset kernel, each query row on its own
@@ -652,6 +666,16 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
                                          fuse_q ? &qn : nullptr, kcp));
   }
   if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, nabla ? (pre ? d->nabla_grp_now : 4) : 4, (a.pref.as<int>() + (size_t)pref_slot * H), s));
+  if (f8_out) {
+    K5CHK(d->ws_h8.ensure((size_t)rows * D));
+    {
+      Scope sc(d, s, "elementwise");
+      K5CHK(k5_launch_quant_rows_fp8(o, d->ws_h8.p, nullptr, rows, D, D, D, s));
+    }
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_fp8(d->ws_h8.p, a.wo8.p, a.so.as<float>(), resid, rows, D, D, D, D, D, K5_EPI_GATE, resid, D, gate, s, a.bo.as<float>(), 0));
+    return K5_OK;
+  }
   {
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(o, a.wo.p, a.bo.as<float>(), resid, rows, D, D, D, D, D, K5_EPI_GATE, resid, D, gate, s));
@@ -695,9 +719,19 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     kun = d->ws_kc.as<bf16_t>();
     kmeans = d->ws_kmeans.as<bf16_t>();
   }
+  // opt-in e4m3 projections (k5_dit_set_fp8 bit 1), as on one GPU: the rank's rows of h are quantised once and feed the K, V^T and Q GEMMs
+  const bool f8_in = (d->fp8_mask & 2) && a.wqk8.p && rows >= 256 && !((rows_pad / ((!nabla && d->sp_slices > 1 && P > 1) ? d->sp_slices : 1)) & 15);
+  const uint8_t* wq8 = a.wqk8.as<uint8_t>();
+  const uint8_t* wk8 = wq8 ? wq8 + (size_t)D * D : nullptr;
+  if (f8_in) {
+    K5CHK(d->ws_h8.ensure((size_t)rows * D));
+    Scope sc(d, s, "elementwise");
+    K5CHK(k5_launch_quant_rows_fp8(h, d->ws_h8.p, nullptr, rows, D, D, D, s));
+  }
   {
     Scope sc(d, s, "gemm");
-    K5CHK(k5_launch_gemm_bf16(h, wk, a.bqk.as<float>() + D, kun, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    if (f8_in) K5CHK(k5_launch_gemm_fp8(d->ws_h8.p, wk8, a.sqk.as<float>() + D, kun, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s, a.bqk.as<float>() + D, 0));
+    else K5CHK(k5_launch_gemm_bf16(h, wk, a.bqk.as<float>() + D, kun, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   }
   {
     Scope sc(d, s, "elementwise");
@@ -720,14 +754,17 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     for (int sl = 0; sl < S; ++sl) {
       const int nsl = std::min(cols, rows - sl * cols);
       if (nsl <= 0) break;
-      K5CHK(k5_launch_gemm_bf16(a.wv.p, (const bf16_t*)h + (size_t)sl * cols * D, a.bv.as<float>(), vtloc + (size_t)sl * D * cols, D, nsl, D, D, D,
-                                cols, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+      if (f8_in) K5CHK(k5_launch_gemm_fp8(a.wv8.p, d->ws_h8.as<uint8_t>() + (size_t)sl * cols * D, a.sv.as<float>(), vtloc + (size_t)sl * D * cols, D, nsl, D, D, D,
+                                          cols, K5_EPI_BIAS, nullptr, 0, nullptr, s, a.bv.as<float>(), 1));
+      else K5CHK(k5_launch_gemm_bf16(a.wv.p, (const bf16_t*)h + (size_t)sl * cols * D, a.bv.as<float>(), vtloc + (size_t)sl * D * cols, D, nsl, D, D, D,
+                                     cols, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
     }
   }
   HIPCHK(hipEventRecord(d->ev_v, s));
   {
     Scope sc(d, s, "gemm");
-    K5CHK(k5_launch_gemm_bf16(h, wq, a.bqk.as<float>(), q, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+    if (f8_in) K5CHK(k5_launch_gemm_fp8(d->ws_h8.p, wq8, a.sqk.as<float>(), q, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s, a.bqk.as<float>(), 0));
+    else K5CHK(k5_launch_gemm_bf16(h, wq, a.bqk.as<float>(), q, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
   }
   // see run_self_attention; here only with "attn_fuse_qnorm" = 2: every pass of the schedule redoes the norm, and at shard sizes that
   // costs what the standalone pass over the local queries does (emulated P = 8: 82.8 vs 82.6 ms per step)
@@ -1784,19 +1821,24 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
 extern "C" int k5_dit_set_fp8(k5_dit* d, int enabled) {
   g_err[0] = 0;
   if (!d || !d->finalized) { k5_set_error("k5_dit_set_fp8: handle not finalized"); return K5_ERR_STATE; }
+  if (enabled < 0 || enabled > 7) { k5_set_error("k5_dit_set_fp8: a bit mask 0..7 (1 feed-forward, 2 q|k|v projections, 4 out projection)"); return K5_ERR_ARG; }
   if (enabled && ((d->D % 128) || (d->FF % 128) || d->D < 256 || d->FF < 256)) {
     k5_set_error("k5_dit_set_fp8: model_dim and ff_dim must be multiples of 128 and >= 256"); return K5_ERR_UNSUPPORTED;
   }
-  if (enabled)
-    for (auto& b : d->vblocks) {
-      if (b.w1_f8.p) continue;
-      K5CHK(b.w1_f8.ensure((size_t)d->FF * d->D)); K5CHK(b.s1_f8.ensure((size_t)d->FF * 4));
-      K5CHK(b.w2_f8.ensure((size_t)d->D * d->FF)); K5CHK(b.s2_f8.ensure((size_t)d->D * 4));
-      K5CHK(k5_launch_quant_rows_fp8(b.w1.p, b.w1_f8.p, b.s1_f8.as<float>(), d->FF, d->D, d->D, d->D, nullptr));
-      K5CHK(k5_launch_quant_rows_fp8(b.w2.p, b.w2_f8.p, b.s2_f8.as<float>(), d->D, d->FF, d->FF, d->FF, nullptr));
-    }
+  const size_t D = d->D, FF = d->FF;
+  auto quant = [&](const DevBuf& w, DevBuf& w8, DevBuf& sc, size_t rows, size_t K) -> int {
+    if (w8.p) return K5_OK;
+    K5CHK(w8.ensure(rows * K)); K5CHK(sc.ensure(rows * 4));
+    return k5_launch_quant_rows_fp8(w.p, w8.p, sc.as<float>(), (int)rows, (int)K, (int)K, (int)K, nullptr);
+  };
+  for (auto& b : d->vblocks) {
+    if (enabled & 1) { K5CHK(quant(b.w1, b.w1_f8, b.s1_f8, FF, D)); K5CHK(quant(b.w2, b.w2_f8, b.s2_f8, D, FF)); }
+    if (enabled & 2) { K5CHK(quant(b.self_attn.wqk, b.self_attn.wqk8, b.self_attn.sqk, 2 * D, D)); K5CHK(quant(b.self_attn.wv, b.self_attn.wv8, b.self_attn.sv, D, D)); }
+    if (enabled & 4) K5CHK(quant(b.self_attn.wo, b.self_attn.wo8, b.self_attn.so, D, D));
+  }
   HIPCHK(hipDeviceSynchronize());
-  d->use_fp8 = enabled != 0;
+  d->use_fp8 = (enabled & 1) != 0;
+  d->fp8_mask = enabled;
   return K5_OK;
 }
 

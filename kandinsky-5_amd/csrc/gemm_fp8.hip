@@ -36,7 +36,9 @@ constexpr int F8_UNIT = 16384, F8_XOFF = 65536, F8_LDS = 131072;   // W units at
 
 struct Gemm8P {
   const uint8_t* A; const uint8_t* W; void* C;
-  const float* w_scale;   // per n
+  const float* w_scale;   // per n (per m when scale_m: the operand-swapped V^T projection, whose weights are the "A" rows)
+  const float* bias;      // nullable; per n, or per m when scale_m (fp32 holding bf16-rounded values, as in the bf16 GEMM)
+  int scale_m;
   const bf16_t* resid; const float* gate;   // EPI_GATE
   int M, N, K, lda, ldw, ldc, ldr;
   int tiles_m, tiles_n, lid_limit;
@@ -226,7 +228,10 @@ __global__ __launch_bounds__(512) void gemm_fp8_k8_kernel(Gemm8P p) {
         if (n >= p.N) continue;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = n + e < p.N ? acc[i][j][e] * p.w_scale[n + e] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          if (p.scale_m) v[e] = fmaf(acc[i][j][e], p.w_scale[m], p.bias ? p.bias[m] : 0.f);
+          else v[e] = n + e < p.N ? fmaf(acc[i][j][e], p.w_scale[n + e], p.bias ? p.bias[n + e] : 0.f) : 0.f;
+        }
         if (EPI == K5_EPI_GELU) {
           uint8_t* cp = reinterpret_cast<uint8_t*>(p.C) + (size_t)m * p.ldc + n;
           const uint32_t pk = pack_fp8x4(gelu_erf(bf_round(v[0])), gelu_erf(bf_round(v[1])), gelu_erf(bf_round(v[2])), gelu_erf(bf_round(v[3])));
@@ -391,13 +396,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int e_l15 = tid2 & 15, e_lc = (tid2 >> 4) & 3, e_wave = tid2 >> 6;
     const int e_wn = e_wave & 1, e_wm = e_wave >> 1;
     const int nb = n0 + 128 * e_wn + 4 * e_lc;          // + 16 i: this lane's four columns of n-tile i
-    f32x4 svec[8];
+    f32x4 svec[8], bvec[8];
+    const bool has_bias = p.bias != nullptr, scale_m = p.scale_m != 0;   // workgroup-uniform
 #pragma unroll
-    for (int i = 0; i < 8; ++i) svec[i] = *reinterpret_cast<const f32x4*>(p.w_scale + min(nb + 16 * i, p.N - 4));
+    for (int i = 0; i < 8; ++i) {
+      svec[i] = scale_m ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(p.w_scale + min(nb + 16 * i, p.N - 4));
+      bvec[i] = (has_bias && !scale_m) ? *reinterpret_cast<const f32x4*>(p.bias + min(nb + 16 * i, p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int m = m0 + 128 * e_wm + 16 * j + e_l15;
       const int mc = min(m, p.M - 1);
+      const float sm = scale_m ? p.w_scale[mc] : 1.f, bm = (scale_m && has_bias) ? p.bias[mc] : 0.f;
       if constexpr (EPI == K5_EPI_GELU) {
         // e4m3(GELU(bf16(acc * s))): four values per n-tile = one dword; a 4 x 4 dword transpose over the lanes that share the row (16 apart)
         // gives every lane 16 consecutive bytes -> 2 stores of 16 B per token tile
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int i = 4 * ih + ii;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = bf_round(acc[i][j][e] * svec[i][e]);
+            for (int e = 0; e < 4; ++e) v[e] = bf_round(fmaf(acc[i][j][e], svec[i][e], bvec[i][e]));
             gelu_erf_x2(v[0], v[1]); gelu_erf_x2(v[2], v[3]);
             dw[ii] = pack_fp8x4(v[0], v[1], v[2], v[3]);
           }
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int i = 2 * iq + h;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * svec[i][e];
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[i][j][e], svec[i][e] * sm, bvec[i][e] + bm);   // one of each pair is the identity: a single rounding, as in the 8-wave kernel
             if constexpr (EPI == K5_EPI_GATE) {
               const f32x4 gv = *reinterpret_cast<const f32x4*>(p.gate + min(nb + 16 * i, p.N - 4));
               v[0] = __uint_as_float(rr[i][0] << 16) + gv[0] * bf_round(v[0]);
@@ -529,12 +539,14 @@ int launch_f8(Gemm8P p, hipStream_t stream) {
 // A8 [M][K] fp8, W8 [N][K] fp8 (K a multiple of 128, rows 16-B aligned), w_scale [N] fp32.
 // epi: K5_EPI_BIAS -> C bf16 [M][ldc];  K5_EPI_GELU -> C fp8 [M][ldc] = e4m3(GELU(bf16(.)));  K5_EPI_GATE -> bf16, gated residual.
 int k5_launch_gemm_fp8(const void* A8, const void* W8, const float* w_scale, void* C, int M, int N, int K, int lda, int ldw, int ldc,
-                       int epi, const void* resid, int ldr, const float* gate, hipStream_t stream) {
+                       int epi, const void* resid, int ldr, const float* gate, hipStream_t stream, const float* bias, int scale_m) {
   if (M <= 0 || N <= 0 || K <= 0 || !w_scale) return K5_ERR_ARG;
+  if (scale_m && epi != K5_EPI_BIAS) return K5_ERR_ARG;   // per-row scale / bias: the plain bf16-out epilogue only (V^T projection)
   if ((K % F8_BK) || (lda & 15) || (ldw & 15) || K < 2 * F8_BK) return K5_ERR_ALIGN;
   if (epi == K5_EPI_GATE && (!resid || !gate)) return K5_ERR_ARG;
   Gemm8P p;
   p.A = (const uint8_t*)A8; p.W = (const uint8_t*)W8; p.C = C; p.w_scale = w_scale; p.resid = (const bf16_t*)resid; p.gate = gate;
+  p.bias = bias; p.scale_m = scale_m;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   switch (epi) {
     case K5_EPI_BIAS: return launch_f8<K5_EPI_BIAS>(p, stream);

@@ -73,7 +73,7 @@ int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_ro
 
 // ---- fp8 (e4m3) feed-forward path, opt-in (gemm_fp8.hip) ----
 int k5_launch_gemm_fp8(const void* A8, const void* W8, const float* w_scale, void* C, int M, int N, int K, int lda, int ldw, int ldc,
-                       int epi, const void* resid, int ldr, const float* gate, hipStream_t stream);
+                       int epi, const void* resid, int ldr, const float* gate, hipStream_t stream, const float* bias = nullptr, int scale_m = 0);
 int k5_launch_quant_rows_fp8(const void* x, void* out, float* scale, int rows, int K, int ldx, int ldo, hipStream_t stream);
 
 // ---- NABLA (block-sparse) ----

@@ -140,7 +140,7 @@ class DiffusionTransformer3D(nn.Module):
         """Engine state that lives on the handle (not in the parameters) survives a rebuild."""
         st = self._settings
         if st["fp8"]:
-            E.check(E.lib().k5_dit_set_fp8(self._handle, 1), "k5_dit_set_fp8")
+            E.check(E.lib().k5_dit_set_fp8(self._handle, int(st["fp8"])), "k5_dit_set_fp8")
         if st["graph"]:
             E.check(E.lib().k5_dit_set_graph(self._handle, 1), "k5_dit_set_graph")
         for k, v in st["options"].items():
@@ -410,9 +410,12 @@ class DiffusionTransformer3D(nn.Module):
         return a.value, b.value
 
     def set_fp8(self, on=True):
-        """opt-in, lossy: visual feed-forward GEMMs in W8A8 e4m3 (k5_dit_set_fp8; BASELINE config 5)"""
-        E.check(E.lib().k5_dit_set_fp8(self._handle, int(on)), "k5_dit_set_fp8")
-        self._settings["fp8"] = bool(on)
+        """opt-in, lossy: linear layers of the visual blocks in W8A8 e4m3 (k5_dit_set_fp8; BASELINE config 5).  `on`: True / 1 = the
+        feed-forward GEMMs; a bit mask adds 2 = the q | k | V^T projections and 4 = the out projection of the visual self-attention
+        (7 = all three); False / 0 = off."""
+        mask = int(on) if not isinstance(on, bool) else (1 if on else 0)
+        E.check(E.lib().k5_dit_set_fp8(self._handle, mask), "k5_dit_set_fp8")
+        self._settings["fp8"] = mask
         return self
 
     def set_graph(self, on=True):

@@ -358,10 +358,27 @@ def nabla_block_mask(q: Tensor, k: Tensor, sta: Tensor, thr: float, mode: str) -
 # ------------------------------------------------------------------------------------------
 # blocks / forward
 # ------------------------------------------------------------------------------------------
+FP8_QKV = False  # test switches: the engine's opt-in e4m3 q | k | V^T / out projections of the visual self-attention (k5_dit_set_fp8 bits 1 / 2)
+FP8_OUT = False
+
+
+def _linear_fp8(x, w, b, mode):
+    """W8A8 e4m3 linear as csrc/gemm_fp8.hip computes it: activations with the static scale 1, weights per output channel (max|w| / 448),
+    fp32 accumulate, one rounding of acc * scale + bias"""
+    w = _r(w, mode)
+    s = w.abs().amax(1) / 448.0
+    y = (_q8(_r(x, mode)) @ _q8(w / s[:, None]).t()) * s
+    if b is not None:
+        y = y + _r(b, mode)
+    return _r(y, mode)
+
+
 def _attn_qkv(sd, prefix, xq, xkv, mode, H):
-    q = _linear(xq, sd[f"{prefix}.to_query.weight"].float(), sd[f"{prefix}.to_query.bias"].float(), mode)
-    k = _linear(xkv, sd[f"{prefix}.to_key.weight"].float(), sd[f"{prefix}.to_key.bias"].float(), mode)
-    v = _linear(xkv, sd[f"{prefix}.to_value.weight"].float(), sd[f"{prefix}.to_value.bias"].float(), mode)
+    lin = _linear_fp8 if (FP8_QKV and mode == "bf16" and xq.shape[0] >= 256 and prefix.startswith("visual_transformer_blocks")
+                          and prefix.endswith("self_attention")) else _linear
+    q = lin(xq, sd[f"{prefix}.to_query.weight"].float(), sd[f"{prefix}.to_query.bias"].float(), mode)
+    k = lin(xkv, sd[f"{prefix}.to_key.weight"].float(), sd[f"{prefix}.to_key.bias"].float(), mode)
+    v = lin(xkv, sd[f"{prefix}.to_value.weight"].float(), sd[f"{prefix}.to_value.bias"].float(), mode)
     q = q.reshape(q.shape[0], H, -1)
     k = k.reshape(k.shape[0], H, -1)
     v = v.reshape(v.shape[0], H, -1)
@@ -377,15 +394,16 @@ def self_attention(sd, prefix, x, cos, sin, cfg, mode, sparse=None, taps=None):
     q = apply_rotary(q, cos, sin, mode)
     k = apply_rotary(k, cos, sin, mode, SOFTMAX_C if pre else 1.0)
     bm = None
+    lin_o = _linear_fp8 if (FP8_OUT and mode == "bf16" and x.shape[0] >= 256 and prefix.startswith("visual_transformer_blocks")) else _linear
     if pre:
         o = sdpa(q, k, v, mode, None, base2=True)
-        return _linear(o, sd[f"{prefix}.out_layer.weight"].float(), sd[f"{prefix}.out_layer.bias"].float(), mode)
+        return lin_o(o, sd[f"{prefix}.out_layer.weight"].float(), sd[f"{prefix}.out_layer.bias"].float(), mode)
     if sparse is not None:
         bm = nabla_block_mask(q, k, sparse["sta_mask"], sparse["P"], mode)
         if taps is not None:
             taps.setdefault("nabla_masks", []).append(bm)
     o = sdpa(q, k, v, mode, bm)
-    return _linear(o, sd[f"{prefix}.out_layer.weight"].float(), sd[f"{prefix}.out_layer.bias"].float(), mode)
+    return lin_o(o, sd[f"{prefix}.out_layer.weight"].float(), sd[f"{prefix}.out_layer.bias"].float(), mode)
 
 
 def cross_attention(sd, prefix, x, cond, cfg, mode):

@@ -245,7 +245,7 @@ def test_tiny_sampler_P_ranks_on_one_gpu(golden_meta, tiny_sd, P, w):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("P,sparse,fp8", [(8, False, False), (4, True, True), (4, True, False), (4, False, True)])
+@pytest.mark.parametrize("P,sparse,fp8", [(8, False, 0), (4, True, 3), (4, True, 0), (4, False, 1)])   # fp8: k5_dit_set_fp8 mask (3 = feed-forward + q | k | V^T projections)
 def test_config5_sequence_length_P_ranks_on_one_gpu(P, sparse, fp8):
     """BASELINE's last configuration at its real sequence length: 1280x768, 10 s -> latent (61, 96, 160) -> 234 240 tokens = 3660
     blocks, 2B-Lite width, one visual block.  (8, dense, bf16): 3660 blocks over 8 ranks = 7 x 458 + 454, the uneven layout.
@@ -271,7 +271,7 @@ def test_config5_sequence_length_P_ranks_on_one_gpu(P, sparse, fp8):
         d = d.to("cuda:0")
         if fp8:
             d.engine("cuda:0")
-            d.set_fp8(True)
+            d.set_fp8(fp8)
         return d
 
     def call(d, r):
