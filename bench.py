@@ -334,12 +334,14 @@ def main():
         dt = tt.item()
     dit.set_profiling(0)
 
+    sp_on_early = sp_world > 1 or args.force_sp or args.emulate_shard > 1
     FAMS = ("attn_self", "attn_cross", "attn_text", "gemm", "elementwise", "prologue", "epilogue", "comm", "nabla_map")
     fam = {f: dit.get_profile(f) for f in FAMS}
     self_blocks = dit.get_profile("self_blocks")[1]      # visual blocks whose self-attention ran inside the timed region
     fam_steps = args.steps
     n_fixed, n_online = dit.attn_variant_counts()
     nabla_counts = dit.nabla_block_counts() if wl["attn"] == "nabla" else None
+    nabla_exec = dit.nabla_executed_blocks() if wl["attn"] == "nabla" and not sp_on_early else None
     if args.profile_level == 2 and not args.no_breakdown:
         # per-family breakdown from a SEPARATE short pass: an event pair at every family switch (~15 per block) drains the stream
         # each time, which costs the step 1-2 % at one GPU and ~8 % at 8-GPU shard sizes — not something to leave inside `value`
@@ -460,7 +462,9 @@ def main():
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "flop_per_launch": attn_flop * blocks_run / max(attn_n, 1), "avg_launch_ms": attn_ms / max(attn_n, 1),
                          "launches": attn_n, "blocks_run": blocks_run, "launches_per_block": attn_n / max(blocks_run, 1),
-                         "kept_block_density": density},
+                         "kept_block_density": density,
+                         **({"executed_block_density": nabla_exec / nabla_counts[1], "union_efficiency": nabla_counts[0] / nabla_exec,
+                             "achieved_on_executed_tiles": achieved * nabla_exec / nabla_counts[0]} if nabla_exec and nabla_counts and nabla_counts[0] else {})},
             "roofline_gemm": gemm_roof,
             "kernel_time_ms_per_step": {k: v[0] / fam_steps for k, v in fam_break.items() if v[1]},
             "kernel_time_source": ("HIP events inside the timed region" if fam_break is fam else

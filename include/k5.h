@@ -364,6 +364,10 @@ int k5_sp_pick_schedule(const float* times, int ncand, int world, const int* val
 int k5_dit_attn_variant_counts(k5_dit* dit, long long* fixed_heads, long long* online_heads, int reset);
 /* kept / possible 64x64 blocks of the NABLA maps computed while profiling was on, since that reset (realised density). */
 int k5_dit_nabla_block_counts(k5_dit* dit, long long* kept, long long* possible);
+/* ... and the blocks the list-driven attention executed for those maps (one-GPU path): the rows of a workgroup share ONE key-tile list, the
+ * union of what they selected (replaces flex_attention's per-row block walk, nn.py:257-280), so a row also steps over tiles only its
+ * neighbours wanted; kept / executed is the launch's union efficiency. */
+int k5_dit_nabla_executed_blocks(k5_dit* dit, long long* executed);
 
 /* ------------------------------------------------------------------------------------------
  * HunyuanVideo 3D-VAE decoder (kandinsky/models/vae.py): post_quant_conv + HunyuanVideoDecoder3D.forward

@@ -188,10 +188,16 @@ __device__ __forceinline__ uint32_t st_ml_off(int q, int h, int slot, int nqb, i
 // map share a key-tile list instead of four — a wave only computes the tiles its own row selected, so the launch's efficiency is
 // (sum of the rows' lists) / (rows x their union), and two rows' union is tighter than four rows'.  Every wave then brings in two
 // 1-KB pieces of K and of V^T per tile (twice the L2 -> LDS traffic per FLOP; four workgroups per CU instead of two).
-template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false, bool QN = false, bool HALF = false>
+// GR (round 4, generalising round 2's HALF): 64-query rows of the block map per workgroup = per key-tile list.  4: 8 waves, 256 queries.
+// 2: 4 waves (HALF above).  1: TWO waves, one row per list — the list IS the row's selection, nothing is stepped over for a neighbour's sake
+// (measured union efficiency of the 2-row lists on the 10 s clip: 0.80 at kept density 0.048, 0.73 at 0.122, while the kernel executes its
+// tiles at the dense kernel's rate — the union was the whole loss); each wave then brings in four 1-KB pieces of K and of V^T per tile.
+template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false, bool QN = false, int GR = 4>
 __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_kernel(AttnP p) {
+  constexpr bool HALF = GR != 4;     // fewer than 8 waves: one tile per barrier, every wave stages several pieces
+  static_assert(GR == 4 || GR == 2 || GR == 1, "rows per list: 4, 2 or 1");
   static_assert(BOUNDED || PRE, "the online-max form of this kernel takes pre-scaled keys (attn_fwd32_kernel serves the rest)");
-  static_assert(!HALF || (SPARSE && PRE && !RANGE && !QN), "128-query workgroups: the list-driven single-launch form only");
+  static_assert(!HALF || (SPARSE && PRE && !RANGE && !QN), "128- / 64-query workgroups: the list-driven single-launch form only");
   // K5_ATTN_PAIR: two key tiles per barrier (four LDS slots per operand instead of two) for the 256-query workgroups — same arithmetic in
   // the same order, half the barriers; the 128-query form keeps one tile per barrier (four workgroups per CU: 32 KB each)
   constexpr bool PAIR = K5_ATTN_PAIR && !HALF;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
       if (hf == 2) { if (p.late_pass != 2) return; late = true; }
     }
   }
-  const int q0 = qb * (HALF ? QB / 2 : QB) + wave * 32;   // this wave: queries q0 .. q0+31 = two 16-query MFMA tiles (qt = 0, 1)
+  const int q0 = qb * (64 * GR) + wave * 32;   // this wave: queries q0 .. q0+31 = two 16-query MFMA tiles (qt = 0, 1)
 
   // Q^T fragments (MFMA 16x16x32 B operand): lane (l15, g) holds Q[q0 + 16 qt + l15][32 ks + 8 g .. +8]
   bf16x8 qf[2][2];
@@ -345,6 +351,8 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   typedef __attribute__((address_space(3))) void lds_void_t;
   typedef const __attribute__((address_space(1))) void gbl_void_t;
   const uint32_t kvoff = (uint32_t)lrow * kstride + klane;
+  // GR == 1: lane offset of the pieces whose rows are lrow + 16 (mod 32): the swizzle term of row bit 4 flips
+  const uint32_t kvoff16 = (uint32_t)lrow * kstride + (uint32_t)(h * 64 + 8 * (lc ^ ((((lrow + 16) >> 1) & 1) | ((((lrow + 16) >> 3) & 3) << 1)))) * 2u;
   const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)p.K, 0, -1, 0x00020000);   // 4 GB window from the base
   const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)p.Vt, 0, -1, 0x00020000);
   auto load_tile = [&](int e, int buf) {   // e = position in the tile sequence; tile t = tile_of(e) -> LDS buffer `buf`
@@ -358,11 +366,21 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     if (PRE) {   // whole tiles only (launcher): constant per-lane offsets, the tile rides in the instruction's SGPR offset: no address VALU
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_void_t*)(sK + buf * TILE + wave_u * 1024), 16, kvoff, (uint32_t)kv0 * kstride, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_void_t*)(sV + buf * TILE + wave_u * 1024), 16, vlane, (uint32_t)(vsrc - Vb), 0, 0);
-      if (HALF) {   // four waves: rows 32..63 of both tiles as well (the swizzles only involve row bits 1..4: same lane offsets + 32 rows)
+      if (GR == 2) {   // four waves: rows 32..63 of both tiles as well (the swizzles only involve row bits 1..4: same lane offsets + 32 rows)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_void_t*)(sK + buf * TILE + (wave_u + 4) * 1024), 16, kvoff + 32u * kstride,
                                                  (uint32_t)kv0 * kstride, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_void_t*)(sV + buf * TILE + (wave_u + 4) * 1024), 16, vlane + 64u * (uint32_t)p.ldvt,
                                                  (uint32_t)(vsrc - Vb), 0, 0);
+      }
+      if (GR == 1) {   // two waves (rows 0..15 between them): rows + 16, + 32, + 48 as well.  The K swizzle involves row bit 4, so the pieces at
+                       // + 16 / + 48 rows take their own lane offset (kvoff16); V^T's only involves bits 1..3
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_void_t*)(sK + buf * TILE + (wave_u + 2 * j) * 1024), 16, ((j & 1) ? kvoff16 : kvoff) + (uint32_t)(16 * j) * kstride,
+                                                   (uint32_t)kv0 * kstride, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_void_t*)(sV + buf * TILE + (wave_u + 2 * j) * 1024), 16, vlane + (uint32_t)(32 * j) * (uint32_t)p.ldvt,
+                                                   (uint32_t)(vsrc - Vb), 0, 0);
+        }
       }
       return;
     }
@@ -1114,11 +1132,11 @@ size_t k5_attention_state_bytes(int H, int q_len) { return (size_t)H * ((q_len +
 constexpr int K5_ATTN_MAX_SPLITS = 6;
 // + the per-job fallback flags of the per-row-offset form (AttnP::job_flags): one int per (head, 128-query group)
 size_t k5_attention_balance_bytes(int H, int q_len) {
-  return (size_t)K5_ATTN_MAX_SPLITS * k5_attention_state_bytes(H, q_len) + (size_t)H * ((q_len + QB / 2 - 1) / (QB / 2) + 1) * sizeof(int);
+  return (size_t)K5_ATTN_MAX_SPLITS * k5_attention_state_bytes(H, q_len) + (size_t)H * ((q_len + 63) / 64 + 1) * sizeof(int);   // one flag per job; the smallest job is a 64-query row
 }
 namespace {
 inline int* attn_job_flags(float* ws, int H, int q_len) { return reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (size_t)K5_ATTN_MAX_SPLITS * k5_attention_state_bytes(H, q_len)); }
-inline size_t attn_job_flags_bytes(int H, int q_len) { return (size_t)H * ((q_len + QB / 2 - 1) / (QB / 2) + 1) * sizeof(int); }
+inline size_t attn_job_flags_bytes(int H, int q_len) { return (size_t)H * ((q_len + 63) / 64 + 1) * sizeof(int); }
 }  // namespace
 
 namespace {
@@ -1135,7 +1153,7 @@ int attn_slots() {
 
 int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_rows, int* prefer_online, hipStream_t stream) {
   if (!balance_ws || !prefer_online || H <= 0 || q_len <= 0) return K5_ERR_ARG;
-  const int nqb = group_rows == 2 ? (q_len + QB / 2 - 1) / (QB / 2) : (q_len + QB - 1) / QB;
+  const int nqb = (q_len + 64 * group_rows - 1) / (64 * group_rows);
   hipLaunchKernelGGL(attn_pref_update_kernel, dim3(H), dim3(64), 0, stream, attn_job_flags(balance_ws, H, q_len), nqb, H, prefer_online);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
@@ -1300,9 +1318,9 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   AttnP p;
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
   p.H = H; p.q_len = q_len; p.kv_len = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
-  if (group_rows != 4 && (group_rows != 2 || !k_prescaled || pass)) return K5_ERR_ARG;   // lists of 2 rows: 128-query workgroups (ws: job flags only)
-  const bool half = group_rows == 2;
-  p.nqb = half ? (q_len + QB / 2 - 1) / (QB / 2) : (q_len + QB - 1) / QB;
+  if (group_rows != 4 && ((group_rows != 2 && group_rows != 1) || !k_prescaled || pass)) return K5_ERR_ARG;   // lists of 2 rows / 1 row: 128- / 64-query workgroups (ws: job flags only)
+  const bool half = group_rows != 4;
+  p.nqb = (q_len + 64 * group_rows - 1) / (64 * group_rows);
   p.c = 0.125f * 1.44269504088896340736f;
   p.head_flags = nullptr; p.my_flag = 0;
   if (kmax && (!head_flags || !k_prescaled || variant != K5_ATTN_AUTO)) return K5_ERR_ARG;
@@ -1332,9 +1350,12 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
     p.head_flags = (run_fixed && run_online) ? head_flags : nullptr;
     auto launch = [&](int njobs, bool rangek) {
       const dim3 g(njobs);
-      if (half) {
-        if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, true, false, true, false, true>), g, dim3(256), 0, stream, p); }
-        if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, true, false, true, false, true>), g, dim3(256), 0, stream, p); }
+      if (group_rows == 1) {
+        if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, true, false, true, false, 1>), g, dim3(128), 0, stream, p); }
+        if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, true, false, true, false, 1>), g, dim3(128), 0, stream, p); }
+      } else if (half) {
+        if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, true, false, true, false, 2>), g, dim3(256), 0, stream, p); }
+        if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, true, false, true, false, 2>), g, dim3(256), 0, stream, p); }
       } else if (rangek) {
         if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, true, true, true>), g, block, 0, stream, p); }
         if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, true, true, true>), g, block, 0, stream, p); }

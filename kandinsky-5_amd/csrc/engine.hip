@@ -320,6 +320,7 @@ struct k5_dit {
   // two u64 counters: heads that ran the fixed-offset / the online-max kernel since the last reset
   DevBuf ws_attn_stats, ws_attn_flags, ws_attn_cnt, ws_attn_part;   // ws_attn_part: per-block partial maxima of the norm kernel
   long long nabla_possible = 0;                    // profiling: 64x64 blocks the NABLA maps could have kept (kept: ws_attn_cnt[2])
+  int nabla_list_rows = 4;                         // rows per key-tile list of the last profiled map (ws_attn_cnt[3] = sum of list lengths)
   int attn_mode = 0;                               // K5_ATTN_AUTO / K5_ATTN_ONLINE (k5_dit_set_option "attn_mode")
   int sp_pass1_tiles = 0;                          // k5_dit_set_option "sp_pass1_tiles" (0 = all local key tiles)
   // "nabla_group_rows": 64-query rows per key-tile list = per attention workgroup (one GPU).  4: 256-query workgroups; 2: 128-query
@@ -643,10 +644,12 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
       K5CHK(k5_launch_nabla_select_rect(qk, (const bf16_t*)qk + D, 2 * D, 2 * D, H, rows, 0, rows, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
                                         nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, 0, 0, grp));
     }
-    if (d->profiling) {   // realised density of the map (bench.py: attention FLOPs actually done)
+    if (d->profiling) {   // realised density of the map (bench.py: attention FLOPs actually done) and tiles the launch executes for it
       K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
       K5CHK(k5_launch_nabla_count(d->ws_nabla.p, H, nb, nb, d->ws_attn_cnt.as<unsigned long long>() + 2, s));
+      K5CHK(k5_launch_nabla_count_lists(d->ws_nabla.p, H, nb, nb, grp, d->ws_attn_cnt.as<unsigned long long>() + 3, s));
       d->nabla_possible += (long long)H * nb * nb;
+      d->nabla_list_rows = grp;
     }
     K5CHK(nabla_density_hint(d, H, nb, nb, s));
     const int *list, *cnt;
@@ -836,7 +839,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     const int nb = N / 64;
     // sparse maps: 128-query workgroups (lists per two rows, see nabla_group_rows) — without the split-job / two-pass machinery, which
     // lives on the 256-query form; dense maps: that form, balanced
-    const int grp = (d->nabla_grp_now == 2 && d->sp_nabla_passes == 1) ? 2 : 4;
+    const int grp = (d->nabla_grp_now < 4 && d->sp_nabla_passes == 1) ? d->nabla_grp_now : 4;
     K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb, rows / 64)));   // the logits region by the rank's own query-block rows
     {
       Scope sc(d, s, "nabla_map");
@@ -853,11 +856,11 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt, &cnt_local);
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     K5CHK(nabla_density_hint(d, H, rows / 64, nb, s));
-    if (grp == 2) {
+    if (grp < 4) {
       HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
-                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, d->ws_attn_bal.as<float>(), 2, true, kcp));
+                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, d->ws_attn_bal.as<float>(), grp, true, kcp));
     } else if (d->sp_nabla_passes > 1 && P > 1) {
       // two passes over every list: the rank's own key blocks (they lead the lists; K' / V^T of them are in place) while the other
       // ranks' keys travel — state out —, then the rest once the gather has landed (resume, normalise); late fallback as in the dense
@@ -932,7 +935,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       }
     }
   }
-  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, (nabla && d->nabla_grp_now == 2 && d->sp_nabla_passes == 1) ? 2 : 4, (a.pref.as<int>() + (size_t)pref_slot * H), s));
+  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, (nabla && d->nabla_grp_now < 4 && d->sp_nabla_passes == 1) ? d->nabla_grp_now : 4, (a.pref.as<int>() + (size_t)pref_slot * H), s));
   {
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(o, a.wo.p, a.bo.as<float>(), resid, rows, D, D, D, D, D, K5_EPI_GATE, resid, D, gate, s));
@@ -1997,7 +2000,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_anchor")) { d->anchor = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_pref_reset")) return reset_attn_pref(d, nullptr, true);   // an action, not a state: the per-step path (k5_dit_forward) calls it per run
-  if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }
+  if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 1 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }
   if (!strcmp(name, "sp_nabla_passes")) { if (value < 1 || value > 2) return K5_ERR_ARG; d->sp_nabla_passes = value; d->sp_user_set |= 4; return K5_OK; }
   if (!strcmp(name, "attn_fuse_qnorm")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->fuse_qnorm = value; return K5_OK; }
   if (!strcmp(name, "sp_slices")) {
@@ -2057,6 +2060,18 @@ extern "C" int k5_dit_nabla_block_counts(k5_dit* d, long long* kept, long long* 
   }
   if (kept) *kept = (long long)c[2];
   if (possible) *possible = d->nabla_possible;
+  return K5_OK;
+}
+// ... and the blocks the list-driven attention EXECUTED for them: sum of the union lists' lengths x rows per list (one GPU path) — the
+// launch's union efficiency is kept / executed
+extern "C" int k5_dit_nabla_executed_blocks(k5_dit* d, long long* executed) {
+  if (!d || !executed) return K5_ERR_ARG;
+  unsigned long long c[4] = {0, 0, 0, 0};
+  if (d->ws_attn_cnt.p) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(c, d->ws_attn_cnt.p, 32, hipMemcpyDeviceToHost));
+  }
+  *executed = (long long)c[3] * d->nabla_list_rows;
   return K5_OK;
 }
 

@@ -93,6 +93,7 @@ int k5_launch_nabla_key_means_from_slots(const void* gathered, int H, int nb, in
 int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void* out, hipStream_t s);
 // *acc += number of kept (query block, key block) pairs of the map in `workspace` (H x nqb rows)
 int k5_launch_nabla_count(const void* workspace, int H, int nqb, int nb, unsigned long long* acc, hipStream_t s);
+int k5_launch_nabla_count_lists(const void* workspace, int H, int nqb, int nb, int group_rows, unsigned long long* acc, hipStream_t s);
 int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt, void* O, int H, int q_len, int kv_len, int ldq,
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled = false,

@@ -323,6 +323,18 @@ int k5_launch_nabla_count(const void* workspace, int H, int nqb, int nb, unsigne
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
+// profiling: key tiles the list-driven attention EXECUTES = sum over (head, row group) of the union list's length (x the rows of a group:
+// every row of the group computes or masks every tile of the list) — against k5_launch_nabla_count (tiles the rows WANT) this is the
+// launch's union efficiency
+int k5_launch_nabla_count_lists(const void* workspace, int H, int nqb, int nb, int group_rows, unsigned long long* acc, hipStream_t s) {
+  if (!workspace || !acc || H <= 0 || nqb <= 0 || group_rows <= 0) return K5_ERR_ARG;
+  const int* cnt;
+  k5_nabla_workspace_views(const_cast<void*>(workspace), H, nb, nullptr, nullptr, nullptr, &cnt);
+  const int n = H * ((nqb + group_rows - 1) / group_rows);
+  hipLaunchKernelGGL(nabla_count_kernel, dim3((n + 4095) / 4096), dim3(256), 0, s, cnt, n, acc);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
 int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void* out, hipStream_t s) {
   if (H <= 0 || nqb <= 0 || nqb > nb) return K5_ERR_ARG;
   const unsigned long long* bits;
@@ -342,8 +354,8 @@ size_t k5_nabla_workspace_bytes(int H, int nb, int nqb) {
   return (size_t)2 * H * nb * 64 * 2      // qa, ka
          + (size_t)H * nb * nw * 8         // bits
          + (size_t)H * nb * 4              // kv_nb
-         + (size_t)H * ((nb + 1) / 2) * nb * 4         // union lists (sized for lists per 2 rows; per 4 rows uses half)
-         + (size_t)2 * H * ((nb + 1) / 2) * 4 + 256    // counts, counts of the leading local entries (sequence parallelism)
+         + (size_t)H * nb * nb * 4                     // key-tile lists (sized for one list per ROW — round 4; lists per 2 / 4 rows use a half / quarter)
+         + (size_t)2 * H * nb * 4 + 256                // counts, counts of the leading local entries (sequence parallelism)
          + (size_t)H * (nqb + 4) * sel_row_nv((int)nw) * 64 * 2;   // bf16 block logits [H][nqb rows][64 NV] (round 3: one matmul per head, read back per row)
 }
 
@@ -370,13 +382,13 @@ int k5_launch_nabla_key_means_from_slots(const void* gathered, int H, int nb, in
 int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
                                 int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s, int local_block0, int local_blocks,
                                 int group_rows) {
-  if (group_rows != 2 && group_rows != 4) return K5_ERR_ARG;
+  if (group_rows != 1 && group_rows != 2 && group_rows != 4) return K5_ERR_ARG;
   if (local_blocks < 0 || local_block0 < 0 || (local_blocks > 0 && local_block0 + local_blocks > N / 64)) return K5_ERR_ARG;
   if (H <= 0 || N <= 0 || Nq <= 0 || (N % 64) || (Nq % 64) || T * Hb * Wb * 64 != N) return K5_ERR_ARG;
   if (q_block0 < 0 || q_block0 * 64 + Nq > N) return K5_ERR_ARG;
   if ((ldq & 7) || (k && (ldk & 7))) return K5_ERR_ALIGN;
   const int nb = N / 64, nqb = Nq / 64, nw = (nb + 63) / 64, ng = (nqb + group_rows - 1) / group_rows;
-  const size_t ngmax = (size_t)(nb + 1) / 2;   // region sizes (k5_nabla_workspace_bytes / _views)
+  const size_t ngmax = (size_t)nb;   // region sizes (k5_nabla_workspace_bytes / _views)
   if (nb > SEL_MAXNB) return K5_ERR_UNSUPPORTED;
   char* ws = (char*)workspace;
   bf16_t* qa = (bf16_t*)ws; ws += (size_t)H * nb * 64 * 2;
@@ -429,7 +441,7 @@ int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H
 // views into the workspace filled above
 void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned long long** bits, const int** kv_nb, const int** list,
                               const int** cnt, const int** cnt_local) {
-  const size_t nw = (nb + 63) / 64, ng = (nb + 1) / 2;   // region sizes
+  const size_t nw = (nb + 63) / 64, ng = (size_t)nb;   // region sizes
   char* ws = (char*)workspace + (size_t)2 * H * nb * 64 * 2;
   if (bits) *bits = (const unsigned long long*)ws;
   ws += (size_t)H * nb * nw * 8;

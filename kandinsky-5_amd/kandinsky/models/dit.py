@@ -409,6 +409,12 @@ class DiffusionTransformer3D(nn.Module):
         E.check(E.lib().k5_dit_nabla_block_counts(self._handle, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def nabla_executed_blocks(self):
+        """64x64 blocks the list-driven attention executed for those maps (union lists x rows per list): kept / executed = union efficiency."""
+        a = C.c_longlong()
+        E.check(E.lib().k5_dit_nabla_executed_blocks(self._handle, C.byref(a)))
+        return a.value
+
     def set_fp8(self, on=True):
         """opt-in, lossy: linear layers of the visual blocks in W8A8 e4m3 (k5_dit_set_fp8; BASELINE config 5).  `on`: True / 1 = the
         feed-forward GEMMs; a bit mask adds 2 = the q | k | V^T projections and 4 = the out projection of the visual self-attention

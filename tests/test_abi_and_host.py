@@ -330,11 +330,12 @@ def test_attention_tile_prefetch_survives_the_compiler():
             if dma and blocks[name]["loop"]:
                 res.append(walk(name, dma[-1] + 1, {name}))
         return res
-    # <BOUNDED, SPARSE, RANGE, PRE, QN, HALF>: dense fixed / online, the same with the fused query norm, NABLA fixed: one launch, one pass of
+    # <BOUNDED, SPARSE, RANGE, PRE, QN, GR>: dense fixed / online, the same with the fused query norm, NABLA fixed: one launch, one pass of
     # the sharded schedule, 128-query workgroups (all on pre-scaled keys)
-    for tag, pick in (("ILb1ELb0ELb1ELb1ELb0ELb0E", min), ("ILb0ELb0ELb1ELb1ELb0ELb0E", min), ("ILb1ELb0ELb1ELb1ELb1ELb0E", min),
-                      ("ILb0ELb0ELb1ELb1ELb1ELb0E", min), ("ILb1ELb1ELb0ELb1ELb0ELb0E", max), ("ILb1ELb1ELb1ELb1ELb0ELb0E", max),
-                      ("ILb1ELb1ELb0ELb1ELb0ELb1E", max)):
+    # (round 4: the last parameter is GR, the 64-query rows per list — 4: 256-query workgroups, 2: 128, 1: 64)
+    for tag, pick in (("ILb1ELb0ELb1ELb1ELb0ELi4E", min), ("ILb0ELb0ELb1ELb1ELb0ELi4E", min), ("ILb1ELb0ELb1ELb1ELb1ELi4E", min),
+                      ("ILb0ELb0ELb1ELb1ELb1ELi4E", min), ("ILb1ELb1ELb0ELb1ELb0ELi4E", max), ("ILb1ELb1ELb1ELb1ELb0ELi4E", max),
+                      ("ILb1ELb1ELb0ELb1ELb0ELi2E", max), ("ILb1ELb1ELb0ELb1ELb0ELi1E", max)):
         need = 24
         body = [v for k, v in kernels.items() if tag in k]
         assert len(body) == 1, tag

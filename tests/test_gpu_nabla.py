@@ -393,7 +393,7 @@ def test_lists_per_two_rows_give_the_same_bits(gain, anchor):
     t = torch.tensor([875.0])
     sp = {"P": 0.6, "wT": 3, "wH": 3, "wW": 3, "to_fractal": True}
     outs = []
-    for grp in (4, 2):
+    for grp in (4, 2, 1):         # 1 (round 4): one list per 64-query row, 64-query workgroups of two waves
         d = DiffusionTransformer3D(**c)
         d.load_state_dict(sd, assign=True)
         d = d.to("cuda:0")
@@ -405,7 +405,7 @@ def test_lists_per_two_rows_give_the_same_bits(gain, anchor):
         assert (n_online == 0) if gain <= 3.0 else (n_fixed == 0), (gain, grp, n_fixed, n_online)
         del d
     assert torch.isfinite(outs[0].float()).all()
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_nabla_graph_captured_step_is_bit_identical(tiny_sd, golden, golden_meta):

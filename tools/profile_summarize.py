@@ -49,9 +49,14 @@ def attn_template_args(name):
     m = re.search(r"attn_fwd_kernel<([^>]*)>", name)
     if not m:
         return None
-    vals = [v.strip() == "true" for v in m.group(1).split(",")]
-    vals += [False] * (len(ATTN_TPARAMS) - len(vals))
-    return dict(zip(ATTN_TPARAMS, vals))
+    raw = [v.strip() for v in m.group(1).split(",")]
+    vals = [v == "true" for v in raw[:5]]
+    vals += [False] * (5 - len(vals))
+    gr = int(raw[5]) if len(raw) > 5 and raw[5].lstrip("-").isdigit() else (2 if len(raw) > 5 and raw[5] == "true" else 4)   # GR (round 4); 'true' = round 2-3's HALF
+    d = dict(zip(ATTN_TPARAMS[:5], vals))
+    d["GR"] = gr
+    d["HALF"] = gr != 4
+    return d
 
 
 def attention_block_summary(trace_rows, tokens=47616, heads=28):
