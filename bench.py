@@ -118,7 +118,8 @@ def cpu_baseline(N, budget_s=3.0):   # the full-size sample runs ~3.5x slower th
     t_c1 = time.perf_counter() - t0
     return {"value": 1.0 / (32 * t_block), "unit": "steps/s", "cores": cores, "host_cpus": ncpu, "kind": "port",
             "sample": f"fp32 torch-CPU oracle, 1 of 32 decoder blocks, {nq} of {N} query rows against all {N} keys "
-                      f"({t_s:.1f} s measured), scaled to the full block and x32 blocks",
+                      f"({t_s:.1f} s measured), scaled to the full block and x32 blocks; {cores} torch threads = the fastest of {{8, 16, 32, 64}} "
+                      f"calibrated on this host ({ncpu} logical CPUs; more threads measured slower: the container's CPU quota is below the host's core count)",
             "ms_per_step": 32 * t_block * 1e3,
             "config1_forward_s": t_c1,
             "config1_sample": f"BASELINE config 1 (256x256 2 s latent (13,32,32), {n1} tokens): 32 full decoder blocks timed in full, "
@@ -397,7 +398,7 @@ def main():
                    f"all zero when the bound is <= 90); beyond 190 the fixed form runs on offsets anchored at sampled scores (one-GPU path) "
                    f"unless the layer's jobs kept falling back")
     traffic, traffic_source = None, None   # HBM-side bytes per attention launch: NOT measured in this run (PMC counters need their own
-    for tf in ("r03_attention_traffic.json", "r02_attention_traffic.json"):   # rocprofv3 --pmc passes) but read from the committed profile,
+    for tf in ("r04_attention_traffic.json", "r03_attention_traffic.json", "r02_attention_traffic.json"):   # rocprofv3 --pmc passes) but read from the committed profile,
         try:                                                                  # and only quoted for the exact workload it was measured on
             with open(os.path.join(ROOT, "profiles", tf)) as f:
                 tj = json.load(f)
@@ -466,6 +467,7 @@ def main():
                          **({"executed_block_density": nabla_exec / nabla_counts[1], "union_efficiency": nabla_counts[0] / nabla_exec,
                              "achieved_on_executed_tiles": achieved * nabla_exec / nabla_counts[0]} if nabla_exec and nabla_counts and nabla_counts[0] else {})},
             "roofline_gemm": gemm_roof,
+            "roofline_attention": None,     # set below when the GEMM family, not the attention, is what bounds this workload's step
             "kernel_time_ms_per_step": {k: v[0] / fam_steps for k, v in fam_break.items() if v[1]},
             "kernel_time_source": ("HIP events inside the timed region" if fam_break is fam else
                                    f"attn_self: HIP events inside the timed region; other families: separate {fam_steps}-step pass with an "
@@ -475,6 +477,14 @@ def main():
                            "note": "50 x measured ms_per_step + measured HunyuanVideo VAE decode (14 temporal tiles, uint8 out); "
                                    "text encoding excluded (no weights offline); reference README: 77 s on 1xH100 incl. text encoder"},
         }
+        # `roofline` names the STEP-DOMINANT kernel family of THIS workload: the attention on the dense configurations, the
+        # linear layers' GEMM family on the NABLA configurations at their operating densities — the other one stays in the line under its own key
+        attn_ms_step = attn_ms / max(args.steps, 1)
+        if gemm_roof is not None and gemm_roof["ms_per_step"] > attn_ms_step:
+            out["roofline_attention"] = out["roofline"]
+            out["roofline"] = dict(gemm_roof, traffic=None, dominant_because=f"GEMM family {gemm_roof['ms_per_step']:.1f} ms per step > visual self-attention {attn_ms_step:.1f} ms")
+        else:
+            out.pop("roofline_attention")
         out["parity_check"] = parity
         out["latent_pin"] = pin
         if pin is not None and pin.get("status") == "FAILED":

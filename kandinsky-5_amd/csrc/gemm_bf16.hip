@@ -943,6 +943,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef W4_TRACE   // tools/gemm_w4_trace.py: wall-clock (100 MHz) stamps per workgroup and tile: tile start | K loop done | epilogue done
   unsigned long long* tr_lds = reinterpret_cast<unsigned long long*>(dsm + W4_LDS);
   int tr_i = 0;
+  if (tid == 0) tr_lds[W4_TRACE_N - 2] = __builtin_amdgcn_s_memtime();   // shader-clock ticks at the first / after the last tile: the clock this kernel ran at
 #define W4_STAMP() do { if (tid == 0 && tr_i < W4_TRACE_N) tr_lds[tr_i] = __builtin_amdgcn_s_memrealtime(); ++tr_i; } while (0)
 #else
 #define W4_STAMP() do {} while (0)
@@ -1109,9 +1110,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     W4_STAMP();
   }
 #ifdef W4_TRACE
+  if (tid == 0) tr_lds[W4_TRACE_N - 1] = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   if (p.trace && tid < 64)
-    for (int i = tid; i < W4_TRACE_N; i += 64) p.trace[(size_t)blockIdx.x * W4_TRACE_N + i] = i < tr_i ? tr_lds[i] : 0ull;
+    for (int i = tid; i < W4_TRACE_N; i += 64) p.trace[(size_t)blockIdx.x * W4_TRACE_N + i] = (i < tr_i || i >= W4_TRACE_N - 2) ? tr_lds[i] : 0ull;
 #endif
 #undef W4_VEC_FETCH
 #undef W4_STAMP

@@ -38,6 +38,8 @@ def run(name, M, N, K, epi):
     g = torch.Generator(device="cuda").manual_seed(0)
     a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    if "--zero" in sys.argv:    # zero operands: the same instruction stream at the clock an idle-power chip gives it
+        a.zero_(); w.zero_()
     out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
     bias = torch.randn(M if epi == "bias_m" else N, device="cuda")
     gate = torch.randn(N, device="cuda")
@@ -58,7 +60,10 @@ def run(name, M, N, K, epi):
     ms = e0.elapsed_time(e1) / 10
     if TIMES_ONLY:
         return {"shape": name, "M": M, "N": N, "K": K, "ms": ms, "tflops": 2.0 * M * N * K / ms / 1e9}
-    t = trace.cpu().reshape(256, NT // 3, 3).double() * 10.0      # ns
+    raw = trace.cpu().reshape(256, NT)
+    ticks = (raw[:, NT - 1] - raw[:, NT - 2]).double()            # s_memtime: shader-clock ticks between the first tile's start and the last tile's end
+    t = raw.reshape(256, NT // 3, 3).double() * 10.0      # ns
+    t[:, NT // 3 - 1] = 0
     ntile = int((t[:, :, 0] > 0).sum(1).max())
     t = t[:, :ntile]
     valid = t[:, :, 0] > 0
@@ -69,6 +74,10 @@ def run(name, M, N, K, epi):
            "k_loop_us": float(loop.mean()) / 1e3, "k_tile_ns": float(loop.mean()) / nk, "epilogue_us": float(epi_t.mean()) / 1e3,
            "epilogue_us_max": float(epi_t.max()) / 1e3, "epilogue_frac": float(epi_t.sum() / (loop.sum() + epi_t.sum())),
            "kernel_span_us": float((t[:, :, 2][valid].max() - t0) / 1e3)}
+    span = torch.stack([t[w, int(valid[w].sum()) - 1, 2] - t[w, 0, 0] for w in range(256)])        # ns, per workgroup
+    res["shader_clock_ghz"] = float((ticks / span).mean())
+    res["shader_clock_ghz_minmax"] = [float((ticks / span).min()), float((ticks / span).max())]
+    res["k_tile_cycles"] = res["k_tile_ns"] * res["shader_clock_ghz"]
     res["per_xcd_k_tile_ns"] = [float((t[x::8, :, 1] - t[x::8, :, 0])[valid[x::8]].mean()) / nk for x in range(8)]
     rounds = []
     for r in range(ntile):
@@ -93,7 +102,8 @@ def main():
             continue
         print(f"{r['shape']:22s} {r['M']}x{r['N']}x{r['K']}: {r['ms'] * 1e3:7.1f} us = {r['tflops']:6.0f} TFLOP/s; {r['tiles_per_wg']} tiles per workgroup; "
               f"K loop {r['k_loop_us']:.1f} us ({r['k_tile_ns']:.0f} ns per K-tile), epilogue {r['epilogue_us']:.2f} us (max {r['epilogue_us_max']:.2f}) = "
-              f"{100 * r['epilogue_frac']:.1f} % of a tile; main launch span {r['kernel_span_us']:.1f} us")
+              f"{100 * r['epilogue_frac']:.1f} % of a tile; main launch span {r['kernel_span_us']:.1f} us; shader clock {r['shader_clock_ghz']:.3f} GHz ({r['shader_clock_ghz_minmax'][0]:.3f}-{r['shader_clock_ghz_minmax'][1]:.3f}) "
+              f"=> {r['k_tile_cycles']:.0f} cycles per K-tile (128 MFMA x 16 = 2048)")
         print("      per-XCD ns per K-tile:", " ".join(f"{v:.0f}" for v in r["per_xcd_k_tile_ns"]))
         for rd in r["rounds"]:
             print(f"      round {rd['round']}: {rd['wgs']} workgroups, {rd['k_tile_ns']:.0f} ns per K-tile, epilogue {rd['epilogue_us']:.2f} us, epilogues start within {rd['epilogue_start_spread_us']:.2f} us (std {rd['epilogue_start_std_us']:.2f}), "

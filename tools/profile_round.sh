@@ -27,6 +27,7 @@ python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --attn-online 2>
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --qk-gain 3 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --qk-gain 6 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl   # beyond the window: anchored offsets
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --qk-gain 6 --engine-option attn_anchor=0 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl   # ... the online form
+for m in 1 3 7; do python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --fp8 $m 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl; done   # W8A8 e4m3: FF | FF + q,k,v | + out (lossy, INVALID_AS_BENCH)
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --workload 5s_sft 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vae --workload 2s_256 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
 python bench.py --steps 45 --warmup 5 --no-cpu-baseline --no-vae --magcache 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
@@ -36,4 +37,5 @@ for sh in 2 4 8; do for sl in 1 2; do python bench.py --steps 6 --warmup 2 --no-
 for np in 0.9 0.0; do for ps in 1 2; do python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vae --workload 10s_nabla --nabla-p $np --emulate-shard 4 --engine-option sp_nabla_passes=$ps 2>/dev/null | grep "^{" >> $OUT/${TAG}_shards.jsonl; done; done
 # 8. BASELINE config 5's shape (1280x768, 10 s: 3660 blocks) as rank 0 of 4, STA-only and near-dense maps
 for np in 0.0 0.9; do python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-vae --workload 10s_hd_nabla --nabla-p $np --emulate-shard 4 2>/dev/null | grep "^{" >> $OUT/${TAG}_shards.jsonl; done
+python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-vae --workload 10s_hd_nabla --nabla-p 0.0 --emulate-shard 4 --fp8 3 2>/dev/null | grep "^{" >> $OUT/${TAG}_shards.jsonl   # BASELINE config 5 is the fp8 configuration
 wc -l $OUT/${TAG}_workloads.jsonl $OUT/${TAG}_shards.jsonl
