@@ -126,6 +126,7 @@ struct AttnP {
   int vt_chunk_keys; long long vt_chunk_stride;
   // SPARSE (NABLA): per workgroup (head, 256-query group) a list of kv-block ids | (4-bit membership << 24) and its length
   const int* sp_list; const int* sp_cnt; int sp_stride;
+  int pair_stride = 0;       // SPARSE, 128-query workgroups: rows of a group = k5_pair_row(group, 0 / 1, pair_stride, q_len / 64) (0: adjacent rows)
   // key-tile range of this launch (dense): sequence position e -> tile e + tile_off0, plus tile_skip_n once that reaches
   // tile_skip_at (lets pass 2 of the sequence-parallel schedule walk "every chunk except mine").  state/flags: resume
   // from (flags & 1) and/or leave (flags & 2) the fp32 running state {O^T accumulators, m, l} instead of normalising.
@@ -220,7 +221,9 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
       if (hf == 2) { if (p.late_pass != 2) return; late = true; }
     }
   }
-  const int q0 = qb * (64 * GR) + wave * 32;   // this wave: queries q0 .. q0+31 = two 16-query MFMA tiles (qt = 0, 1)
+  // this wave: queries q0 .. q0+31 = two 16-query MFMA tiles (qt = 0, 1); the two rows of a 128-query group need not be adjacent (frame pairing)
+  const int q0 = (GR == 2 && p.pair_stride > 0) ? k5_pair_row(qb, wave >> 1, p.pair_stride, p.q_len >> 6) * 64 + (wave & 1) * 32
+                                                : qb * (64 * GR) + wave * 32;
 
   // Q^T fragments (MFMA 16x16x32 B operand): lane (l15, g) holds Q[q0 + 16 qt + l15][32 ks + 8 g .. +8]
   bf16x8 qf[2][2];
@@ -1310,8 +1313,9 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
                                     int ldk, int ldvt, int ldo, float score_bound, const int* list, const int* cnt, int list_stride,
                                     int vt_chunk_keys, long long vt_chunk_stride, hipStream_t stream, bool k_prescaled,
                                     const int* head_flags, int variant, const float* kmax, const K5SparsePass* pass, float* ws,
-                                    int group_rows, bool balance, const K5KeyCentre* kc) {
+                                    int group_rows, bool balance, const K5KeyCentre* kc, int pair_stride) {
   if (H <= 0 || q_len <= 0 || kv_len <= 0 || (q_len % KB) || (kv_len % KB) || !list || !cnt) return K5_ERR_ARG;
+  if (pair_stride < 0 || (pair_stride > 0 && group_rows != 2)) return K5_ERR_ARG;
   if ((ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3)) return K5_ERR_ALIGN;
   if (vt_chunk_keys < 0 || (vt_chunk_keys % KB) || (vt_chunk_stride & 7)) return K5_ERR_ALIGN;
   if ((head_flags || variant != K5_ATTN_AUTO) && !k_prescaled) return K5_ERR_ARG;
@@ -1335,6 +1339,7 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
   }
   p.vt_chunk_keys = vt_chunk_keys; p.vt_chunk_stride = vt_chunk_stride;
   p.sp_list = list; p.sp_cnt = cnt; p.sp_stride = list_stride; p.sp_begin = nullptr;
+  p.pair_stride = pair_stride;
   p.tile_off0 = 0; p.tile_cnt = 0; p.tile_skip_at = 0x7fffffff; p.tile_skip_n = 0; p.state = nullptr; p.flags = 0;
   if (pass) {   // one pass of a two-pass walk of the lists (sequence parallelism): [begin, cnt) of every list, fp32 state in / out
     if (!k_prescaled || !pass->state || (pass->flags & ~3) || pass->late_pass < 0 || pass->late_pass > 2 || (pass->late_pass && !kmax)) return K5_ERR_ARG;

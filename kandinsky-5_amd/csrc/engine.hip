@@ -328,6 +328,10 @@ struct k5_dit {
   // chosen per forward from the kept density of the PREVIOUS forward's first map (counted on the device, copied to pinned host memory
   // without a synchronisation: a stale or missing value only costs speed)
   int nabla_group_rows = 0, nabla_grp_now = 4;
+  // "nabla_pair_frames" (round 4): the two 64-query rows of a 128-query list are the same spatial tile in ADJACENT FRAMES (k5_pair_row) instead
+  // of adjacent tiles of one frame: their sliding-tile windows share 10 of 11 frames.  Same arithmetic per row (a row's key tiles are walked
+  // in the same ascending order), so outputs are bit-identical with it on or off.
+  int nabla_pair_frames = 1;
   DevBuf ws_nabla_kept;                            // u64 kept-block count of the forward's first NABLA map
   unsigned long long* h_nabla_kept = nullptr;      // its pinned host copy
   long long nabla_hint_possible = 0;               // blocks that map could have kept
@@ -638,11 +642,12 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   if (nabla) {  // nablaT_v2 map (utils.py:136-163) + block-sparse attention (nn.py:257-280)
     const int nb = rows / 64;
     const int grp = pre ? d->nabla_grp_now : 4;   // 64-query rows per key-tile list = per attention workgroup
+    const int pair = (grp == 2 && d->nabla_pair_frames) ? nabla->Hb * nabla->Wb : 0;
     K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
     {
       Scope sc(d, s, "nabla_map");
       K5CHK(k5_launch_nabla_select_rect(qk, (const bf16_t*)qk + D, 2 * D, 2 * D, H, rows, 0, rows, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
-                                        nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, 0, 0, grp));
+                                        nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, 0, 0, grp, pair));
     }
     if (d->profiling) {   // realised density of the map (bench.py: attention FLOPs actually done) and tiles the launch executes for it
       K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
@@ -660,7 +665,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     // 0.05; a token shard's 5 rounds are another matter, run_self_attention_sp)
     K5CHK(k5_launch_attention_bf16_sparse(qk, pre ? d->ws_kc.as<bf16_t>() : (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, pre ? D : 2 * D,
                                           ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant, kmax, nullptr,
-                                          pre ? d->ws_attn_bal.as<float>() : nullptr, grp, false, kcp));
+                                          pre ? d->ws_attn_bal.as<float>() : nullptr, grp, false, kcp, pair));
   } else {
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     Scope sc(d, s, fam_attn);
@@ -840,12 +845,13 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     // sparse maps: 128-query workgroups (lists per two rows, see nabla_group_rows) — without the split-job / two-pass machinery, which
     // lives on the 256-query form; dense maps: that form, balanced
     const int grp = (d->nabla_grp_now < 4 && d->sp_nabla_passes == 1) ? d->nabla_grp_now : 4;
+    const int pair = (grp == 2 && d->nabla_pair_frames) ? nabla->Hb * nabla->Wb : 0;   // rows l and l + S of the rank's shard: same tile, next frame
     K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb, rows / 64)));   // the logits region by the rank's own query-block rows
     {
       Scope sc(d, s, "nabla_map");
       K5CHK(k5_launch_nabla_key_means_from_slots(kmeans, H, nb, slot_blocks, d->ws_nabla.p, s));
       K5CHK(k5_launch_nabla_select_rect(q, nullptr, D, 0, H, rows, r * slot_blocks, N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
-                                        nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, r * slot_blocks, rows / 64, grp));   // own key blocks lead the lists
+                                        nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, r * slot_blocks, rows / 64, grp, pair));   // own key blocks lead the lists
     }
     if (d->profiling) {
       K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
@@ -860,7 +866,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       HIPCHK(hipStreamWaitEvent(s, d->ev_gathered, 0));
       Scope sc(d, s, "attn_self");
       K5CHK(k5_launch_attention_bf16_sparse(q, kfull, vtfull, o, H, rows, N, D, D, ldv, D, 0.f, list, cnt, nb, rows_pad,
-                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, d->ws_attn_bal.as<float>(), grp, true, kcp));
+                                            (long long)D * ldv, s, true, hflags, variant, kmax, nullptr, d->ws_attn_bal.as<float>(), grp, true, kcp, pair));
     } else if (d->sp_nabla_passes > 1 && P > 1) {
       // two passes over every list: the rank's own key blocks (they lead the lists; K' / V^T of them are in place) while the other
       // ranks' keys travel — state out —, then the rest once the gather has landed (resume, normalise); late fallback as in the dense
@@ -1972,6 +1978,8 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //                     depending on how the compiler schedules the tile loop of the extra instantiation), hence opt-in.
 //   "nabla_group_rows" 0 (default) / 2 / 4: 64-query rows per NABLA key-tile list = per attention workgroup on one GPU; 0 picks 2 (128-query
 //                     workgroups) when the previous forward's first map kept less than half of its blocks, else 4; same bits either way
+//   "nabla_pair_frames" 1 (default) / 0: which two 64-query rows share a 128-query list — the same spatial tile of adjacent frames, or adjacent
+//                     tiles of one frame (round 3); same bits, tighter unions under the sliding-tile window (k5_pair_row)
 //   "sp_nabla_passes" 1 (default) / 2: NABLA under sequence parallelism walks every list in one pass after the gather, or in two — the
 //                     rank's own key blocks while the other ranks' keys travel, the rest after the gather (costs 12 % of the attention
 //                     in compute, emulated P = 4; pays when the exposed part of the gather is longer than that — a property of the node)
@@ -2000,6 +2008,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_anchor")) { d->anchor = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_pref_reset")) return reset_attn_pref(d, nullptr, true);   // an action, not a state: the per-step path (k5_dit_forward) calls it per run
+  if (!strcmp(name, "nabla_pair_frames")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->nabla_pair_frames = value; return K5_OK; }
   if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 1 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }
   if (!strcmp(name, "sp_nabla_passes")) { if (value < 1 || value > 2) return K5_ERR_ARG; d->sp_nabla_passes = value; d->sp_user_set |= 4; return K5_OK; }
   if (!strcmp(name, "attn_fuse_qnorm")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->fuse_qnorm = value; return K5_OK; }
@@ -2030,6 +2039,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "sp_autotune")) *value = d->sp_autotune ? 1 : 0;
   else if (!strcmp(name, "sp_tuned")) *value = d->sp_tuned ? 1 : 0;
   else if (!strcmp(name, "nabla_group_rows")) *value = d->nabla_group_rows;
+  else if (!strcmp(name, "nabla_pair_frames")) *value = d->nabla_pair_frames;
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
   else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }

@@ -15,6 +15,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define K5_DEV __device__ __forceinline__
+#define K5_HD __host__ __device__ __forceinline__
 
 // ---- bf16 <-> f32 (round-to-nearest-even, hardware v_cvt_pk_bf16_f32 on gfx950) ----
 K5_DEV float bf2f(bf16_t v) { return (float)v; }
@@ -71,6 +72,17 @@ K5_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678
 // gelu_erf, so the bits are the same — 21 VALU instructions per pair instead of 36.  For epilogues with no MFMA beside them (beside MFMAs
 // packed math is an anti-lever, which is why the build runs with -fno-slp-vectorize).
 typedef float k5_f32x2 __attribute__((ext_vector_type(2)));
+// NABLA lists shared by TWO 64-query rows (128-query attention workgroups): which rows group g holds.  S = 0: the adjacent rows 2g, 2g + 1.
+// S > 0 (round 4, "frame pairing"): S = blocks per latent frame of the fractal token order — rows b and b + S are the SAME 8 x 8 spatial tile
+// in adjacent frames, whose sliding-tile windows overlap in 10 of 11 frames (adjacent tiles of one frame: in 2 of 3 columns), so the union
+// list is tighter.  Whole chunks of 2S rows pair i with i + S; a last, shorter chunk falls back to adjacent pairs; ceil(n / 2) groups either way.
+K5_HD int k5_pair_row(int g, int r, int S, int n) {
+  if (S <= 0) return 2 * g + r;
+  const int c = g / S, base = 2 * S * c;
+  if (base + 2 * S <= n) return base + (g - c * S) + r * S;
+  return base + 2 * (g - c * S) + r;
+}
+
 K5_DEV void gelu_erf_x2(float& a, float& b) {
   const k5_f32x2 x0 = {a, b};
   const k5_f32x2 x = x0 * k5_f32x2{0.70710678118654752440f, 0.70710678118654752440f};

@@ -85,7 +85,8 @@ void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned lon
 int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
                                 int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s,
                                 int local_block0 = 0, int local_blocks = 0,   // > 0: these key blocks lead every list (cnt_local of them)
-                                int group_rows = 4);                          // 64-query rows per list (4, or 2 for the 128-query workgroups)
+                                int group_rows = 4,                           // 64-query rows per list (4, or 2 for the 128-query workgroups)
+                                int pair_stride = 0);                         // group_rows 2: which two rows share a list (k5_pair_row; 0 = adjacent)
 // sequence parallelism: a rank's key-block means (k5_launch_nabla_block_means into its slot of a [P][H][slot_blocks][64] buffer),
 // gathered, re-laid into the workspace (k5_launch_nabla_key_means_from_slots); k5_launch_nabla_select_rect(k = nullptr) selects from them
 int k5_launch_nabla_block_means(const void* x, int ld, int H, int nblocks, int stride_blocks, void* out, hipStream_t s);
@@ -101,7 +102,8 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
                                     const K5SparsePass* pass = nullptr, float* balance_ws = nullptr,   // k5_attention_balance_bytes; pre-scaled keys
                                     int group_rows = 4,    // 2: lists per TWO 64-query rows (k5_launch_nabla_select_rect group_rows = 2), 128-query workgroups
                                     bool balance = true,   // false: balance_ws only carries the per-job fallback flags of the per-row-offset form
-                                    const K5KeyCentre* key_centre = nullptr);
+                                    const K5KeyCentre* key_centre = nullptr,
+                                    int pair_stride = 0);  // group_rows 2: rows of a group per k5_pair_row (the stride the lists were built with)
 
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,

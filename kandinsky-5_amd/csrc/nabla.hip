@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
 // cnt_local[h*ng+g] says how many they are: the attention runs them as a first pass while the other ranks' keys travel.
 __global__ __launch_bounds__(256) void nabla_union_kernel(const unsigned long long* __restrict__ bits, int* __restrict__ list,
                                                           int* __restrict__ cnt, int* __restrict__ cnt_local, int H, int nqb, int nb,
-                                                          int nw, int ng, int loc0, int locn, int G) {
+                                                          int nw, int ng, int loc0, int locn, int G, int pair_stride) {
   const int lane = threadIdx.x & 63;
   const int gi = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gi >= H * ng) return;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void nabla_union_kernel(const unsigned long lo
       unsigned long long w[4], u = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qb = G * g + r;
+        const int qb = (G == 2 && pair_stride > 0) ? k5_pair_row(g, r, pair_stride, nqb) : G * g + r;
         w[r] = (r < G && qb < nqb) ? bits[((size_t)h * nqb + qb) * nw + c] & take : 0ull;
         u |= w[r];
       }
@@ -381,8 +381,9 @@ int k5_launch_nabla_key_means_from_slots(const void* gathered, int H, int nb, in
 // k == nullptr: the key-block means are already in the workspace (k5_launch_nabla_key_means_from_slots)
 int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
                                 int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s, int local_block0, int local_blocks,
-                                int group_rows) {
+                                int group_rows, int pair_stride) {
   if (group_rows != 1 && group_rows != 2 && group_rows != 4) return K5_ERR_ARG;
+  if (pair_stride < 0 || (pair_stride > 0 && group_rows != 2)) return K5_ERR_ARG;
   if (local_blocks < 0 || local_block0 < 0 || (local_blocks > 0 && local_block0 + local_blocks > N / 64)) return K5_ERR_ARG;
   if (H <= 0 || N <= 0 || Nq <= 0 || (N % 64) || (Nq % 64) || T * Hb * Wb * 64 != N) return K5_ERR_ARG;
   if (q_block0 < 0 || q_block0 * 64 + Nq > N) return K5_ERR_ARG;
@@ -429,7 +430,7 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
     }
   }
   hipLaunchKernelGGL(nabla_union_kernel, dim3((H * ng + 3) / 4), dim3(256), 0, s, bits, list, cnt, cnt_local, H, nqb, nb, nw, ng, local_block0,
-                     local_blocks, group_rows);
+                     local_blocks, group_rows, pair_stride);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 

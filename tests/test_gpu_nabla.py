@@ -393,19 +393,23 @@ def test_lists_per_two_rows_give_the_same_bits(gain, anchor):
     t = torch.tensor([875.0])
     sp = {"P": 0.6, "wT": 3, "wH": 3, "wW": 3, "to_fractal": True}
     outs = []
-    for grp in (4, 2, 1):         # 1 (round 4): one list per 64-query row, 64-query workgroups of two waves
+    # 1 (round 4): one list per 64-query row, 64-query workgroups of two waves.  "nabla_pair_frames" (round 4, default 1): the two rows of a
+    # 128-query list are the same spatial tile in adjacent frames (2 blocks per frame here: rows b and b + 2; 4 whole chunks of 4 rows and a
+    # 2-row remainder that pairs adjacent rows) instead of rows 2g, 2g + 1 — a row still walks its own tiles in ascending order
+    for grp, pair in ((4, 1), (2, 1), (2, 0), (1, 1)):
         d = DiffusionTransformer3D(**c)
         d.load_state_dict(sd, assign=True)
         d = d.to("cuda:0")
         d.engine("cuda:0")
         d.set_option("nabla_group_rows", grp)
+        d.set_option("nabla_pair_frames", pair)
         d.set_option("attn_anchor", anchor)
         outs.append(d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(37), scale_factor=(1.0, 2.0, 2.0), sparse_params=sp))
         n_fixed, n_online = d.attn_variant_counts()
         assert (n_online == 0) if gain <= 3.0 else (n_fixed == 0), (gain, grp, n_fixed, n_online)
         del d
     assert torch.isfinite(outs[0].float()).all()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
 
 
 def test_nabla_graph_captured_step_is_bit_identical(tiny_sd, golden, golden_meta):
