@@ -1248,6 +1248,19 @@ int launch_tail(GemmP p, hipStream_t stream, int full, int rem) {
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
+// a WHOLE small GEMM as quadrants of its 256x256 logical tiles on the deep-prefetch 128x128 kernel (config-1 shapes: 91 tiles = 364 quadrants)
+template <int EPI>
+int launch_q4_whole(GemmP p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_bf16_q4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS) != hipSuccess) return K5_ERR_HIP;
+    attr_set = true;
+  }
+  p.tiles256_m = (p.M + 255) / 256; p.tiles256_n = (p.N + 255) / 256; p.tail_base = 0;
+  hipLaunchKernelGGL(gemm_bf16_q4_kernel<EPI>, dim3(4 * p.tiles256_m * p.tiles256_n), dim3(256), Q4_LDS, stream, p);
+  return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+}
+
 template <int EPI>
 int launch_w4(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
   static bool attr_set = false;
@@ -1323,6 +1336,15 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
       case K5_EPI_BIAS_M: return launch_k8<K5_EPI_BIAS_M>(p, stream);
       case K5_EPI_GELU: return launch_k8<K5_EPI_GELU>(p, stream);
       case K5_EPI_GATE: return launch_k8<K5_EPI_GATE>(p, stream);
+      default: return K5_ERR_ARG;
+    }
+  }
+  if (w4_ok && force_v1 == 5) {   // A/B: the whole GEMM on the deep-prefetch quadrant kernel
+    switch (epi) {
+      case K5_EPI_BIAS: return launch_q4_whole<K5_EPI_BIAS>(p, stream);
+      case K5_EPI_BIAS_M: return launch_q4_whole<K5_EPI_BIAS_M>(p, stream);
+      case K5_EPI_GELU: return launch_q4_whole<K5_EPI_GELU>(p, stream);
+      case K5_EPI_GATE: return launch_q4_whole<K5_EPI_GATE>(p, stream);
       default: return K5_ERR_ARG;
     }
   }
