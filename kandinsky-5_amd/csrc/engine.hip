@@ -305,6 +305,7 @@ struct k5_dit {
   hipEvent_t ev_vel_ready = nullptr, ev_vel_done = nullptr;
   DevBuf ws_vel_pair;                              // [2][T H W 16] bf16: slot 0 = conditional, 1 = unconditional velocity
   bool use_fp8 = false;                            // visual feed-forward GEMMs in W8A8 e4m3 (k5_dit_set_fp8 bit 0)
+  int fp8_fuse_ln = 1;                             // fp8 modes: the LayerNorm in front of an fp8 projection writes e4m3 directly (same bits as LayerNorm + quantisation pass)
   int fp8_mask = 0;                                // k5_dit_set_fp8: bit 0 feed-forward, bit 1 q | k | V^T projections, bit 2 out projection of the visual self-attention
   DevBuf ws_h8, ws_ff8;                            // fp8 activations of that path
   DevBuf ws_sched;                                 // sampler tables on the device: t*1000 [steps] | dt [steps] | step counter
@@ -572,17 +573,29 @@ int nabla_density_hint(k5_dit* d, int H, int nqb, int nb, hipStream_t s) {
   return K5_OK;
 }
 
+// do the q | k | V^T projections of the VISUAL self-attention take the e4m3 activations (k5_dit_set_fp8 bit 1)?  One rule for the callee and for
+// the block loop, which then lets the LayerNorm write ws_h8 directly (h8_ready) instead of a bf16 h + a quantisation pass
+bool sa_fp8_in(const k5_dit* d, const AttnW& a, int rows) {
+  return (d->fp8_mask & 2) && a.wqk8.p && rows >= 256 && !((int)rup(rows, 8) & 15);
+}
+bool sa_sp_fp8_in(const k5_dit* d, const AttnW& a, int rows, int rows_pad, bool nabla) {
+  const int P = d->sp_world;
+  return (d->fp8_mask & 2) && a.wqk8.p && rows >= 256 && !((rows_pad / ((!nabla && d->sp_slices > 1 && P > 1) ? d->sp_slices : 1)) & 15);
+}
+bool ff_fp8_in(const k5_dit* d, const BlockW& b, int rows) { return d->use_fp8 && b.w1_f8.p && rows >= 256; }
+
 int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, void* qk, void* vt,
                        void* o, const float* cosT, const float* sinT, void* resid, const float* gate,
-                       const char* fam_attn, const NablaArgs* nabla = nullptr, int pref_slot = 0) {
+                       const char* fam_attn, const NablaArgs* nabla = nullptr, int pref_slot = 0, bool h8_ready = false) {
   const int D = d->D, H = d->Hh;
   const int ldvt = (int)rup(rows, 8);
   const bool vis = !strcmp(fam_attn, "attn_self");
-  const bool f8_in = vis && (d->fp8_mask & 2) && a.wqk8.p && rows >= 256 && !(ldvt & 15);   // opt-in lossy mode: e4m3 projections (gemm_fp8.hip)
+  const bool f8_in = vis && sa_fp8_in(d, a, rows);   // opt-in lossy mode: e4m3 projections (gemm_fp8.hip)
   const bool f8_out = vis && (d->fp8_mask & 4) && a.wo8.p && rows >= 256;
+  if (h8_ready && !f8_in) { k5_set_error("internal: e4m3 activations handed to a bf16 projection"); return K5_ERR_ARG; }
   if (f8_in) {
     K5CHK(d->ws_h8.ensure((size_t)rows * D));
-    {
+    if (!h8_ready) {
       Scope sc(d, s, "elementwise");
       K5CHK(k5_launch_quant_rows_fp8(h, d->ws_h8.p, nullptr, rows, D, D, D, s));
     }
@@ -699,7 +712,8 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
 // own fewer (rows < rows_pad), so the padded row index of every real key equals its global index and the unused tail of the
 // last slot is never read (the key-tile ranges stop at N).
 int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, int rows_pad, int N, void* o,
-                          const float* cosT, const float* sinT, void* resid, const float* gate, const NablaArgs* nabla = nullptr, int pref_slot = 0) {
+                          const float* cosT, const float* sinT, void* resid, const float* gate, const NablaArgs* nabla = nullptr, int pref_slot = 0,
+                          bool h8_ready = false) {
   const int D = d->D, H = d->Hh, P = d->sp_world, r = d->sp_rank;
   const int ldv = rows_pad;  // rows, rows_pad, N are multiples of 64 (checked by the caller)
   bf16_t* q = d->ws_q.as<bf16_t>();
@@ -728,10 +742,11 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     kmeans = d->ws_kmeans.as<bf16_t>();
   }
   // opt-in e4m3 projections (k5_dit_set_fp8 bit 1), as on one GPU: the rank's rows of h are quantised once and feed the K, V^T and Q GEMMs
-  const bool f8_in = (d->fp8_mask & 2) && a.wqk8.p && rows >= 256 && !((rows_pad / ((!nabla && d->sp_slices > 1 && P > 1) ? d->sp_slices : 1)) & 15);
+  const bool f8_in = sa_sp_fp8_in(d, a, rows, rows_pad, nabla != nullptr);
   const uint8_t* wq8 = a.wqk8.as<uint8_t>();
   const uint8_t* wk8 = wq8 ? wq8 + (size_t)D * D : nullptr;
-  if (f8_in) {
+  if (h8_ready && !f8_in) { k5_set_error("internal: e4m3 activations handed to a bf16 projection"); return K5_ERR_ARG; }
+  if (f8_in && !h8_ready) {
     K5CHK(d->ws_h8.ensure((size_t)rows * D));
     Scope sc(d, s, "elementwise");
     K5CHK(k5_launch_quant_rows_fp8(h, d->ws_h8.p, nullptr, rows, D, D, D, s));
@@ -1087,13 +1102,14 @@ int run_cross_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h,
   return K5_OK;
 }
 
-int run_ff(k5_dit* d, hipStream_t s, const BlockW& b, const void* h, int rows, void* ff, void* resid, const float* gate) {
+int run_ff(k5_dit* d, hipStream_t s, const BlockW& b, const void* h, int rows, void* ff, void* resid, const float* gate, bool h8_ready = false) {
   const int D = d->D, FF = d->FF;
-  if (d->use_fp8 && b.w1_f8.p && rows >= 256) {
-    // opt-in lossy path: h -> e4m3 (static scale), FF1 on the fp8 MFMA with the GELU epilogue writing e4m3, FF2 likewise
-    // with the gated-residual epilogue (gemm_fp8.hip)
+  if (h8_ready && !ff_fp8_in(d, b, rows)) { k5_set_error("internal: e4m3 activations handed to a bf16 feed-forward"); return K5_ERR_ARG; }
+  if (ff_fp8_in(d, b, rows)) {
+    // opt-in lossy path: h -> e4m3 (static scale; by the LayerNorm itself when h8_ready), FF1 on the fp8 MFMA with the GELU epilogue writing
+    // e4m3, FF2 likewise with the gated-residual epilogue (gemm_fp8.hip)
     K5CHK(d->ws_h8.ensure((size_t)rows * D)); K5CHK(d->ws_ff8.ensure((size_t)rows * FF));
-    {
+    if (!h8_ready) {
       Scope sc(d, s, "elementwise");
       K5CHK(k5_launch_quant_rows_fp8(h, d->ws_h8.p, nullptr, rows, D, D, D, s));
     }
@@ -1118,10 +1134,12 @@ int reset_attn_pref(k5_dit* d, hipStream_t s, bool sync = false) {
   return K5_OK;
 }
 
-int ln_mod(k5_dit* d, hipStream_t s, const void* x, const float* mod3, void* out, int rows) {
-  // mod3 = [shift | scale | gate] (dit.py:36,40,64,69,74)
+int ln_mod(k5_dit* d, hipStream_t s, const void* x, const float* mod3, void* out, int rows, bool to_e4m3 = false) {
+  // mod3 = [shift | scale | gate] (dit.py:36,40,64,69,74).  to_e4m3: every consumer of this h is an fp8 GEMM — the rows go to ws_h8 as e4m3
+  // (the bf16 rounding, then the e4m3 one: what the separate quantisation pass made of the bf16 h), and no bf16 h is written at all
+  if (to_e4m3) K5CHK(d->ws_h8.ensure((size_t)rows * d->D));
   Scope sc(d, s, "elementwise");
-  return k5_launch_ln_modulate(x, mod3 + d->D, mod3, out, rows, d->D, d->D, d->D, s);
+  return k5_launch_ln_modulate(x, mod3 + d->D, mod3, to_e4m3 ? nullptr : out, rows, d->D, d->D, d->D, s, to_e4m3 ? d->ws_h8.p : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1458,21 +1476,25 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     const float* m = mod + b.mod_off;
     const float* vcos = d->ws_vcos.as<float>() + (size_t)tok0 * 32;
     const float* vsin = d->ws_vsin.as<float>() + (size_t)tok0 * 32;
-    K5CHK(ln_mod(d, s, d->ws_vis.p, m, d->ws_h.p, n));
+    const bool ulysses = sp && d->sp_mode == 1 && !nabla && d->sp_world > 1 && d->Hh % d->sp_world == 0 && !d->emulated;
+    // fp8 modes: the LayerNorm writes the e4m3 rows the projections read (no bf16 h, no quantisation pass) — "fp8_fuse_ln" = 0 keeps the two passes
+    const bool h8_sa = d->fp8_fuse_ln && !ulysses && (sp ? sa_sp_fp8_in(d, b.self_attn, n, n_pad, nabla) : sa_fp8_in(d, b.self_attn, n));
+    K5CHK(ln_mod(d, s, d->ws_vis.p, m, d->ws_h.p, n, h8_sa));
     if (d->profiling) ++d->prof_self_blocks;   // bench.py: FLOPs of the roofline kernel = per-block FLOPs x the blocks that RAN
-    if (sp && d->sp_mode == 1 && !nabla && d->sp_world > 1 && d->Hh % d->sp_world == 0 && !d->emulated) {
+    if (ulysses) {
       K5CHK(run_self_attention_ulysses(d, s, b.self_attn, d->ws_h.p, n, n_pad, N, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D, text_slot > 0 ? 1 : 0));
     } else if (sp) {
-      K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, n_pad, N, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D, nabla ? &na : nullptr, text_slot > 0 ? 1 : 0));
+      K5CHK(run_self_attention_sp(d, s, b.self_attn, d->ws_h.p, n, n_pad, N, d->ws_o.p, vcos, vsin, d->ws_vis.p, m + 2 * D, nabla ? &na : nullptr, text_slot > 0 ? 1 : 0, h8_sa));
     } else {
       K5CHK(run_self_attention(d, s, b.self_attn, d->ws_h.p, n, d->ws_qk.p, d->ws_vt.p, d->ws_o.p, vcos, vsin, d->ws_vis.p,
-                               m + 2 * D, "attn_self", nabla ? &na : nullptr, text_slot > 0 ? 1 : 0));
+                               m + 2 * D, "attn_self", nabla ? &na : nullptr, text_slot > 0 ? 1 : 0, h8_sa));
     }
     K5CHK(ln_mod(d, s, d->ws_vis.p, m + 3 * D, d->ws_h.p, n));
     K5CHK(run_cross_attention(d, s, b.cross_attn, d->ws_h.p, n, d->ws_text.p, L, d->ws_qk.p, d->ws_ck.p, d->ws_cvt.p,
                               d->ws_o.p, d->ws_vis.p, m + 5 * D));
-    K5CHK(ln_mod(d, s, d->ws_vis.p, m + 6 * D, d->ws_h.p, n));
-    K5CHK(run_ff(d, s, b, d->ws_h.p, n, d->ws_ff.p, d->ws_vis.p, m + 8 * D));
+    const bool h8_ff = d->fp8_fuse_ln && ff_fp8_in(d, b, n);
+    K5CHK(ln_mod(d, s, d->ws_vis.p, m + 6 * D, d->ws_h.p, n, h8_ff));
+    K5CHK(run_ff(d, s, b, d->ws_h.p, n, d->ws_ff.p, d->ws_vis.p, m + 8 * D, h8_ff));
   }
   if (mg.on) {
     if (!mag_skip) {  // residual = visual_embed - ori_visual_embed (bf16), :84
@@ -1978,6 +2000,8 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //                     depending on how the compiler schedules the tile loop of the extra instantiation), hence opt-in.
 //   "nabla_group_rows" 0 (default) / 2 / 4: 64-query rows per NABLA key-tile list = per attention workgroup on one GPU; 0 picks 2 (128-query
 //                     workgroups) when the previous forward's first map kept less than half of its blocks, else 4; same bits either way
+//   "fp8_fuse_ln"     1 (default) / 0: under k5_dit_set_fp8 the LayerNorm in front of an e4m3 projection writes the e4m3 rows itself (no bf16 h, no
+//                     quantisation pass: two passes of N x D less per block); same bits as with 0
 //   "nabla_pair_frames" 1 (default) / 0: which two 64-query rows share a 128-query list — the same spatial tile of adjacent frames, or adjacent
 //                     tiles of one frame (round 3); same bits, tighter unions under the sliding-tile window (k5_pair_row)
 //   "sp_nabla_passes" 1 (default) / 2: NABLA under sequence parallelism walks every list in one pass after the gather, or in two — the
@@ -2008,6 +2032,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_anchor")) { d->anchor = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_pref_reset")) return reset_attn_pref(d, nullptr, true);   // an action, not a state: the per-step path (k5_dit_forward) calls it per run
+  if (!strcmp(name, "fp8_fuse_ln")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->fp8_fuse_ln = value; return K5_OK; }
   if (!strcmp(name, "nabla_pair_frames")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->nabla_pair_frames = value; return K5_OK; }
   if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 1 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }
   if (!strcmp(name, "sp_nabla_passes")) { if (value < 1 || value > 2) return K5_ERR_ARG; d->sp_nabla_passes = value; d->sp_user_set |= 4; return K5_OK; }
@@ -2040,6 +2065,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "sp_tuned")) *value = d->sp_tuned ? 1 : 0;
   else if (!strcmp(name, "nabla_group_rows")) *value = d->nabla_group_rows;
   else if (!strcmp(name, "nabla_pair_frames")) *value = d->nabla_pair_frames;
+  else if (!strcmp(name, "fp8_fuse_ln")) *value = d->fp8_fuse_ln;
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
   else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }

@@ -44,13 +44,6 @@ struct Gemm8P {
   int tiles_m, tiles_n, lid_limit;
 };
 
-K5_DEV uint32_t pack_fp8x4(float a, float b, float c, float d) {   // saturating e4m3 conversion of four values
-  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
-  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
-  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
-  return (uint32_t)r;
-}
 
 // EPI: K5_EPI_BIAS -> bf16 out (no bias: FF layers have none), K5_EPI_GELU -> fp8 out = e4m3(GELU(bf16(acc * s))),
 //      K5_EPI_GATE -> bf16 out = bf16(resid + gate * bf16(acc * s)) (in place on the residual stream)

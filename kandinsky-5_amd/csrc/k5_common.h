@@ -72,6 +72,14 @@ K5_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678
 // gelu_erf, so the bits are the same — 21 VALU instructions per pair instead of 36.  For epilogues with no MFMA beside them (beside MFMAs
 // packed math is an anti-lever, which is why the build runs with -fno-slp-vectorize).
 typedef float k5_f32x2 __attribute__((ext_vector_type(2)));
+K5_DEV uint32_t pack_fp8x4(float a, float b, float c, float d) {   // saturating e4m3 conversion of four values
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (uint32_t)r;
+}
+
 // NABLA lists shared by TWO 64-query rows (128-query attention workgroups): which rows group g holds.  S = 0: the adjacent rows 2g, 2g + 1.
 // S > 0 (round 4, "frame pairing"): S = blocks per latent frame of the fractal token order — rows b and b + S are the SAME 8 x 8 spatial tile
 // in adjacent frames, whose sliding-tile windows overlap in 10 of 11 frames (adjacent tiles of one frame: in 2 of 3 columns), so the union

@@ -106,8 +106,10 @@ int k5_launch_attention_bf16_sparse(const void* Q, const void* K, const void* Vt
                                     int pair_stride = 0);  // group_rows 2: rows of a group per k5_pair_row (the stride the lists were built with)
 
 // K1: out = bf16( LayerNorm(x; eps 1e-5, no affine) * (scale + 1) + shift )
+// out_e4m3 (nullable, [rows][D] bytes): also — or, with out == nullptr, only — e4m3(bf16(.)) at the static scale 1: the activation operand of
+// the fp8 GEMMs without a separate quantisation pass (what k5_launch_quant_rows_fp8(scale = nullptr) makes of the bf16 rows, bit for bit)
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows,
-                          int D, int ldx, int ldo, hipStream_t stream);
+                          int D, int ldx, int ldo, hipStream_t stream, void* out_e4m3 = nullptr);
 // K5 + K3: in place over [rows][ld] (H heads of 64): RMSNorm(eps, weight) -> bf16 -> RoPE (optional)
 //   x holds H heads per row; head h uses weight[(h / heads_per_weight)*64 ..]; RoPE (cos/sin [rows][32]) on heads
 //   < rope_heads.  heads_cfg = host pointer to {heads_per_weight, rope_heads} or null (= {H, H}).

@@ -23,7 +23,8 @@ constexpr int MAXC = 4;  // 16-B chunks per lane per row: D <= 64*8*4 = 2048
 template <bool AFFINE>
 __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, const float* __restrict__ a,
                                                  const float* __restrict__ b, bf16_t* __restrict__ out,
-                                                 float* __restrict__ out_f32, int rows, int D, int ldx, int ldo) {
+                                                 float* __restrict__ out_f32, int rows, int D, int ldx, int ldo,
+                                                 uint8_t* __restrict__ out8 = nullptr) {   // e4m3(bf16(.)), static scale 1, row stride D (fp8 modes of the engine)
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -74,6 +75,12 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, c
       if (out_f32) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) out_f32[(size_t)row * D + 8 * ch + j] = bf_round(o[j]);
+      }
+      if (out8) {   // what k5_launch_quant_rows_fp8 (static scale) makes of the bf16 row: the bf16 rounding first, then the saturating e4m3 one
+        uint2 q8;
+        q8.x = pack_fp8x4(bf_round(o[0]), bf_round(o[1]), bf_round(o[2]), bf_round(o[3]));
+        q8.y = pack_fp8x4(bf_round(o[4]), bf_round(o[5]), bf_round(o[6]), bf_round(o[7]));
+        *reinterpret_cast<uint2*>(out8 + (size_t)row * D + 8 * ch) = q8;
       }
     }
   }
@@ -419,12 +426,12 @@ inline int done() { return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }  // namespace
 
 int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift, void* out, int rows, int D,
-                          int ldx, int ldo, hipStream_t s) {
-  if (rows <= 0 || D <= 0) return K5_ERR_ARG;
+                          int ldx, int ldo, hipStream_t s, void* out_e4m3) {
+  if (rows <= 0 || D <= 0 || (!out && !out_e4m3)) return K5_ERR_ARG;
   if ((D & 7) || (ldx & 7) || (ldo & 7)) return K5_ERR_ALIGN;
   if (D > 64 * 8 * MAXC) return K5_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(ln_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, scale, shift,
-                     (bf16_t*)out, (float*)nullptr, rows, D, ldx, ldo);
+                     (bf16_t*)out, (float*)nullptr, rows, D, ldx, ldo, (uint8_t*)out_e4m3);
   return done();
 }
 

@@ -371,6 +371,9 @@ def test_fp8_feed_forward_mode(mask):
     plain = dit(*args, scale_factor=(1.0, 2.0, 2.0))
     dit.set_fp8(mask)
     out8 = dit(*args, scale_factor=(1.0, 2.0, 2.0))
+    dit.set_option("fp8_fuse_ln", 0)     # LayerNorm -> bf16 h -> quantisation pass, instead of the LayerNorm writing the e4m3 rows itself: the same bits
+    assert torch.equal(dit(*args, scale_factor=(1.0, 2.0, 2.0)), out8)
+    dit.set_option("fp8_fuse_ln", 1)
     dit.set_fp8(False)
     assert torch.equal(dit(*args, scale_factor=(1.0, 2.0, 2.0)), plain)          # switching back restores the bf16 path exactly
     xin = torch.cat([x, torch.zeros(5, 16, 16, 17)], dim=-1)
