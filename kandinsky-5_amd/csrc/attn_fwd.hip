@@ -71,6 +71,9 @@ inline float anchor_spread(int kv_total) {
 }
 constexpr float K5_ATTN_ROW_MAX = 5.1922969e33f;   // 2^112
 constexpr int K5_ANCHOR_TILES = 32;
+#ifndef K5_ATTN_WAVE_ROWS_DEFAULT
+#define K5_ATTN_WAVE_ROWS_DEFAULT 32   // query rows per wave of the dense fixed-offset launch (32: 8 waves per workgroup; 64: 4 — K5_ATTN_WAVE_ROWS overrides)
+#endif
 #ifndef K5_ATTN_PAIR
 #define K5_ATTN_PAIR 1   // A/B switch (tools/build_variant.sh -DK5_ATTN_PAIR=0): one key tile per barrier
 #endif                // 16-key sample tiles per row: 4 of the row's own block + 28 strided over all keys
@@ -193,8 +196,15 @@ __device__ __forceinline__ uint32_t st_ml_off(int q, int h, int slot, int nqb, i
 // 2: 4 waves (HALF above).  1: TWO waves, one row per list — the list IS the row's selection, nothing is stepped over for a neighbour's sake
 // (measured union efficiency of the 2-row lists on the 10 s clip: 0.80 at kept density 0.048, 0.73 at 0.122, while the kernel executes its
 // tiles at the dense kernel's rate — the union was the whole loss); each wave then brings in four 1-KB pieces of K and of V^T per tile.
-template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false, bool QN = false, int GR = 4>
-__global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_kernel(AttnP p) {
+// QT (round 4): 16-query MFMA tiles per wave.  2: 32 query rows per wave, 8 waves per 256-query workgroup, 4 waves per SIMD (every round so far).
+// 4: 64 rows per wave, FOUR waves per 256-query workgroup, 2 waves per SIMD — every K / V^T fragment read from LDS feeds four MFMAs instead of
+// two (half the ds_read_b128 per MFMA, the ledger's remaining non-essential class: profiles/r04_attention_issue_ledger.md), each wave stages
+// two 1-KB pieces of a tile per operand.  Same arithmetic per query row in the same order: bit-identical outputs.
+template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false, bool QN = false, int GR = 4, int QT = 2>
+__global__ __launch_bounds__(QT == 4 ? 256 : 512, QT == 4 ? 2 : (BOUNDED ? 4 : K5_ONLINE_WPS)) void attn_fwd_kernel(AttnP p) {
+  static_assert(QT == 2 || (QT == 4 && GR == 4), "64-row waves: the 256-query workgroups only");
+  constexpr int NW = 4 * GR / QT;     // waves per workgroup: 8 (256 queries, 32-row waves), 4 (128 queries, or 256 with 64-row waves), 2 (64 queries)
+  constexpr int RW = 16 * QT;         // query rows per wave
   constexpr bool HALF = GR != 4;     // fewer than 8 waves: one tile per barrier, every wave stages several pieces
   static_assert(GR == 4 || GR == 2 || GR == 1, "rows per list: 4, 2 or 1");
   static_assert(BOUNDED || PRE, "the online-max form of this kernel takes pre-scaled keys (attn_fwd32_kernel serves the rest)");
@@ -223,32 +233,32 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   }
   // this wave: queries q0 .. q0+31 = two 16-query MFMA tiles (qt = 0, 1); the two rows of a 128-query group need not be adjacent (frame pairing)
   const int q0 = (GR == 2 && p.pair_stride > 0) ? k5_pair_row(qb, wave >> 1, p.pair_stride, p.q_len >> 6) * 64 + (wave & 1) * 32
-                                                : qb * (64 * GR) + wave * 32;
+                                                : qb * (64 * GR) + wave * RW;
 
   // Q^T fragments (MFMA 16x16x32 B operand): lane (l15, g) holds Q[q0 + 16 qt + l15][32 ks + 8 g .. +8]
-  bf16x8 qf[2][2];
+  bf16x8 qf[QT][2];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const bf16_t* qp = p.Q + (size_t)min(q0 + 16 * qt + l15, p.q_len - 1) * p.ldq + h * 64 + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
   }
   if (PRE && QN) {   // fused norm_qk + apply_rotary of the queries, same arithmetic and rounding points as rmsnorm_rope_kernel
     // every load first (weights, both query tiles' table rows: none depends on q), so that the prologue is ONE memory round trip
-    f32x4 wa[2], wb[2], cs[2][2], sn[2][2];
+    f32x4 wa[2], wb[2], cs[QT][2], sn[QT][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       wa[ks] = *reinterpret_cast<const f32x4*>(p.q_norm_w + 32 * ks + 8 * g);
       wb[ks] = *reinterpret_cast<const f32x4*>(p.q_norm_w + 32 * ks + 8 * g + 4);
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < QT; ++qt) {
         const int row = min(q0 + 16 * qt + l15, p.q_len - 1);
         cs[qt][ks] = *reinterpret_cast<const f32x4*>(p.q_cos + (size_t)row * 32 + 16 * ks + 4 * g);
         sn[qt][ks] = *reinterpret_cast<const f32x4*>(p.q_sin + (size_t)row * 32 + 16 * ks + 4 * g);
       }
     }
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
       float v[16], ss = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   }
   if (!PRE && p.q_norm_w) {   // fused RMSNorm(q): the query's 64 dimensions sit in its four lanes (l15 + 16 g), 16 each
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
       float v[16], ss = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     if (t >= p.tile_skip_at) t += p.tile_skip_n;
     return t;
   };
-  const int my_bit = 1 << (24 + (wave >> 1));         // this wave's 64-query block inside the 256-query workgroup
+  const int my_bit = 1 << (24 + ((wave * RW) >> 6));  // this wave's 64-query block inside the 256-query workgroup
   const int tiles_per_chunk = p.vt_chunk_keys > 0 ? p.vt_chunk_keys / KB : 0x7fffffff;
   typedef __attribute__((address_space(3))) void lds_void_t;
   typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -369,13 +379,13 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     if (PRE) {   // whole tiles only (launcher): constant per-lane offsets, the tile rides in the instruction's SGPR offset: no address VALU
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_void_t*)(sK + buf * TILE + wave_u * 1024), 16, kvoff, (uint32_t)kv0 * kstride, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_void_t*)(sV + buf * TILE + wave_u * 1024), 16, vlane, (uint32_t)(vsrc - Vb), 0, 0);
-      if (GR == 2) {   // four waves: rows 32..63 of both tiles as well (the swizzles only involve row bits 1..4: same lane offsets + 32 rows)
+      if (NW == 4) {   // four waves: rows 32..63 of both tiles as well (the swizzles only involve row bits 1..4: same lane offsets + 32 rows)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_void_t*)(sK + buf * TILE + (wave_u + 4) * 1024), 16, kvoff + 32u * kstride,
                                                  (uint32_t)kv0 * kstride, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_void_t*)(sV + buf * TILE + (wave_u + 4) * 1024), 16, vlane + 64u * (uint32_t)p.ldvt,
                                                  (uint32_t)(vsrc - Vb), 0, 0);
       }
-      if (GR == 1) {   // two waves (rows 0..15 between them): rows + 16, + 32, + 48 as well.  The K swizzle involves row bit 4, so the pieces at
+      if (NW == 2) {   // two waves (rows 0..15 between them): rows + 16, + 32, + 48 as well.  The K swizzle involves row bit 4, so the pieces at
                        // + 16 / + 48 rows take their own lane offset (kvoff16); V^T's only involves bits 1..3
 #pragma unroll
         for (int j = 1; j < 4; ++j) {
@@ -406,14 +416,16 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   // 32 (kt>>1) + 8 (i>>2) + 4 (kt&1) + (i&3): the two tiles' registers of a lane ARE its 8 consecutive keys.
   const int krow = 8 * (l15 >> 2) + (l15 & 3);        // + 32 (kt>>1) + 4 (kt&1): immediates
 
-  f32x4 ot[4][2];   // O^T accumulators: [d tile of 16][query tile]: lane (l15, g) holds d = 16 dt + 4 g + r, query 16 qt + l15
+  f32x4 ot[4][QT];   // O^T accumulators: [d tile of 16][query tile]: lane (l15, g) holds d = 16 dt + 4 g + r, query 16 qt + l15
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) ot[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < QT; ++qt) ot[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float c = p.c;
   // !BOUNDED: nm[qt] = MINUS the softmax offset of the lane's query (exp2 domain), four copies = the S^T accumulators' start
-  f32x4 nm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 nm[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) nm[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   bool fresh = true;             // !BOUNDED, wave-uniform: no tile processed yet -> the first one SETS the offset
   bool over_limit = false;
   bool anchored = false;   // workgroup-uniform: the head runs on anchored offsets (dense: a part's sum may underflow harmlessly; the row's cannot)
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     anchored = km_raw < 0.f && p.row_anchor;
     if (anchored) {   // workgroup-uniform
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < QT; ++qt) {
         const float off = p.row_anchor[(size_t)h * p.q_len + min(q0 + 16 * qt + l15, p.q_len - 1)];
         nm[qt] = f32x4{-off, -off, -off, -off};
       }
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
       }
     }
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
       float ss = 0.f, tc = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -492,19 +504,21 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   // turns the NABLA list loads (int*, scalar loads) into vector loads whose vmcnt wait drains the DMA as well.  Either costs 6-14 %
   // of the whole kernel (measured, same box) — tests/test_abi_and_host.py pins the prefetch distance in the ISA.
   const bool wave_over = BOUNDED && PRE && QN && p.kmax && __any(over_limit);
-  f32x4 lt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 lt[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) lt[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16x8 onesf = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
   // addresses of this lane's running state (recomputed where needed: not kept live across the main loop)
   auto state_base = [&]() { return part == 0 ? p.state : p.split_state + (size_t)(part - 1) * p.split_stride; };
   // st_o_off / st_ml_off of (q0 + 16 qt + l15, h, 4 g): everything but the lane term is wave-uniform
-  const uint32_t st_job = ((uint32_t)(h * p.nqb + qb) * 16u + 2u * (uint32_t)wave) * 4u;
+  const uint32_t st_job = ((uint32_t)(h * p.nqb + qb) * 16u + (uint32_t)QT * (uint32_t)wave) * 4u;
   auto state_o = [&](int qt) { return state_base() + ((st_job + 4u * (uint32_t)qt) * 256u + (uint32_t)lane * 4u); };   // + 256 dt: the d tile
   auto state_ml = [&](int qt, int slot) {
     return state_base() + ((uint32_t)(p.H * p.nqb) * (256u * 64u) + (st_job + 4u * (uint32_t)qt + (uint32_t)slot) * 32u + (uint32_t)l15 * 2u);
   };
   if (RANGE && (p.flags & 1) && part == 0 && !(!BOUNDED && late)) {   // resume: accumulators of an earlier launch over other key tiles
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
       if (q0 + 16 * qt + l15 < p.q_len) {
         const float* st_o = state_o(qt);
 #pragma unroll
@@ -513,8 +527,14 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         { const float L = (state_ml(qt, 0)[1] + state_ml(qt, 1)[1]) + (state_ml(qt, 2)[1] + state_ml(qt, 3)[1]); lt[qt] = f32x4{L, L, L, L}; }   // the four slots' row sums
       }
     if (!BOUNDED) {   // a state left by a launch that saw no tile carries m = -1e30: still fresh (wave-uniform by construction:
-      fresh = __all(nm[0][0] > 1e29f && nm[1][0] > 1e29f);   // every query of a wave sees the same tiles; rows >= q_len keep 0)
-      if (fresh) { nm[0] = f32x4{0.f, 0.f, 0.f, 0.f}; nm[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      bool allf = true;                                       // every query of a wave sees the same tiles; rows >= q_len keep 0)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) allf = allf && nm[qt][0] > 1e29f;
+      fresh = __all(allf);
+      if (fresh) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) nm[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
 
@@ -538,24 +558,25 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     if (SPARSE) seen = true;
     {
     // ---- S^T = K Q^T : four 16-key x two 16-query MFMA tiles, two k-steps over d; K fragments streamed from LDS ----
-    f32x4 st[4][2];
+    f32x4 st[4][QT];
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {   // first k-step starts from the constant 0, or from minus the query's softmax offset
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), g));
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
 #ifdef K5_ATTN_NO_ROW_OFFSETS   // A/B build (tools/build_variant.sh): the fixed form's S^T starts from the inline constant 0
-      st[kt][0] = mfma16(kf, qf[0][0], BOUNDED ? zero4 : nm[0]);
-      st[kt][1] = mfma16(kf, qf[1][0], BOUNDED ? zero4 : nm[1]);
+        st[kt][qt] = mfma16(kf, qf[qt][0], BOUNDED ? zero4 : nm[qt]);
 #else
-      st[kt][0] = mfma16(kf, qf[0][0], (BOUNDED && !PRE) ? zero4 : nm[0]);   // BOUNDED && PRE: nm = minus the row's constant offset (0 without kmax)
-      st[kt][1] = mfma16(kf, qf[1][0], (BOUNDED && !PRE) ? zero4 : nm[1]);
+        st[kt][qt] = mfma16(kf, qf[qt][0], (BOUNDED && !PRE) ? zero4 : nm[qt]);   // BOUNDED && PRE: nm = minus the row's constant offset (0 without kmax)
 #endif
+      }
     }
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), 4 + g));
-      st[kt][0] = mfma16(kf, qf[0][1], st[kt][0]);
-      st[kt][1] = mfma16(kf, qf[1][1], st[kt][1]);
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) st[kt][qt] = mfma16(kf, qf[qt][1], st[kt][qt]);
     }
     // lane (query l15 of tile qt, g): st[kt][qt][r] is key  t*64 + 32 (kt>>1) + 8 g + 4 (kt&1) + r
     if (!SPARSE && !PRE && t >= nfull) {  // ragged last tile (wave-uniform branch)
@@ -564,15 +585,18 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = t * KB + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r;
-          if (key >= p.kv_len) { st[kt][0][r] = -1e30f; st[kt][1][r] = -1e30f; }
+          if (key >= p.kv_len) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) st[kt][qt][r] = -1e30f;
+          }
         }
     }
     if (!BOUNDED) {
       // lazy online max: st = score - offset.  Fold the lane's 16 values per query tile; nothing else happens unless some
       // lane's maximum left the safe window (or this is the wave's first tile, which sets the offset).
-      float mx[2];
+      float mx[QT];
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < QT; ++qt) {
         mx[qt] = max3(-3.0e38f, st[0][qt][0], st[0][qt][1]);   // a constant first operand: no canonicalising v_max
         mx[qt] = max3(mx[qt], st[0][qt][2], st[0][qt][3]);
         mx[qt] = max3(mx[qt], st[1][qt][0], st[1][qt][1]);
@@ -582,9 +606,12 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
         mx[qt] = max3(mx[qt], st[3][qt][0], st[3][qt][1]);
         mx[qt] = max3(mx[qt], st[3][qt][2], st[3][qt][3]);
       }
-      if (fresh || __any(fmaxf(mx[0], mx[1]) > ONLINE_THR)) {   // wave-uniform, rare
+      float mxa = mx[0];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 1; qt < QT; ++qt) mxa = fmaxf(mxa, mx[qt]);
+      if (fresh || __any(mxa > ONLINE_THR)) {   // wave-uniform, rare
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
           float mf = mx[qt];   // the query's four lanes (l15 + 16 g) combine -> identical offsets in all of them
           {
             const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mf), __float_as_uint(mf), false, false);
@@ -612,9 +639,9 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     // ---- P = exp2(S c - m c) -> bf16 fragments; O^T += V^T P^T (two k-steps of 32 keys), V^T fragments streamed ----
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {   // both query tiles' probabilities first (8 live registers), V^T fragments streamed
-        bf16x8 pf[2];
+        bf16x8 pf[QT];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
           float e[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -628,8 +655,8 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cV + lds_swz(16 * dt + l15, 4 * ks2 + g));
-          ot[dt][0] = mfma16(vf, pf[0], ot[dt][0]);
-          ot[dt][1] = mfma16(vf, pf[1], ot[dt][1]);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) ot[dt][qt] = mfma16(vf, pf[qt], ot[dt][qt]);
         }
       }
     }
@@ -638,18 +665,18 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
     if (BOUNDED && PRE && !SPARSE) {
 #if K5_ATTN_SGB == 1      // one VALU behind every MFMA
 #pragma unroll
-      for (int i = 0; i < 36; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); }
+      for (int i = 0; i < 18 * QT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); }
 #elif K5_ATTN_SGB == 2    // S phase: MFMA + LDS read; then MFMA + 2 VALU
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+      for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, QT / 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
 #pragma unroll
-      for (int i = 0; i < 28; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+      for (int i = 0; i < 14 * QT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
 #elif K5_ATTN_SGB == 3    // two MFMAs, then three VALU
 #pragma unroll
-      for (int i = 0; i < 18; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+      for (int i = 0; i < 9 * QT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
 #elif K5_ATTN_SGB == 4    // LDS reads up front in pairs with MFMAs, transcendental after each MFMA, converts wherever
 #pragma unroll
-      for (int i = 0; i < 36; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x400, 1, 0); }
+      for (int i = 0; i < 18 * QT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x400, 1, 0); }
 #endif
     }
 #endif
@@ -682,7 +709,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
   }
   if (RANGE && (p.flags & 2)) {   // leave the running state for a later launch; no output yet
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
       if (q0 + 16 * qt + l15 < p.q_len) {
         float* st_o = state_o(qt); float* st_ml = state_ml(qt, g);
 #pragma unroll
@@ -700,7 +727,7 @@ __global__ __launch_bounds__(512, BOUNDED ? 4 : K5_ONLINE_WPS) void attn_fwd_ker
 
   // ---- epilogue: normalise, store O[q][h*64 + d] ----
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const float l_tot = lt[qt][0];   // the ones-MFMA left the whole row sum in every lane of the query's column
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int q = q0 + 16 * qt + l15;
@@ -1264,7 +1291,13 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
         if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true, true>), grid, block, 0, stream, p); }
         if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, false, true, true, true>), grid, block, 0, stream, p); }
       } else {
-        if (run_fixed) { p.my_flag = 1; hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true>), grid, block, 0, stream, p); }
+        // the fixed form in 64-row waves (QT = 4: four waves per 256-query workgroup) when asked for — same bits, see the kernel's header
+        static const int wave_rows = getenv("K5_ATTN_WAVE_ROWS") ? atoi(getenv("K5_ATTN_WAVE_ROWS")) : K5_ATTN_WAVE_ROWS_DEFAULT;
+        if (run_fixed) {
+          p.my_flag = 1;
+          if (wave_rows == 64) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true, false, 4, 4>), grid, dim3(256), 0, stream, p);
+          else hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true>), grid, block, 0, stream, p);
+        }
         if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, false, true, true>), grid, block, 0, stream, p); }
       }
     }

@@ -522,3 +522,35 @@ def test_attention_prescaled_keys(E):
     with pytest.raises(RuntimeError):                                       # ... and whole key tiles
         E.check(L.k5_attention_bf16_prescaled(qd.data_ptr(), kcd.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Sq, Sk - 8, qd.stride(0),
                                               kcd.stride(0), vt.stride(0), out.stride(0), 64 * 1.05, E.stream_ptr()))
+
+
+def test_attention_64_row_waves_give_the_same_bits():
+    """K5_ATTN_WAVE_ROWS=64 (round 4, opt-in): the dense fixed-offset launch in 64-row waves — four waves per 256-query workgroup, every K / V^T
+    fragment read feeding four MFMAs instead of two — is the same arithmetic per query row in the same order: its output must equal the
+    default launch's BIT FOR BIT (ragged query count, balanced tail split, per-row offsets).  The switch is read once per process, hence the
+    two child processes."""
+    import hashlib, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import hashlib, sys, torch
+        sys.path.insert(0, %r)
+        from kandinsky import _engine as E
+        H, N = 5, 9 * 256 + 192
+        g = torch.Generator().manual_seed(23)
+        def rms(x): return x / x.pow(2).mean(-1, keepdim=True).sqrt()
+        q = (rms(torch.randn(N, H, 64, generator=g)) * 2.5).reshape(N, H * 64).bfloat16().cuda()
+        k = (rms(torch.randn(N, H, 64, generator=g)) * 2.5 * 0.18033688011112042).reshape(N, H * 64).bfloat16().cuda()
+        vt = torch.randn(H * 64, N, generator=g).bfloat16().cuda()
+        o = torch.empty(N, H * 64, dtype=torch.bfloat16, device="cuda")
+        E.check(E.lib().k5_attention_bf16_prescaled(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), H, N, N, q.stride(0), k.stride(0),
+                                                    vt.stride(0), o.stride(0), 64 * 2.5 * 2.5 * 1.01, E.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(o.float()).all()
+        print("SHA", hashlib.sha256(o.cpu().view(torch.int16).numpy().tobytes()).hexdigest())
+    """ % os.path.join(root, "kandinsky-5_amd"))
+    shas = []
+    for rows in ("32", "64"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, K5_ATTN_WAVE_ROWS=rows), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        shas.append([l for l in out.stdout.splitlines() if l.startswith("SHA")][-1])
+    assert shas[0] == shas[1], shas

@@ -83,6 +83,9 @@ def attn_case(zero=False):
 
 def main():
     N = 47616
+    if "--attention" in sys.argv:     # the attention launch only (A/B of kernel variants through the environment, e.g. K5_ATTN_WAVE_ROWS=64)
+        measure(f"dense attention, random data, K5_ATTN_WAVE_ROWS={os.environ.get('K5_ATTN_WAVE_ROWS', 'default')}", attn_case(), 200.0, 4.0 * N * N * 64 * 28)
+        return
     measure("idle (nothing on the main stream)", lambda: None, 20.0)
     measure("dense attention, 47 616 tokens x 28 heads, random data", attn_case(), 150.0, 4.0 * N * N * 64 * 28)
     measure("dense attention, zero operands", attn_case(True), 150.0, 4.0 * N * N * 64 * 28)
