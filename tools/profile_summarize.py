@@ -56,6 +56,7 @@ def attn_template_args(name):
     d = dict(zip(ATTN_TPARAMS[:5], vals))
     d["GR"] = gr
     d["HALF"] = gr != 4
+    d["QT"] = int(raw[6]) if len(raw) > 6 and raw[6].isdigit() else 2    # 16-query tiles per wave (round 4: 4 = 64-row waves, opt-in)
     return d
 
 
