@@ -334,9 +334,10 @@ def test_attention_tile_prefetch_survives_the_compiler():
     # <BOUNDED, SPARSE, RANGE, PRE, QN, GR>: dense fixed / online, the same with the fused query norm, NABLA fixed: one launch, one pass of
     # the sharded schedule, 128-query workgroups (all on pre-scaled keys)
     # (round 4: the last parameter is GR, the 64-query rows per list — 4: 256-query workgroups, 2: 128, 1: 64)
-    for tag, pick in (("ILb1ELb0ELb1ELb1ELb0ELi4E", min), ("ILb0ELb0ELb1ELb1ELb0ELi4E", min), ("ILb1ELb0ELb1ELb1ELb1ELi4E", min),
-                      ("ILb0ELb0ELb1ELb1ELb1ELi4E", min), ("ILb1ELb1ELb0ELb1ELb0ELi4E", max), ("ILb1ELb1ELb1ELb1ELb0ELi4E", max),
-                      ("ILb1ELb1ELb0ELb1ELb0ELi2E", max), ("ILb1ELb1ELb0ELb1ELb0ELi1E", max)):
+    # (the parameter after GR is QT, the 16-query tiles per wave: 2 everywhere, 4 = the opt-in 64-row-wave form of the dense fixed-offset launch)
+    for tag, pick in (("ILb1ELb0ELb1ELb1ELb0ELi4ELi2E", min), ("ILb0ELb0ELb1ELb1ELb0ELi4ELi2E", min), ("ILb1ELb0ELb1ELb1ELb1ELi4ELi2E", min),
+                      ("ILb0ELb0ELb1ELb1ELb1ELi4ELi2E", min), ("ILb1ELb1ELb0ELb1ELb0ELi4ELi2E", max), ("ILb1ELb1ELb1ELb1ELb0ELi4ELi2E", max),
+                      ("ILb1ELb1ELb0ELb1ELb0ELi2ELi2E", max), ("ILb1ELb1ELb0ELb1ELb0ELi1ELi2E", max), ("ILb1ELb0ELb1ELb1ELb0ELi4ELi4E", min)):
         need = 24
         body = [v for k, v in kernels.items() if tag in k]
         assert len(body) == 1, tag
