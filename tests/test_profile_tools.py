@@ -16,13 +16,14 @@ import profile_summarize as P  # noqa: E402
 
 def test_template_arguments_are_read_by_position():
     a = P.attn_template_args("void (anonymous namespace)::attn_fwd_kernel<true, false, true, true, false, false>(AttnP)")
-    assert a == dict(BOUNDED=True, SPARSE=False, RANGE=True, PRE=True, QN=False, HALF=False, GR=4)       # a round-2/3 trace: bool HALF
+    assert a == dict(BOUNDED=True, SPARSE=False, RANGE=True, PRE=True, QN=False, HALF=False, GR=4, QT=2)       # a round-2/3 trace: bool HALF
     a = P.attn_template_args("void attn_fwd_kernel<false, true, false, true, false, true>(AttnP)")
     assert a["SPARSE"] and a["PRE"] and a["HALF"] and a["GR"] == 2 and not a["BOUNDED"] and not a["QN"]
     a = P.attn_template_args("void attn_fwd_kernel<true, true, false, true, false, 1>(AttnP)")                # round 4: int GR (rows per key-tile list)
     assert a["SPARSE"] and a["HALF"] and a["GR"] == 1
     assert P.attn_template_args("void attn_fwd_kernel<true, false, true, true, false, 4>(AttnP)")["HALF"] is False
     assert P.attn_template_args("void attn_fwd_kernel<true, false, true>(AttnP)")["PRE"] is False        # defaults for missing trailing ones
+    assert P.attn_template_args("void attn_fwd_kernel<true, false, true, true, false, 4, 4>(AttnP)")["QT"] == 4    # round 4: 64-row waves
     assert P.attn_template_args("void gemm_bf16_w4_kernel<3>(GemmP)") is None
 
 
