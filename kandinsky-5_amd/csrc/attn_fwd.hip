@@ -650,7 +650,12 @@ __global__ __launch_bounds__(QT == 4 ? 256 : 512, QT == 4 ? 2 : (BOUNDED ? 4 : K
           }
           u32x4 pk = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
           pf[qt] = __builtin_bit_cast(bf16x8, pk);
+#ifdef K5_ATTN_NO_ROWSUM_MFMA   // A/B build for the ledger (tools/build_variant.sh -DK5_ATTN_NO_ROWSUM_MFMA): results WRONG, timing only — what the four
+          if (ks2 == 7) lt[qt] = mfma16(onesf, pf[qt], lt[qt]);   // ones-row MFMAs per wave-tile cost in time (and, through the clock, in energy)
+          else lt[qt][0] += 1.0f;
+#else
           lt[qt] = mfma16(onesf, pf[qt], lt[qt]);   // every row = sum over the 32 keys of bf16(p) for query l15
+#endif
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
