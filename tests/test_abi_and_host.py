@@ -363,3 +363,15 @@ def test_committed_bench_line_keeps_the_contract():
     assert r["traffic"] is None or r["traffic"] > 4 * 47616 * 28 * 64 * 2                 # HBM-side bytes >= the algorithmic ones
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # round 4: the line also carries the check of the TIMED configuration against the reference's generate() at full size and the latent pin
+    d4 = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "roofline_gemm", "cpu_baseline", "parity_check", "latent_pin"):
+        assert k in d4, k
+    assert d4["dtype"] == "bf16" and "INVALID_AS_BENCH" not in d4 and d4["config"]["visual_blocks"] == 32
+    pc = d4["parity_check"]
+    assert pc["status"] == "ok" and len(pc["steps"]) == 2 and all(st["rel_l2_update"] <= pc["tolerance_rel_l2_update"] for st in pc["steps"])
+    assert d4["latent_pin"]["status"] == "ok"
+    r4 = d4["roofline"]
+    assert r4["kernel"].startswith("attn_fwd_kernel") and abs(r4["frac"] - r4["achieved"] / r4["peak"]) < 1e-9 and r4["blocks_run"] == 32 * d4["steps"]
+    assert "16 torch threads" in d4["cpu_baseline"]["sample"] or "torch threads" in d4["cpu_baseline"]["sample"]
