@@ -1278,10 +1278,18 @@ int sp_autotune_run(k5_dit* d, hipStream_t s, int N, int L, const NablaArgs* nab
     HIPCHK(hipMemsetAsync(d->ws_mod.p, 0, d->mod_rows * 4, s));
     const float* cosT = d->ws_vcos.as<float>() + (size_t)tok0 * 32; const float* sinT = d->ws_vsin.as<float>() + (size_t)tok0 * 32;
     const bool uly = d->sp_mode == 1;
-    for (int it = 0; it < 3; ++it) {
+    // a line per candidate BEFORE it runs: if an exchange never used on this node hangs, the log says which ("sp_autotune" = 0 / K5_SP_AUTOTUNE=0 skip the tuning)
+    if (d->sp_rank == 0) fprintf(stderr, "libk5: sequence-parallel schedule: timing candidate %d of %d: %s\n", c + 1, nc, cands[c].name);
+    int trial_rc = K5_OK;   // a candidate that REFUSES its arguments does so on every rank alike (argument checks only): it is disqualified, not fatal
+    for (int it = 0; it < 3 && trial_rc == K5_OK; ++it) {
       if (it == 1) HIPCHK(hipEventRecord(e0, s));
-      if (uly) K5CHK(run_self_attention_ulysses(d, s, a, d->ws_h.p, n, n_pad, N, d->ws_o.p, cosT, sinT, d->ws_vis.p, d->ws_mod.as<float>()));
-      else K5CHK(run_self_attention_sp(d, s, a, d->ws_h.p, n, n_pad, N, d->ws_o.p, cosT, sinT, d->ws_vis.p, d->ws_mod.as<float>(), nabla));
+      trial_rc = uly ? run_self_attention_ulysses(d, s, a, d->ws_h.p, n, n_pad, N, d->ws_o.p, cosT, sinT, d->ws_vis.p, d->ws_mod.as<float>())
+                     : run_self_attention_sp(d, s, a, d->ws_h.p, n, n_pad, N, d->ws_o.p, cosT, sinT, d->ws_vis.p, d->ws_mod.as<float>(), nabla);
+    }
+    if (trial_rc != K5_OK) {
+      if (c == 0) return trial_rc;       // the default schedule itself fails: nothing to fall back to
+      HIPCHK(hipStreamSynchronize(s));
+      continue;
     }
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipEventSynchronize(e1));
@@ -1893,6 +1901,7 @@ extern "C" int k5_comm_unique_id(const char* rccl_lib_path, void* out128) {
 
 static int comm_common_init(k5_dit* d, int rank, int world) {
   d->comm.rank = rank; d->comm.world = world;
+  if (const char* e = getenv("K5_SP_AUTOTUNE")) d->sp_autotune = atoi(e) != 0;   // K5_SP_AUTOTUNE=0: keep the default exchange without timing anything
   if (d->comm.loop) d->sp_autotune = false;   // loopback ranks (tests of specific schedules on one GPU) tune only when asked to ("sp_autotune" = 1)
   d->sp_rank = rank; d->sp_world = world;
   HIPCHK(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
