@@ -263,6 +263,14 @@ __global__ __launch_bounds__(256) void nabla_union_kernel(const unsigned long lo
   if (gi >= H * ng) return;
   const int h = gi / ng, g = gi % ng;
   int pos = 0;
+  // the rows' bitmaps once, word `lane` of each row in lane `lane` (nw <= 64: SEL_MAXNB) — the loops below broadcast a word with a readlane
+  // instead of a dependent global load per word and sweep (round 4: 115 -> 67 us per layer on a 4-GPU shard of the 3660-block clip)
+  unsigned long long wrow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qb = (G == 2 && pair_stride > 0) ? k5_pair_row(g, r, pair_stride, nqb) : G * g + r;
+    wrow[r] = (r < G && qb < nqb && lane < nw) ? bits[((size_t)h * nqb + qb) * nw + lane] : 0ull;
+  }
   for (int sweep = locn > 0 ? 0 : 1; sweep < 2; ++sweep) {
     for (int c = 0; c < nw; ++c) {
       // bit mask of the local blocks inside word c
@@ -274,8 +282,9 @@ __global__ __launch_bounds__(256) void nabla_union_kernel(const unsigned long lo
       unsigned long long w[4], u = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qb = (G == 2 && pair_stride > 0) ? k5_pair_row(g, r, pair_stride, nqb) : G * g + r;
-        w[r] = (r < G && qb < nqb) ? bits[((size_t)h * nqb + qb) * nw + c] & take : 0ull;
+        const unsigned int wl = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)wrow[r], c);
+        const unsigned int wh = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(wrow[r] >> 32), c);
+        w[r] = (((unsigned long long)wh << 32) | wl) & take;
         u |= w[r];
       }
       if ((u >> lane) & 1ull) {
