@@ -333,6 +333,7 @@ struct k5_dit {
   // of adjacent tiles of one frame: their sliding-tile windows share 10 of 11 frames.  Same arithmetic per row (a row's key tiles are walked
   // in the same ascending order), so outputs are bit-identical with it on or off.
   int nabla_pair_frames = 1;
+  int nabla_fuse_means = 1;   // the q / k block means come out of the norm + RoPE pass (k5_launch_rmsnorm_rope mean_q / mean_k); 0: their own pass (rounds 1-3)
   DevBuf ws_nabla_kept;                            // u64 kept-block count of the forward's first NABLA map
   unsigned long long* h_nabla_kept = nullptr;      // its pinned host copy
   long long nabla_hint_possible = 0;               // blocks that map could have kept
@@ -622,8 +623,16 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   {
     Scope sc(d, s, "elementwise");
     const int32_t hc[2] = {H, 2 * H};
-    void* kc = nullptr;   // NABLA: the block map needs the unscaled keys -> the scaled copy goes to its own buffer
-    if (pre && nabla) { K5CHK(d->ws_kc.ensure((size_t)rows * D * 2)); kc = d->ws_kc.p; }
+    // NABLA: the block map needs the 64-token means of the UNSCALED keys (and queries).  Round 4 ("nabla_fuse_means", default): the norm pass
+    // takes them itself, so the keys are scaled in place as on the dense path — no second read of q | k, no scaled copy.  Otherwise (rounds
+    // 1-3) the unscaled keys stay in place for k5_launch_nabla_select_rect's own means pass and the scaled copy goes to its own buffer.
+    void* kc = nullptr;
+    void *mq = nullptr, *mk = nullptr;
+    const bool fuse_means = pre && nabla && d->nabla_fuse_means;
+    if (fuse_means) {
+      K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, rows / 64)));
+      k5_nabla_workspace_means(d->ws_nabla.p, H, rows / 64, &mq, &mk);
+    } else if (pre && nabla) { K5CHK(d->ws_kc.ensure((size_t)rows * D * 2)); kc = d->ws_kc.p; }
     float* stats = nullptr;
     if (by_data) stats = d->ws_attn_stats.as<float>();   // [q heads | k' heads] = the call's 2H heads (| squared key radii with the centred offsets)
     // centred per-row offsets (K5KeyCentre): the keys' sample-mean centre and their radius around it come out of the same pass
@@ -633,7 +642,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
                                    stats ? stats + H : nullptr, d->ws_attn_part.as<float>(), centre));
     else
       K5CHK(k5_launch_rmsnorm_rope(qk, a.norm.as<float>(), cosT, sinT, rows, 2 * H, 2 * D, hc, s, K5_SOFTMAX_C, pre ? H : 0x7fffffff, kc, D, stats, d->ws_attn_part.as<float>(),
-                                   pre ? centre : nullptr));
+                                   pre ? centre : nullptr, mq, rows / 64, mk, rows / 64));
     if (by_data) {
       hflags = d->ws_attn_flags.as<int>();
       float* kmax_w = d->row_offsets ? d->ws_attn_flags.as<float>() + H : nullptr;
@@ -659,7 +668,8 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
     {
       Scope sc(d, s, "nabla_map");
-      K5CHK(k5_launch_nabla_select_rect(qk, (const bf16_t*)qk + D, 2 * D, 2 * D, H, rows, 0, rows, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
+      const bool fm = pre && d->nabla_fuse_means;   // the means are in the workspace already
+      K5CHK(k5_launch_nabla_select_rect(fm ? nullptr : qk, fm ? nullptr : (const bf16_t*)qk + D, 2 * D, 2 * D, H, rows, 0, rows, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
                                         nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, 0, 0, grp, pair));
     }
     if (d->profiling) {   // realised density of the map (bench.py: attention FLOPs actually done) and tiles the launch executes for it
@@ -676,7 +686,8 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     Scope sc(d, s, fam_attn);
     // (no tail balancing here: 10 248 jobs are 20 rounds of unequal lists — measured -0.6 % at density 0.81, +1 % at 0.12, +2.4 % at
     // 0.05; a token shard's 5 rounds are another matter, run_self_attention_sp)
-    K5CHK(k5_launch_attention_bf16_sparse(qk, pre ? d->ws_kc.as<bf16_t>() : (const bf16_t*)qk + D, vt, o, H, rows, rows, 2 * D, pre ? D : 2 * D,
+    const bool kin = !pre || d->nabla_fuse_means;   // keys in place in the fused q | k buffer (scaled there when pre)
+    K5CHK(k5_launch_attention_bf16_sparse(qk, kin ? (const bf16_t*)qk + D : d->ws_kc.as<bf16_t>(), vt, o, H, rows, rows, 2 * D, kin ? 2 * D : D,
                                           ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant, kmax, nullptr,
                                           pre ? d->ws_attn_bal.as<float>() : nullptr, grp, false, kcp, pair));
   } else {
@@ -759,10 +770,13 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   {
     Scope sc(d, s, "elementwise");
     // dense: scaled in place; NABLA: unscaled in place (kun), the scaled copy goes to this rank's slot of the gather buffer
+    // NABLA: the unscaled keys' block means (all the map needs of them) come out of this pass ("nabla_fuse_means"; before: a second pass over kun)
+    const bool fm = nabla && d->nabla_fuse_means;
     K5CHK(k5_launch_rmsnorm_rope(kun, a.norm.as<float>() + 64, cosT, sinT, rows, H, D, nullptr, s, K5_SOFTMAX_C, 0,
-                                 nabla ? kloc : nullptr, nabla ? D : 0, by_data ? kstat + (size_t)r * H : nullptr, d->ws_attn_part.as<float>()));
+                                 nabla ? kloc : nullptr, nabla ? D : 0, by_data ? kstat + (size_t)r * H : nullptr, d->ws_attn_part.as<float>(), nullptr,
+                                 nullptr, 0, fm ? kmeans + (size_t)r * H * slot_blocks * 64 : nullptr, slot_blocks));
   }
-  if (nabla) {
+  if (nabla && !d->nabla_fuse_means) {
     Scope sc(d, s, "nabla_map");
     K5CHK(k5_launch_nabla_block_means(kun, D, H, rows / 64, slot_blocks, kmeans + (size_t)r * H * slot_blocks * 64, s));
   }
@@ -795,8 +809,14 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   const K5QueryNorm qn{a.norm.as<float>(), cosT, sinT, by_data ? d->ws_attn_cnt.as<unsigned long long>() : nullptr};
   const K5QueryNorm* qnp = fuse_q ? &qn : nullptr;
   if (!fuse_q) {
+    void* mq = nullptr;
+    if (nabla && d->nabla_fuse_means) {   // the query-block means of the rank's rows, straight into the map's workspace
+      K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, N / 64, rows / 64)));
+      k5_nabla_workspace_means(d->ws_nabla.p, H, N / 64, &mq, nullptr);
+    }
     Scope sc(d, s, "elementwise");
-    K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), cosT, sinT, rows, H, D, nullptr, s, 1.f, 0x7fffffff, nullptr, 0, qstat, d->ws_attn_part.as<float>()));
+    K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), cosT, sinT, rows, H, D, nullptr, s, 1.f, 0x7fffffff, nullptr, 0, qstat, d->ws_attn_part.as<float>(), nullptr,
+                                 mq, rows / 64, nullptr, 0));
   }
   // all-gathers on the side stream (they only need k / v^T, which are complete at ev_k / ev_v) ...
   hipStream_t cs = d->comm_stream;
@@ -865,7 +885,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     {
       Scope sc(d, s, "nabla_map");
       K5CHK(k5_launch_nabla_key_means_from_slots(kmeans, H, nb, slot_blocks, d->ws_nabla.p, s));
-      K5CHK(k5_launch_nabla_select_rect(q, nullptr, D, 0, H, rows, r * slot_blocks, N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
+      K5CHK(k5_launch_nabla_select_rect(d->nabla_fuse_means ? nullptr : q, nullptr, D, 0, H, rows, r * slot_blocks, N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
                                         nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, r * slot_blocks, rows / 64, grp, pair));   // own key blocks lead the lists
     }
     if (d->profiling) {
@@ -2009,6 +2029,8 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //                     depending on how the compiler schedules the tile loop of the extra instantiation), hence opt-in.
 //   "nabla_group_rows" 0 (default) / 2 / 4: 64-query rows per NABLA key-tile list = per attention workgroup on one GPU; 0 picks 2 (128-query
 //                     workgroups) when the previous forward's first map kept less than half of its blocks, else 4; same bits either way
+//   "nabla_fuse_means" 1 (default) / 0: the 64-token block means NABLA's map is built from are taken by the norm + RoPE pass itself (one read of q | k
+//                     less per block, and on one GPU the keys are scaled in place: no scaled copy); same bits as with 0
 //   "fp8_fuse_ln"     1 (default) / 0: under k5_dit_set_fp8 the LayerNorm in front of an e4m3 projection writes the e4m3 rows itself (no bf16 h, no
 //                     quantisation pass: two passes of N x D less per block); same bits as with 0
 //   "nabla_pair_frames" 1 (default) / 0: which two 64-query rows share a 128-query list — the same spatial tile of adjacent frames, or adjacent
@@ -2041,6 +2063,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_anchor")) { d->anchor = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_pref_reset")) return reset_attn_pref(d, nullptr, true);   // an action, not a state: the per-step path (k5_dit_forward) calls it per run
+  if (!strcmp(name, "nabla_fuse_means")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->nabla_fuse_means = value; return K5_OK; }
   if (!strcmp(name, "fp8_fuse_ln")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->fp8_fuse_ln = value; return K5_OK; }
   if (!strcmp(name, "nabla_pair_frames")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->nabla_pair_frames = value; return K5_OK; }
   if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 1 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }
@@ -2075,6 +2098,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "nabla_group_rows")) *value = d->nabla_group_rows;
   else if (!strcmp(name, "nabla_pair_frames")) *value = d->nabla_pair_frames;
   else if (!strcmp(name, "fp8_fuse_ln")) *value = d->fp8_fuse_ln;
+  else if (!strcmp(name, "nabla_fuse_means")) *value = d->nabla_fuse_means;
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
   else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }

@@ -90,6 +90,7 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
 // sequence parallelism: a rank's key-block means (k5_launch_nabla_block_means into its slot of a [P][H][slot_blocks][64] buffer),
 // gathered, re-laid into the workspace (k5_launch_nabla_key_means_from_slots); k5_launch_nabla_select_rect(k = nullptr) selects from them
 int k5_launch_nabla_block_means(const void* x, int ld, int H, int nblocks, int stride_blocks, void* out, hipStream_t s);
+void k5_nabla_workspace_means(void* workspace, int H, int nb, void** qa, void** ka);   // the means' regions (k5_launch_rmsnorm_rope mean_q / mean_k write them directly)
 int k5_launch_nabla_key_means_from_slots(const void* gathered, int H, int nb, int slot_blocks, void* workspace, hipStream_t s);
 int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void* out, hipStream_t s);
 // *acc += number of kept (query block, key block) pairs of the map in `workspace` (H x nqb rows)
@@ -117,7 +118,11 @@ int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cos, const
                            int H, int ld, const int32_t* heads_cfg, hipStream_t stream,
                            float out_scale = 1.f, int scale_from_head = 0x7fffffff, void* scaled_out = nullptr, int ld_scaled = 0,
                            float* stats = nullptr, float* stats_ws = nullptr,
-                           float* key_centre = nullptr);   // OUT [H - scale_from_head][64]: sample-mean key per scaled head; stats then also gets H - scale_from_head squared radii |k' - c|^2
+                           float* key_centre = nullptr,    // OUT [H - scale_from_head][64]: sample-mean key per scaled head; stats then also gets H - scale_from_head squared radii |k' - c|^2
+                           // NABLA (rows % 64 == 0): 64-token block means of the UNSCALED normalised + rotated heads, taken in this pass (what
+                           // k5_launch_nabla_block_means computes from the stored tensor): heads < scale_from_head -> mean_q [head][mq_stride][64] bf16,
+                           // the others -> mean_k [head - scale_from_head][mk_stride][64]
+                           void* mean_q = nullptr, int mq_stride = 0, void* mean_k = nullptr, int mk_stride = 0);
 size_t k5_rmsnorm_stats_workspace_bytes(int H);
 // Ulysses sequence parallelism: (q | k) rows [rows][2 D] -> per-destination blocks [P][slot_rows][2 D / P]; outputs [P][slot_rows][D / P] -> [rows][D]
 int k5_launch_ulysses_pack_qk(const void* x, void* out, int rows, int slot_rows, int D, int P, hipStream_t s);

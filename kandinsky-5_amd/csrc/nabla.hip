@@ -355,6 +355,12 @@ int k5_launch_nabla_mask_u8(const void* workspace, int H, int nqb, int nb, void*
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
+// where the block means live in the workspace: qa [H][nqb][64] (indexed with the SELECTION's nqb), ka [H][nb][64]
+void k5_nabla_workspace_means(void* workspace, int H, int nb, void** qa, void** ka) {
+  if (qa) *qa = workspace;
+  if (ka) *ka = (char*)workspace + (size_t)H * nb * 64 * 2;
+}
+
 // nqb = query-block rows the selection will handle (a sequence-parallel rank selects nb / P of the nb rows): only the bf16 logits matrix —
 // by far the largest region, 840 MB at 3660 blocks — scales with it; every other region keeps its nb-row size (the views index by nb)
 size_t k5_nabla_workspace_bytes(int H, int nb, int nqb) {
@@ -387,7 +393,8 @@ int k5_launch_nabla_key_means_from_slots(const void* gathered, int H, int nb, in
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
-// k == nullptr: the key-block means are already in the workspace (k5_launch_nabla_key_means_from_slots)
+// k == nullptr: the key-block means are already in the workspace (k5_launch_nabla_key_means_from_slots, or k5_launch_rmsnorm_rope's mean_k);
+// q == nullptr: so are the query-block means (k5_launch_rmsnorm_rope's mean_q into k5_nabla_workspace_means(..).qa)
 int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
                                 int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s, int local_block0, int local_blocks,
                                 int group_rows, int pair_stride) {
@@ -396,7 +403,7 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   if (local_blocks < 0 || local_block0 < 0 || (local_blocks > 0 && local_block0 + local_blocks > N / 64)) return K5_ERR_ARG;
   if (H <= 0 || N <= 0 || Nq <= 0 || (N % 64) || (Nq % 64) || T * Hb * Wb * 64 != N) return K5_ERR_ARG;
   if (q_block0 < 0 || q_block0 * 64 + Nq > N) return K5_ERR_ARG;
-  if ((ldq & 7) || (k && (ldk & 7))) return K5_ERR_ALIGN;
+  if ((q && (ldq & 7)) || (k && (ldk & 7))) return K5_ERR_ALIGN;
   const int nb = N / 64, nqb = Nq / 64, nw = (nb + 63) / 64, ng = (nqb + group_rows - 1) / group_rows;
   const size_t ngmax = (size_t)nb;   // region sizes (k5_nabla_workspace_bytes / _views)
   if (nb > SEL_MAXNB) return K5_ERR_UNSUPPORTED;
@@ -409,7 +416,7 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   int* cnt = (int*)ws;
   int* cnt_local = cnt + (size_t)H * ngmax;
   bf16_t* logits = (bf16_t*)(((uintptr_t)(cnt_local + (size_t)H * ngmax) + 255) & ~(uintptr_t)255);   // 256-B aligned: inside the + 256 slack
-  hipLaunchKernelGGL(block_mean_kernel, dim3(nqb), dim3(256), 0, s, (const bf16_t*)q, qa, H, nqb, ldq);
+  if (q) hipLaunchKernelGGL(block_mean_kernel, dim3(nqb), dim3(256), 0, s, (const bf16_t*)q, qa, H, nqb, ldq);
   if (k) hipLaunchKernelGGL(block_mean_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)k, ka, H, nb, ldk);
   SelP p;
   p.qa = qa; p.ka = ka; p.bits = bits; p.kv_nb = kv_nb; p.H = H; p.nb = nb; p.nw = nw; p.T = T; p.Hb = Hb; p.Wb = Wb;

@@ -90,11 +90,18 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, c
 // K5 + K3: one thread per 16-B chunk (8 of the 64 head elements); 8-lane groups own one head.  Grid-stride over rows with a
 // stride that is a multiple of H*8 threads, so a thread keeps its (head, chunk) and can carry the head's running
 // max |x|^2 in a register: one atomic per 8-lane group per launch instead of one per head vector.
+// MEANS (round 4, NABLA): the pass also leaves the 64-token BLOCK MEANS of the heads' unscaled, normalised + rotated values — what
+// block_mean_kernel (nabla.hip) computed by reading q | k once more: fp32 sum of the bf16-rounded values in row order, x 1/64, one bf16 rounding
+// (the reference's bf16 `.mean(-2)`, utils.py:140-143).  A thread then walks whole blocks of 64 CONSECUTIVE rows (block bb = slot, slot + S, ...)
+// instead of rows `stride` apart, so the sums stay in its registers; heads < scale_from_head go to mean_q [head][mq_stride blocks][64], the others
+// to mean_k [head - scale_from_head][mk_stride][64].  With the means taken here the unscaled keys need not be stored: scaled in place.
+template <bool MEANS>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                            const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                            int rows, int H, int heads_per_weight, int ld, int rope_heads,
                                                            float out_scale, int scale_from_head, bf16_t* __restrict__ scaled_out,
-                                                           int ld_scaled, float* __restrict__ stats, const float* __restrict__ centre) {
+                                                           int ld_scaled, float* __restrict__ stats, const float* __restrict__ centre,
+                                                           bf16_t* __restrict__ mean_q, int mq_stride, bf16_t* __restrict__ mean_k, int mk_stride) {
   // stats: per-head maxima of this block: |x_h|^2 for the H heads of a row, then (centre given) |k'_h - c_h|^2 for the scaled heads —
   // the radius of a head's keys around the centre key_centre_kernel estimated; H + (H - scale_from_head) <= 256 entries
   __shared__ unsigned int smax[256];
@@ -111,6 +118,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
   const bool rope = cosT && head < rope_heads;
   const bool scaled = head >= scale_from_head;
   float n2max = 0.f, r2max = 0.f;
+  float msum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool centred = stats && centre && scaled;
   if (centred) {
@@ -119,10 +127,25 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
   }
   // every lane of a wave runs the same number of iterations except in the last one (shuffles need the whole 8-lane group:
   // groups never straddle the end because total is a multiple of 8)
-  for (int64_t g = g0; g < total; g += stride) {
-    const int row = (int)((g >> 3) / H);
+  const int slot0 = (int)(g0 / (H * 8)), nslot = (int)(stride / (H * 8)), nblk = rows >> 6;
+  // MEANS: iteration i = (block, t): block = slot0 + (i / 64) * nslot, row = 64 block + t; otherwise row i of this thread's stride
+  // MEANS: the NEXT row's 16 bytes are requested before this row is worked on and stored (the compiler cannot move a load of x above a store
+  // to x by itself): two loads in flight per thread — with whole 64-row blocks per thread the launch is a little over one round of resident
+  // workgroups, and one load per thread did not keep HBM busy through its second round
+  u32x4 raw_pf = {0u, 0u, 0u, 0u};
+  if (MEANS && slot0 < nblk) raw_pf = *reinterpret_cast<const u32x4*>(x + (size_t)(64 * slot0) * ld + head * 64 + 8 * c);
+  for (int64_t g = g0, it = 0; MEANS ? (slot0 + (int)(it >> 6) * nslot < nblk) : (g < total); g += stride, ++it) {
+    const int mblk = MEANS ? slot0 + (int)(it >> 6) * nslot : 0, mt = (int)(it & 63);
+    const int row = MEANS ? 64 * mblk + mt : (int)((g >> 3) / H);
     bf16_t* px = x + (size_t)row * ld + head * 64 + 8 * c;
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(px);
+    u32x4 raw;
+    if (MEANS) {
+      raw = raw_pf;
+      const int nblk_next = slot0 + (int)((it + 1) >> 6) * nslot;
+      if (nblk_next < nblk) raw_pf = *reinterpret_cast<const u32x4*>(x + (size_t)(64 * nblk_next + (int)((it + 1) & 63)) * ld + head * 64 + 8 * c);
+    } else {
+      raw = *reinterpret_cast<const u32x4*>(px);
+    }
     float v[8];
     float sq = 0.f;
 #pragma unroll
@@ -146,6 +169,21 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
         const float x0 = y[2 * j], x1 = y[2 * j + 1];
         y[2 * j] = __fadd_rn(__fmul_rn(cs[j], x0), __fmul_rn(-sn[j], x1));
         y[2 * j + 1] = __fadd_rn(__fmul_rn(sn[j], x0), __fmul_rn(cs[j], x1));
+      }
+    }
+    if (MEANS) {
+      if (mt == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) msum[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) msum[j] += bf_round(y[j]);       // the bf16 values the unscaled tensor holds (held), in row order
+      if (mt == 63) {
+        const u32x4 mk = {pack_bf16x2(msum[0] * (1.f / 64), msum[1] * (1.f / 64)), pack_bf16x2(msum[2] * (1.f / 64), msum[3] * (1.f / 64)),
+                          pack_bf16x2(msum[4] * (1.f / 64), msum[5] * (1.f / 64)), pack_bf16x2(msum[6] * (1.f / 64), msum[7] * (1.f / 64))};
+        bf16_t* mo = head < scale_from_head ? (mean_q ? mean_q + ((size_t)head * mq_stride + mblk) * 64 + 8 * c : nullptr)
+                                            : (mean_k ? mean_k + ((size_t)(head - scale_from_head) * mk_stride + mblk) * 64 + 8 * c : nullptr);
+        if (mo) *reinterpret_cast<u32x4*>(mo) = mk;
       }
     }
     u32x4 pks = {0u, 0u, 0u, 0u};
@@ -187,7 +225,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
   // 28 addresses cost more than the kernel): LDS max per block, one partial row per block, reduced by stats_reduce_kernel.
   if (stats) {
     const int Hs = centre ? H + (H - scale_from_head) : H;
-    if (c == 0 && g0 < total) {
+    if (c == 0 && (MEANS ? slot0 < nblk : g0 < total)) {
       atomicMax(&smax[head], __float_as_uint(n2max));
       if (centred) atomicMax(&smax[H + head - scale_from_head], __float_as_uint(r2max));
     }
@@ -469,9 +507,11 @@ size_t k5_rmsnorm_stats_workspace_bytes(int H) { return (size_t)4096 * 2 * H * s
 
 int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, const float* sinT, int rows, int H,
                            int ld, const int32_t* heads_cfg, hipStream_t s, float out_scale, int scale_from_head, void* scaled_out,
-                           int ld_scaled, float* stats, float* stats_ws, float* key_centre) {
+                           int ld_scaled, float* stats, float* stats_ws, float* key_centre, void* mean_q, int mq_stride, void* mean_k, int mk_stride) {
   // heads_cfg (host pointer, optional): {heads_per_weight, rope_heads}; default: one weight, rope on all heads
   if (rows <= 0 || H <= 0) return K5_ERR_ARG;
+  const bool means = mean_q || mean_k;
+  if (means && ((rows & 63) || (mean_q && mq_stride < rows / 64) || (mean_k && mk_stride < rows / 64))) return K5_ERR_ARG;
   if (ld & 7) return K5_ERR_ALIGN;
   const int hpw = heads_cfg ? heads_cfg[0] : H;
   const int rope_heads = heads_cfg ? heads_cfg[1] : H;
@@ -486,6 +526,13 @@ int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, cons
   int64_t blocks = (total + 255) / 256;
   if (blocks > cap) blocks = cap;
   blocks = (blocks + unit - 1) / unit * unit;           // <= cap: cap is a multiple of unit
+  if (means) {   // slots (threads per head chunk) = blocks * 256 / (H * 8): every slot the same number k of 64-row blocks where the cap allows
+    const int64_t nblk = rows / 64, smax_ = cap * 256 / b8;
+    const int64_t k = (nblk + smax_ - 1) / smax_, want = (nblk + k - 1) / k;
+    blocks = (want * b8 + 255) / 256;
+    blocks = (blocks + unit - 1) / unit * unit;
+    if (blocks > cap) blocks = cap;
+  }
   // key_centre (nullable, with stats and scaled heads only): [H - scale_from_head][64] floats OUT = the centres of the scaled (key) heads;
   // stats then has H + (H - scale_from_head) entries: the squared norms, then the squared radii around the centres
   const bool centred = key_centre && stats && scale_from_head < H;
@@ -494,9 +541,14 @@ int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, cons
                        rope_heads, out_scale, rows < K5_CENTRE_SAMPLE ? rows : K5_CENTRE_SAMPLE, key_centre);
   const int Hs = centred ? H + (H - scale_from_head) : H;
   if (Hs > 256) return K5_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)x, weight,
-                     cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled, stats ? stats_ws : nullptr,
-                     centred ? key_centre : nullptr);
+  if (means)
+    hipLaunchKernelGGL(rmsnorm_rope_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)x, weight,
+                       cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled, stats ? stats_ws : nullptr,
+                       centred ? key_centre : nullptr, (bf16_t*)mean_q, mq_stride, (bf16_t*)mean_k, mk_stride);
+  else
+    hipLaunchKernelGGL(rmsnorm_rope_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)x, weight,
+                       cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled, stats ? stats_ws : nullptr,
+                       centred ? key_centre : nullptr, (bf16_t*)nullptr, 0, (bf16_t*)nullptr, 0);
   if (stats) hipLaunchKernelGGL(stats_reduce_kernel, dim3(blocks >= 2048 ? 64 : (blocks >= 512 ? 16 : 1)), dim3(256), 0, s, stats_ws, (int)blocks, Hs, stats);
   return done();
 }

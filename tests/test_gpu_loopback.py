@@ -207,6 +207,9 @@ def test_full_width_nabla_P_ranks_on_one_gpu(P, gain, passes, grp):
     if grp == 2:   # frame-paired lists (default) against adjacent-row lists on the ranks' shards: the same bits
         res0 = run_ranks(P, make, call, options={"sp_nabla_passes": passes, "nabla_group_rows": grp, "nabla_pair_frames": 0})
         assert torch.equal(res0[0][0], outs[0]), "frame-paired and adjacent-row lists differ"
+    else:          # block means from the norm pass (default) against their own pass over the stored keys / queries: the same bits
+        res0 = run_ranks(P, make, call, options={"sp_nabla_passes": passes, "nabla_group_rows": grp, "nabla_fuse_means": 0})
+        assert torch.equal(res0[0][0], outs[0]), "fused and separate block means differ"
     for n_fixed, n_online in [counts1] + [cnt for _, cnt in res]:
         assert n_fixed + n_online == 2 * 28
         assert (n_online == 0) if gain <= 3.0 else (n_fixed == 0), (gain, n_fixed, n_online)

@@ -396,20 +396,23 @@ def test_lists_per_two_rows_give_the_same_bits(gain, anchor):
     # 1 (round 4): one list per 64-query row, 64-query workgroups of two waves.  "nabla_pair_frames" (round 4, default 1): the two rows of a
     # 128-query list are the same spatial tile in adjacent frames (2 blocks per frame here: rows b and b + 2; 4 whole chunks of 4 rows and a
     # 2-row remainder that pairs adjacent rows) instead of rows 2g, 2g + 1 — a row still walks its own tiles in ascending order
-    for grp, pair in ((4, 1), (2, 1), (2, 0), (1, 1)):
+    # "nabla_fuse_means" (round 4, default 1): the block means come out of the norm + RoPE pass and the keys are scaled in place; 0 = the means'
+    # own pass over the stored unscaled tensor + a scaled key copy (rounds 1-3) — the same bits
+    for grp, pair, fuse in ((4, 1, 1), (2, 1, 1), (2, 0, 1), (1, 1, 1), (4, 1, 0)):
         d = DiffusionTransformer3D(**c)
         d.load_state_dict(sd, assign=True)
         d = d.to("cuda:0")
         d.engine("cuda:0")
         d.set_option("nabla_group_rows", grp)
         d.set_option("nabla_pair_frames", pair)
+        d.set_option("nabla_fuse_means", fuse)
         d.set_option("attn_anchor", anchor)
         outs.append(d(x.cuda(), text.cuda(), pooled.cuda(), t, pos, torch.arange(37), scale_factor=(1.0, 2.0, 2.0), sparse_params=sp))
         n_fixed, n_online = d.attn_variant_counts()
         assert (n_online == 0) if gain <= 3.0 else (n_fixed == 0), (gain, grp, n_fixed, n_online)
         del d
     assert torch.isfinite(outs[0].float()).all()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 def test_nabla_graph_captured_step_is_bit_identical(tiny_sd, golden, golden_meta):
