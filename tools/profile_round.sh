@@ -4,6 +4,7 @@
 # writes gpurun_out/prof_<tag>/... (scratch) and the summaries gpurun_out/<tag>_*.{md,json} to copy into profiles/.
 TAG=${1:-r01}
 export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT; cd /tmp
+if [ -z "$LINES_ONLY" ]; then   # LINES_ONLY=1: only the workload / shard lines of steps 6-8 (a rebuild that does not touch the profiled default path)
 # 1. kernel trace + stats of the bench command (no counters in this pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-breakdown > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 grep "^{" $OUT/${TAG}_bench_under_rocprof.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json   # the line of THIS run: what the kernel-trace figure must agree with
@@ -21,6 +22,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_vae -o 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_nabla -o nabla -- python $R/bench.py --workload 10s_nabla --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-breakdown > $OUT/${TAG}_nabla_under_rocprof.log 2>&1
 cd $R
 python tools/profile_summarize.py $TAG
+fi
+cd $R
 # 6. the other workloads and the emulated shard sizes, one JSON line each (no profiler)
 : > $OUT/${TAG}_workloads.jsonl; : > $OUT/${TAG}_shards.jsonl
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-vae --attn-online 2>/dev/null | grep "^{" >> $OUT/${TAG}_workloads.jsonl
