@@ -583,6 +583,12 @@ bool sa_sp_fp8_in(const k5_dit* d, const AttnW& a, int rows, int rows_pad, bool 
   const int P = d->sp_world;
   return (d->fp8_mask & 2) && a.wqk8.p && rows >= 256 && !((rows_pad / ((!nabla && d->sp_slices > 1 && P > 1) ? d->sp_slices : 1)) & 15);
 }
+// "nabla_fuse_means": the fused form gives every thread 64 consecutive rows of one 16-byte column chunk, i.e. the launch has rows / 64 x heads x 8
+// threads — a sequence-parallel shard of the 10 s clip (366 blocks x 28 heads: 82 k threads, a sixth of the resident capacity) runs it latency-
+// bound and loses 3 ms per step to gain 1 (measured, incl. an 8-deep prefetch ring); from ~150 k threads up it wins.  2 = always.
+bool nabla_means_fused(const k5_dit* d, int rows, int heads) {
+  return d->nabla_fuse_means == 2 || (d->nabla_fuse_means == 1 && (long long)(rows / 64) * heads * 8 >= 150000);
+}
 bool ff_fp8_in(const k5_dit* d, const BlockW& b, int rows) { return d->use_fp8 && b.w1_f8.p && rows >= 256; }
 
 int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, void* qk, void* vt,
@@ -628,7 +634,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     // 1-3) the unscaled keys stay in place for k5_launch_nabla_select_rect's own means pass and the scaled copy goes to its own buffer.
     void* kc = nullptr;
     void *mq = nullptr, *mk = nullptr;
-    const bool fuse_means = pre && nabla && d->nabla_fuse_means;
+    const bool fuse_means = pre && nabla && nabla_means_fused(d, rows, 2 * H);
     if (fuse_means) {
       K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, rows / 64)));
       k5_nabla_workspace_means(d->ws_nabla.p, H, rows / 64, &mq, &mk);
@@ -668,7 +674,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
     {
       Scope sc(d, s, "nabla_map");
-      const bool fm = pre && d->nabla_fuse_means;   // the means are in the workspace already
+      const bool fm = pre && nabla_means_fused(d, rows, 2 * H);   // the means are in the workspace already
       K5CHK(k5_launch_nabla_select_rect(fm ? nullptr : qk, fm ? nullptr : (const bf16_t*)qk + D, 2 * D, 2 * D, H, rows, 0, rows, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
                                         nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, 0, 0, grp, pair));
     }
@@ -686,7 +692,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     Scope sc(d, s, fam_attn);
     // (no tail balancing here: 10 248 jobs are 20 rounds of unequal lists — measured -0.6 % at density 0.81, +1 % at 0.12, +2.4 % at
     // 0.05; a token shard's 5 rounds are another matter, run_self_attention_sp)
-    const bool kin = !pre || d->nabla_fuse_means;   // keys in place in the fused q | k buffer (scaled there when pre)
+    const bool kin = !pre || nabla_means_fused(d, rows, 2 * H);   // keys in place in the fused q | k buffer (scaled there when pre)
     K5CHK(k5_launch_attention_bf16_sparse(qk, kin ? (const bf16_t*)qk + D : d->ws_kc.as<bf16_t>(), vt, o, H, rows, rows, 2 * D, kin ? 2 * D : D,
                                           ldvt, D, pre ? 0.f : a.score_bound, list, cnt, nb, 0, 0, s, pre, hflags, variant, kmax, nullptr,
                                           pre ? d->ws_attn_bal.as<float>() : nullptr, grp, false, kcp, pair));
@@ -771,12 +777,12 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     Scope sc(d, s, "elementwise");
     // dense: scaled in place; NABLA: unscaled in place (kun), the scaled copy goes to this rank's slot of the gather buffer
     // NABLA: the unscaled keys' block means (all the map needs of them) come out of this pass ("nabla_fuse_means"; before: a second pass over kun)
-    const bool fm = nabla && d->nabla_fuse_means;
+    const bool fm = nabla && nabla_means_fused(d, rows, H);
     K5CHK(k5_launch_rmsnorm_rope(kun, a.norm.as<float>() + 64, cosT, sinT, rows, H, D, nullptr, s, K5_SOFTMAX_C, 0,
                                  nabla ? kloc : nullptr, nabla ? D : 0, by_data ? kstat + (size_t)r * H : nullptr, d->ws_attn_part.as<float>(), nullptr,
                                  nullptr, 0, fm ? kmeans + (size_t)r * H * slot_blocks * 64 : nullptr, slot_blocks));
   }
-  if (nabla && !d->nabla_fuse_means) {
+  if (nabla && !nabla_means_fused(d, rows, H)) {
     Scope sc(d, s, "nabla_map");
     K5CHK(k5_launch_nabla_block_means(kun, D, H, rows / 64, slot_blocks, kmeans + (size_t)r * H * slot_blocks * 64, s));
   }
@@ -810,7 +816,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   const K5QueryNorm* qnp = fuse_q ? &qn : nullptr;
   if (!fuse_q) {
     void* mq = nullptr;
-    if (nabla && d->nabla_fuse_means) {   // the query-block means of the rank's rows, straight into the map's workspace
+    if (nabla && nabla_means_fused(d, rows, H)) {   // the query-block means of the rank's rows, straight into the map's workspace
       K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, N / 64, rows / 64)));
       k5_nabla_workspace_means(d->ws_nabla.p, H, N / 64, &mq, nullptr);
     }
@@ -885,7 +891,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     {
       Scope sc(d, s, "nabla_map");
       K5CHK(k5_launch_nabla_key_means_from_slots(kmeans, H, nb, slot_blocks, d->ws_nabla.p, s));
-      K5CHK(k5_launch_nabla_select_rect(d->nabla_fuse_means ? nullptr : q, nullptr, D, 0, H, rows, r * slot_blocks, N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
+      K5CHK(k5_launch_nabla_select_rect(nabla_means_fused(d, rows, H) ? nullptr : q, nullptr, D, 0, H, rows, r * slot_blocks, N, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
                                         nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, r * slot_blocks, rows / 64, grp, pair));   // own key blocks lead the lists
     }
     if (d->profiling) {
@@ -2029,7 +2035,7 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //                     depending on how the compiler schedules the tile loop of the extra instantiation), hence opt-in.
 //   "nabla_group_rows" 0 (default) / 2 / 4: 64-query rows per NABLA key-tile list = per attention workgroup on one GPU; 0 picks 2 (128-query
 //                     workgroups) when the previous forward's first map kept less than half of its blocks, else 4; same bits either way
-//   "nabla_fuse_means" 1 (default) / 0: the 64-token block means NABLA's map is built from are taken by the norm + RoPE pass itself (one read of q | k
+//   "nabla_fuse_means" 1 (default: where the launch has >= 150 k threads) / 2 (always) / 0: the 64-token block means NABLA's map is built from are taken by the norm + RoPE pass itself (one read of q | k
 //                     less per block, and on one GPU the keys are scaled in place: no scaled copy); same bits as with 0
 //   "fp8_fuse_ln"     1 (default) / 0: under k5_dit_set_fp8 the LayerNorm in front of an e4m3 projection writes the e4m3 rows itself (no bf16 h, no
 //                     quantisation pass: two passes of N x D less per block); same bits as with 0
@@ -2063,7 +2069,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_anchor")) { d->anchor = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_pref_reset")) return reset_attn_pref(d, nullptr, true);   // an action, not a state: the per-step path (k5_dit_forward) calls it per run
-  if (!strcmp(name, "nabla_fuse_means")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->nabla_fuse_means = value; return K5_OK; }
+  if (!strcmp(name, "nabla_fuse_means")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->nabla_fuse_means = value; return K5_OK; }
   if (!strcmp(name, "fp8_fuse_ln")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->fp8_fuse_ln = value; return K5_OK; }
   if (!strcmp(name, "nabla_pair_frames")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->nabla_pair_frames = value; return K5_OK; }
   if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 1 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }

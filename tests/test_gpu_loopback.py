@@ -200,12 +200,12 @@ def test_full_width_nabla_P_ranks_on_one_gpu(P, gain, passes, grp):
         return out, d.attn_variant_counts()
 
     fused, counts1 = call(make(), 0)
-    res = run_ranks(P, make, call, options={"sp_nabla_passes": passes, "nabla_group_rows": grp})
+    res = run_ranks(P, make, call, options={"sp_nabla_passes": passes, "nabla_group_rows": grp, "nabla_fuse_means": 2})   # 2: block means in the norm pass whatever the size
     outs = [o for o, _ in res]
     for r in range(1, P):
         assert torch.equal(outs[r], outs[0]), f"rank {r} differs from rank 0"
     if grp == 2:   # frame-paired lists (default) against adjacent-row lists on the ranks' shards: the same bits
-        res0 = run_ranks(P, make, call, options={"sp_nabla_passes": passes, "nabla_group_rows": grp, "nabla_pair_frames": 0})
+        res0 = run_ranks(P, make, call, options={"sp_nabla_passes": passes, "nabla_group_rows": grp, "nabla_pair_frames": 0, "nabla_fuse_means": 2})
         assert torch.equal(res0[0][0], outs[0]), "frame-paired and adjacent-row lists differ"
     else:          # block means from the norm pass (default) against their own pass over the stored keys / queries: the same bits
         res0 = run_ranks(P, make, call, options={"sp_nabla_passes": passes, "nabla_group_rows": grp, "nabla_fuse_means": 0})

@@ -398,7 +398,7 @@ def test_lists_per_two_rows_give_the_same_bits(gain, anchor):
     # 2-row remainder that pairs adjacent rows) instead of rows 2g, 2g + 1 — a row still walks its own tiles in ascending order
     # "nabla_fuse_means" (round 4, default 1): the block means come out of the norm + RoPE pass and the keys are scaled in place; 0 = the means'
     # own pass over the stored unscaled tensor + a scaled key copy (rounds 1-3) — the same bits
-    for grp, pair, fuse in ((4, 1, 1), (2, 1, 1), (2, 0, 1), (1, 1, 1), (4, 1, 0)):
+    for grp, pair, fuse in ((4, 1, 2), (2, 1, 2), (2, 0, 2), (1, 1, 2), (4, 1, 0), (4, 1, 1)):   # fuse 2 = always (1 keeps small launches on the separate pass)
         d = DiffusionTransformer3D(**c)
         d.load_state_dict(sd, assign=True)
         d = d.to("cuda:0")
