@@ -308,6 +308,11 @@ struct k5_dit {
   int fp8_fuse_ln = 1;                             // fp8 modes: the LayerNorm in front of an fp8 projection writes e4m3 directly (same bits as LayerNorm + quantisation pass)
   int fp8_mask = 0;                                // k5_dit_set_fp8: bit 0 feed-forward, bit 1 q | k | V^T projections, bit 2 out projection of the visual self-attention
   DevBuf ws_h8, ws_ff8;                            // fp8 activations of that path
+  // Cross-attention keys / values of ALL visual blocks in one go (round 4, "cross_kv_batched"): they depend on the text stream only, so the 2 x
+  // num_visual_blocks projections of 256 text rows (34 + 32 us each: 28-tile launches) become two GEMMs against the stacked weights
+  // [blocks * D][D] before the visual stack, the key RMSNorms one launch — same kernels on the same per-element sums: bit-identical
+  DevBuf cx_wk_all, cx_wv_all, cx_bk_all, cx_bv_all, cx_knorm_all, ws_ck_all, ws_cvt_all;
+  int cross_kv_batched = 1;
   DevBuf ws_sched;                                 // sampler tables on the device: t*1000 [steps] | dt [steps] | step counter
   bool use_graph = false;                          // k5_sample replays one captured step (k5_dit_set_graph)
   hipStream_t graph_stream = nullptr;              // capture needs a real stream: the caller's may be the legacy null stream
@@ -1094,15 +1099,36 @@ int run_self_attention_ulysses(k5_dit* d, hipStream_t s, const AttnW& a, const v
   return K5_OK;
 }
 
+// keys and V^T of every visual block's cross-attention from the text stream (k5_dit::cross_kv_batched): ws_ck_all [L][blocks * D] (normalised
+// keys), ws_cvt_all [blocks * D][rup(L, 8)].  The key projection is the launch it was per block (128 x 128 tiles for 256 rows); the V^T one is forced
+// onto the same 128 x 128 kernel the per-block call took (57 344 weight rows would otherwise pick a 256-row kernel: another summation order).
+int cross_kv_batched_run(k5_dit* d, hipStream_t s, const void* text, int L) {
+  const int D = d->D, H = d->Hh, nbv = (int)d->vblocks.size();
+  const int ldvt = (int)rup(L, 8);
+  K5CHK(d->ws_ck_all.ensure((size_t)L * nbv * D * 2)); K5CHK(d->ws_cvt_all.ensure((size_t)nbv * D * ldvt * 2));
+  {
+    Scope sc(d, s, "gemm");
+    K5CHK(k5_launch_gemm_bf16(text, d->cx_wk_all.p, d->cx_bk_all.as<float>(), d->ws_ck_all.p, L, nbv * D, D, D, D, nbv * D, K5_EPI_BIAS, nullptr, 0, nullptr, s, 2));
+    K5CHK(k5_launch_gemm_bf16(d->cx_wv_all.p, text, d->cx_bv_all.as<float>(), d->ws_cvt_all.p, nbv * D, L, D, D, D, ldvt, K5_EPI_BIAS_M, nullptr, 0, nullptr, s, 2));
+  }
+  Scope sc(d, s, "elementwise");
+  const int32_t hc[2] = {H, 0};   // one norm weight per block's H heads, no RoPE
+  return k5_launch_rmsnorm_rope(d->ws_ck_all.p, d->cx_knorm_all.as<float>(), nullptr, nullptr, L, nbv * H, nbv * D, hc, s);
+}
+
+// kv_ready: ck (row stride ldck) / cvt already hold this block's normalised keys and V^T (cross_kv_batched_run)
 int run_cross_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, int rows, const void* text,
-                        int L, void* q, void* ck, void* cvt, void* o, void* resid, const float* gate) {
+                        int L, void* q, void* ck, void* cvt, void* o, void* resid, const float* gate, bool kv_ready = false, int ldck = 0) {
   const int D = d->D, H = d->Hh;
   const int ldvt = (int)rup(L, 8);
+  if (!kv_ready) ldck = D;
   {
     Scope sc(d, s, "gemm");
     K5CHK(k5_launch_gemm_bf16(h, a.wq.p, a.bq.as<float>(), q, rows, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
-    K5CHK(k5_launch_gemm_bf16(text, a.wk.p, a.bk.as<float>(), ck, L, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
-    K5CHK(k5_launch_gemm_bf16(a.wv.p, text, a.bv.as<float>(), cvt, D, L, D, D, D, ldvt, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+    if (!kv_ready) {
+      K5CHK(k5_launch_gemm_bf16(text, a.wk.p, a.bk.as<float>(), ck, L, D, D, D, D, D, K5_EPI_BIAS, nullptr, 0, nullptr, s));
+      K5CHK(k5_launch_gemm_bf16(a.wv.p, text, a.bv.as<float>(), cvt, D, L, D, D, D, ldvt, K5_EPI_BIAS_M, nullptr, 0, nullptr, s));
+    }
   }
   // RMSNorm of the queries (no RoPE in cross-attention, nn.py:330-334) is fused into the attention kernel's Q-fragment load when the
   // weight-derived bound admits the fixed-offset kernel: one pass over the (rows, D) projection less per block
@@ -1110,16 +1136,16 @@ int run_cross_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h,
   {
     Scope sc(d, s, "elementwise");
     if (!fuse_qnorm) K5CHK(k5_launch_rmsnorm_rope(q, a.norm.as<float>(), nullptr, nullptr, rows, H, D, nullptr, s));
-    K5CHK(k5_launch_rmsnorm_rope(ck, a.norm.as<float>() + 64, nullptr, nullptr, L, H, D, nullptr, s));
+    if (!kv_ready) K5CHK(k5_launch_rmsnorm_rope(ck, a.norm.as<float>() + 64, nullptr, nullptr, L, H, D, nullptr, s));
   }
   {
     Scope sc(d, s, "attn_cross");
     const K5QueryNorm qn{a.norm.as<float>(), nullptr, nullptr, nullptr};
     if (fuse_qnorm)
-      K5CHK(k5_launch_attention_bf16_range(q, ck, cvt, o, H, rows, L, D, D, ldvt, D, a.score_bound, 0, 0, 0, -1, 0x7fffffff, 0, nullptr, 0, s,
+      K5CHK(k5_launch_attention_bf16_range(q, ck, cvt, o, H, rows, L, D, ldck, ldvt, D, a.score_bound, 0, 0, 0, -1, 0x7fffffff, 0, nullptr, 0, s,
                                            nullptr, false, nullptr, K5_ATTN_AUTO, nullptr, nullptr, 0, &qn));
     else
-      K5CHK(k5_launch_attention_bf16_bounded(q, ck, cvt, o, H, rows, L, D, D, ldvt, D, a.score_bound, s));
+      K5CHK(k5_launch_attention_bf16_bounded(q, ck, cvt, o, H, rows, L, D, ldck, ldvt, D, a.score_bound, s));
   }
   {
     Scope sc(d, s, "gemm");
@@ -1505,6 +1531,9 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
     }
   }
   // ---- visual blocks (dit.py:176-178, 61-79) ----
+  const bool cx_all = !mag_skip && d->cross_kv_batched && c.num_visual_blocks > 1 && d->cx_wk_all.p;
+  if (cx_all) K5CHK(cross_kv_batched_run(d, s, d->ws_text.p, L));
+  const int Lr8 = (int)rup(L, 8);
   for (int i = 0; i < (mag_skip ? 0 : c.num_visual_blocks); ++i) {
     const BlockW& b = d->vblocks[i];
     const float* m = mod + b.mod_off;
@@ -1524,8 +1553,12 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
                                m + 2 * D, "attn_self", nabla ? &na : nullptr, text_slot > 0 ? 1 : 0, h8_sa));
     }
     K5CHK(ln_mod(d, s, d->ws_vis.p, m + 3 * D, d->ws_h.p, n));
-    K5CHK(run_cross_attention(d, s, b.cross_attn, d->ws_h.p, n, d->ws_text.p, L, d->ws_qk.p, d->ws_ck.p, d->ws_cvt.p,
-                              d->ws_o.p, d->ws_vis.p, m + 5 * D));
+    if (cx_all)
+      K5CHK(run_cross_attention(d, s, b.cross_attn, d->ws_h.p, n, d->ws_text.p, L, d->ws_qk.p, d->ws_ck_all.as<bf16_t>() + (size_t)i * D,
+                                d->ws_cvt_all.as<bf16_t>() + (size_t)i * D * Lr8, d->ws_o.p, d->ws_vis.p, m + 5 * D, true, c.num_visual_blocks * D));
+    else
+      K5CHK(run_cross_attention(d, s, b.cross_attn, d->ws_h.p, n, d->ws_text.p, L, d->ws_qk.p, d->ws_ck.p, d->ws_cvt.p,
+                                d->ws_o.p, d->ws_vis.p, m + 5 * D));
     const bool h8_ff = d->fp8_fuse_ln && ff_fp8_in(d, b, n);
     K5CHK(ln_mod(d, s, d->ws_vis.p, m + 6 * D, d->ws_h.p, n, h8_ff));
     K5CHK(run_ff(d, s, b, d->ws_h.p, n, d->ws_ff.p, d->ws_vis.p, m + 8 * D, h8_ff));
@@ -1733,6 +1766,22 @@ extern "C" int k5_dit_finalize(k5_dit* d) {
     if (!shape_ok(d, p + ".feed_forward.in_layer.weight", FF, D) || !shape_ok(d, p + ".feed_forward.out_layer.weight", D, FF)) return K5_ERR_ARG;
     K5CHK(pack_bf16(d->vblocks[i].w1, find(d, p + ".feed_forward.in_layer.weight"), FF, D, D));
     K5CHK(pack_bf16(d->vblocks[i].w2, find(d, p + ".feed_forward.out_layer.weight"), D, FF, FF));
+  }
+  {   // stacked cross-attention key / value weights of the visual blocks (device-to-device copies of the packed per-block buffers)
+    const size_t nbv = (size_t)c.num_visual_blocks;
+    if (nbv) {
+      K5CHK(d->cx_wk_all.ensure(nbv * D * D * 2)); K5CHK(d->cx_wv_all.ensure(nbv * D * D * 2));
+      K5CHK(d->cx_bk_all.ensure(nbv * D * 4)); K5CHK(d->cx_bv_all.ensure(nbv * D * 4)); K5CHK(d->cx_knorm_all.ensure(nbv * 64 * 4));
+      for (size_t i = 0; i < nbv; ++i) {
+        const AttnW& a = d->vblocks[i].cross_attn;
+        if (!a.wk.p || !a.wv.p || !a.bk.p || !a.bv.p || !a.norm.p) { d->cross_kv_batched = 0; break; }
+        HIPCHK(hipMemcpy((char*)d->cx_wk_all.p + i * D * D * 2, a.wk.p, D * D * 2, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy((char*)d->cx_wv_all.p + i * D * D * 2, a.wv.p, D * D * 2, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy((char*)d->cx_bk_all.p + i * D * 4, a.bk.p, D * 4, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy((char*)d->cx_bv_all.p + i * D * 4, a.bv.p, D * 4, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy((char*)d->cx_knorm_all.p + i * 64 * 4, a.norm.as<float>() + 64, 64 * 4, hipMemcpyDeviceToDevice));
+      }
+    }
   }
   d->out_mod_off = off;
   if (!put_mod("out_layer.modulation.out_layer", 2 * D)) return K5_ERR_ARG;
@@ -2035,6 +2084,8 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //                     depending on how the compiler schedules the tile loop of the extra instantiation), hence opt-in.
 //   "nabla_group_rows" 0 (default) / 2 / 4: 64-query rows per NABLA key-tile list = per attention workgroup on one GPU; 0 picks 2 (128-query
 //                     workgroups) when the previous forward's first map kept less than half of its blocks, else 4; same bits either way
+//   "cross_kv_batched" 1 (default) / 0: the cross-attention key / V^T projections of all visual blocks as two GEMMs against stacked weights before
+//                     the visual stack (they depend on the text stream only), their key norms as one launch; same bits as the per-block launches
 //   "nabla_fuse_means" 1 (default: where the launch has >= 150 k threads) / 2 (always) / 0: the 64-token block means NABLA's map is built from are taken by the norm + RoPE pass itself (one read of q | k
 //                     less per block, and on one GPU the keys are scaled in place: no scaled copy); same bits as with 0
 //   "fp8_fuse_ln"     1 (default) / 0: under k5_dit_set_fp8 the LayerNorm in front of an e4m3 projection writes the e4m3 rows itself (no bf16 h, no
@@ -2069,6 +2120,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   if (!strcmp(name, "attn_row_offsets")) { d->row_offsets = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_anchor")) { d->anchor = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_pref_reset")) return reset_attn_pref(d, nullptr, true);   // an action, not a state: the per-step path (k5_dit_forward) calls it per run
+  if (!strcmp(name, "cross_kv_batched")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->cross_kv_batched = value; return K5_OK; }
   if (!strcmp(name, "nabla_fuse_means")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->nabla_fuse_means = value; return K5_OK; }
   if (!strcmp(name, "fp8_fuse_ln")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->fp8_fuse_ln = value; return K5_OK; }
   if (!strcmp(name, "nabla_pair_frames")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->nabla_pair_frames = value; return K5_OK; }
@@ -2105,6 +2157,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "nabla_pair_frames")) *value = d->nabla_pair_frames;
   else if (!strcmp(name, "fp8_fuse_ln")) *value = d->fp8_fuse_ln;
   else if (!strcmp(name, "nabla_fuse_means")) *value = d->nabla_fuse_means;
+  else if (!strcmp(name, "cross_kv_batched")) *value = d->cross_kv_batched;
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
   else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }

@@ -1289,7 +1289,7 @@ int launch_w4(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
 // Host launcher (C++ linkage, used by the C-ABI layer in k5_api.hip and by the engine).
 int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K,
                         int lda, int ldw, int ldc, int epi, const void* resid, int ldr,
-                        const float* gate, hipStream_t stream) {
+                        const float* gate, hipStream_t stream, int force_kernel) {
   if (M <= 0 || N <= 0 || K <= 0) return K5_ERR_ARG;
   if ((K & 7) || (lda & 7) || (ldw & 7)) return K5_ERR_ALIGN;  // 16-B aligned rows
   if (epi == K5_EPI_GATE && (!resid || !gate)) return K5_ERR_ARG;
@@ -1302,7 +1302,8 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   static const int dbg = getenv("K5_GEMM_DBG") ? atoi(getenv("K5_GEMM_DBG")) : 0;
   p.dbg = dbg;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
-  static const int force_v1 = getenv("K5_GEMM_V1") ? atoi(getenv("K5_GEMM_V1")) : 0;  // A/B switch for benchmarking
+  static const int force_env = getenv("K5_GEMM_V1") ? atoi(getenv("K5_GEMM_V1")) : 0;  // A/B switch for benchmarking
+  const int force_v1 = force_kernel ? force_kernel : force_env;   // force_kernel: a caller that needs ONE kernel whatever the shape (same numbering)
   // K5_GEMM_V1=3 selects the 256x128 3-stage counted-vmcnt variant.  Measured (round 1, model shapes): within +-3 % of the
   // 128x128 direct-to-LDS kernel (ff2 844 vs 827, ff1 698 vs 719 TFLOP/s) -> L2-miss latency is not the limiter; not default.
   // default for the model's large projections: the 256x256 two-group ping-pong kernel (K5_GEMM_V1=2 keeps the 128x128 one)

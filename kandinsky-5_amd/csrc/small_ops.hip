@@ -540,7 +540,7 @@ int k5_launch_rmsnorm_rope(void* x, const float* weight, const float* cosT, cons
     hipLaunchKernelGGL(key_centre_kernel, dim3(H - scale_from_head), dim3(256), 0, s, (const bf16_t*)x, weight, cosT, sinT, rows, ld, scale_from_head, hpw,
                        rope_heads, out_scale, rows < K5_CENTRE_SAMPLE ? rows : K5_CENTRE_SAMPLE, key_centre);
   const int Hs = centred ? H + (H - scale_from_head) : H;
-  if (Hs > 256) return K5_ERR_UNSUPPORTED;
+  if (stats && Hs > 256) return K5_ERR_UNSUPPORTED;   // the statistics live in a 256-entry LDS table; without them any head count goes (cross-attention keys of all blocks: 896)
   if (means)
     hipLaunchKernelGGL(rmsnorm_rope_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)x, weight,
                        cosT, sinT, rows, H, hpw, ld, rope_heads, out_scale, scale_from_head, (bf16_t*)scaled_out, ld_scaled, stats ? stats_ws : nullptr,

@@ -502,3 +502,24 @@ def test_config3_cfg_step_at_full_length_vs_reference_golden():
     assert r_upd <= 3e-2, r_upd
     assert r_lat <= 3e-2, r_lat
     assert abs(ss - c["update_sumsq"]) <= 5e-2 * c["update_sumsq"]
+
+
+def test_cross_attention_keys_of_all_blocks_in_one_go_same_bits():
+    """"cross_kv_batched" (round 4, default 1): the cross-attention key / V^T projections of all visual blocks are two GEMMs against stacked
+    weights before the visual stack (they depend on the text stream only) and their key RMSNorms one launch — same kernels, same per-element
+    sums: the velocity must equal the per-block launches' bit for bit, for a 37-token and a 256-token prompt (ragged / whole key tiles)."""
+    dit, _, _ = _two_block_model(1.0)
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(5, 16, 16, 16, generator=g)
+    pooled = torch.randn(1, 768, generator=g)
+    pos = [torch.arange(5), torch.arange(8), torch.arange(8)]
+    dit.engine("cuda:0")
+    for L in (37, 256):
+        text = torch.randn(L, 3584, generator=g)
+        args = (x.cuda(), text.cuda(), pooled.cuda(), torch.tensor([625.0]), pos, torch.arange(L))
+        assert dit.get_option("cross_kv_batched") == 1
+        a = dit(*args, scale_factor=(1.0, 2.0, 2.0))
+        dit.set_option("cross_kv_batched", 0)
+        b = dit(*args, scale_factor=(1.0, 2.0, 2.0))
+        dit.set_option("cross_kv_batched", 1)
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b), L
