@@ -86,6 +86,16 @@ def main():
     if "--attention" in sys.argv:     # the attention launch only (A/B of kernel variants through the environment, e.g. K5_ATTN_WAVE_ROWS=64)
         measure(f"dense attention, random data, K5_ATTN_WAVE_ROWS={os.environ.get('K5_ATTN_WAVE_ROWS', 'default')}", attn_case(), 200.0, 4.0 * N * N * 64 * 28)
         return
+    if "--blaslt" in sys.argv:        # the vendor library's GEMM (torch.matmul -> hipBLASLt) on the model's shapes under the same monitor: is it granted a higher clock?
+        for name, (M, Nn, K) in {"q|k": (N, 3584, 1792), "FF1": (N, 7168, 1792), "FF2": (N, 1792, 7168), "4096 x 4096 x 32768": (4096, 4096, 32768)}.items():
+            g = torch.Generator(device="cuda").manual_seed(0)
+            a = torch.randn(M, K, device="cuda", generator=g).to(BF)
+            w = (torch.randn(Nn, K, device="cuda", generator=g) * 0.05).to(BF)
+            out = torch.empty(M, Nn, dtype=BF, device="cuda")
+            measure(f"hipBLASLt (torch.matmul) {name} {M}x{Nn}x{K}, random data", lambda: torch.matmul(a, w.t(), out=out), 60.0, 2.0 * M * Nn * K)
+            bias = torch.randn(Nn, device="cuda")
+            measure(f"libk5 w4 (bias epilogue)  {name} {M}x{Nn}x{K}, random data", lambda: E.gemm(a, w, out=out, bias=bias, epilogue=E.EPI_BIAS), 60.0, 2.0 * M * Nn * K)
+        return
     measure("idle (nothing on the main stream)", lambda: None, 20.0)
     measure("dense attention, 47 616 tokens x 28 heads, random data", attn_case(), 150.0, 4.0 * N * N * 64 * 28)
     measure("dense attention, zero operands", attn_case(True), 150.0, 4.0 * N * N * 64 * 28)
