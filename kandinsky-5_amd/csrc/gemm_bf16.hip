@@ -1060,8 +1060,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const auto sw = __builtin_amdgcn_permlane16_swap(o[0][d], o[1][d], false, false);
             o[0][d] = sw[0]; o[1][d] = sw[1];
           }
+#ifdef W4_STORE_ABL   // timing-only A/B (tools/build_variant.sh -DW4_STORE_ABL, results WRONG): the same bytes to the same lines, but every store
+          // instruction covers 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B — what a transposing epilogue would buy
+          const int m_a = m0 + 128 * e_wm + 16 * j + 8 * (iq >> 1) + (e_l15 >> 1);
+          const int n_a = n0 + 128 * e_wn + 64 * (iq & 1) + 8 * (4 * (e_l15 & 1) + e_lc);
+          if (m_a < p.M && n_a < p.N) *reinterpret_cast<u32x4*>(p.C + (size_t)m_a * p.ldc + n_a) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+#else
           const int n = n0 + 128 * e_wn + 16 * (2 * iq + (e_lc & 1)) + 8 * (e_lc >> 1);
           if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(p.C + (size_t)m * p.ldc + n) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+#endif
         }
       };
       if constexpr (EPI == K5_EPI_GATE) {

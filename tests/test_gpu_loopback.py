@@ -666,6 +666,7 @@ def test_self_tuning_schedule_on_loopback_ranks(P, sparse):
     assert reps[0]["gather_GBps_in"] > 0
     for r in range(P):
         assert torch.equal(res[r][0], res[0][0]) and torch.equal(res[r][1], res[r][0])                        # ranks identical; second forward identical
-        assert res[r][2] == (2 * 28, 0), res[r][2]                                                            # 2 blocks x 28 heads of ONE forward: no trial launches counted
+        heads_here = 28 // P if "Ulysses" in reps[0]["chosen"] else 28      # the all-to-all schedule gives a rank 28 / P heads of every row; which one wins is the box's timing
+        assert res[r][2] == (2 * heads_here, 0), res[r][2]                                                    # 2 blocks x the rank's heads of ONE forward: no trial launches counted
     print(f"self-tuned schedule, P={P} sparse={sparse}: {reps[0]['chosen']} of {list(zip(names, [round(v, 3) for v in costs]))}; sharded vs fused {rel(res[0][0], fused):.3e}")
     assert rel(res[0][0], fused) <= 6e-3, rel(res[0][0], fused)

@@ -28,6 +28,9 @@ SHAPES = [  # name, M, N, K, epilogue
     ("FF1 + GELU", N_TOK, 7168, 1792, "gelu"),
     ("FF2 + gate", N_TOK, 1792, 7168, "gate"),
 ]
+if "--plain" in sys.argv:      # the model's shapes with the plain bf16 store (what a vendor-library call does)
+    SHAPES = [("q|k shape, plain store", N_TOK, 3584, 1792, "none"), ("out shape, plain store", N_TOK, 1792, 1792, "none"),
+              ("FF1 shape, plain store", N_TOK, 7168, 1792, "none"), ("FF2 shape, plain store", N_TOK, 1792, 7168, "none")]
 if "--ablate" in sys.argv:     # which part of an epilogue's time is the shape (output row stride, bytes) and which the arithmetic
     SHAPES = [("FF1 shape, plain store", N_TOK, 7168, 1792, "none"), ("FF1 shape, GELU", N_TOK, 7168, 1792, "gelu"),
               ("q|k shape, GELU", N_TOK, 3584, 1792, "gelu"), ("q|k shape, bias", N_TOK, 3584, 1792, "bias"),
