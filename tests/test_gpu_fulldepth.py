@@ -154,3 +154,36 @@ def test_tiny_50_step_schedule_vs_reference(w):
     print(f"tiny, 50 steps, w = {w}: engine vs reference fp32 {r_ref:.3e}, vs bf16-island oracle {r_16:.3e}; bf16 oracle vs reference {yard:.3e}")
     assert r_16 <= 1e-2, r_16
     assert r_ref <= 3e-2, r_ref
+
+
+@pytest.mark.parametrize("mask", [1, 3])
+def test_config1_in_full_what_fp8_costs_at_depth(full_dit, meta, mask):
+    """The fp8 modes (k5_dit_set_fp8 mask 1 = feed-forward, 3 = + q | k | V^T projections; opt-in, lossy) over BASELINE config 1 IN FULL — 32
+    blocks x 16 steps — against the reference's fp32 generate(): what 3 mantissa bits per operand cost on the FINAL LATENT, where the 2-block
+    velocity tests (tests/test_gpu_dit.py) say 5-6e-2 per forward.  Stated, not tuned: the bound is 10 x the bf16 path's own distance."""
+    from safetensors.torch import load_file
+    from kandinsky.generation_utils import sigma_schedule
+    c = meta["c1"]
+    G = load_file(os.path.join(HERE, "dit_fulldepth_c1.safetensors"))
+    T, H, W = c["latent"]
+    g = torch.Generator().manual_seed(c["xseed"])
+    te = {"text_embeds": torch.randn(c["L"], 3584, generator=g).cuda(), "pooled_embed": torch.randn(1, 768, generator=g).cuda()}
+    ne = {"text_embeds": torch.randn(c["Lnull"], 3584, generator=g).cuda(), "pooled_embed": torch.randn(1, 768, generator=g).cuda()}
+    pos = [torch.arange(T), torch.arange(H // 2), torch.arange(W // 2)]
+    noise = torch.randn(T, H, W, 16, generator=torch.Generator().manual_seed(c["seed"]))
+    sig = sigma_schedule(c["steps"], c["s"]).tolist()
+    lat = noise.clone().cuda()
+    full_dit.set_fp8(mask)
+    try:
+        full_dit.sample(lat, sig, te, ne, pos, torch.arange(c["L"]), torch.arange(c["Lnull"]), c["w"], scale_factor=(1.0, 2.0, 2.0))
+        torch.cuda.synchronize()
+    finally:
+        full_dit.set_fp8(False)
+    idx = G["sample_idx"]
+    got = lat.reshape(-1)[idx.cuda()].cpu()
+    nz = noise.reshape(-1)[idx]
+    r_ref, u_ref = rel(got, G["final_ref"]), rel(got - nz, G["final_ref"] - nz)
+    print(f"config 1 in full with fp8 mask {mask}: final latent vs reference fp32 {r_ref:.3e} (bf16 path: {c['bf16_oracle_vs_ref_final']:.3e}), "
+          f"on the applied update {u_ref:.3e} (bf16 path: {c['update_bf16_oracle_vs_ref']:.3e})")
+    assert torch.isfinite(lat).all()
+    assert r_ref <= 10 * max(c["bf16_oracle_vs_ref_final"], 1e-2), r_ref
