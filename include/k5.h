@@ -31,7 +31,7 @@ typedef enum { K5_EPI_BIAS = 0, K5_EPI_BIAS_M = 1, K5_EPI_GELU = 2, K5_EPI_GATE 
 
 /* bumped whenever an entry point is added or changes meaning; the host binding checks it BEFORE binding symbols, so that a stale
  * libk5.so fails with a clear message instead of a missing-symbol lookup (round 3: 4) */
-#define K5_ABI_VERSION 6
+#define K5_ABI_VERSION 7
 int k5_abi_version(void);
 const char* k5_last_error(void);
 
@@ -46,6 +46,12 @@ const char* k5_last_error(void);
  * K5_EPI_BIAS_M adds bias[m] (used to emit V^T = W_v . X^T directly). bias/gate are fp32. */
 int k5_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda,
                  int ldw, int ldc, int epilogue, const void* resid, int ldr, const float* gate, void* stream);
+/* The same GEMM on a NAMED kernel (tests and A/B tools; k5_gemm_bf16 picks by shape and cost): kernel 0 = as k5_gemm_bf16, 2 = 128 x 128 tiles,
+ * 4 = the four-wave persistent kernel, 5 = 128 x 128 quadrants with deep prefetch, 8 = the eight-wave ping-pong kernel (a kernel whose shape
+ * conditions do not hold falls through to the next one, as in the automatic choice); token_tile 0 = by cost, 128 / 192 / 256 = rows of the
+ * four-wave kernel's workgroup tile (ABI 7).  Every kernel sums a K column in the same order: results are bit-identical across them. */
+int k5_gemm_bf16_variant(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                         int epilogue, const void* resid, int ldr, const float* gate, void* stream, int kernel, int token_tile);
 
 /* S_f32[M][N] = alpha * A[M][K] . W[N][K]^T — the fp32 attention scores of the VAE mid block (diffusers Attention called from
  * HunyuanVideoMidBlock3D, kandinsky/models/vae.py:341-362, with prepare_causal_attention_mask vae.py:110-122).  causal_hw > 0:

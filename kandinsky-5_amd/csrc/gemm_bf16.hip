@@ -687,8 +687,22 @@ constexpr int W4_TRACE_BYTES = 0;
 constexpr int W4_PF_BYTES = 4 * 1024;   // EPI_GATE: per-wave bias | gate vectors of the epilogue
 typedef __attribute__((address_space(3))) void w4_lds_t;
 
-template <int EPI>
+// Round 5 — the token side of the tile is a template parameter: MT = 16-row token tiles per wave = 8 (256-row workgroup tile, the shape described
+// above), 6 (192 rows) or 4 (128 rows); the weight side stays 256 wide.  Small launches are decided by tile quantisation, not by the K loop: an
+// 8-GPU token shard (5952 rows) of an N = 1792 projection is 168 tiles of 256 x 256 on 256 CUs but 217 of 192 x 256 — one round at 3/4 of the
+// work; BASELINE config 1 (3328 rows) is 91 tiles of 256 x 256 but 182 of 128 x 256 — one round at half the work (the dispatch at the end of the
+// file picks by cost).  A K-tile is 16 MT MFMAs per wave; fragment reads per MFMA grow from 16/64 to 14/48 and 12/32, the W-operand stream per
+// MFMA by 4/3 and 2, which is why the big launches stay on MT = 8.  MT = 6 keeps the 256-row X image in LDS (its DMA instructions gather rows
+// 16 apart, so the unused quarter cannot be skipped per instruction: 12.5 % more global -> LDS bytes) and wave wm = 1 reads rows 96..191 through
+// two base registers; MT = 4 stages only the first 128-row half of the image (four X pieces per wave instead of eight).
+template <int EPI, int MT = 8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4_kernel(GemmP p) {
+  static_assert(MT == 8 || MT == 6 || MT == 4, "token tiles per wave");
+  static_assert(EPI != K5_EPI_F32 || MT == 8, "the frame-causal tile walk is written for 256-row tiles");
+  constexpr int TM = 32 * MT;            // token rows of the workgroup tile
+  constexpr int NM = 16 * MT, HM = 8 * MT;   // MFMAs per K-tile / per k-step and wave
+  constexpr int XD = MT == 4 ? 4 : 8;    // X-operand DMA instructions per wave and K-tile
+  constexpr int ND = 8 + XD;             // DMA instructions per wave and K-tile
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wm = wave >> 1;
@@ -717,7 +731,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     const int g = lid / per_group, first_m = g * GM;
     const int gsz = min(p.tiles_m - first_m, GM);
-    m0 = (first_m + (lid % per_group) % gsz) * K8_BM;
+    m0 = (first_m + (lid % per_group) % gsz) * TM;
     n0 = ((lid % per_group) / gsz) * K8_BN;
   };
   if (slot >= x_cnt) return;
@@ -728,6 +742,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const uint32_t vx0 = (uint32_t)(16 * (lane >> 3)) * lda2 + (uint32_t)(lane & 7) * 16u;
   const int drow = 128 * (wave >> 1) + 8 * (wave & 1);   // first row of this wave's 8 DMA instructions per operand
   const int dslot = 8 * wave;                            // ... and their LDS piece
+  const int drow_x = MT == 4 ? 4 * wave : drow, dslot_x = MT == 4 ? 4 * wave : dslot;   // MT = 4: the 16 pieces of the first 128 rows, 4 per wave
   uint32_t vw = vw0, vx = vx0;                           // lane offsets incl. the K advance of the DMA cursor
   __amdgpu_buffer_rsrc_t rW, rX;
   int d_ti = slot, d_kt = 0, d_cnt = 0;                  // DMA cursor: tile (index into this workgroup's walk), K-tile, K-tiles done
@@ -737,14 +752,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto set_dma_tile = [&](int ti) {
     int m0, n0;
     tile_origin(x_first + ti, m0, n0);
-    const int rows_w = min(p.N - n0, K8_BN), rows_x = min(p.M - m0, K8_BM);
+    const int rows_w = min(p.N - n0, K8_BN), rows_x = min(p.M - m0, MT == 4 ? 128 : K8_BM);
     rW = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.W) + (size_t)n0 * ldw2), 0,
                                            (int)(((uint32_t)(rows_w - 1) * (uint32_t)p.ldw + (uint32_t)p.K) * 2u), 0x00020000);
     rX = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.A) + (size_t)m0 * lda2), 0,
                                            (int)(((uint32_t)(rows_x - 1) * (uint32_t)p.lda + (uint32_t)p.K) * 2u), 0x00020000);
     // staggered start: each tile walks K from its own offset and wraps (the sum is order-independent up to fp32 rounding), so
     // the workgroups that run in lockstep do not all pull the same K columns - i.e. the same few L2 channels - at once
-    d_kt = W4_STAGGER ? (int)((unsigned)(W4_STAGGER * (m0 / K8_BM + n0 / K8_BN)) % (unsigned)nk) : 0;
+    d_kt = W4_STAGGER ? (int)((unsigned)(W4_STAGGER * (m0 / TM + n0 / K8_BN)) % (unsigned)nk) : 0;
     d_cnt = 0;
     vw = vw0 + (uint32_t)d_kt * (2 * BK); vx = vx0 + (uint32_t)d_kt * (2 * BK);
   };
@@ -759,9 +774,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   auto dma_x = [&](int stage) {
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + stage * W4_STAGE + W4_OP + (dslot + jj) * W4_PAD), 16, vx,
-                                               (uint32_t)(drow + jj) * lda2, 0, W4_AUX);
+    for (int jj = 0; jj < XD; ++jj)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + stage * W4_STAGE + W4_OP + (dslot_x + jj) * W4_PAD), 16, vx,
+                                               (uint32_t)(drow_x + jj) * lda2, 0, W4_AUX);
   };
   // after a K-tile's 16 DMAs: move the cursor; past the last tile it wraps onto the same tile (harmless loads that keep
   // the vmcnt arithmetic uniform; nothing reads them)
@@ -776,17 +791,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // fragment read addresses (LDS byte addresses; one base register per operand and stage, everything else an immediate)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(w4_lds_t*)dsm;
-  uint32_t wbs[2], xbs[2];
+  // X rows of wave wm: 16 MT wm + 16 j + l15.  Row q of the image sits in piece 16 (q >> 7) + (q & 15) at slot (q >> 4) & 7, so for MT = 8 / 4 one base
+  // (+ 128 j) does, and for MT = 6 wave 1 (rows 96 .. 191) needs two: slots 6, 7 of the first 16 pieces (j < 2), slots 0 .. 3 of the second (j >= 2).
+  uint32_t wbs[2], xbs[2], xbs2[2];
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
     wbs[st] = lds0 + st * W4_STAGE + (16 * wn + l15) * W4_PAD + lc * 16;
-    xbs[st] = lds0 + st * W4_STAGE + W4_OP + (16 * wm + l15) * W4_PAD + lc * 16;
+    const uint32_t h0 = lds0 + st * W4_STAGE + W4_OP + l15 * W4_PAD + lc * 16;
+    xbs2[st] = 0;
+    if (MT == 8) xbs[st] = h0 + wm * (16 * W4_PAD);
+    else if (MT == 6) { xbs[st] = h0 + wm * 768; xbs2[st] = h0 + wm * (16 * W4_PAD - 256); }
+    else xbs[st] = h0 + wm * 512;
     asm volatile("" : "+v"(wbs[st]), "+v"(xbs[st]));   // keep them in registers: the stage offset does not fit the 16-bit immediate
+    if (MT == 6) asm volatile("" : "+v"(xbs2[st]));
   }
+#define W4_XB(ST, J) ((MT == 6 && (J) >= 2) ? xbs2[ST] : xbs[ST])
   // fragment registers: k-step 0 of the current K-tile, and k-step 1 in one of two buffers (the other one receives the NEXT
   // K-tile's k-step 1 while this one is in use; k-step 0 of the next K-tile goes to wf0/xf0, dead after the first 64 MFMAs)
-  bf16x8 wf0[8], xf0[8], wf1[2][8], xf1[2][8];
-  f32x4 acc[8][8];   // [n-tile][m-tile]; written (not accumulated) by the first k-step of every output tile
+  bf16x8 wf0[8], xf0[MT], wf1[2][8], xf1[2][MT];
+  f32x4 acc[8][MT];   // [n-tile][m-tile]; written (not accumulated) by the first k-step of every output tile
 
   // ds_read_b128 as asm: the compiler would otherwise guard every fragment read with s_waitcnt vmcnt(..) against the LDS-DMA
   // writes in flight (it cannot tell the stages apart) and serialise the prefetch.  All waits are explicit below.
@@ -807,19 +830,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (dbg & 1) return;
     if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + stage * W4_STAGE + (dslot + d) * W4_PAD), 16, vw,
                                                         (uint32_t)(drow + d) * ldw2, 0, W4_AUX);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + stage * W4_STAGE + W4_OP + (dslot + d - 8) * W4_PAD), 16, vx,
-                                                  (uint32_t)(drow + d - 8) * lda2, 0, W4_AUX);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + stage * W4_STAGE + W4_OP + (dslot_x + d - 8) * W4_PAD), 16, vx,
+                                                  (uint32_t)(drow_x + d - 8) * lda2, 0, W4_AUX);
   };
 
   set_dma_tile(slot);
   dma_w(0); dma_x(0); dma_advance();
   dma_w(1); dma_x(1); dma_advance();
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND) : "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < 8; ++i) { W4_RD(wf0[i], wbs[0], i * 128); W4_RD(wf1[0][i], wbs[0], i * 128 + 64); }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { W4_RD(xf0[j], xbs[0], j * 128); W4_RD(xf1[0][j], xbs[0], j * 128 + 64); }
+  for (int j = 0; j < MT; ++j) { W4_RD(xf0[j], W4_XB(0, j), j * 128); W4_RD(xf1[0][j], W4_XB(0, j), j * 128 + 64); }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // (schedule 2 re-reads the k-step-1 fragments at the start of the K-tile; the extra 16 reads here happen once per workgroup)
 
@@ -835,9 +858,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4P 8, 64, 2   // measured: read spacing 1 -> 2 is +4-6 % on every shape; barrier at 16..64 and DMA spacing 6/8: equal within noise
 #endif
   constexpr int w4p[3] = {W4P};
-  constexpr int W4_DS = w4p[0], W4_BB = w4p[1], W4_RS = w4p[2];   // DMA spacing, barrier position, fragment-read spacing
-  static_assert(W4_DS * 15 < 128 && W4_BB >= 1, "schedule does not fit");
-  constexpr int W4_NB = (W4_BB + W4_DS - 1) / W4_DS < 16 ? (W4_BB + W4_DS - 1) / W4_DS : 16;   // this K-tile's DMAs issued before m = W4_BB
+  // MT = 6: 96 MFMAs, 16 DMAs 6 apart, barrier after m = 39, k-step-1 reads (14) from m = 40, k-step-0 reads from m = 68; MT = 4: 64 MFMAs, 12 DMAs 5
+  // apart, barrier after m = 15, reads (12 + 12) from m = 16 and m = 40
+  constexpr int W4_DS = MT == 8 ? w4p[0] : NM / ND, W4_BB = MT == 8 ? w4p[1] : (MT == 6 ? 40 : 16), W4_RS = w4p[2];   // DMA spacing, barrier position, fragment-read spacing
+  static_assert(W4_DS * (ND - 1) < NM && W4_BB >= 1, "schedule does not fit");
+  constexpr int W4_NB = (W4_BB + W4_DS - 1) / W4_DS < ND ? (W4_BB + W4_DS - 1) / W4_DS : ND;   // this K-tile's DMAs issued before m = W4_BB
+  constexpr int NR = 8 + MT;   // fragment reads per k-step
   auto ktile = [&](auto STC, auto FIRSTC) {
     constexpr int st = decltype(STC)::value;
     constexpr bool first = decltype(FIRSTC)::value;
@@ -846,11 +872,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int m = decltype(BASEC)::value; m < decltype(BASEC)::value + 16; ++m) {
         if (!(dbg & 8)) {
-          if (m < 64 && first) W4_MF0(wf0, xf0, m);
-          else if (m < 64) W4_MF(wf0, xf0, m);
-          else W4_MF(wf1[st], xf1[st], m - 64);
+          if (m < HM && first) W4_MF0(wf0, xf0, m);
+          else if (m < HM) W4_MF(wf0, xf0, m);
+          else W4_MF(wf1[st], xf1[st], m - HM);
         }
-        if (m % W4_DS == 0 && m / W4_DS < 16) dma1(st, m / W4_DS);
+        if (m % W4_DS == 0 && m / W4_DS < ND) dma1(st, m / W4_DS);
         if (m == W4_BB - 1) {
           if (dbg & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W4_NB) : "memory");
           else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(W4_NB) : "memory");
@@ -858,25 +884,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // fragment reads of K-tile t+1, W4_RS MFMAs apart (back to back they saturate the LDS: four waves x 1 KB per 16 cycles).
         // k-step 1 goes to the idle buffer and may start at the barrier; k-step 0 reuses wf0/xf0, free from m = 64
         if (!(dbg & 2)) {
-          constexpr int K1_AT = W4_BB >= 64 ? W4_BB + 16 * W4_RS : W4_BB;                       // first k-step-1 read
-          constexpr int K0_AT = W4_BB >= 64 ? W4_BB : (W4_BB + 16 * W4_RS > 64 ? W4_BB + 16 * W4_RS : 64);
-          static_assert(K0_AT + 15 * W4_RS < 128 && K1_AT + 15 * W4_RS < 128, "fragment reads do not fit");
-          if (m >= K0_AT && m < K0_AT + 16 * W4_RS && (m - K0_AT) % W4_RS == 0) {
+          constexpr int K1_AT = W4_BB >= HM ? W4_BB + NR * W4_RS : W4_BB;                       // first k-step-1 read
+          constexpr int K0_AT = W4_BB >= HM ? W4_BB : (W4_BB + NR * W4_RS > HM ? W4_BB + NR * W4_RS : HM);
+          static_assert(K0_AT + (NR - 1) * W4_RS < NM && K1_AT + (NR - 1) * W4_RS < NM, "fragment reads do not fit");
+          if (m >= K0_AT && m < K0_AT + NR * W4_RS && (m - K0_AT) % W4_RS == 0) {
             const int r = (m - K0_AT) / W4_RS;
             if (r < 8) W4_RD(wf0[r & 7], wbs[st ^ 1], (r & 7) * 128);
-            else W4_RD(xf0[r & 7], xbs[st ^ 1], (r & 7) * 128);
+            else W4_RD(xf0[r - 8], W4_XB(st ^ 1, r - 8), (r - 8) * 128);
           }
-          if (m >= K1_AT && m < K1_AT + 16 * W4_RS && (m - K1_AT) % W4_RS == 0) {
+          if (m >= K1_AT && m < K1_AT + NR * W4_RS && (m - K1_AT) % W4_RS == 0) {
             const int r = (m - K1_AT) / W4_RS;
             if (r < 8) W4_RD(wf1[st ^ 1][r & 7], wbs[st ^ 1], (r & 7) * 128 + 64);
-            else W4_RD(xf1[st ^ 1][r & 7], xbs[st ^ 1], (r & 7) * 128 + 64);
+            else W4_RD(xf1[st ^ 1][r - 8], W4_XB(st ^ 1, r - 8), (r - 8) * 128 + 64);
           }
         }
       }
     };
     chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 16>{}); chunk(std::integral_constant<int, 32>{});
-    chunk(std::integral_constant<int, 48>{}); chunk(std::integral_constant<int, 64>{}); chunk(std::integral_constant<int, 80>{});
-    chunk(std::integral_constant<int, 96>{}); chunk(std::integral_constant<int, 112>{});
+    chunk(std::integral_constant<int, 48>{});
+    if constexpr (MT >= 6) { chunk(std::integral_constant<int, 64>{}); chunk(std::integral_constant<int, 80>{}); }
+    if constexpr (MT >= 8) { chunk(std::integral_constant<int, 96>{}); chunk(std::integral_constant<int, 112>{}); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // K-tile t+1's fragments
     dma_advance();
   };
@@ -900,6 +927,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int S2_R0 = 98, S2_R0S = 2;         // k-step-0 reads of K-tile t+1: W at m = 98, 100, .. 112 and X at m = 99, 101, .. 113
   static_assert(S2_DX + 7 * S2_DXS < S2_WAIT, "all 16 DMAs of the K-tile are issued before the wait (vmcnt(16) = the tile before)");
   auto ktile2 = [&](auto STC, auto FIRSTC) {
+    static_assert(MT == 8, "schedule 2 is written for the 256-row tile");
     constexpr int st = decltype(STC)::value;
     constexpr bool first = decltype(FIRSTC)::value;
     auto chunk = [&](auto BASEC) {
@@ -975,8 +1003,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if constexpr (EPI == K5_EPI_F32) {                  // raw fp32 scores: C is float*, one 16-B store per quad
         float* cf = reinterpret_cast<float*>(p.C);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int m = m0 + 128 * e_wm + 16 * j + e_l15;
+        for (int j = 0; j < MT; ++j) {
+          const int m = m0 + 16 * MT * e_wm + 16 * j + e_l15;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int n = nb + 16 * i;
@@ -1017,7 +1045,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_VEC_FETCH(IQ, B) do { W4_RD(bq[B][0], vaddr, 128 * (IQ)); W4_RD(bq[B][1], vaddr, 128 * (IQ) + 64); \
                                 W4_RD(gq[B][0], vaddr, 512 + 128 * (IQ)); W4_RD(gq[B][1], vaddr, 512 + 128 * (IQ) + 64); } while (0)
       auto finish_rows = [&](int j, float bm, const u32x2 (&rr)[8]) {
-        const int m = m0 + 128 * e_wm + 16 * j + e_l15;
+        const int m = m0 + 16 * MT * e_wm + 16 * j + e_l15;
         if constexpr (EPI == K5_EPI_GATE) W4_VEC_FETCH(0, 0);
 #pragma unroll
         for (int iq = 0; iq < 4; ++iq) {     // n-tiles 2 iq and 2 iq + 1 together
@@ -1062,7 +1090,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
 #ifdef W4_STORE_ABL   // timing-only A/B (tools/build_variant.sh -DW4_STORE_ABL, results WRONG): the same bytes to the same lines, but every store
           // instruction covers 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B — what a transposing epilogue would buy
-          const int m_a = m0 + 128 * e_wm + 16 * j + 8 * (iq >> 1) + (e_l15 >> 1);
+          const int m_a = m0 + 16 * MT * e_wm + 16 * j + 8 * (iq >> 1) + (e_l15 >> 1);
           const int n_a = n0 + 128 * e_wn + 64 * (iq & 1) + 8 * (4 * (e_l15 & 1) + e_lc);
           if (m_a < p.M && n_a < p.N) *reinterpret_cast<u32x4*>(p.C + (size_t)m_a * p.ldc + n_a) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
 #else
@@ -1082,26 +1110,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // are in lockstep, not latency-bound.
         u32x2 rr[2][8];
         auto load_rows = [&](int j, u32x2 (&dst)[8]) {
-          const int m = min(m0 + 128 * e_wm + 16 * j + e_l15, p.M - 1);
+          const int m = min(m0 + 16 * MT * e_wm + 16 * j + e_l15, p.M - 1);
 #pragma unroll
           for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const u32x2*>(p.resid + (size_t)m * p.ldr + min(nb + 16 * i, p.N - 4));
         };
         load_rows(0, rr[0]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (j + 1 < 8) load_rows(j + 1, rr[(j + 1) & 1]);
+        for (int j = 0; j < MT; ++j) {
+          if (j + 1 < MT) load_rows(j + 1, rr[(j + 1) & 1]);
           asm volatile("" ::: "memory");
           finish_rows(j, 0.f, rr[j & 1]);
           asm volatile("" ::: "memory");
         }
       } else {
-        constexpr int G = 4;        // token tiles per phase
+        constexpr int G = MT == 6 ? 3 : 4;        // token tiles per phase
 #pragma unroll
-        for (int jh = 0; jh < 8 / G; ++jh) {
+        for (int jh = 0; jh < MT / G; ++jh) {
           float bias_m[G];
 #pragma unroll
           for (int jj = 0; jj < G; ++jj)
-            bias_m[jj] = (EPI == K5_EPI_BIAS_M && has_bias) ? p.bias[min(m0 + 128 * e_wm + 16 * (G * jh + jj) + e_l15, p.M - 1)] : 0.f;
+            bias_m[jj] = (EPI == K5_EPI_BIAS_M && has_bias) ? p.bias[min(m0 + 16 * MT * e_wm + 16 * (G * jh + jj) + e_l15, p.M - 1)] : 0.f;
           const u32x2 none[8] = {};
 #pragma unroll
           for (int jj = 0; jj < G; ++jj) finish_rows(G * jh + jj, bias_m[jj], none);
@@ -1123,6 +1151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = tid; i < W4_TRACE_N; i += 64) p.trace[(size_t)blockIdx.x * W4_TRACE_N + i] = (i < tr_i || i >= W4_TRACE_N - 2) ? tr_lds[i] : 0ull;
 #endif
 #undef W4_VEC_FETCH
+#undef W4_XB
 #undef W4_STAMP
 #undef W4_KT
 #undef W4_MF
@@ -1268,27 +1297,58 @@ int launch_q4_whole(GemmP p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
-template <int EPI>
-int launch_w4(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
+template <int EPI, int MT>
+int launch_w4_mt(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS + W4_TRACE_BYTES + W4_PF_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS + W4_TRACE_BYTES + W4_PF_BYTES) != hipSuccess)
       return K5_ERR_HIP;
     attr_set = true;
   }
 #ifdef W4_TRACE
   p.trace = getenv("K5_GEMM_TRACE") ? (unsigned long long*)strtoull(getenv("K5_GEMM_TRACE"), nullptr, 16) : nullptr;
 #endif
-  p.tiles_m = (p.M + K8_BM - 1) / K8_BM; p.tiles_n = (p.N + K8_BN - 1) / K8_BN;
+  p.tiles_m = (p.M + 32 * MT - 1) / (32 * MT); p.tiles_n = (p.N + K8_BN - 1) / K8_BN;
   const int tiles = p.tiles_m * p.tiles_n;
   const int full = tiles / num_cu * num_cu, rem = tiles - full;
-  const bool split_tail = !no_tail && full > 0 && rem > 0 && 2 * rem < num_cu;   // see launch_k8_mt
+  const bool split_tail = MT == 8 && !no_tail && full > 0 && rem > 0 && 2 * rem < num_cu;   // see launch_k8_mt
   p.lid_limit = split_tail ? full : tiles;
   p.tiles256_m = p.tiles_m; p.tiles256_n = p.tiles_n;
-  hipLaunchKernelGGL((gemm_bf16_w4_kernel<EPI>), dim3(min(p.lid_limit, num_cu)), dim3(256), W4_LDS + W4_TRACE_BYTES + W4_PF_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_w4_kernel<EPI, MT>), dim3(min(p.lid_limit, num_cu)), dim3(256), W4_LDS + W4_TRACE_BYTES + W4_PF_BYTES, stream, p);
   if (hipGetLastError() != hipSuccess) return K5_ERR_HIP;
   if (split_tail) return launch_tail<EPI>(p, stream, full, rem);
   return K5_OK;
+}
+
+// Which token-tile height: rounds of the CUs x the measured relative cost of a round (tools/gemm_block_shapes.py, profiles/r05_gemm_block_shapes_mt.log:
+// N = K = 1792, one round: 40-43 us at 256 rows, 34-37 at 192, 25-27 at 128 — a K-tile is paced by the global -> LDS round trip of a two-stage
+// pipeline, not by its MFMA count, so a shorter tile costs more than its share); a ragged last round of 256-row tiles costs nearly a whole one
+// even when the quadrant kernel takes it over (82 us for 1 round + 73 tiles).  Ties go to the taller tile.  K5_GEMM_MT=4/6/8 forces one (A/B).
+inline int w4_pick_mt(int M, int N, int num_cu, bool no_tail, int force_mt = 0, double* cost_out = nullptr) {
+  static const int force_env = getenv("K5_GEMM_MT") ? atoi(getenv("K5_GEMM_MT")) : 0;
+  const int force = force_mt ? force_mt : force_env;
+  const int tn = (N + K8_BN - 1) / K8_BN;
+  const double rel[3] = {1.0, 0.85, 0.63};
+  const int mts[3] = {8, 6, 4};
+  int best = 8; double best_cost = 1e30;
+  for (int v = 0; v < 3; ++v) {
+    const int tiles = ((M + 32 * mts[v] - 1) / (32 * mts[v])) * tn;
+    const int full = tiles / num_cu, rem = tiles % num_cu;
+    double c = rel[v] * (full + (rem == 0 ? 0.0 : (mts[v] == 8 && !no_tail && full > 0 && 2 * rem < num_cu ? 0.85 : 1.0)));
+    if (force == mts[v]) c = -1.0;
+    if (c < best_cost - 1e-9) { best_cost = c; best = mts[v]; }
+  }
+  if (cost_out) *cost_out = best_cost;
+  return best;
+}
+
+template <int EPI>
+int launch_w4(GemmP p, hipStream_t stream, int num_cu, bool no_tail, int mt) {
+  switch (mt) {
+    case 4: return launch_w4_mt<EPI, 4>(p, stream, num_cu, no_tail);
+    case 6: return launch_w4_mt<EPI, 6>(p, stream, num_cu, no_tail);
+    default: return launch_w4_mt<EPI, 8>(p, stream, num_cu, no_tail);
+  }
 }
 
 }  // namespace
@@ -1296,8 +1356,9 @@ int launch_w4(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
 // Host launcher (C++ linkage, used by the C-ABI layer in k5_api.hip and by the engine).
 int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K,
                         int lda, int ldw, int ldc, int epi, const void* resid, int ldr,
-                        const float* gate, hipStream_t stream, int force_kernel) {
+                        const float* gate, hipStream_t stream, int force_kernel, int force_mt) {
   if (M <= 0 || N <= 0 || K <= 0) return K5_ERR_ARG;
+  if (force_mt != 0 && force_mt != 4 && force_mt != 6 && force_mt != 8) return K5_ERR_ARG;
   if ((K & 7) || (lda & 7) || (ldw & 7)) return K5_ERR_ALIGN;  // 16-B aligned rows
   if (epi == K5_EPI_GATE && (!resid || !gate)) return K5_ERR_ARG;
   GemmP p;
@@ -1322,19 +1383,26 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   // 4-GPU token shards (329 tiles) +6-10 %; 8-GPU shards (168 tiles) lose 3-8 % to the 8-wave kernel's 192-row tile option,
   // which therefore keeps the range below 256 tiles).  K5_GEMM_V1=4 / 8 force one of them.
   const bool w4_ok = (K % (2 * BK)) == 0 && K >= 4 * BK && M >= 512 && N >= 256 && !(N & 7) && !(ldc & 7) && (epi != K5_EPI_GATE || !(ldr & 3));
-  if (w4_ok && (force_v1 == 4 || (force_v1 == 0 && tiles256 >= 256))) {
-    static int num_cu = 0;
-    if (!num_cu) {
-      int dev = 0; hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
-      num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    static const bool no_tail = getenv("K5_GEMM_NO_TAIL") != nullptr;
+  // Round 5: with the token-tile height chosen per launch (w4_pick_mt: 256 / 192 / 128 rows) the four-wave kernel also takes the launches below one
+  // round of 256 x 256 tiles — 8-GPU token shards (168 such tiles -> 217 of 192 rows) and BASELINE config 1 (91 -> 182 of 128 rows) — from
+  // K5_GEMM_W4_MIN (default 96) tiles of the chosen height up (measured, profiles/r05_gemm_block_shapes_*.log; until round 4 those ran on the
+  // 8-wave kernel / the 128 x 128 kernel).
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  static const bool no_tail = getenv("K5_GEMM_NO_TAIL") != nullptr;
+  static const int w4_min = getenv("K5_GEMM_W4_MIN") ? atoi(getenv("K5_GEMM_W4_MIN")) : 96;
+  const int mt_pick = w4_ok ? w4_pick_mt(M, N, num_cu, no_tail, force_mt) : 8;
+  const long long tiles_pick = (long long)((M + 32 * mt_pick - 1) / (32 * mt_pick)) * ((N + 255) / 256);
+  if (w4_ok && (force_v1 == 4 || (force_v1 == 0 && tiles_pick >= w4_min))) {
     switch (epi) {
-      case K5_EPI_BIAS: return launch_w4<K5_EPI_BIAS>(p, stream, num_cu, no_tail);
-      case K5_EPI_BIAS_M: return launch_w4<K5_EPI_BIAS_M>(p, stream, num_cu, no_tail);
-      case K5_EPI_GELU: return launch_w4<K5_EPI_GELU>(p, stream, num_cu, no_tail);
-      case K5_EPI_GATE: return launch_w4<K5_EPI_GATE>(p, stream, num_cu, no_tail);
+      case K5_EPI_BIAS: return launch_w4<K5_EPI_BIAS>(p, stream, num_cu, no_tail, mt_pick);
+      case K5_EPI_BIAS_M: return launch_w4<K5_EPI_BIAS_M>(p, stream, num_cu, no_tail, mt_pick);
+      case K5_EPI_GELU: return launch_w4<K5_EPI_GELU>(p, stream, num_cu, no_tail, mt_pick);
+      case K5_EPI_GATE: return launch_w4<K5_EPI_GATE>(p, stream, num_cu, no_tail, mt_pick);
       default: return K5_ERR_ARG;
     }
   }

@@ -20,6 +20,13 @@ int k5_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M
              "k5_gemm_bf16");
 }
 
+int k5_gemm_bf16_variant(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
+                         int ldc, int epilogue, const void* resid, int ldr, const float* gate, void* stream, int kernel, int token_tile) {
+  if (token_tile != 0 && token_tile != 128 && token_tile != 192 && token_tile != 256) return ret(K5_ERR_ARG, "k5_gemm_bf16_variant");
+  return ret(k5_launch_gemm_bf16(A, W, bias, C, M, N, K, lda, ldw, ldc, epilogue, resid, ldr, gate, (hipStream_t)stream, kernel, token_tile / 32),
+             "k5_gemm_bf16_variant");
+}
+
 int k5_causal_softmax_bf16(const float* scores, void* P, int S, int hw, int lds, int ldp, void* stream) {
   if (!scores || !P || lds < S) return K5_ERR_ARG;
   return ret(k5_launch_causal_softmax(scores, P, S, hw, lds, ldp, (hipStream_t)stream), "k5_causal_softmax_bf16");

@@ -8,7 +8,8 @@
 int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K,
                         int lda, int ldw, int ldc, int epi, const void* resid, int ldr,
                         const float* gate, hipStream_t stream,
-                        int force_kernel = 0);   // K5_GEMM_V1's numbering: 2 = the 128 x 128 direct-to-LDS kernel whatever the shape (callers that must keep a summation order)
+                        int force_kernel = 0,    // K5_GEMM_V1's numbering: 2 = the 128 x 128 direct-to-LDS kernel whatever the shape (callers that must keep a summation order)
+                        int force_mt = 0);       // four-wave kernel: 16-row token tiles per wave, 8 / 6 / 4 = 256- / 192- / 128-row workgroup tiles (0 = by cost)
 
 // Attention: O[q][h*64+d] = softmax(Q K^T / 8) V, bf16, head_dim 64, non-causal.
 //   Q  [q_len][ldq]  (head h at columns h*64..), K [kv_len][ldk], Vt [H*64][ldvt] = V transposed, O [q_len][ldo].

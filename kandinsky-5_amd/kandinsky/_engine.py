@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("K5_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libk5.so"))
 
 K5_OK = 0
-ABI_VERSION = 6          # include/k5.h K5_ABI_VERSION
+ABI_VERSION = 7          # include/k5.h K5_ABI_VERSION
 K5_F32, K5_BF16, K5_F16 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_M, EPI_GELU, EPI_GATE = 0, 1, 2, 3
 
@@ -61,6 +61,7 @@ SYMBOLS = {
     "k5_abi_version": (_I, []),
     "k5_last_error": (C.c_char_p, []),
     "k5_gemm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "k5_gemm_bf16_variant": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I]),
     "k5_gemm_bf16_f32out": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "k5_causal_softmax_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "k5_vae_attention512_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
@@ -239,13 +240,19 @@ def _need_cuda(*ts):
             raise RuntimeError("libk5 kernels run on the GPU only: got a CPU tensor (no CPU fallback)")
 
 
-def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, out=None):
-    """out[M,N] = a[M,K] @ w[N,K]^T (+bias) with fused epilogue. a, w bf16; bias/gate fp32."""
+def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, out=None, kernel=0, token_tile=0):
+    """out[M,N] = a[M,K] @ w[N,K]^T (+bias) with fused epilogue. a, w bf16; bias/gate fp32.
+    kernel / token_tile != 0: the named kernel / tile height (k5_gemm_bf16_variant; tests and A/B tools)."""
     _need_cuda(a, w, bias, resid, gate)
     M, K = a.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    if kernel or token_tile:
+        check(lib().k5_gemm_bf16_variant(ptr(a), ptr(w), ptr(bias), ptr(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
+                                         epilogue, ptr(resid), 0 if resid is None else resid.stride(0), ptr(gate),
+                                         stream_ptr(a.device), int(kernel), int(token_tile)), "k5_gemm_bf16_variant")
+        return out
     check(lib().k5_gemm_bf16(ptr(a), ptr(w), ptr(bias), ptr(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
                              epilogue, ptr(resid), 0 if resid is None else resid.stride(0), ptr(gate),
                              stream_ptr(a.device)), "k5_gemm_bf16")

@@ -115,6 +115,41 @@ def test_gemm_four_wave_kernel_is_race_free_and_handles_edges(E):
     assert torch.count_nonzero(out[:, N:]) == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(5952, 1792, 1792), (3328, 1792, 384), (3328 - 40, 2048 - 24, 256), (1792, 5952, 256), (700, 1000, 512)])
+def test_gemm_four_wave_token_tile_heights(E, M, N, K):
+    """Round 5: the four-wave kernel with 256- / 192- / 128-row token tiles (8 / 6 / 4 MFMA row tiles per wave; the dispatch picks by
+    tile quantisation: 8-GPU shards, BASELINE config 1).  Every height sums a K column in the same order as the 128 x 128 kernel: the
+    results must be BIT-identical to it for every epilogue, repeatable (the LDS traffic is ordered by counted waits only), and right."""
+    a, w = bfr(rnd(M, K, seed=81)), bfr(rnd(N, K, seed=82, scale=0.05))
+    ad, wd = a.cuda().to(BF), w.cuda().to(BF)
+    acc = a @ w.t()
+    b, bm = bfr(rnd(N, seed=83, scale=0.1)), bfr(rnd(M, seed=84))
+    resid, gate = bfr(rnd(M, N, seed=85)), rnd(N, seed=86)
+    ld = (N + 7) // 8 * 8 + 8
+
+    def run(kernel, tile):
+        out = {}
+        out["bias"] = E.gemm(ad, wd, b.cuda(), E.EPI_BIAS, kernel=kernel, token_tile=tile)
+        out["nobias"] = E.gemm(ad, wd, None, E.EPI_BIAS, kernel=kernel, token_tile=tile)
+        out["gelu"] = E.gemm(ad, wd, None, E.EPI_GELU, kernel=kernel, token_tile=tile)
+        r = resid.cuda().to(BF)
+        out["gate"] = E.gemm(ad, wd, b.cuda(), E.EPI_GATE, resid=r, gate=gate.cuda(), out=r, kernel=kernel, token_tile=tile)
+        o = torch.zeros(M, ld, dtype=BF, device="cuda")
+        E.gemm(ad, wd, bm.cuda(), E.EPI_BIAS_M, out=o, kernel=kernel, token_tile=tile)
+        out["bias_m"] = o
+        return out
+    base = run(2, 0)                                                     # the 128 x 128 kernel
+    assert_bf16_close(base["bias"], bfr(acc + b), what="128x128 bias")
+    assert_bf16_close(base["gelu"], bfr(torch.nn.functional.gelu(bfr(acc))), what="128x128 gelu")
+    assert_bf16_close(base["bias_m"][:, :N], bfr(acc + bm[:, None]), what="128x128 bias_m")
+    for tile in (256, 192, 128):
+        for rep in range(3):
+            got = run(4, tile)
+            for k in base:
+                assert torch.equal(got[k], base[k]), f"{M}x{N}x{K} token tile {tile} {k} (run {rep}): {int((got[k] != base[k]).sum())} values differ from the 128x128 kernel"
+        assert torch.count_nonzero(got["bias_m"][:, N:]) == 0
+
+
 def test_gemm_is_transpose_correct(E):
     """A = I with an asymmetric W catches any row/col swap in the MFMA C/D mapping (guide rule 16)."""
     n = 256
