@@ -1056,6 +1056,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (iq < 3) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            // the fetched quads stay LIVE up to here whether or not they are used: without a bias the bias quads are dead values to the compiler, which
+            // may hand their registers to something else right behind the ds_read — and the data, arriving later, lands on top of it (round 5: wrong
+            // gated outputs without a bias on the 192- / 128-row tiles; the 256-row form happened to get away with it)
+            asm volatile("" : "+v"(bq[iq & 1][0]), "+v"(bq[iq & 1][1]), "+v"(gq[iq & 1][0]), "+v"(gq[iq & 1][1]));
           }
           u32x2 o[2];
 #pragma unroll

@@ -134,6 +134,8 @@ def test_gemm_four_wave_token_tile_heights(E, M, N, K):
         out["gelu"] = E.gemm(ad, wd, None, E.EPI_GELU, kernel=kernel, token_tile=tile)
         r = resid.cuda().to(BF)
         out["gate"] = E.gemm(ad, wd, b.cuda(), E.EPI_GATE, resid=r, gate=gate.cuda(), out=r, kernel=kernel, token_tile=tile)
+        r2 = resid.cuda().to(BF)      # the feed-forward's gated residual has NO bias (nn.py:352-361): its own instantiation of the epilogue
+        out["gate_nobias"] = E.gemm(ad, wd, None, E.EPI_GATE, resid=r2, gate=gate.cuda(), out=r2, kernel=kernel, token_tile=tile)
         o = torch.zeros(M, ld, dtype=BF, device="cuda")
         E.gemm(ad, wd, bm.cuda(), E.EPI_BIAS_M, out=o, kernel=kernel, token_tile=tile)
         out["bias_m"] = o
@@ -142,6 +144,10 @@ def test_gemm_four_wave_token_tile_heights(E, M, N, K):
     assert_bf16_close(base["bias"], bfr(acc + b), what="128x128 bias")
     assert_bf16_close(base["gelu"], bfr(torch.nn.functional.gelu(bfr(acc))), what="128x128 gelu")
     assert_bf16_close(base["bias_m"][:, :N], bfr(acc + bm[:, None]), what="128x128 bias_m")
+    inner = bfr(acc)
+    ref = bfr(resid + gate * inner)
+    err = (base["gate_nobias"].float().cpu() - ref).abs()
+    assert not (err > 1e-3 + 3 * 2.0 ** -7 * ref.abs() + gate.abs() * 2.0 ** -7 * inner.abs()).any(), f"128x128 gate without bias: max abs err {err.max():.4g}"
     for tile in (256, 192, 128):
         for rep in range(3):
             got = run(4, tile)
