@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """bench.py — DiT denoising steps/sec of the MI355X engine on BASELINE.json's metric/config.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, the reference's launch
+contract: README.md:269-276, kandinsky/utils.py:40-55).  Called WITHOUT that environment, `python bench.py --gpus N` launches itself:
+it re-executes under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` with every
+flag forwarded, rank 0 prints the one JSON line, and the exit code is the launcher's (non-zero if any rank failed).
 
 A "step" = one Euler update of the flow-matching sampler = one DiT forward (guidance_weight = 1,
 config_5s_nocfg) over the synthetic 5 s 768x512 latent (31,64,96,16) -> N = 47 616 visual tokens,
@@ -187,6 +192,17 @@ def parity_check(dit, noise, dev, sig, te, ne, vpos, tpos, ntpos, wl, sparse):
     return out
 
 
+def self_launch_command(argv, gpus, port=None):
+    """`python bench.py --gpus N ...` outside torch.distributed.run: the command that runs the same flags as N ranks on this node."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +223,9 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true", help="skip the separate per-family timing pass")
     ap.add_argument("--sp-slices", type=int, default=1, help="sequence parallelism: exchange K / V^T of a block in this many slices and attend "
                     "each slice as it lands (engine option sp_slices; 1 = one in-place all-gather per block)")
+    ap.add_argument("--sp-autotune", action="store_true",
+                    help="N > 1: let the engine time the admissible exchanges at the first sharded forward and keep the fastest (opt-in: the choice depends "
+                         "on timings and the schedules differ in summation order; recorded in the line as sp_schedule)")
     ap.add_argument("--cfg-parallel", action="store_true",
                     help="N even, a workload with guidance (5s_sft, 10s_hd_sft): ranks [0, N/2) run the conditional forward, [N/2, N) the unconditional "
                          "one, each group sequence-parallel inside; the pair exchange lives in the engine (k5_dit_cfg_pair_init)")
@@ -229,9 +248,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: become one (the ranks then take the branch below); every flag is forwarded verbatim
+        import subprocess
+        cmd = self_launch_command(sys.argv[1:], args.gpus)
+        print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with --nproc-per-node {args.gpus} (or call bench.py without a launcher)")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        raise SystemExit(f"bench.py rank {rank}: needs {args.gpus} devices on this node, found {ndev}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -275,6 +302,8 @@ def main():
         dit.set_option("emulate_world", args.emulate_shard)
     if args.sp_slices > 1:
         dit.set_option("sp_slices", args.sp_slices)
+    if args.sp_autotune:
+        dit.set_option("sp_autotune", 1)
     for kv in args.engine_option:
         dit.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if args.attn_online:
@@ -491,6 +520,7 @@ def main():
             invalid.append("the latent after the timed steps differs from the committed pin of this (workload, steps) beyond the stated tolerance (latent_pin)")
         if parity is not None and parity.get("status") == "FAILED":
             invalid.append("the first two steps of this configuration differ from the reference golden beyond the stated tolerance (parity_check)")
+        out["rccl_ranks_seen"] = dit.get_option("rccl_ranks")   # ncclCommCount of the engine's communicator: N under RCCL, 0 on one GPU, -1 for a loopback / emulated group
         if world > 1:
             out["sp_schedule"] = dit.sp_schedule()     # which exchange the engine's self-tuning picked on this node, and what it measured
         if rank_check is not None:

@@ -359,8 +359,10 @@ int k5_dit_get_option(k5_dit* dit, const char* name, int* value);
  * the node.  The first sharded forward of a handle with more than one rank therefore times one block's self-attention section under
  * every admissible candidate on its own shapes; the ranks exchange their times, each candidate costs its slowest rank, the cheapest is
  * kept for the life of the handle (every rank decides alike from the same table).  Options set explicitly through k5_dit_set_option
- * ("sp_mode", "sp_slices", "sp_nabla_passes") are left alone; "sp_autotune" 0 switches the tuner off (the default for loopback groups),
- * 2 makes the next sharded forward tune again.  k5_dit_sp_schedule: JSON text of what was measured and chosen, incl. the bare gather's
+ * ("sp_mode", "sp_slices", "sp_nabla_passes") are left alone, and a tuning run only assigns the options it varied (dense: "sp_mode" /
+ * "sp_slices"; NABLA: "sp_nabla_passes").  The tuner is OPT-IN ("sp_autotune" 1; K5_SP_AUTOTUNE=1): its choice comes from timings and the
+ * schedules sum in different orders, so with it on the same seed may give different bits on two nodes; off (the default) a handle runs the
+ * all-gather schedule.  2 makes the next sharded forward tune again.  k5_dit_sp_schedule: JSON text of what was measured and chosen, incl. the bare gather's
  * bytes and GB/s ("{}" before the first tuning run); returns the text length, copies at most len - 1 characters + NUL (buf may be null).
  * k5_sp_pick_schedule: the selection rule alone (host arithmetic, no GPU): times[rank * ncand + cand] in ms, <= 0 / non-finite = did not
  * run on that rank; valid (nullable) masks candidates; returns the chosen candidate or -1, max-over-ranks per candidate in cost_out. */
@@ -370,6 +372,13 @@ int k5_sp_pick_schedule(const float* times, int ncand, int world, const int* val
 int k5_dit_attn_variant_counts(k5_dit* dit, long long* fixed_heads, long long* online_heads, int reset);
 /* kept / possible 64x64 blocks of the NABLA maps computed while profiling was on, since that reset (realised density). */
 int k5_dit_nabla_block_counts(k5_dit* dit, long long* kept, long long* possible);
+/* Diagnostics (ABI 7): while a tap is set, every NABLA map the handle computes on the one-GPU path — one per visual block and forward, in execution
+ * order — is expanded to uint8 [H][N/64][N/64] (1 = kept; row = query block, fractal order) behind the ones already taken in the caller's device
+ * buffer, as long as it fits; k5_dit_nabla_tap_count: maps computed since the tap was set (a count beyond capacity / map size = the buffer was
+ * too small).  dev_u8 = NULL removes the tap.  Lets a test put the engine's map of block b at step s next to the reference's own
+ * (nablaT_v2, kandinsky/models/utils.py:136-163, as nn.py:257-298 calls it inside every block): tests/test_gpu_fulldepth.py. */
+int k5_dit_set_nabla_tap(k5_dit* dit, void* dev_u8, long long capacity_bytes);
+int k5_dit_nabla_tap_count(k5_dit* dit, long long* maps);
 /* ... and the blocks the list-driven attention executed for those maps (one-GPU path): the rows of a workgroup share ONE key-tile list, the
  * union of what they selected (replaces flex_attention's per-row block walk, nn.py:257-280), so a row also steps over tiles only its
  * neighbours wanted; kept / executed is the launch's union efficiency. */

@@ -55,21 +55,22 @@ namespace {
 struct DevBuf {   // owning device buffer (move-only): freed with whatever holds it — the handle, a staged tensor, a block's weights
   void* p = nullptr;
   size_t bytes = 0;
+  bool owned = true;   // false: a view into somebody else's buffer (alias), never freed from here
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
-  DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) { o.p = nullptr; o.bytes = 0; o.owned = true; }
+  DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; owned = o.owned; o.p = nullptr; o.bytes = 0; o.owned = true; } return *this; }
   ~DevBuf() { release(); }
   int ensure(size_t n) {
     if (n <= bytes) return K5_OK;
-    if (p) (void)hipFree(p);
-    p = nullptr; bytes = 0;
+    release();
     HIPCHK(hipMalloc(&p, n));
     bytes = n;
     return K5_OK;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  void release() { if (p && owned) (void)hipFree(p); p = nullptr; bytes = 0; owned = true; }
+  void alias(void* ptr, size_t n) { release(); p = ptr; bytes = n; owned = false; }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -150,6 +151,7 @@ struct Comm {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;   // optional: what the communicator itself says its size is (k5_dit_get_option "rccl_ranks")
   int open(const char* path) {
     if (lib) return K5_OK;
     const char* cands[] = {path, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
@@ -166,6 +168,7 @@ struct Comm {
     GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
     Send = (decltype(Send))dlsym(lib, "ncclSend"); Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
     GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+    CommCount = (decltype(CommCount))dlsym(lib, "ncclCommCount");
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) {
       k5_set_error("RCCL library lacks a required nccl* symbol"); return K5_ERR_STATE;
     }
@@ -338,6 +341,7 @@ struct k5_dit {
   // of adjacent tiles of one frame: their sliding-tile windows share 10 of 11 frames.  Same arithmetic per row (a row's key tiles are walked
   // in the same ascending order), so outputs are bit-identical with it on or off.
   int nabla_pair_frames = 1;
+  void* nabla_tap = nullptr; long long nabla_tap_cap = 0, nabla_tap_n = 0;   // k5_dit_set_nabla_tap: caller's device buffer, its size, maps taken so far
   int nabla_fuse_means = 1;   // the q / k block means come out of the norm + RoPE pass (k5_launch_rmsnorm_rope mean_q / mean_k); 0: their own pass (rounds 1-3)
   DevBuf ws_nabla_kept;                            // u64 kept-block count of the forward's first NABLA map
   unsigned long long* h_nabla_kept = nullptr;      // its pinned host copy
@@ -358,8 +362,11 @@ struct k5_dit {
   // all-to-all; for NABLA one or two passes over the lists — is a property of the NODE (xGMI link rates, how RCCL drives them) that no
   // single-GPU box can measure.  So the first sharded forward of a handle (world > 1) times one block's self-attention section under
   // every admissible candidate on its own shapes, the ranks agree on max-over-ranks per candidate, and the fastest is kept for the life
-  // of the handle.  Knobs the caller set explicitly are left alone; "sp_autotune" = 0 switches it off.
-  bool sp_autotune = true, sp_tuned = false;
+  // of the handle.  Knobs the caller set explicitly are left alone, and only the knobs a run VARIED are assigned from its winner.
+  // OPT-IN since round 5 ("sp_autotune" = 1, K5_SP_AUTOTUNE=1, bench.py --sp-autotune): the winner comes from wall-clock timings and the schedules
+  // sum in different orders (one or two NABLA passes, gather / sliced exchange / Ulysses), so with it on the same seed may give different bits on
+  // two nodes or two runs; off, a handle always runs the all-gather schedule unless told otherwise.
+  bool sp_autotune = false, sp_tuned = false;
   int sp_user_set = 0;                             // bit 0: sp_mode, 1: sp_slices, 2: sp_nabla_passes were set through k5_dit_set_option
   std::string sp_report;                           // JSON text of the last tuning run (k5_dit_sp_schedule)
   DevBuf ws_tune;
@@ -591,6 +598,11 @@ bool sa_sp_fp8_in(const k5_dit* d, const AttnW& a, int rows, int rows_pad, bool 
 // "nabla_fuse_means": the fused form gives every thread 64 consecutive rows of one 16-byte column chunk, i.e. the launch has rows / 64 x heads x 8
 // threads — a sequence-parallel shard of the 10 s clip (366 blocks x 28 heads: 82 k threads, a sixth of the resident capacity) runs it latency-
 // bound and loses 3 ms per step to gain 1 (measured, incl. an 8-deep prefetch ring); from ~150 k threads up it wins.  2 = always.
+// bytes of the NABLA workspace for nqb selected rows of nb: the lists are per group of >= 2 rows unless "nabla_group_rows" = 1 was asked for
+size_t nabla_ws_bytes(const k5_dit* d, int H, int nb, int nqb) {
+  const int gmin = d->nabla_group_rows == 1 ? 1 : 2;
+  return k5_nabla_workspace_bytes(H, nb, nqb, (nqb + gmin - 1) / gmin);
+}
 bool nabla_means_fused(const k5_dit* d, int rows, int heads) {
   return d->nabla_fuse_means == 2 || (d->nabla_fuse_means == 1 && (long long)(rows / 64) * heads * 8 >= 150000);
 }
@@ -641,7 +653,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     void *mq = nullptr, *mk = nullptr;
     const bool fuse_means = pre && nabla && nabla_means_fused(d, rows, 2 * H);
     if (fuse_means) {
-      K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, rows / 64)));
+      K5CHK(d->ws_nabla.ensure(nabla_ws_bytes(d, H, rows / 64, rows / 64)));
       k5_nabla_workspace_means(d->ws_nabla.p, H, rows / 64, &mq, &mk);
     } else if (pre && nabla) { K5CHK(d->ws_kc.ensure((size_t)rows * D * 2)); kc = d->ws_kc.p; }
     float* stats = nullptr;
@@ -676,12 +688,18 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
     const int nb = rows / 64;
     const int grp = pre ? d->nabla_grp_now : 4;   // 64-query rows per key-tile list = per attention workgroup
     const int pair = (grp == 2 && d->nabla_pair_frames) ? nabla->Hb * nabla->Wb : 0;
-    K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb)));
+    K5CHK(d->ws_nabla.ensure(nabla_ws_bytes(d, H, nb, nb)));
     {
       Scope sc(d, s, "nabla_map");
       const bool fm = pre && nabla_means_fused(d, rows, 2 * H);   // the means are in the workspace already
       K5CHK(k5_launch_nabla_select_rect(fm ? nullptr : qk, fm ? nullptr : (const bf16_t*)qk + D, 2 * D, 2 * D, H, rows, 0, rows, nabla->T, nabla->Hb, nabla->Wb, nabla->wT,
                                         nabla->wH, nabla->wW, nabla->P, d->ws_nabla.p, s, 0, 0, grp, pair));
+    }
+    if (d->nabla_tap) {   // diagnostics (k5_dit_set_nabla_tap): this launch's map, expanded, behind the ones already taken
+      const long long sz = (long long)H * nb * nb;
+      if ((d->nabla_tap_n + 1) * sz <= d->nabla_tap_cap)
+        K5CHK(k5_launch_nabla_mask_u8(d->ws_nabla.p, H, nb, nb, (char*)d->nabla_tap + d->nabla_tap_n * sz, s));
+      ++d->nabla_tap_n;
     }
     if (d->profiling) {   // realised density of the map (bench.py: attention FLOPs actually done) and tiles the launch executes for it
       K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
@@ -822,7 +840,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
   if (!fuse_q) {
     void* mq = nullptr;
     if (nabla && nabla_means_fused(d, rows, H)) {   // the query-block means of the rank's rows, straight into the map's workspace
-      K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, N / 64, rows / 64)));
+      K5CHK(d->ws_nabla.ensure(nabla_ws_bytes(d, H, N / 64, rows / 64)));
       k5_nabla_workspace_means(d->ws_nabla.p, H, N / 64, &mq, nullptr);
     }
     Scope sc(d, s, "elementwise");
@@ -892,7 +910,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
     // lives on the 256-query form; dense maps: that form, balanced
     const int grp = (d->nabla_grp_now < 4 && d->sp_nabla_passes == 1) ? d->nabla_grp_now : 4;
     const int pair = (grp == 2 && d->nabla_pair_frames) ? nabla->Hb * nabla->Wb : 0;   // rows l and l + S of the rank's shard: same tile, next frame
-    K5CHK(d->ws_nabla.ensure(k5_nabla_workspace_bytes(H, nb, rows / 64)));   // the logits region by the rank's own query-block rows
+    K5CHK(d->ws_nabla.ensure(nabla_ws_bytes(d, H, nb, rows / 64)));   // the logits and list regions by the rank's own query-block rows
     {
       Scope sc(d, s, "nabla_map");
       K5CHK(k5_launch_nabla_key_means_from_slots(kmeans, H, nb, slot_blocks, d->ws_nabla.p, s));
@@ -905,7 +923,7 @@ int run_self_attention_sp(k5_dit* d, hipStream_t s, const AttnW& a, const void* 
       d->nabla_possible += (long long)H * (rows / 64) * nb;
     }
     const int *list, *cnt, *cnt_local;
-    k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt, &cnt_local);
+    k5_nabla_workspace_views(d->ws_nabla.p, H, nb, nullptr, nullptr, &list, &cnt, &cnt_local, rows / 64);
     K5CHK(d->ws_attn_bal.ensure(k5_attention_balance_bytes(H, rows)));
     K5CHK(nabla_density_hint(d, H, rows / 64, nb, s));
     if (grp < 4) {
@@ -1292,7 +1310,7 @@ int sp_pick(const float* times, int ncand, int world, const int* valid, float* c
 
 int sp_autotune_run(k5_dit* d, hipStream_t s, int N, int L, const NablaArgs* nabla) {
   const int P = d->sp_world, H = d->Hh, D = d->D;
-  d->sp_tuned = true;                                  // whatever happens below: once per handle
+  d->sp_tuned = true;                                  // once per handle; the guard below takes it back if the run does not complete
   std::vector<SpCand> cands;
   if (!nabla) {
     cands.push_back({0, 1, 1, "K / V^T all-gather"});
@@ -1305,13 +1323,26 @@ int sp_autotune_run(k5_dit* d, hipStream_t s, int N, int L, const NablaArgs* nab
   const int nc = (int)cands.size();
   if (nc < 2) { d->sp_report = "{\"tuned\": false, \"reason\": \"one admissible schedule\"}"; return K5_OK; }
   const int save_mode = d->sp_mode, save_slices = d->sp_slices, save_passes = d->sp_nabla_passes, save_prof = d->profiling;
+  // every exit path — the failure returns inside the candidate loop included — leaves the handle as it found it: the caller's options and profiling
+  // level, no leaked events, the RoPE cache invalidated (the trial runs zeroed the tables), and "not tuned" unless the run completed
+  struct Guard {
+    k5_dit* d; int mode, slices, passes, prof; hipEvent_t e0 = nullptr, e1 = nullptr; bool done = false;
+    ~Guard() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      d->profiling = prof;
+      d->key_vpos.clear(); d->key_shape[0] = d->key_shape[1] = d->key_shape[2] = 0;
+      d->nabla_hint_pending = false;
+      if (!done) { d->sp_mode = mode; d->sp_slices = slices; d->sp_nabla_passes = passes; d->sp_tuned = false; }
+    }
+  } guard{d, save_mode, save_slices, save_passes, save_prof};
   d->profiling = 0;
   unsigned long long cnt_save[4] = {0, 0, 0, 0};       // the trial launches must not show up in the softmax-form counters (k5_dit_attn_variant_counts)
   K5CHK(ensure_zeroed(d->ws_attn_cnt, 32, s));
   HIPCHK(hipMemcpyAsync(cnt_save, d->ws_attn_cnt.p, 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventCreate(&guard.e0)); HIPCHK(hipEventCreate(&guard.e1));
+  const hipEvent_t e0 = guard.e0, e1 = guard.e1;
   std::vector<float> mine(nc, -1.f);
   double comm_ms = -1.0, comm_bytes = 0.0;
   const AttnW& a = d->vblocks[0].self_attn;
@@ -1365,17 +1396,18 @@ int sp_autotune_run(k5_dit* d, hipStream_t s, int N, int L, const NablaArgs* nab
   std::vector<float> all((size_t)P * nc), cost(nc);
   HIPCHK(hipMemcpyAsync(all.data(), d->ws_tune.p, all.size() * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   const int best = sp_pick(all.data(), nc, P, nullptr, cost.data());
-  d->profiling = save_prof;
   // the trial runs used the handle's workspaces with made-up operands: put back what outlives a forward
   HIPCHK(hipMemcpyAsync(d->ws_attn_cnt.p, cnt_save, 32, hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));                     // cnt_save is a local
   K5CHK(reset_attn_pref(d, s));
-  d->key_vpos.clear(); d->key_shape[0] = d->key_shape[1] = d->key_shape[2] = 0;   // the RoPE tables were zeroed: rebuild them
-  d->nabla_hint_pending = false;
-  if (best < 0) { d->sp_mode = save_mode; d->sp_slices = save_slices; d->sp_nabla_passes = save_passes; d->sp_report = "{\"tuned\": false, \"reason\": \"no candidate ran\"}"; return K5_OK; }
-  d->sp_mode = cands[best].mode; d->sp_slices = cands[best].slices; d->sp_nabla_passes = cands[best].passes;
+  guard.done = true;                                   // from here on the run counts as tuned (the guard still restores profiling and drops the RoPE cache)
+  d->sp_mode = save_mode; d->sp_slices = save_slices; d->sp_nabla_passes = save_passes;
+  if (best < 0) { d->sp_report = "{\"tuned\": false, \"reason\": \"no candidate ran\"}"; return K5_OK; }
+  // only what this run VARIED is taken from the winner (a dense run never touches "sp_nabla_passes", a NABLA run never "sp_mode" / "sp_slices"),
+  // and a knob the caller set is never a varied one (the candidate lists above leave it out)
+  if (!nabla) { d->sp_mode = cands[best].mode; d->sp_slices = cands[best].slices; }
+  else d->sp_nabla_passes = cands[best].passes;
   char buf[256];
   std::string rep = "{\"tuned\": true, \"world\": " + std::to_string(P) + ", \"tokens\": " + std::to_string(N) + ", \"attention\": \"" + (nabla ? "nabla" : "dense") +
                     "\", \"chosen\": \"" + cands[best].name + "\", \"unit\": \"ms per block's self-attention section, max over ranks\", \"candidates\": [";
@@ -1772,14 +1804,27 @@ extern "C" int k5_dit_finalize(k5_dit* d) {
     if (nbv) {
       K5CHK(d->cx_wk_all.ensure(nbv * D * D * 2)); K5CHK(d->cx_wv_all.ensure(nbv * D * D * 2));
       K5CHK(d->cx_bk_all.ensure(nbv * D * 4)); K5CHK(d->cx_bv_all.ensure(nbv * D * 4)); K5CHK(d->cx_knorm_all.ensure(nbv * 64 * 4));
-      for (size_t i = 0; i < nbv; ++i) {
+      bool complete = true;
+      for (size_t i = 0; i < nbv && complete; ++i) {
         const AttnW& a = d->vblocks[i].cross_attn;
-        if (!a.wk.p || !a.wv.p || !a.bk.p || !a.bv.p || !a.norm.p) { d->cross_kv_batched = 0; break; }
-        HIPCHK(hipMemcpy((char*)d->cx_wk_all.p + i * D * D * 2, a.wk.p, D * D * 2, hipMemcpyDeviceToDevice));
-        HIPCHK(hipMemcpy((char*)d->cx_wv_all.p + i * D * D * 2, a.wv.p, D * D * 2, hipMemcpyDeviceToDevice));
-        HIPCHK(hipMemcpy((char*)d->cx_bk_all.p + i * D * 4, a.bk.p, D * 4, hipMemcpyDeviceToDevice));
-        HIPCHK(hipMemcpy((char*)d->cx_bv_all.p + i * D * 4, a.bv.p, D * 4, hipMemcpyDeviceToDevice));
+        complete = a.wk.p && a.wv.p && a.bk.p && a.bv.p && a.norm.p;
+      }
+      if (!complete) {
+        d->cross_kv_batched = 0;
+        d->cx_wk_all.release(); d->cx_wv_all.release(); d->cx_bk_all.release(); d->cx_bv_all.release(); d->cx_knorm_all.release();
+      }
+      // the stacked copy REPLACES the per-block buffers (they become views into it) instead of doubling them — 4 nbv D^2 bytes, 411 MB on
+      // 2B-Lite; the per-block path ("cross_kv_batched" = 0) reads the same memory through the views
+      for (size_t i = 0; i < nbv && complete; ++i) {
+        AttnW& a = d->vblocks[i].cross_attn;
+        char* wk = (char*)d->cx_wk_all.p + i * D * D * 2; char* wv = (char*)d->cx_wv_all.p + i * D * D * 2;
+        char* bk = (char*)d->cx_bk_all.p + i * D * 4; char* bv = (char*)d->cx_bv_all.p + i * D * 4;
+        HIPCHK(hipMemcpy(wk, a.wk.p, D * D * 2, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(wv, a.wv.p, D * D * 2, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(bk, a.bk.p, D * 4, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(bv, a.bv.p, D * 4, hipMemcpyDeviceToDevice));
         HIPCHK(hipMemcpy((char*)d->cx_knorm_all.p + i * 64 * 4, a.norm.as<float>() + 64, 64 * 4, hipMemcpyDeviceToDevice));
+        a.wk.alias(wk, D * D * 2); a.wv.alias(wv, D * D * 2); a.bk.alias(bk, D * 4); a.bv.alias(bv, D * 4);
       }
     }
   }
@@ -1976,7 +2021,7 @@ extern "C" int k5_comm_unique_id(const char* rccl_lib_path, void* out128) {
 
 static int comm_common_init(k5_dit* d, int rank, int world) {
   d->comm.rank = rank; d->comm.world = world;
-  if (const char* e = getenv("K5_SP_AUTOTUNE")) d->sp_autotune = atoi(e) != 0;   // K5_SP_AUTOTUNE=0: keep the default exchange without timing anything
+  if (const char* e = getenv("K5_SP_AUTOTUNE")) d->sp_autotune = atoi(e) != 0;   // K5_SP_AUTOTUNE=1: time the admissible exchanges at the first sharded forward (opt-in)
   if (d->comm.loop) d->sp_autotune = false;   // loopback ranks (tests of specific schedules on one GPU) tune only when asked to ("sp_autotune" = 1)
   d->sp_rank = rank; d->sp_world = world;
   HIPCHK(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
@@ -2097,9 +2142,11 @@ extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->
 //                     in compute, emulated P = 4; pays when the exposed part of the gather is longer than that — a property of the node)
 //   "sp_mode"         0 (default): every rank gathers all K / V^T (any rank count, dense and NABLA); 1: Ulysses — two all-to-alls trade token rows
 //                     for heads and back (run_self_attention_ulysses; needs heads % ranks == 0 and dense attention, else the gather is used)
-//   "sp_autotune"     1 (default) / 0: the first sharded forward of a handle with more than one rank times one block's self-attention section under
+//   "sp_autotune"     0 (default since round 5) / 1: the first sharded forward of a handle with more than one rank times one block's self-attention section under
 //                     every admissible schedule (all-gather; 2 slices; Ulysses — NABLA: one / two passes) and keeps the fastest (max over ranks; every
-//                     rank takes the same decision from the gathered table).  A knob set explicitly through this call is left alone.  2 = tune again.
+//                     rank takes the same decision from the gathered table).  A knob set explicitly through this call is left alone, and a run only assigns
+//                     the knobs it varied.  The winner depends on timings and the schedules differ in fp32 summation order: with tuning on, bits may
+//                     differ between nodes / runs.  2 = tune again.
 //                     k5_dit_sp_schedule returns what was measured and chosen.
 //   "sp_slices"       S in 1..4: exchange K / V^T of a block in S slices (grouped send/recv to every peer at once) and attend each
 //                     slice as it lands — the gather hides behind the attention of the slices before it (dense attention; NABLA and
@@ -2153,6 +2200,11 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "sp_nabla_passes")) *value = d->sp_nabla_passes;
   else if (!strcmp(name, "sp_autotune")) *value = d->sp_autotune ? 1 : 0;
   else if (!strcmp(name, "sp_tuned")) *value = d->sp_tuned ? 1 : 0;
+  else if (!strcmp(name, "rccl_ranks")) {   // the size the RCCL communicator reports (ncclCommCount): 0 = no communicator, -1 = a loopback group / no such symbol
+    *value = 0;
+    if (d->comm.comm && d->comm.CommCount) { int n = 0; *value = d->comm.CommCount(d->comm.comm, &n) == ncclSuccess ? n : -1; }
+    else if (d->comm.active()) *value = -1;
+  }
   else if (!strcmp(name, "nabla_group_rows")) *value = d->nabla_group_rows;
   else if (!strcmp(name, "nabla_pair_frames")) *value = d->nabla_pair_frames;
   else if (!strcmp(name, "fp8_fuse_ln")) *value = d->fp8_fuse_ln;
@@ -2179,6 +2231,16 @@ extern "C" int k5_dit_attn_variant_counts(k5_dit* d, long long* fixed_heads, lon
   return K5_OK;
 }
 // NABLA maps computed while profiling was on: kept / possible 64x64 blocks since the last k5_dit_attn_variant_counts reset
+extern "C" int k5_dit_set_nabla_tap(k5_dit* d, void* dev_u8, long long capacity_bytes) {
+  if (!d || capacity_bytes < 0 || (dev_u8 && capacity_bytes == 0)) return K5_ERR_ARG;
+  d->nabla_tap = dev_u8; d->nabla_tap_cap = dev_u8 ? capacity_bytes : 0; d->nabla_tap_n = 0;
+  return K5_OK;
+}
+extern "C" int k5_dit_nabla_tap_count(k5_dit* d, long long* maps) {
+  if (!d || !maps) return K5_ERR_ARG;
+  *maps = d->nabla_tap_n;
+  return K5_OK;
+}
 extern "C" int k5_dit_nabla_block_counts(k5_dit* d, long long* kept, long long* possible) {
   if (!d) return K5_ERR_ARG;
   unsigned long long c[4] = {0, 0, 0, 0};

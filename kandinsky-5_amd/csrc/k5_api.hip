@@ -199,9 +199,9 @@ int k5_nabla_select_rect_bf16(const void* q, const void* k, int ldq, int ldk, in
 int k5_attention_nabla_rect_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int Nq, int N, int ldq, int ldk,
                                  int ldvt, int ldo, float score_bound, const void* workspace, int vt_chunk_keys,
                                  int64_t vt_chunk_stride, void* stream) {
-  if (!workspace || N <= 0 || (N % 64)) return ret(K5_ERR_ARG, "k5_attention_nabla_rect_bf16");
+  if (!workspace || N <= 0 || (N % 64) || Nq <= 0 || (Nq % 64)) return ret(K5_ERR_ARG, "k5_attention_nabla_rect_bf16");
   const int *list, *cnt;
-  k5_nabla_workspace_views(const_cast<void*>(workspace), H, N / 64, nullptr, nullptr, &list, &cnt);
+  k5_nabla_workspace_views(const_cast<void*>(workspace), H, N / 64, nullptr, nullptr, &list, &cnt, nullptr, Nq / 64);   // as k5_nabla_select_rect_bf16 laid it out
   return ret(k5_launch_attention_bf16_sparse(Q, K, Vt, O, H, Nq, N, ldq, ldk, ldvt, ldo, score_bound, list, cnt, N / 64,
                                              vt_chunk_keys, (long long)vt_chunk_stride, (hipStream_t)stream),
              "k5_attention_nabla_rect_bf16");
@@ -222,7 +222,8 @@ int k5_attention_nabla_rect_prescaled_pass(const void* Q, const void* Kc, const 
   if (!workspace || N <= 0 || (N % 64) || pass < 0 || pass > 2 || (pass && !state) || !head_flags || !kmax)
     return ret(K5_ERR_ARG, "k5_attention_nabla_rect_prescaled_pass");
   const int *list, *cnt, *cnt_local;
-  k5_nabla_workspace_views(const_cast<void*>(workspace), H, N / 64, nullptr, nullptr, &list, &cnt, &cnt_local);
+  if (Nq <= 0 || (Nq % 64)) return ret(K5_ERR_ARG, "k5_attention_nabla_rect_prescaled_pass");
+  k5_nabla_workspace_views(const_cast<void*>(workspace), H, N / 64, nullptr, nullptr, &list, &cnt, &cnt_local, Nq / 64);
   const K5SparsePass p1{nullptr, state, 2, 1}, p2{cnt_local, state, 1, 2};
   return ret(k5_launch_attention_bf16_sparse(Q, Kc, Vt, O, H, Nq, N, ldq, ldk, ldvt, ldo, 0.f, list, pass == 1 ? cnt_local : cnt, N / 64,
                                              vt_chunk_keys, (long long)vt_chunk_stride, (hipStream_t)stream, true, head_flags, K5_ATTN_AUTO,

@@ -79,11 +79,11 @@ int k5_launch_gemm_fp8(const void* A8, const void* W8, const float* w_scale, voi
 int k5_launch_quant_rows_fp8(const void* x, void* out, float* scale, int rows, int K, int ldx, int ldo, hipStream_t stream);
 
 // ---- NABLA (block-sparse) ----
-size_t k5_nabla_workspace_bytes(int H, int nb, int nqb = 0);   // nqb: query-block rows selected here (0 = all nb)
+size_t k5_nabla_workspace_bytes(int H, int nb, int nqb = 0, int list_rows = 0);   // nqb: query-block rows selected here (0 = all nb); list_rows: key-tile lists per head (0 = one per row)
 int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H, int N, int T, int Hb, int Wb, int wT, int wH,
                            int wW, float P, void* workspace, hipStream_t s);
 void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned long long** bits, const int** kv_nb, const int** list,
-                              const int** cnt, const int** cnt_local = nullptr);
+                              const int** cnt, const int** cnt_local = nullptr, int nqb = 0);   // nqb as given to k5_nabla_workspace_bytes (the lists sit behind that many rows of logits)
 int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T, int Hb,
                                 int Wb, int wT, int wH, int wW, float P, void* workspace, hipStream_t s,
                                 int local_block0 = 0, int local_blocks = 0,   // > 0: these key blocks lead every list (cnt_local of them)

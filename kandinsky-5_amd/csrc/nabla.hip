@@ -363,15 +363,18 @@ void k5_nabla_workspace_means(void* workspace, int H, int nb, void** qa, void** 
 
 // nqb = query-block rows the selection will handle (a sequence-parallel rank selects nb / P of the nb rows): only the bf16 logits matrix —
 // by far the largest region, 840 MB at 3660 blocks — scales with it; every other region keeps its nb-row size (the views index by nb)
-size_t k5_nabla_workspace_bytes(int H, int nb, int nqb) {
+// Round 5: the key-tile lists are the LAST region and sized by the lists that will exist — list_rows per head, one per group of rows
+// (0 = one per selected row, the largest case) — instead of nb x nb entries per head whoever asks (1.5 GB at 3660 blocks, on every rank).
+size_t k5_nabla_workspace_bytes(int H, int nb, int nqb, int list_rows) {
   const size_t nw = (nb + 63) / 64;
   if (nqb <= 0 || nqb > nb) nqb = nb;
+  if (list_rows <= 0 || list_rows > nqb) list_rows = nqb;
   return (size_t)2 * H * nb * 64 * 2      // qa, ka
          + (size_t)H * nb * nw * 8         // bits
          + (size_t)H * nb * 4              // kv_nb
-         + (size_t)H * nb * nb * 4                     // key-tile lists (sized for one list per ROW — round 4; lists per 2 / 4 rows use a half / quarter)
          + (size_t)2 * H * nb * 4 + 256                // counts, counts of the leading local entries (sequence parallelism)
-         + (size_t)H * (nqb + 4) * sel_row_nv((int)nw) * 64 * 2;   // bf16 block logits [H][nqb rows][64 NV] (round 3: one matmul per head, read back per row)
+         + (size_t)H * (nqb + 4) * sel_row_nv((int)nw) * 64 * 2    // bf16 block logits [H][nqb rows][64 NV] (round 3: one matmul per head, read back per row)
+         + (size_t)H * list_rows * nb * 4;             // key-tile lists [H][groups][nb]
 }
 
 // q: [Nq][ldq] bf16 = the query rows handled here (global 64-token blocks [q_block0, q_block0 + Nq/64)), k: [N][ldk] = all
@@ -405,17 +408,16 @@ int k5_launch_nabla_select_rect(const void* q, const void* k, int ldq, int ldk, 
   if (q_block0 < 0 || q_block0 * 64 + Nq > N) return K5_ERR_ARG;
   if ((q && (ldq & 7)) || (k && (ldk & 7))) return K5_ERR_ALIGN;
   const int nb = N / 64, nqb = Nq / 64, nw = (nb + 63) / 64, ng = (nqb + group_rows - 1) / group_rows;
-  const size_t ngmax = (size_t)nb;   // region sizes (k5_nabla_workspace_bytes / _views)
   if (nb > SEL_MAXNB) return K5_ERR_UNSUPPORTED;
   char* ws = (char*)workspace;
   bf16_t* qa = (bf16_t*)ws; ws += (size_t)H * nb * 64 * 2;
   bf16_t* ka = (bf16_t*)ws; ws += (size_t)H * nb * 64 * 2;
   unsigned long long* bits = (unsigned long long*)ws; ws += (size_t)H * nb * nw * 8;
   int* kv_nb = (int*)ws; ws += (size_t)H * nb * 4;
-  int* list = (int*)ws; ws += (size_t)H * ngmax * nb * 4;
   int* cnt = (int*)ws;
-  int* cnt_local = cnt + (size_t)H * ngmax;
-  bf16_t* logits = (bf16_t*)(((uintptr_t)(cnt_local + (size_t)H * ngmax) + 255) & ~(uintptr_t)255);   // 256-B aligned: inside the + 256 slack
+  int* cnt_local = cnt + (size_t)H * nb;
+  bf16_t* logits = (bf16_t*)(((uintptr_t)(cnt_local + (size_t)H * nb) + 255) & ~(uintptr_t)255);   // 256-B aligned: inside the + 256 slack
+  int* list = (int*)(logits + (size_t)H * (nqb + 4) * sel_row_nv(nw) * 64);                           // last region: [H][ng][nb] (k5_nabla_workspace_views)
   if (q) hipLaunchKernelGGL(block_mean_kernel, dim3(nqb), dim3(256), 0, s, (const bf16_t*)q, qa, H, nqb, ldq);
   if (k) hipLaunchKernelGGL(block_mean_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)k, ka, H, nb, ldk);
   SelP p;
@@ -457,15 +459,16 @@ int k5_launch_nabla_select(const void* q, const void* k, int ldq, int ldk, int H
 
 // views into the workspace filled above
 void k5_nabla_workspace_views(void* workspace, int H, int nb, const unsigned long long** bits, const int** kv_nb, const int** list,
-                              const int** cnt, const int** cnt_local) {
-  const size_t nw = (nb + 63) / 64, ng = (size_t)nb;   // region sizes
+                              const int** cnt, const int** cnt_local, int nqb) {
+  const size_t nw = (nb + 63) / 64;
+  if (nqb <= 0 || nqb > nb) nqb = nb;
   char* ws = (char*)workspace + (size_t)2 * H * nb * 64 * 2;
   if (bits) *bits = (const unsigned long long*)ws;
   ws += (size_t)H * nb * nw * 8;
   if (kv_nb) *kv_nb = (const int*)ws;
   ws += (size_t)H * nb * 4;
-  if (list) *list = (const int*)ws;
-  ws += (size_t)H * ng * nb * 4;
   if (cnt) *cnt = (const int*)ws;
-  if (cnt_local) *cnt_local = (const int*)ws + (size_t)H * ng;
+  if (cnt_local) *cnt_local = (const int*)ws + (size_t)H * nb;
+  const bf16_t* logits = (const bf16_t*)(((uintptr_t)((const int*)ws + (size_t)2 * H * nb) + 255) & ~(uintptr_t)255);
+  if (list) *list = (const int*)(logits + (size_t)H * (nqb + 4) * sel_row_nv((int)nw) * 64);   // behind the logits of the nqb rows selected here
 }

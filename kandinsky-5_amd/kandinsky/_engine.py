@@ -96,6 +96,8 @@ SYMBOLS = {
     "k5_sp_pick_schedule": (_I, [C.POINTER(C.c_float), _I, _I, C.POINTER(_I), C.POINTER(C.c_float)]),
     "k5_dit_attn_variant_counts": (_I, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _I]),
     "k5_dit_nabla_block_counts": (_I, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "k5_dit_set_nabla_tap": (_I, [_P, _P, C.c_longlong]),
+    "k5_dit_nabla_tap_count": (_I, [_P, C.POINTER(C.c_longlong)]),
     "k5_dit_nabla_executed_blocks": (_I, [_P, C.POINTER(C.c_longlong)]),
     "k5_attention_balance_size": (_I64, [_I, _I]),
     "k5_attention_bf16_balanced": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),

@@ -409,6 +409,19 @@ class DiffusionTransformer3D(nn.Module):
         E.check(E.lib().k5_dit_nabla_block_counts(self._handle, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def set_nabla_tap(self, buf=None):
+        """Diagnostics: every NABLA map computed from now on (one-GPU path) is expanded to uint8 [H][nb][nb] into `buf` (a CUDA uint8 tensor the
+        caller keeps alive), one after the other; None removes the tap."""
+        if buf is not None and (not buf.is_cuda or buf.dtype != torch.uint8 or not buf.is_contiguous()):
+            raise ValueError("the NABLA tap needs a contiguous CUDA uint8 tensor")
+        self._nabla_tap = buf
+        E.check(E.lib().k5_dit_set_nabla_tap(self._handle, E.ptr(buf), 0 if buf is None else buf.numel()), "k5_dit_set_nabla_tap")
+
+    def nabla_tap_count(self):
+        a = C.c_longlong()
+        E.check(E.lib().k5_dit_nabla_tap_count(self._handle, C.byref(a)), "k5_dit_nabla_tap_count")
+        return a.value
+
     def nabla_executed_blocks(self):
         """64x64 blocks the list-driven attention executed for those maps (union lists x rows per list): kept / executed = union efficiency."""
         a = C.c_longlong()

@@ -27,6 +27,38 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert not any(line.startswith("{") for line in out.stdout.splitlines())
 
 
+def test_bench_launches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus N` without a launcher re-executes under torch.distributed.run with every flag forwarded; the
+    command is built by one function, checked here; --gpus 1 stays a plain in-process run."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("k5_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    argv = ["--gpus", "4", "--steps", "3", "--warmup", "1", "--workload", "10s_nabla", "--no-vae"]
+    cmd = b.self_launch_command(argv, 4, port=29555)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                                  # every flag forwarded, in order
+    free = b.self_launch_command(argv, 2)
+    assert 1024 <= int(free[free.index("--master-port") + 1]) < 65536
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"WORLD_SIZE" not in os.environ and args.gpus > 1' in src      # one GPU never takes the launcher path
+
+
+def test_bench_self_launch_reports_missing_devices_after_spawning():
+    """On a box with fewer devices than --gpus the ranks are really spawned and each says what is missing (no usage message, rc != 0)."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two devices are present")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-vae",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode != 0
+    assert "torch.distributed.run" in out.stderr and "launching" in out.stderr
+    assert "needs 2 devices on this node, found" in out.stderr
+    assert not any(line.startswith("{") for line in out.stdout.splitlines())
+
+
 @pytest.mark.gpu
 def test_bench_json_line_contract():
     """One JSON line with the contract's keys; two visual blocks keep it short (the engine path is the same)."""
