@@ -200,9 +200,16 @@ __device__ __forceinline__ uint32_t st_ml_off(int q, int h, int slot, int nqb, i
 // 4: 64 rows per wave, FOUR waves per 256-query workgroup, 2 waves per SIMD — every K / V^T fragment read from LDS feeds four MFMAs instead of
 // two (half the ds_read_b128 per MFMA, the ledger's remaining non-essential class: profiles/r04_attention_issue_ledger.md), each wave stages
 // two 1-KB pieces of a tile per operand.  Same arithmetic per query row in the same order: bit-identical outputs.
-template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false, bool QN = false, int GR = 4, int QT = 2>
-__global__ __launch_bounds__(QT == 4 ? 256 : 512, QT == 4 ? 2 : (BOUNDED ? 4 : K5_ONLINE_WPS)) void attn_fwd_kernel(AttnP p) {
+// PIPE (round 5; VERDICT r4 #4 — the one experiment the issue ledger pointed to): 64-row waves, ONE wave per SIMD (one 256-query workgroup per CU, up
+// to 512 registers), software-pipelined over HALF key tiles: in every unit of 32 keys the wave issues three independent streams — the S^T MFMAs of the
+// half tile one tile ahead (16), the exponentials + packs of the half tile before that (32 + 16 VALU), and the P V MFMAs + row sums of the half tile
+// whose probabilities are ready (20) — so the exponentials of one tile run under the matrix work of its neighbours inside ONE wave instead of
+// relying on four waves per SIMD to fall out of step.  K / V^T tiles in a ring of three PAIRS (6 slots per operand, 96 KB of dynamic LDS): pair p + 2
+// is fetched while pair p is attended and the S^T of pair p + 1 is formed.  Same arithmetic per query row in the same order: bit-identical outputs.
+template <bool BOUNDED, bool SPARSE, bool RANGE, bool PRE = false, bool QN = false, int GR = 4, int QT = 2, bool PIPE = false>
+__global__ __launch_bounds__(QT == 4 ? 256 : 512, PIPE ? (QT == 4 ? 1 : 2) : (QT == 4 ? 2 : (BOUNDED ? 4 : K5_ONLINE_WPS))) void attn_fwd_kernel(AttnP p) {
   static_assert(QT == 2 || (QT == 4 && GR == 4), "64-row waves: the 256-query workgroups only");
+  static_assert(!PIPE || (BOUNDED && PRE && !SPARSE && !QN && GR == 4), "the pipelined form: dense, fixed-offset softmax, pre-scaled keys, 256-query workgroups");
   constexpr int NW = 4 * GR / QT;     // waves per workgroup: 8 (256 queries, 32-row waves), 4 (128 queries, or 256 with 64-row waves), 2 (64 queries)
   constexpr int RW = 16 * QT;         // query rows per wave
   constexpr bool HALF = GR != 4;     // fewer than 8 waves: one tile per barrier, every wave stages several pieces
@@ -212,8 +219,10 @@ __global__ __launch_bounds__(QT == 4 ? 256 : 512, QT == 4 ? 2 : (BOUNDED ? 4 : K
   // K5_ATTN_PAIR: two key tiles per barrier (four LDS slots per operand instead of two) for the 256-query workgroups — same arithmetic in
   // the same order, half the barriers; the 128-query form keeps one tile per barrier (four workgroups per CU: 32 KB each)
   constexpr bool PAIR = K5_ATTN_PAIR && !HALF;
-  constexpr int NBUF = PAIR ? 4 : 2;
-  __shared__ __attribute__((aligned(16))) char smem[2 * NBUF * TILE];
+  constexpr int NBUF = PIPE ? 6 : (PAIR ? 4 : 2);
+  extern __shared__ __attribute__((aligned(16))) char attn_dsm[];                         // PIPE: 96 KB, beyond the static limit
+  __shared__ __attribute__((aligned(16))) char smem_static[PIPE ? 16 : 2 * NBUF * TILE];
+  char* smem = PIPE ? attn_dsm : smem_static;
   char* sK = smem;
   char* sV = smem + NBUF * TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
@@ -539,6 +548,125 @@ __global__ __launch_bounds__(QT == 4 ? 256 : 512, QT == 4 ? 2 : (BOUNDED ? 4 : K
   }
 
   bool seen = !SPARSE && T > E0;   // wave-uniform: this wave's queries saw at least one key tile in this launch
+  if constexpr (PIPE) {
+    if (T > E0) {
+      // S^T of two tiles in flight: S[parity][half h][kt2][qt] = key sub-tile kt = 2 h + kt2 (16 keys) x query tile qt; pf[h][qt] = the packed probabilities
+      // of half h waiting for their P V MFMAs
+      f32x4 S[2][2][2][QT];
+      bf16x8 pf[2][QT];
+      // K / V^T fragments of a unit are read from LDS ONE UNIT AHEAD into the other of two register sets: with one wave per SIMD nothing else hides the
+      // ~100 cycles of a ds_read (first build: every 4 MFMAs waited for their fragment — 701 TFLOP/s)
+      bf16x8 kfr[2][2][2], vfr[2][4];      // [set][kt2][k-step], [set][d tile]
+      auto ld_k = [&](auto SETC, auto HC, auto SLOTC) {
+        constexpr int set = decltype(SETC)::value, hh = decltype(HC)::value, slot = decltype(SLOTC)::value;
+        const char* cK = sK + slot * TILE;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+          const int kt = 2 * hh + kt2;
+          kfr[set][kt2][0] = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), g));
+          kfr[set][kt2][1] = *reinterpret_cast<const bf16x8*>(cK + lds_swz_k(krow + 32 * (kt >> 1) + 4 * (kt & 1), 4 + g));
+        }
+      };
+      auto ld_v = [&](auto SETC, auto HC, auto SLOTC) {
+        constexpr int set = decltype(SETC)::value, hh = decltype(HC)::value, slot = decltype(SLOTC)::value;
+        const char* cV = sV + slot * TILE;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vfr[set][dt] = *reinterpret_cast<const bf16x8*>(cV + lds_swz(16 * dt + l15, 4 * hh + g));
+      };
+      auto qk_half = [&](auto PARC, auto HC) {      // 16 MFMAs on fragment set HC
+        constexpr int par = decltype(PARC)::value, hh = decltype(HC)::value;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) S[par][hh][kt2][qt] = mfma16(kfr[hh][kt2][0], qf[qt][0], nm[qt]);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) S[par][hh][kt2][qt] = mfma16(kfr[hh][kt2][1], qf[qt][1], S[par][hh][kt2][qt]);
+        }
+      };
+      auto exp_half = [&](auto PARC, auto HC) {                 // 32 exponentials + 16 packs per lane
+        constexpr int par = decltype(PARC)::value, hh = decltype(HC)::value;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          float e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(S[par][hh][j >> 2][qt][j & 3]);
+          const u32x4 pk = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
+          pf[hh][qt] = __builtin_bit_cast(bf16x8, pk);
+        }
+      };
+      auto pv_half = [&](auto HC) {                 // 4 + 16 MFMAs on fragment set HC
+        constexpr int hh = decltype(HC)::value;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) lt[qt] = mfma16(onesf, pf[hh][qt], lt[qt]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) ot[dt][qt] = mfma16(vfr[hh][dt], pf[hh][qt], ot[dt][qt]);
+        }
+      };
+      // a unit's three streams are independent: ask for them interleaved, 3 matrix instructions to 4 vector ones (36 : 48), the 8 fragment reads of
+      // the next unit up front
+      auto mix = [&]() {
+#ifndef K5_ATTN_PIPE_NOMIX
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int i = 0; i < 3 * QT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+#endif
+      };
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+      // tile e sits in ring slot J (its K was used one body earlier); the next tile's K in slot (J + 1) % 6, the one after in (J + 2) % 6.
+      // Unit (J, h) computes on fragment set h and reads the next unit's fragments — (J, 1), or (J + 1, 0) — into set h ^ 1.
+      auto body = [&](auto JC, int e) {
+        constexpr int J = decltype(JC)::value, PAR = J & 1;
+        using PC = std::integral_constant<int, PAR>; using PN = std::integral_constant<int, PAR ^ 1>;
+        using SV_ = std::integral_constant<int, J>; using SK_ = std::integral_constant<int, (J + 1) % 6>;
+        using SV1 = std::integral_constant<int, (J + 1) % 6>; using SK1 = std::integral_constant<int, (J + 2) % 6>;
+        if ((J & 1) == 0) {   // a pair starts: the pair after this one has landed for every wave, the pair before it is dead — fetch the one after next
+          __syncthreads();
+          if (e + 4 < T) load_tile(e + 4, (J + 4) % 6);
+          if (e + 5 < T) load_tile(e + 5, (J + 5) % 6);
+        }
+        const bool more = e + 1 < T;     // wave-uniform
+        if (more) {      // two units, straight-line (one scheduling region): no branch inside — a fragment set read from a slot that holds no tile is never used
+          ld_k(I1{}, I1{}, SK_{}); ld_v(I1{}, I1{}, SV_{});                                  // fragments of unit (J, 1)
+          qk_half(PN{}, I0{}); exp_half(PC{}, I1{}); pv_half(I0{});
+          ld_k(I0{}, I0{}, SK1{}); ld_v(I0{}, I0{}, SV1{});                                  // fragments of unit (J + 1, 0)
+          qk_half(PN{}, I1{}); exp_half(PN{}, I0{}); pv_half(I1{});
+          mix(); mix();
+        } else {
+          ld_v(I1{}, I1{}, SV_{});
+          exp_half(PC{}, I1{}); pv_half(I0{});
+          pv_half(I1{});
+        }
+      };
+      load_tile(E0, 0);
+      if (E0 + 1 < T) load_tile(E0 + 1, 1);
+      if (E0 + 2 < T) load_tile(E0 + 2, 2);
+      if (E0 + 3 < T) load_tile(E0 + 3, 3);
+      __syncthreads();
+      // prologue: S^T of the first tile (both halves) and the probabilities of its first half; the fragments of unit (0, 0)
+      ld_k(I0{}, I0{}, I0{}); ld_k(I1{}, I1{}, I0{});
+      qk_half(I0{}, I0{}); qk_half(I0{}, I1{}); exp_half(I0{}, I0{});
+      if (E0 + 1 < T) ld_k(I0{}, I0{}, I1{});
+      ld_v(I0{}, I0{}, I0{});
+      for (int e = E0; e < T; e += 6) {
+        body(std::integral_constant<int, 0>{}, e);
+        if (e + 1 >= T) break;
+        body(std::integral_constant<int, 1>{}, e + 1);
+        if (e + 2 >= T) break;
+        body(std::integral_constant<int, 2>{}, e + 2);
+        if (e + 3 >= T) break;
+        body(std::integral_constant<int, 3>{}, e + 3);
+        if (e + 4 >= T) break;
+        body(std::integral_constant<int, 4>{}, e + 4);
+        if (e + 5 >= T) break;
+        body(std::integral_constant<int, 5>{}, e + 5);
+      }
+    }
+  } else {
   if (T > E0) load_tile(E0, 0);
   if (PAIR && T > E0 + 1) load_tile(E0 + 1, 1);
   __syncthreads();   // drains the DMA (vmcnt) and publishes the tile(s)
@@ -704,6 +832,7 @@ __global__ __launch_bounds__(QT == 4 ? 256 : 512, QT == 4 ? 2 : (BOUNDED ? 4 : K
       __syncthreads();
     }
   }
+  }   // !PIPE
   // In a multi-pass schedule (late_pass != 0) the flip writes the LATE flag: the launches of a pass are balanced as fixed(full),
   // online(full), fixed(tail), online(tail), so a flip that comes from a tail job lands after online(full) has skipped the head —
   // its full jobs keep fixed-form state (relative to the per-row offsets), which the online form of a later pass must not resume
@@ -1182,7 +1311,8 @@ int attn_slots() {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 512;
     g_attn_slots = 2 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
   }
-  return g_attn_slots;
+  static const bool pipe = getenv("K5_ATTN_WAVE_ROWS") && atoi(getenv("K5_ATTN_WAVE_ROWS")) > 100;   // the pipelined forms (132, 164): one workgroup per CU
+  return pipe ? g_attn_slots / 2 : g_attn_slots;
 }
 }  // namespace
 
@@ -1301,6 +1431,22 @@ int k5_launch_attention_bf16_range(const void* Q, const void* K, const void* Vt,
         if (run_fixed) {
           p.my_flag = 1;
           if (wave_rows == 64) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true, false, 4, 4>), grid, dim3(256), 0, stream, p);
+          else if (wave_rows == 132) {   // 32-row waves, two per SIMD (one 256-query workgroup per CU), software-pipelined over half tiles
+            static bool attr = false;
+            if (!attr) {
+              if (hipFuncSetAttribute((const void*)attn_fwd_kernel<true, false, true, true, false, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * TILE) != hipSuccess) return;
+              attr = true;
+            }
+            hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true, false, 4, 2, true>), grid, block, 12 * TILE, stream, p);
+          }
+          else if (wave_rows == 164) {   // 64-row waves, one per SIMD, software-pipelined over half tiles (PIPE)
+            static bool attr = false;
+            if (!attr) {
+              if (hipFuncSetAttribute((const void*)attn_fwd_kernel<true, false, true, true, false, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * TILE) != hipSuccess) return;
+              attr = true;
+            }
+            hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true, false, 4, 4, true>), grid, dim3(256), 12 * TILE, stream, p);
+          }
           else hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, true>), grid, block, 0, stream, p);
         }
         if (run_online) { p.my_flag = 0; hipLaunchKernelGGL((attn_fwd_kernel<false, false, true, true>), grid, block, 0, stream, p); }

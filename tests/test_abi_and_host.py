@@ -263,7 +263,7 @@ def test_hot_kernels_keep_their_register_budget():
     for k, v in kernels("conv3d_w4_kernel").items():
         assert v["ScratchSize [bytes/lane]"] <= 128, (k, v)
     for k, v in kernels("attn_fwd_kernelILb1E").items():        # fixed-offset forms: two workgroups per CU
-        cap = 256 if k.endswith("ELi4ELi4EEEvNS_5AttnPE") else 128   # QT = 4 (64-row waves, opt-in): two waves per SIMD by design
+        cap = 256 if "ELi4ELi4ELb" in k else 128   # QT = 4 (64-row waves, opt-in): two waves per SIMD by design (one for the pipelined form)
         assert v["VGPRs"] <= cap and v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
     for k, v in kernels("attn_fwd_kernelILb0E").items():        # online-max forms: no spills at their (larger) budget
         assert v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
