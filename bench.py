@@ -452,8 +452,9 @@ def main():
         invalid.append("emulated shard layout (timing only, results garbage)")
     if args.blocks != 32:
         invalid.append("fewer visual blocks than the model")
+    fp8_eff = dit.get_option("fp8_effective") if args.fp8 else 0   # the layer classes that really ran in e4m3 (the sharded schedules keep some in bf16)
     if args.fp8:
-        invalid.append(f"reduced precision (fp8 linear layers, mask {args.fp8})")
+        invalid.append(f"reduced precision (fp8 linear layers, mask {args.fp8} asked, {fp8_eff} in effect)")
     step_flop = fwd_per_step * flops_forward(N, L, blocks=args.blocks)
     if not torch.isfinite(latent).all():
         invalid.append("the latent holds non-finite values after the timed steps")
@@ -472,7 +473,7 @@ def main():
         out = {
             "metric": "DiT denoising steps/sec (2B Lite, 5s 768x512 latent)", "value": args.steps / dt, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": f"bf16+fp8 mask {args.fp8} (REDUCED PRECISION, not the headline)" if args.fp8 else "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": f"bf16+fp8 mask {fp8_eff} in effect of {args.fp8} asked (REDUCED PRECISION, not the headline)" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": wl["desc"], "tokens": N, "text_len": L, "forwards_per_step": fwd_per_step,
                        "parallelism": "single GPU" if world == 1 else (
                            (f"CFG-parallel x2 (cond / uncond rank groups, velocity exchange inside k5_sample) x " if args.cfg_parallel else "") +

@@ -461,7 +461,8 @@ int k5_quant_rows_fp8(const void* x_bf16, void* out_fp8, float* scale, int rows,
  * static scale 1).  `enabled` is a bit mask: 1 = the feed-forward GEMMs (nn.py:352-361), 2 = the q | k | V^T projections and 4 = the out
  * projection of the visual self-attention (nn.py:233-244, 282-284); 0 = off.  LOSSY and off by default: the distance to the bf16 path per
  * layer class is stated with the parity test tests/test_gpu_dit.py::test_fp8_feed_forward_mode and in DESIGN.md §4.2; from 256 tiles up the
- * GEMMs run on the four-wave e4m3 kernel (gemm_fp8.hip, round 4). */
+ * GEMMs run on the four-wave e4m3 kernel (gemm_fp8.hip, round 4).  The sequence-parallel schedules keep the out projection in bf16 and the Ulysses
+ * schedule also the q | k | V^T projections: k5_dit_get_option(dit, "fp8_effective") returns the mask that is in effect on the handle's path. */
 int k5_dit_set_fp8(k5_dit* dit, int enabled);
 
 /* k5_sample replays ONE hipGraph-captured sampler step (forwards + CFG/Euler, per-step scalars read from device tables at a

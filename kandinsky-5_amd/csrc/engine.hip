@@ -2200,6 +2200,11 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "sp_nabla_passes")) *value = d->sp_nabla_passes;
   else if (!strcmp(name, "sp_autotune")) *value = d->sp_autotune ? 1 : 0;
   else if (!strcmp(name, "sp_tuned")) *value = d->sp_tuned ? 1 : 0;
+  else if (!strcmp(name, "fp8_effective")) {   // the classes of k5_dit_set_fp8 that RUN in e4m3 on this handle's path — the sharded schedules keep the out
+    int m = d->fp8_mask;                       // projection in bf16 (bit 4), Ulysses also the q | k | V^T projections (bit 2); a bench must label its line with THIS mask
+    if (d->comm.active()) { m &= ~4; if (d->sp_mode == 1 && d->sp_world > 1 && d->Hh % d->sp_world == 0 && !d->emulated) m &= ~2; }
+    *value = m;
+  }
   else if (!strcmp(name, "rccl_ranks")) {   // the size the RCCL communicator reports (ncclCommCount): 0 = no communicator, -1 = a loopback group / no such symbol
     *value = 0;
     if (d->comm.comm && d->comm.CommCount) { int n = 0; *value = d->comm.CommCount(d->comm.comm, &n) == ncclSuccess ? n : -1; }
@@ -2261,7 +2266,8 @@ extern "C" int k5_dit_nabla_executed_blocks(k5_dit* d, long long* executed) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(c, d->ws_attn_cnt.p, 32, hipMemcpyDeviceToHost));
   }
-  *executed = (long long)c[3] * d->nabla_list_rows;
+  if (d->comm.active()) { k5_set_error("k5_dit_nabla_executed_blocks: the sharded path does not count its lists"); return K5_ERR_UNSUPPORTED; }
+  *executed = (long long)c[3];      // summed on the device per launch as list length x rows of the group (the group size may change between forwards)
   return K5_OK;
 }
 

@@ -310,9 +310,13 @@ __global__ __launch_bounds__(256) void nabla_expand_kernel(const unsigned long l
 }
 
 // sum of the per-row kept-block counts -> one atomic per workgroup (profiling only: realised map density)
-__global__ __launch_bounds__(256) void nabla_count_kernel(const int* __restrict__ kv_nb, int rows, unsigned long long* acc) {
+// ng > 0: entry i is the list of row group i % ng of its head and counts once per ROW of that group (group_rows of them, fewer in a head's last group)
+__global__ __launch_bounds__(256) void nabla_count_kernel(const int* __restrict__ kv_nb, int rows, unsigned long long* acc, int ng, int group_rows, int nqb) {
   unsigned long long v = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) v += (unsigned long long)kv_nb[i];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) {
+    const int mul = ng > 0 ? min(group_rows, nqb - (i % ng) * group_rows) : 1;
+    v += (unsigned long long)kv_nb[i] * (unsigned long long)mul;
+  }
   __shared__ unsigned long long part[4];
   float dummy = 0.f; (void)dummy;
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -328,7 +332,7 @@ int k5_launch_nabla_count(const void* workspace, int H, int nqb, int nb, unsigne
   const int* kv_nb;
   k5_nabla_workspace_views(const_cast<void*>(workspace), H, nb, nullptr, &kv_nb, nullptr, nullptr);
   const int rows = H * nqb;
-  hipLaunchKernelGGL(nabla_count_kernel, dim3((rows + 4095) / 4096), dim3(256), 0, s, kv_nb, rows, acc);
+  hipLaunchKernelGGL(nabla_count_kernel, dim3((rows + 4095) / 4096), dim3(256), 0, s, kv_nb, rows, acc, 0, 1, 0);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
@@ -339,8 +343,8 @@ int k5_launch_nabla_count_lists(const void* workspace, int H, int nqb, int nb, i
   if (!workspace || !acc || H <= 0 || nqb <= 0 || group_rows <= 0) return K5_ERR_ARG;
   const int* cnt;
   k5_nabla_workspace_views(const_cast<void*>(workspace), H, nb, nullptr, nullptr, nullptr, &cnt);
-  const int n = H * ((nqb + group_rows - 1) / group_rows);
-  hipLaunchKernelGGL(nabla_count_kernel, dim3((n + 4095) / 4096), dim3(256), 0, s, cnt, n, acc);
+  const int ng = (nqb + group_rows - 1) / group_rows, n = H * ng;
+  hipLaunchKernelGGL(nabla_count_kernel, dim3((n + 4095) / 4096), dim3(256), 0, s, cnt, n, acc, ng, group_rows, nqb);   // executed blocks = list length x the rows that walk it
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 

@@ -254,12 +254,26 @@ __global__ __launch_bounds__(256) void key_centre_kernel(const bf16_t* __restric
 #pragma unroll
   for (int j = 0; j < 8; ++j) { wv[j] = w[j]; acc[j] = 0.f; }
   const bool rope = cosT && head < rope_heads;
-  const int niter = (nsample + 31) / 32;
-  for (int it = 0; it < niter; ++it) {
+  // every row this thread samples is requested BEFORE any of them is worked on (round 5: the serial chain of 8 dependent row loads was 10.9 us per
+  // block at 3328 tokens — a launch that costs one memory round trip instead of eight); same values summed in the same order
+  constexpr int NIT = K5_CENTRE_SAMPLE / 32;
+  u32x4 raws[NIT]; f32x4 csv[NIT], snv[NIT]; int rowv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
     const int i = it * 32 + sl;
     const bool live = i < nsample;
-    const int row = (int)(((long long)(live ? i : 0) * rows) / nsample);
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)row * ld + head * 64 + 8 * c);
+    rowv[it] = (int)(((long long)(live ? i : 0) * rows) / nsample);
+    raws[it] = *reinterpret_cast<const u32x4*>(x + (size_t)rowv[it] * ld + head * 64 + 8 * c);
+    if (rope) {
+      csv[it] = *reinterpret_cast<const f32x4*>(cosT + (size_t)rowv[it] * 32 + 4 * c);
+      snv[it] = *reinterpret_cast<const f32x4*>(sinT + (size_t)rowv[it] * 32 + 4 * c);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * 32 + sl;
+    const bool live = i < nsample;
+    const u32x4 raw = raws[it];
     float v[8], sq = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -275,8 +289,7 @@ __global__ __launch_bounds__(256) void key_centre_kernel(const bf16_t* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = bf_round(__fmul_rn(__fmul_rn(v[j], rs), wv[j]));
     if (rope) {
-      const f32x4 cs = *reinterpret_cast<const f32x4*>(cosT + (size_t)row * 32 + 4 * c);
-      const f32x4 sn = *reinterpret_cast<const f32x4*>(sinT + (size_t)row * 32 + 4 * c);
+      const f32x4 cs = csv[it], sn = snv[it];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x0 = y[2 * j], x1 = y[2 * j + 1];
