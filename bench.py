@@ -427,7 +427,7 @@ def main():
                    f"all zero when the bound is <= 90); beyond 190 the fixed form runs on offsets anchored at sampled scores (one-GPU path) "
                    f"unless the layer's jobs kept falling back")
     traffic, traffic_source = None, None   # HBM-side bytes per attention launch: NOT measured in this run (PMC counters need their own
-    for tf in ("r04_attention_traffic.json", "r03_attention_traffic.json", "r02_attention_traffic.json"):   # rocprofv3 --pmc passes) but read from the committed profile,
+    for tf in ("r05_attention_traffic.json", "r04_attention_traffic.json", "r03_attention_traffic.json", "r02_attention_traffic.json"):   # rocprofv3 --pmc passes) but read from the committed profile,
         try:                                                                  # and only quoted for the exact workload it was measured on
             with open(os.path.join(ROOT, "profiles", tf)) as f:
                 tj = json.load(f)

@@ -127,7 +127,7 @@ __global__ void gn_finalize_quads_kernel(const double* __restrict__ part, float*
 // thread -> fixed 16-B chunk column (tid % nch; nch a power of two <= 256), rows strided: the eight channels' affine
 // y = v * (rstd gamma) + (beta - mean rstd gamma) is folded once per thread, SiLU = y * rcp(1 + exp2(-y log2 e)) on the
 // hardware exp2 / rcp (the result is rounded to bf16).  One 16-B load, ~50 VALU, one 16-B store per chunk: HBM-bound.
-template <bool SILU>
+template <bool SILU, int U = 4>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        bf16_t* __restrict__ out, int M, int nch_sh, int cg_sh, int ldx, int ldo,
@@ -141,15 +141,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     sh[j] = beta[c] - stats[2 * g] * sc[j];
   }
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
-  for (int rb = r0 + rsub; rb < r1; rb += 4 * rows_par) {   // four independent 16-B loads in flight per thread
-    u32x4 raw[4];
+  for (int rb = r0 + rsub; rb < r1; rb += U * rows_par) {   // U independent 16-B loads in flight per thread
+    u32x4 raw[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int r = rb + u * rows_par;
       if (r < r1) raw[u] = *reinterpret_cast<const u32x4*>(x + (size_t)r * ldx + 8 * ch);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int r = rb + u * rows_par;
       if (r >= r1) break;
       float o[8];
@@ -293,7 +293,10 @@ int gn_apply(const void* x, const float* stats, const float* gamma, const float*
   while ((1 << cg_sh) < cg) ++cg_sh;
   const int rows_par = 256 >> nch_sh, rows_per_block = 32 * rows_par;   // 32 chunks per thread
   const int nb = (M + rows_per_block - 1) / rows_per_block;
-  if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)out, M,
+  static const int unroll = getenv("K5_GN_UNROLL") ? atoi(getenv("K5_GN_UNROLL")) : 4;   // A/B: 16-B loads in flight per thread
+  if (silu && unroll == 8) hipLaunchKernelGGL((gn_apply_kernel<true, 8>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)out, M,
+                                              nch_sh, cg_sh, ldx, ldo, rows_per_block);
+  else if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)out, M,
                                nch_sh, cg_sh, ldx, ldo, rows_per_block);
   else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)out, M,
                           nch_sh, cg_sh, ldx, ldo, rows_per_block);
