@@ -10,7 +10,10 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 torch.manual_seed(1)
 bad = 0
 for (M, N, K, epi) in ((47616, 1792, 1792, "gate"), (47616, 3584, 1792, "bias"), (1792, 47616, 1792, "bias_m"), (47616, 7168, 1792, "gelu"),
-                       (47616, 1792, 7168, "gate"), (5952, 1792, 1792, "bias"), (11904, 7168, 1792, "gelu"), (4096, 4096, 4096, "bias")):
+                       (47616, 1792, 7168, "gate"), (5952, 1792, 1792, "bias"), (11904, 7168, 1792, "gelu"), (4096, 4096, 4096, "bias"),
+                       # round 5: the 192- / 128-row token tiles (8- / 4-GPU shards, BASELINE config 1), incl. the gated epilogue the feed-forward uses
+                       (5952, 1792, 7168, "gate"), (5952, 3584, 1792, "bias"), (1792, 5952, 1792, "bias_m"), (11904, 1792, 1792, "gate"), (3328, 1792, 7168, "gate"),
+                       (3328, 7168, 1792, "gelu"), (3328, 1792, 1792, "bias")):
     a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
     bias = torch.randn(M if epi == "bias_m" else N, device="cuda")
     resid0 = torch.randn(M, N, device="cuda").to(BF) if epi == "gate" else None
