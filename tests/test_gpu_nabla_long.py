@@ -29,7 +29,7 @@ def _case(tag):
     from safetensors.torch import load_file
     meta = json.load(open(os.path.join(HERE, "dit_nabla_long_meta.json")))[tag]
     G = load_file(os.path.join(HERE, f"dit_nabla_long_{tag}.safetensors"))
-    c = dict(O.LITE_2B, num_visual_blocks=1, num_text_blocks=1)
+    c = dict(O.LITE_2B, num_visual_blocks=meta.get("visual_blocks", 1), num_text_blocks=1)
     sd = O.synthetic_state_dict(O.DitConfig(**c), seed=meta["weights_seed"])
     for k in sd:
         if k.endswith(("query_norm.weight", "key_norm.weight")):
@@ -54,8 +54,10 @@ def _patches(out, meta, blocks):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("tag", ["c4", "c5"])
+@pytest.mark.parametrize("tag", ["c4", "c5", "c4d"])
 def test_nabla_forward_at_config_length_vs_reference_golden(tag):
+    """c4 / c5: one visual block.  c4d (round 5): THREE visual blocks at config 4's length, the reference's attention evaluated on every row, so
+    the second and third blocks' maps are built from — and their attention runs over — activations that already went through a NABLA block."""
     from kandinsky.models.dit import DiffusionTransformer3D
     meta, G, c, sd, (x, text, pooled, pos, sp) = _case(tag)
     dit = DiffusionTransformer3D(**c)
@@ -68,7 +70,7 @@ def test_nabla_forward_at_config_length_vs_reference_golden(tag):
     got = _patches(out, meta, G["sampled_blocks"])
     r = rel(got, G["patches"])
     worst = max(rel(got[i], G["patches"][i]) for i in range(got.shape[0]))
-    print(f"NABLA at BASELINE config {tag[1]}'s length (N = {meta['tokens']}, {meta['blocks']} blocks, reference map density {meta['kept_density_on_sampled_rows']:.3f} on "
+    print(f"NABLA at BASELINE config {tag[1]}'s length, {meta.get('visual_blocks', 1)} visual block(s) (N = {meta['tokens']}, {meta['blocks']} blocks, reference map density {meta['kept_density_on_sampled_rows']:.3f} on "
           f"the sampled rows): engine vs reference fp32 {r:.3e} over {got.shape[0]} sampled blocks (worst block {worst:.3e}); heads fixed / online {n_fixed} / {n_online}")
     assert torch.isfinite(out.float()).all()
     assert r <= 3e-2, r
@@ -77,12 +79,13 @@ def test_nabla_forward_at_config_length_vs_reference_golden(tag):
 
 
 @pytest.mark.timeout(1200)
-def test_nabla_config4_as_4_ranks_vs_reference_golden():
+@pytest.mark.parametrize("tag", ["c4", "c4d"])
+def test_nabla_config4_as_4_ranks_vs_reference_golden(tag):
     """BASELINE config 4 as it is deployed — sequence-parallel x 4 — on one GPU through the loopback group: every rank's gathered velocity
     against the reference golden on the sampled blocks (blocks of every rank's token shard are among them)."""
     from test_gpu_loopback import run_ranks
     from kandinsky.models.dit import DiffusionTransformer3D
-    meta, G, c, sd, (x, text, pooled, pos, sp) = _case("c4")
+    meta, G, c, sd, (x, text, pooled, pos, sp) = _case(tag)
     L = meta["text_len"]
 
     def make():
@@ -99,5 +102,5 @@ def test_nabla_config4_as_4_ranks_vs_reference_golden():
     got = _patches(outs[0], meta, G["sampled_blocks"])
     r = rel(got, G["patches"])
     shard = meta["blocks"] // 4
-    print(f"config 4 as 4 ranks: vs reference fp32 {r:.3e}; sampled blocks per rank shard: {[int(((G['sampled_blocks'] // shard).clamp(max=3) == k).sum()) for k in range(4)]}")
+    print(f"config 4 as 4 ranks, {meta.get('visual_blocks', 1)} visual block(s): vs reference fp32 {r:.3e}; sampled blocks per rank shard: {[int(((G['sampled_blocks'] // shard).clamp(max=3) == k).sum()) for k in range(4)]}")
     assert r <= 3e-2, r
