@@ -679,6 +679,19 @@ int launch_k8(GemmP p, hipStream_t stream) {
 // fetch the next tile, whose first fragments are read while the current tile's last MFMAs run; the epilogue sits between.
 // ---------------------------------------------------------------------------------------------
 constexpr int W4_PAD = 1040, W4_OP = 32 * W4_PAD, W4_STAGE = 2 * W4_OP, W4_LDS = 2 * W4_STAGE;
+// Round 5 (second half) — the 128-row form (MT = 4) runs THREE stages.  Its X image is half of the 256-row one (16 pieces), so a stage is 49 920 B and
+// three of them (149 760 B + the epilogue's 4 KB) fit the 160-KB LDS.  Why: a K-tile of that form is 64 MFMAs per wave = 0.43 us of matrix pipe, but
+// with two stages K-tile t + 2 is requested during K-tile t and has to have landed a quarter into K-tile t + 1 — the global -> LDS round trip (1-2 us,
+// longer when the weights come from HBM, as they do in the model where every projection meets its weights for the first time since the last step) set
+// the pace: 0.93-1.18 us per K-tile (profiles/r05_gemm_block_shapes_mt.log, gpurun r05b config-1 kernel stats).  With three stages K-tile t + 3 is
+// requested during K-tile t: two K-tiles of lead.  Same K order, same MFMA sequence: bit-identical outputs.  -DW4_MT4_NST=2 builds the two-stage form (A/B).
+#ifndef W4_MT4_NST
+#define W4_MT4_NST 3
+#endif
+constexpr int w4_stages(int mt) { return mt == 4 ? W4_MT4_NST : 2; }
+constexpr int w4_stage_bytes(int mt) { return (mt == 4 && W4_MT4_NST == 3) ? W4_OP + 16 * W4_PAD : W4_STAGE; }
+constexpr int w4_ops_bytes(int mt) { return w4_stages(mt) * w4_stage_bytes(mt); }
+static_assert(w4_ops_bytes(4) + 4 * 1024 <= 160 * 1024 && w4_ops_bytes(8) == W4_LDS, "LDS budget of the four-wave kernel");
 #ifdef W4_TRACE
 constexpr int W4_TRACE_N = 192, W4_TRACE_BYTES = W4_TRACE_N * 8;   // 64 tiles x 3 stamps per workgroup
 #else
@@ -703,6 +716,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int NM = 16 * MT, HM = 8 * MT;   // MFMAs per K-tile / per k-step and wave
   constexpr int XD = MT == 4 ? 4 : 8;    // X-operand DMA instructions per wave and K-tile
   constexpr int ND = 8 + XD;             // DMA instructions per wave and K-tile
+  constexpr int NST = w4_stages(MT), STG = w4_stage_bytes(MT), OPS = NST * STG;   // LDS stages, bytes per stage, operand image (see w4_stages)
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wm = wave >> 1;
@@ -766,16 +780,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifndef W4_AUX
 #define W4_AUX 0   // cache policy of the operand DMAs (A/B macro: sc0 = 1, nt = 2, sc1 = 16 — none of them moved the stream)
 #endif
-  auto dma_w = [&](int stage) {
+  auto dma_w = [&](int so) {     // so: byte offset of the stage
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + stage * W4_STAGE + (dslot + jj) * W4_PAD), 16, vw,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + so + (dslot + jj) * W4_PAD), 16, vw,
                                                (uint32_t)(drow + jj) * ldw2, 0, W4_AUX);
   };
-  auto dma_x = [&](int stage) {
+  auto dma_x = [&](int so) {
 #pragma unroll
     for (int jj = 0; jj < XD; ++jj)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + stage * W4_STAGE + W4_OP + (dslot_x + jj) * W4_PAD), 16, vx,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + so + W4_OP + (dslot_x + jj) * W4_PAD), 16, vx,
                                                (uint32_t)(drow_x + jj) * lda2, 0, W4_AUX);
   };
   // after a K-tile's 16 DMAs: move the cursor; past the last tile it wraps onto the same tile (harmless loads that keep
@@ -796,8 +810,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   uint32_t wbs[2], xbs[2], xbs2[2];
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    wbs[st] = lds0 + st * W4_STAGE + (16 * wn + l15) * W4_PAD + lc * 16;
-    const uint32_t h0 = lds0 + st * W4_STAGE + W4_OP + l15 * W4_PAD + lc * 16;
+    wbs[st] = lds0 + st * STG + (16 * wn + l15) * W4_PAD + lc * 16;
+    const uint32_t h0 = lds0 + st * STG + W4_OP + l15 * W4_PAD + lc * 16;
     xbs2[st] = 0;
     if (MT == 8) xbs[st] = h0 + wm * (16 * W4_PAD);
     else if (MT == 6) { xbs[st] = h0 + wm * 768; xbs2[st] = h0 + wm * (16 * W4_PAD - 256); }
@@ -826,18 +840,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_DBG 0
 #endif
   constexpr int dbg = W4_DBG;   // compile-time ablations (benchmarking only): 1 no DMA, 2 no fragment reads, 4 no barriers, 8 no MFMA
-  auto dma1 = [&](int stage, int d) {
+  auto dma1 = [&](int so, int d) {
     if (dbg & 1) return;
-    if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + stage * W4_STAGE + (dslot + d) * W4_PAD), 16, vw,
+    if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + so + (dslot + d) * W4_PAD), 16, vw,
                                                         (uint32_t)(drow + d) * ldw2, 0, W4_AUX);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + stage * W4_STAGE + W4_OP + (dslot_x + d - 8) * W4_PAD), 16, vx,
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + so + W4_OP + (dslot_x + d - 8) * W4_PAD), 16, vx,
                                                   (uint32_t)(drow_x + d - 8) * lda2, 0, W4_AUX);
   };
 
   set_dma_tile(slot);
-  dma_w(0); dma_x(0); dma_advance();
-  dma_w(1); dma_x(1); dma_advance();
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND) : "memory");
+#pragma unroll
+  for (int st = 0; st < NST; ++st) { dma_w(st * STG); dma_x(st * STG); dma_advance(); }
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND * (NST - 1)) : "memory");   // K-tile 0 has landed
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < 8; ++i) { W4_RD(wf0[i], wbs[0], i * 128); W4_RD(wf1[0][i], wbs[0], i * 128 + 64); }
@@ -864,9 +878,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   static_assert(W4_DS * (ND - 1) < NM && W4_BB >= 1, "schedule does not fit");
   constexpr int W4_NB = (W4_BB + W4_DS - 1) / W4_DS < ND ? (W4_BB + W4_DS - 1) / W4_DS : ND;   // this K-tile's DMAs issued before m = W4_BB
   constexpr int NR = 8 + MT;   // fragment reads per k-step
+  // NST stages (2, or 3 on the 128-row form): K-tile t sits in stage t % NST, K-tile t + NST is requested during K-tile t, and the wait below leaves
+  // this K-tile's own DMAs so far AND the NST - 2 whole K-tiles requested after K-tile t + 1 in flight.  The k-step-1 fragment buffer alternates with
+  // the K-tile's parity (st: compile time, nk is even so every output tile starts on buffer 0).  With two stages the LDS stage is that parity too; with
+  // three it ROTATES AT RUN TIME — o_cur (scalar: the stage this K-tile's DMAs refill) and wb_nx / xb_nx (the fragment-read bases of the stage after
+  // it) move on at the end of every K-tile — so the K loop stays the same straight line unrolled by two: any branch on the stage around the asm MFMA
+  // stream makes the register allocator park the accumulators (286 spilled VGPRs with a three-way dispatch per K-tile).
+  int o_cur = 0;
+  uint32_t wb_nx = wbs[0] + STG, xb_nx = xbs[0] + STG;     // (three stages; MT = 4 reads X through one base)
   auto ktile = [&](auto STC, auto FIRSTC) {
-    constexpr int st = decltype(STC)::value;
+    constexpr int st = decltype(STC)::value, nx = st ^ 1;
     constexpr bool first = decltype(FIRSTC)::value;
+    const int so = NST == 2 ? st * STG : o_cur;
+    const uint32_t wbn = NST == 2 ? wbs[nx] : wb_nx;
+    auto xbn = [&](int j) -> uint32_t { return NST == 2 ? W4_XB(nx, j) : xb_nx; };
     if (!(dbg & 4)) asm volatile("s_barrier" ::: "memory");
     auto chunk = [&](auto BASEC) {   // 16 MFMAs at a time: a single 128-trip loop is beyond the full-unroll budget
 #pragma unroll
@@ -876,10 +901,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           else if (m < HM) W4_MF(wf0, xf0, m);
           else W4_MF(wf1[st], xf1[st], m - HM);
         }
-        if (m % W4_DS == 0 && m / W4_DS < ND) dma1(st, m / W4_DS);
+        if (m % W4_DS == 0 && m / W4_DS < ND) dma1(so, m / W4_DS);
         if (m == W4_BB - 1) {
-          if (dbg & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W4_NB) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(W4_NB) : "memory");
+          if (dbg & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W4_NB + ND * (NST - 2)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(W4_NB + ND * (NST - 2)) : "memory");
         }
         // fragment reads of K-tile t+1, W4_RS MFMAs apart (back to back they saturate the LDS: four waves x 1 KB per 16 cycles).
         // k-step 1 goes to the idle buffer and may start at the barrier; k-step 0 reuses wf0/xf0, free from m = 64
@@ -889,13 +914,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           static_assert(K0_AT + (NR - 1) * W4_RS < NM && K1_AT + (NR - 1) * W4_RS < NM, "fragment reads do not fit");
           if (m >= K0_AT && m < K0_AT + NR * W4_RS && (m - K0_AT) % W4_RS == 0) {
             const int r = (m - K0_AT) / W4_RS;
-            if (r < 8) W4_RD(wf0[r & 7], wbs[st ^ 1], (r & 7) * 128);
-            else W4_RD(xf0[r - 8], W4_XB(st ^ 1, r - 8), (r - 8) * 128);
+            if (r < 8) W4_RD(wf0[r & 7], wbn, (r & 7) * 128);
+            else W4_RD(xf0[r - 8], xbn(r - 8), (r - 8) * 128);
           }
           if (m >= K1_AT && m < K1_AT + NR * W4_RS && (m - K1_AT) % W4_RS == 0) {
             const int r = (m - K1_AT) / W4_RS;
-            if (r < 8) W4_RD(wf1[st ^ 1][r & 7], wbs[st ^ 1], (r & 7) * 128 + 64);
-            else W4_RD(xf1[st ^ 1][r - 8], W4_XB(st ^ 1, r - 8), (r - 8) * 128 + 64);
+            if (r < 8) W4_RD(wf1[nx][r & 7], wbn, (r & 7) * 128 + 64);
+            else W4_RD(xf1[nx][r - 8], xbn(r - 8), (r - 8) * 128 + 64);
           }
         }
       }
@@ -906,6 +931,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if constexpr (MT >= 8) { chunk(std::integral_constant<int, 96>{}); chunk(std::integral_constant<int, 112>{}); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // K-tile t+1's fragments
     dma_advance();
+    if constexpr (NST == 3) {
+      const bool wrap = o_cur == STG;      // the stage after o_cur is the last one -> the one after that is stage 0
+      o_cur = o_cur == 2 * STG ? 0 : o_cur + STG;
+      wb_nx = wrap ? wb_nx - 2 * STG : wb_nx + STG;
+      xb_nx = wrap ? xb_nx - 2 * STG : xb_nx + STG;
+    }
   };
 
 #ifndef W4_SCHED
@@ -969,7 +1000,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 
 #ifdef W4_TRACE   // tools/gemm_w4_trace.py: wall-clock (100 MHz) stamps per workgroup and tile: tile start | K loop done | epilogue done
-  unsigned long long* tr_lds = reinterpret_cast<unsigned long long*>(dsm + W4_LDS);
+  unsigned long long* tr_lds = reinterpret_cast<unsigned long long*>(dsm + OPS);
   int tr_i = 0;
   if (tid == 0) tr_lds[W4_TRACE_N - 2] = __builtin_amdgcn_s_memtime();   // shader-clock ticks at the first / after the last tile: the clock this kernel ran at
 #define W4_STAMP() do { if (tid == 0 && tr_i < W4_TRACE_N) tr_lds[tr_i] = __builtin_amdgcn_s_memrealtime(); ++tr_i; } while (0)
@@ -1019,7 +1050,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // bias AND gate would be 64 VGPRs next to two register sets of residual rows and the next tile's 128 fragment registers — they live
       // in this wave's 1-KB LDS slot instead (ds_read_b128 per use: the LDS is idle in the epilogue, and DS reads are not in the vmcnt queue)
       f32x4 bvec[8];
-      float* vslot = reinterpret_cast<float*>(dsm + W4_LDS + W4_TRACE_BYTES + 1024 * e_wave);   // [bias 128 | gate 128]
+      float* vslot = reinterpret_cast<float*>(dsm + OPS + W4_TRACE_BYTES + 1024 * e_wave);   // [bias 128 | gate 128]
       if constexpr (EPI == K5_EPI_GATE) {
         const int l = tid2 & 63;
 #pragma unroll
@@ -1040,7 +1071,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // by v_permlane16_swap so that every lane stores 16 B
       // (gated residual) bias / gate quads of n-tiles 2 iq, 2 iq + 1 from the wave's LDS slot: asm reads with counted lgkmcnt waits — a plain
       // LDS load would make the compiler wait for every LDS-DMA (the next tile's K-tiles) and store in flight first — fetched one pair ahead
-      const uint32_t vaddr = (uint32_t)(uintptr_t)(w4_lds_t*)(dsm + W4_LDS + W4_TRACE_BYTES) + 1024u * (uint32_t)e_wave + 16u * (uint32_t)e_lc;
+      const uint32_t vaddr = (uint32_t)(uintptr_t)(w4_lds_t*)(dsm + OPS + W4_TRACE_BYTES) + 1024u * (uint32_t)e_wave + 16u * (uint32_t)e_lc;
       f32x4 bq[2][2], gq[2][2];
 #define W4_VEC_FETCH(IQ, B) do { W4_RD(bq[B][0], vaddr, 128 * (IQ)); W4_RD(bq[B][1], vaddr, 128 * (IQ) + 64); \
                                 W4_RD(gq[B][0], vaddr, 512 + 128 * (IQ)); W4_RD(gq[B][1], vaddr, 512 + 128 * (IQ) + 64); } while (0)
@@ -1305,7 +1336,7 @@ template <int EPI, int MT>
 int launch_w4_mt(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS + W4_TRACE_BYTES + W4_PF_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, w4_ops_bytes(MT) + W4_TRACE_BYTES + W4_PF_BYTES) != hipSuccess)
       return K5_ERR_HIP;
     attr_set = true;
   }
@@ -1318,7 +1349,7 @@ int launch_w4_mt(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
   const bool split_tail = MT == 8 && !no_tail && full > 0 && rem > 0 && 2 * rem < num_cu;   // see launch_k8_mt
   p.lid_limit = split_tail ? full : tiles;
   p.tiles256_m = p.tiles_m; p.tiles256_n = p.tiles_n;
-  hipLaunchKernelGGL((gemm_bf16_w4_kernel<EPI, MT>), dim3(min(p.lid_limit, num_cu)), dim3(256), W4_LDS + W4_TRACE_BYTES + W4_PF_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_w4_kernel<EPI, MT>), dim3(min(p.lid_limit, num_cu)), dim3(256), w4_ops_bytes(MT) + W4_TRACE_BYTES + W4_PF_BYTES, stream, p);
   if (hipGetLastError() != hipSuccess) return K5_ERR_HIP;
   if (split_tail) return launch_tail<EPI>(p, stream, full, rem);
   return K5_OK;
