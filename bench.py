@@ -192,6 +192,52 @@ def parity_check(dit, noise, dev, sig, te, ne, vpos, tpos, ntpos, wl, sparse):
     return out
 
 
+def live_traffic(tokens, timeout_s=240):
+    """HBM-side bytes of ONE dense self-attention launch, measured by THIS bench run (the line used to quote a committed file):
+    two child runs of this script (2 visual blocks, 1 + 1 steps: the per-launch figure does not depend on the depth) under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` — one counter per pass, kernel trace only, no sys / hip / hsa trace domains, exactly the
+    collection /opt/skills/guides/MI355X_MICROARCH.md prescribes — FETCH_SIZE doubled (gfx950 reports half of a wide coalesced stream), KB units.
+    The launch taken is the main dense launch (largest fetch among attn_fwd_kernel dispatches; the balanced call's tail launches are smaller);
+    `traffic` = the MAX over its dispatches.  Returns (bytes or None, source string).  Never raises: a missing profiler, a timeout or an
+    unreadable CSV leaves the caller on the committed figure, and says why."""
+    import csv, glob, shutil, subprocess, tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="k5_pmc_", dir="/tmp")
+    got = {}
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, c)
+            cmd = [prof, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-vae", "--no-breakdown", "--no-parity-check", "--no-live-traffic", "--blocks", "2"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+            per, names = {}, {}
+            for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(fn) as f:
+                    for row in csv.DictReader(f):
+                        if row.get("Counter_Name") == c:
+                            per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                            names[row["Dispatch_Id"]] = row["Kernel_Name"]
+            vals = [v for i, v in per.items() if "attn_fwd_kernel" in names[i]]
+            if not vals:
+                return None, f"the {c} pass produced no attention dispatch (rc {r.returncode}: {(r.stderr or '')[-200:]!r})"
+            got[c] = vals
+        f_main = max(got["FETCH_SIZE"])
+        main_f = [v for v in got["FETCH_SIZE"] if v > 0.5 * f_main]       # the main launches (tail / text launches fetch far less)
+        w_main = max(got["WRITE_SIZE"])
+        return 2.0 * f_main * 1024 + w_main * 1024, (
+            f"THIS run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate child passes of bench.py --blocks 2 ({len(main_f)} main launches; max taken), "
+            f"FETCH x2 per MI355X_MICROARCH.md; fabric-side counter (Infinity-Cache hits included); algorithmic bytes {4 * tokens * 28 * 64 * 2}")
+    except Exception as e:     # noqa: BLE001 — the bench line must still be printed
+        return None, f"live PMC pass failed: {type(e).__name__}: {str(e)[:200]}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def self_launch_command(argv, gpus, port=None):
     """`python bench.py --gpus N ...` outside torch.distributed.run: the command that runs the same flags as N ranks on this node."""
     if port is None:
@@ -212,6 +258,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed 2-step check against the reference golden (5s_nocfg only)")
     ap.add_argument("--write-pin", default="", metavar="FILE", help="write this run's latent pin entry (to be merged into tests/golden/bench_latent_pins.json)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure `roofline.traffic` (the line then "
+                    "quotes the committed profile, and says so)")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-for-`value`) VAE decode leg")
     ap.add_argument("--force-sp", action="store_true", help="debug: drive the sharded code path through a world=1 RCCL communicator")
     ap.add_argument("--magcache", action="store_true", help="MagCache with the config's ratio table (changes the work per step: not the headline metric)")
@@ -436,6 +484,16 @@ def main():
                 break
         except Exception:
             pass
+    # ... unless this run can measure it itself: the default single-GPU dense workload, on rank 0, after the timed region (nothing here is timed)
+    if (rank == 0 and world == 1 and not args.no_live_traffic and wl["attn"] == "flash" and not args.attn_online and n_online == 0 and args.blocks == 32
+            and args.workload == "5s_nocfg" and not args.emulate_shard and not args.fp8 and not args.force_sp and args.qk_gain == 1.0
+            and not args.engine_option and not args.magcache and not args.graph
+            and not any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) and "rocprof" not in os.environ.get("LD_PRELOAD", "")):   # (not under a profiler already)
+        lt, lsrc = live_traffic(N)
+        if lt is not None:
+            traffic, traffic_source = lt, lsrc
+        else:
+            traffic_source = (traffic_source or "none") + f" [live measurement unavailable: {lsrc}]"
     # the GEMM family (q|k, V^T, out, cross q/out, FF1, FF2 of the visual blocks: 2 * rows * (6 D^2 + 2 D FF) per block on this rank's
     # rows; text-side projections are < 0.1 %) — on the sparse configurations it, not the attention, is the largest family
     g_ms, g_n = fam_break["gemm"]

@@ -83,3 +83,23 @@ def test_bench_json_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "steps/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["value"] / c["value"] > 10.0          # sanity only: the ratio says nothing about kernel quality
+
+
+@pytest.mark.gpu
+def test_bench_measures_its_own_hbm_traffic():
+    """`roofline.traffic` of the default line is measured by the run itself (two rocprofv3 --pmc child passes, FETCH_SIZE x2 + WRITE_SIZE, one counter
+    per pass): the figure must be a plausible per-launch byte count for the 47 616-token dense attention — at least the algorithmic K / V^T / Q / O
+    bytes (0.68 GB), far below re-reading K and V^T for every 256-query workgroup from HBM (62 GB) — and the source string must say it is this run's."""
+    import importlib.util
+    import shutil
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X (torch.cuda.is_available() is False)")
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 is not installed on this box")
+    spec = importlib.util.spec_from_file_location("k5_bench_lt", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    traffic, src = b.live_traffic(47616)
+    assert traffic is not None, src
+    assert 0.6e9 < traffic < 8e9, (traffic, src)
+    assert src.startswith("THIS run")

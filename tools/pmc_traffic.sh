@@ -3,7 +3,7 @@
 # reports half of a wide coalesced stream -> doubled below; units: KB).
 export TMPDIR=/tmp; R=$PWD; cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-vae --blocks 2 > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-live-traffic --no-vae --blocks 2 > /dev/null 2>&1
 done
 cd $R
 python - <<PY

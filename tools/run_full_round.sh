@@ -2,9 +2,9 @@
 # full GPU regression + the bench lines of a round:  bash tools/run_full_round.sh TAG
 cd /root/repo; mkdir -p gpurun_out; T=${1:-x}
 timeout 1500 python -m pytest tests/ -q -m gpu --durations=8 2>&1 | tail -25 > gpurun_out/r05_gputests_$T.log; tail -22 gpurun_out/r05_gputests_$T.log
-timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-vae > gpurun_out/r05_bench_$T.json 2> gpurun_out/r05_bench_$T.err
-for P in 2 4 8; do timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vae --emulate-shard $P 2>/dev/null | grep "^{"; done > gpurun_out/r05_shards_$T.jsonl
-timeout 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-vae --workload 2s_256 2>/dev/null | grep "^{" > gpurun_out/r05_config1_$T.json
+timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-live-traffic --no-vae > gpurun_out/r05_bench_$T.json 2> gpurun_out/r05_bench_$T.err
+for P in 2 4 8; do timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic --no-vae --emulate-shard $P 2>/dev/null | grep "^{"; done > gpurun_out/r05_shards_$T.jsonl
+timeout 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-live-traffic --no-vae --workload 2s_256 2>/dev/null | grep "^{" > gpurun_out/r05_config1_$T.json
 TAG=$T python - <<'P'
 import json,glob,os
 T=os.environ.get("T","x")
