@@ -192,7 +192,7 @@ def parity_check(dit, noise, dev, sig, te, ne, vpos, tpos, ntpos, wl, sparse):
     return out
 
 
-def live_traffic(tokens, timeout_s=240):
+def live_traffic(tokens, timeout_s=150):
     """HBM-side bytes of ONE dense self-attention launch, measured by THIS bench run (the line used to quote a committed file):
     two child runs of this script (2 visual blocks, 1 + 1 steps: the per-launch figure does not depend on the depth) under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` — one counter per pass, kernel trace only, no sys / hip / hsa trace domains, exactly the
