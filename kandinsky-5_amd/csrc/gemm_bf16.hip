@@ -680,11 +680,11 @@ int launch_k8(GemmP p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 constexpr int W4_PAD = 1040, W4_OP = 32 * W4_PAD, W4_STAGE = 2 * W4_OP, W4_LDS = 2 * W4_STAGE;
 // Round 5 (second half) — the 128-row form (MT = 4) runs THREE stages.  Its X image is half of the 256-row one (16 pieces), so a stage is 49 920 B and
-// three of them (149 760 B + the epilogue's 4 KB) fit the 160-KB LDS.  Why: a K-tile of that form is 64 MFMAs per wave = 0.43 us of matrix pipe, but
-// with two stages K-tile t + 2 is requested during K-tile t and has to have landed a quarter into K-tile t + 1 — the global -> LDS round trip (1-2 us,
-// longer when the weights come from HBM, as they do in the model where every projection meets its weights for the first time since the last step) set
-// the pace: 0.93-1.18 us per K-tile (profiles/r05_gemm_block_shapes_mt.log, gpurun r05b config-1 kernel stats).  With three stages K-tile t + 3 is
-// requested during K-tile t: two K-tiles of lead.  Same K order, same MFMA sequence: bit-identical outputs.  -DW4_MT4_NST=2 builds the two-stage form (A/B).
+// three of them (149 760 B + the epilogue's 4 KB) fit the 160-KB LDS: K-tile t + 3 is requested during K-tile t (two K-tiles of lead instead of one).
+// Same K order, same MFMA sequence: bit-identical outputs.  Measured (profiles/r05_gemm_mt4_three_stage_ab.log): +1-6 % on warm operands, -2.3 % of a
+// config-1 step through the engine, where every projection meets its weights for the first time since the last step.  It is a small gain because the
+// lead was a small part of the K-tile's 0.8-0.9 us: 48 KB per K-tile at the 62-72 GB/s a CU can pull out of its L2 (tools/probes/ldsdma_rate.hip) is
+// 0.69 us — this form is bound by the fill rate, not by the 0.43 us of MFMAs (HISTORY.md §R5).  -DW4_MT4_NST=2 builds the two-stage form (A/B).
 #ifndef W4_MT4_NST
 #define W4_MT4_NST 3
 #endif
