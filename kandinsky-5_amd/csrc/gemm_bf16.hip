@@ -666,10 +666,10 @@ int launch_k8(GemmP p, hipStream_t stream) {
 // nothing is zeroed or spilled: q|k 590 -> 924, out+gate 509 -> 815, FF2+gate 961 -> 1150 TFLOP/s.
 //
 // LDS: an operand tile (256 rows x 64 k, 128 B per row) is 32 pieces; piece d = 16 h + r holds rows 128 h + 16 i + r
-// (i = 0..7) back to back, 1024 B + 16 B pad, i.e. row -> (16 h + r) * 1040 + 128 i.  One DMA instruction fills one piece
-// (lane j: row-tile i = j >> 3, 16-B chunk j & 7: eight 128-B global segments).  A fragment read (16 rows r = lane & 15 of
-// row-tile i, k-chunk 4 s + lane>>4) is lane_base + 128 i + 64 s: every offset an immediate, and the 16 lanes of a
-// ds_read_b128 quarter are 1040 B apart = 4 banks apart: conflict-free.  2 stages x 2 operands x 33 280 B = 133 120 B.
+// (i = 0..7) back to back, 1024 B + pad (W4_PAD, see there: 32 B since round 5), i.e. row -> (16 h + r) * W4_PAD + 128 i.  One DMA instruction
+// fills one piece (lane j: row-tile i = j >> 3, 16-B chunk j & 7: eight 128-B global segments).  A fragment read (16 rows r = lane & 15 of
+// row-tile i, k-chunk 4 s + lane>>4) is lane_base + 128 i + 64 s: every offset an immediate, conflict-free with the 32-B pad.
+// 2 stages x 2 operands x 33 792 B = 135 168 B.
 //
 // Pipeline (K-tile t in stage t & 1; there are no staging registers, so a stage is free as soon as its fragments are in
 // registers, and a third fragment buffer lets ALL of K-tile t+1's fragments be read during the last quarter of K-tile t):
