@@ -26,7 +26,10 @@
 
 namespace {
 
-constexpr int VA_KROW = 1040;                 // bytes per staged key row (1024 + 16)
+constexpr int VA_KROW = 1056;                 // bytes per staged key row (1024 + 32: conflict-free under the real ds_read_b128 lane groups, see gemm_bf16.hip W4_PAD; 1040 until round 5)
+// chunk swizzle of the V^T tile (rows 64 B apart): quarter q = (row >> 2) & 3 of a 16-row fragment XORs its chunk with VA_SWZ(q) = 0, 2, 3, 1 — with the
+// plain q of rounds 3-5 two (lane group, quarter) pairs of every b128 read group met on the same banks (SQ_LDS_BANK_CONFLICT = 0.50 of the LDS cycles)
+#define VA_SWZ(q) ((0x78 >> (2 * (q))) & 3)
 constexpr int VA_KT = 32 * VA_KROW;           // K tile
 constexpr int VA_VT = 512 * 64;               // V^T tile
 constexpr int VA_BUF = VA_KT + VA_VT;
@@ -76,9 +79,9 @@ __global__ __launch_bounds__(256) void vae_attn512_kernel(VaP p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int d0 = 16 * (8 * wave + i);
-      // LDS position (row = lane >> 2, chunk = lane & 3) receives SOURCE chunk (lane & 3) ^ ((row >> 2) & 3): rows 64 B apart share a
+      // LDS position (row = lane >> 2, chunk = lane & 3) receives SOURCE chunk (lane & 3) ^ VA_SWZ((row >> 2) & 3): rows 64 B apart share a
       // bank row in fours, the swizzle spreads the 16 rows of a fragment read over all 64 banks
-      const bf16_t* src = p.vt + (size_t)(d0 + (lane >> 2)) * p.ldvt + key0 + 8 * ((lane & 3) ^ ((lane >> 4) & 3));   // ldvt covers whole 32-key tiles (launcher)
+      const bf16_t* src = p.vt + (size_t)(d0 + (lane >> 2)) * p.ldvt + key0 + 8 * ((lane & 3) ^ VA_SWZ((lane >> 4) & 3));   // ldvt covers whole 32-key tiles (launcher)
       __builtin_amdgcn_global_load_lds((va_gbl_t*)src, (va_lds_t*)(vb + d0 * 64), 16, 0, 0);
     }
   };
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void vae_attn512_kernel(VaP p) {
   for (int b = 0; b < 2; ++b) {
     ka[b][0] = lds0 + b * VA_BUF + l15 * VA_KROW + 16 * g;
     ka[b][1] = ka[b][0] + 16 * VA_KROW;
-    va[b] = lds0 + b * VA_BUF + VA_KT + l15 * 64 + 16 * (g ^ ((l15 >> 2) & 3));
+    va[b] = lds0 + b * VA_BUF + VA_KT + l15 * 64 + 16 * (g ^ VA_SWZ((l15 >> 2) & 3));
   }
   if (T > 0) load_tile(0, 0);
   __syncthreads();
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void vae_attn512_kernel(VaP p) {
       const char* vb = vsm + buf * VA_BUF + VA_KT;
 #pragma unroll
       for (int dt = 0; dt < 32; ++dt) {
-        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + (16 * dt + l15) * 64 + 16 * (g ^ ((l15 >> 2) & 3)));
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + (16 * dt + l15) * 64 + 16 * (g ^ VA_SWZ((l15 >> 2) & 3)));
         ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, ot[dt], 0, 0, 0);
       }
     }
