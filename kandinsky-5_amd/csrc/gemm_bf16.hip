@@ -878,10 +878,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifndef W4P
 #define W4P 8, 80, 1   // round 5 (after the 32-B piece pad: a fragment read is 4 LDS cycles, back-to-back reads no longer saturate the LDS): reads every MFMA, barrier at m = 80 — -0.8 % per block against 8, 64, 2 (profiles/r05_gemm_piece_pad_ab.log); rounds 2-5: read spacing 1 -> 2 was +4-6 % with the conflicting layout
 #endif
+#ifndef W4_BB6
+#define W4_BB6 40
+#endif
+#ifndef W4_BB4
+#define W4_BB4 16
+#endif
   constexpr int w4p[3] = {W4P};
   // MT = 6: 96 MFMAs, 16 DMAs 6 apart, barrier after m = 39, k-step-1 reads (14) from m = 40, k-step-0 reads from m = 68; MT = 4: 64 MFMAs, 12 DMAs 5
   // apart, barrier after m = 15, reads (12 + 12) from m = 16 and m = 40
-  constexpr int W4_DS = MT == 8 ? w4p[0] : NM / ND, W4_BB = MT == 8 ? w4p[1] : (MT == 6 ? 40 : 16), W4_RS = w4p[2];   // DMA spacing, barrier position, fragment-read spacing
+  constexpr int W4_DS = MT == 8 ? w4p[0] : NM / ND, W4_BB = MT == 8 ? w4p[1] : (MT == 6 ? W4_BB6 : W4_BB4), W4_RS = w4p[2];   // DMA spacing, barrier position, fragment-read spacing
   static_assert(W4_DS * (ND - 1) < NM && W4_BB >= 1, "schedule does not fit");
   constexpr int W4_NB = (W4_BB + W4_DS - 1) / W4_DS < ND ? (W4_BB + W4_DS - 1) / W4_DS : ND;   // this K-tile's DMAs issued before m = W4_BB
   constexpr int NR = 8 + MT;   // fragment reads per k-step
