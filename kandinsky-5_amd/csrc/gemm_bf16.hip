@@ -787,17 +787,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifndef W4_AUX
 #define W4_AUX 0   // cache policy of the operand DMAs (A/B macro: sc0 = 1, nt = 2, sc1 = 16 — none of them moved the stream)
 #endif
+#ifndef W4_AUX_W   // ... per operand (round 5: the weight panels stream through the L2 46 times per FF1 launch and evict the token panels a round would re-use)
+#define W4_AUX_W W4_AUX
+#endif
+#ifndef W4_AUX_X
+#define W4_AUX_X W4_AUX
+#endif
   auto dma_w = [&](int so) {     // so: byte offset of the stage
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + so + (dslot + jj) * W4_PAD), 16, vw,
-                                               (uint32_t)(drow + jj) * ldw2, 0, W4_AUX);
+                                               (uint32_t)(drow + jj) * ldw2, 0, W4_AUX_W);
   };
   auto dma_x = [&](int so) {
 #pragma unroll
     for (int jj = 0; jj < XD; ++jj)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + so + W4_OP + (dslot_x + jj) * W4_PAD), 16, vx,
-                                               (uint32_t)(drow_x + jj) * lda2, 0, W4_AUX);
+                                               (uint32_t)(drow_x + jj) * lda2, 0, W4_AUX_X);
   };
   // after a K-tile's 16 DMAs: move the cursor; past the last tile it wraps onto the same tile (harmless loads that keep
   // the vmcnt arithmetic uniform; nothing reads them)
@@ -850,9 +856,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto dma1 = [&](int so, int d) {
     if (dbg & 1) return;
     if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (w4_lds_t*)(dsm + so + (dslot + d) * W4_PAD), 16, vw,
-                                                        (uint32_t)(drow + d) * ldw2, 0, W4_AUX);
+                                                        (uint32_t)(drow + d) * ldw2, 0, W4_AUX_W);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + so + W4_OP + (dslot_x + d - 8) * W4_PAD), 16, vx,
-                                                  (uint32_t)(drow_x + d - 8) * lda2, 0, W4_AUX);
+                                                  (uint32_t)(drow_x + d - 8) * lda2, 0, W4_AUX_X);
   };
 
   set_dma_tile(slot);
