@@ -1436,7 +1436,9 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   // q|k 903 vs 841, V^T 983 vs 943, out+gate 814 vs 708, FF1+GELU 1004 vs 946, FF2+gate 1163 vs 1070, 4096^3 1240 vs 1174;
   // 4-GPU token shards (329 tiles) +6-10 %; 8-GPU shards (168 tiles) lose 3-8 % to the 8-wave kernel's 192-row tile option,
   // which therefore keeps the range below 256 tiles).  K5_GEMM_V1=4 / 8 force one of them.
-  const bool w4_ok = (K % (2 * BK)) == 0 && K >= 4 * BK && M >= 512 && N >= 256 && !(N & 7) && !(ldc & 7) && (epi != K5_EPI_GATE || !(ldr & 3));
+  const bool w4_ok = (K % (2 * BK)) == 0 && K >= 4 * BK && M >= 512 && N >= 128 && !(N & 7)   // (N = 128: the VAE's 256 -> 128 shortcut at full resolution, 6.7 M rows — half of the
+                                                                                                    // 256-wide weight tile multiplies zeros the buffer range check supplies, and it is still twice the 128 x 128 kernel's rate)
+                     && !(ldc & 7) && (epi != K5_EPI_GATE || !(ldr & 3));
   // Round 5: with the token-tile height chosen per launch (w4_pick_mt: 256 / 192 / 128 rows) the four-wave kernel also takes the launches below one
   // round of 256 x 256 tiles — 8-GPU token shards (168 such tiles -> 217 of 192 rows) and BASELINE config 1 (91 -> 182 of 128 rows) — from
   // K5_GEMM_W4_MIN (default 96) tiles of the chosen height up (measured, profiles/r05_gemm_block_shapes_*.log; until round 4 those ran on the

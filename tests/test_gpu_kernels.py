@@ -115,7 +115,7 @@ def test_gemm_four_wave_kernel_is_race_free_and_handles_edges(E):
     assert torch.count_nonzero(out[:, N:]) == 0
 
 
-@pytest.mark.parametrize("M,N,K", [(5952, 1792, 1792), (3328, 1792, 384), (3328 - 40, 2048 - 24, 256), (1792, 5952, 256), (700, 1000, 512), (4000, 2304, 512), (9000, 1792, 7168)])
+@pytest.mark.parametrize("M,N,K", [(5952, 1792, 1792), (3328, 1792, 384), (3328 - 40, 2048 - 24, 256), (1792, 5952, 256), (700, 1000, 512), (4000, 2304, 512), (9000, 1792, 7168), (40000, 128, 256)])
 def test_gemm_four_wave_token_tile_heights(E, M, N, K):
     """Round 5: the four-wave kernel with 256- / 192- / 128-row token tiles (8 / 6 / 4 MFMA row tiles per wave; the dispatch picks by
     tile quantisation: 8-GPU shards, BASELINE config 1).  Every height sums a K column in the same order as the 128 x 128 kernel: the
