@@ -214,7 +214,20 @@ def live_traffic(tokens, timeout_s=150):
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+            # own session: on a timeout the WHOLE group goes (rocprofv3 and the bench it launched — subprocess.run would kill only the
+            # profiler and leave a grandchild on the GPU under the VAE leg: ADVICE r5)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                _, err_txt = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                pr.communicate()
+                return None, f"the {c} pass did not finish within {timeout_s} s (process group killed)"
+            r = subprocess.CompletedProcess(cmd, pr.returncode, None, err_txt)
             per, names = {}, {}
             for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(fn) as f:
@@ -277,6 +290,13 @@ def main():
     ap.add_argument("--cfg-parallel", action="store_true",
                     help="N even, a workload with guidance (5s_sft, 10s_hd_sft): ranks [0, N/2) run the conditional forward, [N/2, N) the unconditional "
                          "one, each group sequence-parallel inside; the pair exchange lives in the engine (k5_dit_cfg_pair_init)")
+    ap.add_argument("--transport", default=None, choices=("rccl", "ipc"),
+                    help="N > 1: what moves K / V^T between the ranks — RCCL (default) or the engine's own IPC transport (peers read each other's "
+                         "hipIpc-mapped slots, flags in device memory; k5_dit_comm_init_ipc).  Also K5_SP_TRANSPORT")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="N > 1 ranks on the devices that exist (rank r on device r %% count; one GPU: all on device 0) over the IPC transport — runs the "
+                         "process boundary of the sharded path on a one-GPU box.  INVALID as a bench (the ranks time-slice one GPU); rank_check and "
+                         "ipc_ranks_seen are what it is for")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured step (k5_dit_set_graph; needs --profile-level 0: events cannot be captured)")
     ap.add_argument("--emulate-shard", type=int, default=0, metavar="P",
                     help="debug only (INVALID as a bench): per-rank compute of a P-GPU run on one GPU, collectives move nothing")
@@ -293,6 +313,13 @@ def main():
                     "block softmax is near uniform, so kept density ~ P: 0.0 = STA window only, 0.15 ~ 20 %% density")
     args = ap.parse_args()
 
+    if args.oversubscribe:
+        os.environ["K5_OVERSUBSCRIBE"] = "1"
+        args.transport = args.transport or "ipc"
+        if args.transport != "ipc":
+            raise SystemExit("--oversubscribe needs the IPC transport (RCCL refuses two ranks on one device)")
+    if args.transport:
+        os.environ["K5_SP_TRANSPORT"] = args.transport
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -305,14 +332,17 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with --nproc-per-node {args.gpus} (or call bench.py without a launcher)")
     ndev = torch.cuda.device_count()
-    if local_rank >= ndev:
-        raise SystemExit(f"bench.py rank {rank}: needs {args.gpus} devices on this node, found {ndev}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    from kandinsky.utils import init_rank_process_group, rank_device_index
+    dev_index = rank_device_index(local_rank)     # cuda:LOCAL_RANK (reference utils.py:40-45); --oversubscribe wraps around the devices that exist
+    if dev_index >= ndev:
+        raise SystemExit(f"bench.py rank {rank}: needs {args.gpus} devices on this node, found {ndev} (--oversubscribe runs the ranks on the devices there are)")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    host_group = False
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        init_rank_process_group(local_rank)       # nccl bound to the device, or gloo under the IPC transport
+        host_group = dist.get_backend() == "gloo"
 
     from kandinsky.models.dit import DiffusionTransformer3D
     wl = WORKLOADS[args.workload]
@@ -407,7 +437,7 @@ def main():
     # the reference through parity_check (same model, same noise, first two steps) and tests/test_gpu_fulldepth.py
     pin = latent_pin(latent, noise, args, world)
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if host_group else dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = tt.item()
     dit.set_profiling(0)
@@ -519,6 +549,8 @@ def main():
     rank_check = None
     if world > 1:   # every rank applies the same Euler update to the same gathered velocity: the latents must be BIT-identical
         cs = torch.stack([latent.double().sum(), latent.double().abs().sum(), latent.view(torch.int32).sum(dtype=torch.int64).double()])
+        if host_group:
+            cs = cs.cpu()
         allcs = [torch.empty_like(cs) for _ in range(world)]
         torch.distributed.all_gather(allcs, cs)
         same = all(torch.equal(allcs[0], c) for c in allcs)
@@ -579,6 +611,14 @@ def main():
             invalid.append("the latent after the timed steps differs from the committed pin of this (workload, steps) beyond the stated tolerance (latent_pin)")
         if parity is not None and parity.get("status") == "FAILED":
             invalid.append("the first two steps of this configuration differ from the reference golden beyond the stated tolerance (parity_check)")
+        out["ipc_ranks_seen"] = dit.get_option("ipc_ranks")     # processes of the engine's IPC group (k5_dit_comm_init_ipc): N under --transport ipc, else 0
+        if out["ipc_ranks_seen"]:
+            out["ipc_transport"] = {"collectives": dit.get_option("ipc_collectives"), "pulled_mb_this_rank": dit.get_option("ipc_pulled_mb"),
+                                    "flag_wait_timeouts": dit.get_option("ipc_errors"), "ranks_per_device": -(-world // max(ndev, 1))}
+            if out["ipc_transport"]["flag_wait_timeouts"]:
+                invalid.append("an IPC flag wait ran into its time limit (ipc_transport.flag_wait_timeouts): a peer never signalled")
+        if args.oversubscribe and world > ndev:
+            invalid.append(f"{world} ranks time-slice {ndev} device(s) (--oversubscribe): a run of the process boundary, not a measurement of a {world}-GPU node")
         out["rccl_ranks_seen"] = dit.get_option("rccl_ranks")   # ncclCommCount of the engine's communicator: N under RCCL, 0 on one GPU, -1 for a loopback / emulated group
         if world > 1:
             out["sp_schedule"] = dit.sp_schedule()     # which exchange the engine's self-tuning picked on this node, and what it measured

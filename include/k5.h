@@ -31,7 +31,7 @@ typedef enum { K5_EPI_BIAS = 0, K5_EPI_BIAS_M = 1, K5_EPI_GELU = 2, K5_EPI_GATE 
 
 /* bumped whenever an entry point is added or changes meaning; the host binding checks it BEFORE binding symbols, so that a stale
  * libk5.so fails with a clear message instead of a missing-symbol lookup (round 3: 4) */
-#define K5_ABI_VERSION 7
+#define K5_ABI_VERSION 8
 int k5_abi_version(void);
 const char* k5_last_error(void);
 
@@ -191,7 +191,11 @@ int k5_nabla_mask_u8(const void* workspace, int H, int num_blocks, void* out_u8,
  * [q_block0, q_block0 + Nq/64) and, after the K / V^T all-gather, all N keys; V^T optionally in per-rank chunks
  * [chunk][H*64][vt_chunk_keys] (vt_chunk_keys = 0: plain [H*64][ldvt]).  Map rows are indexed by the LOCAL query block;
  * the workspace is sized by k5_nabla_workspace_size(H, N/64) as above.  Row i of the map equals row q_block0 + i of the
- * square map. mask: uint8 [H][Nq/64][N/64]. */
+ * square map. mask: uint8 [H][Nq/64][N/64].
+ * COUPLING (since the round-5 workspace layout): the key-tile lists sit BEHIND the logits of the Nq/64 selected rows, so their
+ * offset depends on Nq.  The attention / mask / count calls that follow a select on a workspace must be given the SAME Nq (and H, N)
+ * as that select — k5_nabla_select_bf16 counts as Nq = N; nothing in the workspace records it, a different Nq reads another region
+ * without an error. */
 int k5_nabla_select_rect_bf16(const void* q, const void* k, int ldq, int ldk, int H, int Nq, int q_block0, int N, int T,
                               int Hb, int Wb, int wT, int wH, int wW, float P, void* workspace, void* stream);
 int k5_attention_nabla_rect_bf16(const void* Q, const void* K, const void* Vt, void* O, int H, int Nq, int N, int ldq,
@@ -347,6 +351,18 @@ void k5_loopback_destroy(k5_loopback* group);
 int k5_dit_comm_init_loopback(k5_dit* dit, k5_loopback* group, int rank);
 /* the CFG pair as a loopback group of world 2 (tests: 2 x P handles on one GPU = two sequence-parallel groups + P pairs) */
 int k5_dit_cfg_pair_init_loopback(k5_dit* dit, k5_loopback* group, int branch);
+/* IPC group (ABI 8): the second transport of the sharded path, the one SURVEY.md §8(e) names beside RCCL ("direct peer writes over xGMI into
+ * IPC-mapped buffers"); same launch contract (one process per rank, kandinsky/utils.py:40-55; README.md:269-276), same schedules, same bits
+ * as a loopback group of the same size.  Every rank exports its K / V^T slots, velocity and statistics buffers with hipIpcGetMemHandle on
+ * first use, peers map them and READ the slices they need with a copy kernel; ordering is by epoch flags in device memory (system-scope
+ * release stores / bounded polling kernels), not by host rendezvous.  Unlike RCCL it accepts several ranks on ONE device — which is how the
+ * process boundary of the sharded path is exercised on a one-GPU box (bench.py --gpus P --oversubscribe; tests/test_gpu_ipc_ranks.py) —
+ * and on an xGMI node it needs no library at all.  shm_name: name of a POSIX shared-memory control block, unique per group and per run
+ * (the host makes one up on the group's rank 0 and broadcasts it over torch.distributed); collective over the `world` processes of the
+ * group (<= 16).  Not with k5_dit_set_graph (k5_sample runs the step eagerly).  Options (k5_dit_get_option): "ipc_ranks", "ipc_pair_ranks"
+ * (0 = another transport), "ipc_collectives", "ipc_pulled_mb", "ipc_errors" (synchronises; first flag wait that hit K5_IPC_TIMEOUT_S). */
+int k5_dit_comm_init_ipc(k5_dit* dit, const char* shm_name, int rank, int world);
+int k5_dit_cfg_pair_init_ipc(k5_dit* dit, const char* shm_name, int branch);
 /* Engine options by name (all default 0): "attn_mode" 0 = softmax form per head from the data, 1 = online max everywhere;
  * "sp_pass1_tiles" local key tiles attended before the K / V^T gather has landed (0 = all); "emulate_world" P = TIMING
  * ONLY: rank 0's share of a P-rank run on a world = 1 communicator — collectives move nothing, results are garbage and

@@ -301,11 +301,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <int NTW, bool RESID, bool STATS>
 int launch_conv_w4(const ConvW4P& p, int num_cu, hipStream_t stream) {
   constexpr int LDS = 2 * ((32 * NTW / 8) * CW_PAD + 32 * CW_PAD);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3d_w4_kernel<NTW, RESID, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return K5_ERR_HIP;
-    attr_set = true;
-  }
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)conv3d_w4_kernel<NTW, RESID, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);   // once, thread-safe
+  if (attr_rc != hipSuccess) return K5_ERR_HIP;
   const int tiles = p.tiles_m * p.tiles_n;
   hipLaunchKernelGGL((conv3d_w4_kernel<NTW, RESID, STATS>), dim3(min(tiles, num_cu)), dim3(256), LDS, stream, p);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
@@ -598,11 +595,8 @@ int launch_conv_halo(const ConvW4P& p, int num_cu, hipStream_t stream) {
   constexpr int S = NTW == 8 ? 2 : 4;   // weight stages: what fits beside the two halo buffers
   constexpr int LDS = S * (32 * NTW / 8) * CW_PAD + 2 * HALO_BUF;
   static_assert(LDS <= 160 * 1024, "LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3d_halo_kernel<NTW, S, RESID, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return K5_ERR_HIP;
-    attr_set = true;
-  }
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)conv3d_halo_kernel<NTW, S, RESID, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);   // once, thread-safe
+  if (attr_rc != hipSuccess) return K5_ERR_HIP;
   const int tiles = p.tiles_m * p.tiles_n;
   hipLaunchKernelGGL((conv3d_halo_kernel<NTW, S, RESID, STATS>), dim3(min(tiles, num_cu)), dim3(256), LDS, stream, p);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
@@ -627,12 +621,8 @@ int k5_launch_conv3d_w4(const void* X, const void* W, const float* bias, void* o
   p.M = (int)M; p.x_bytes = (unsigned)xb;
   const int bn = Cout == 128 ? 128 : 256;
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = Cout / bn;
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
-    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  static const int num_cu = [] { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1; return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }();   // once, thread-safe
+  if (num_cu <= 0) return K5_ERR_HIP;
   // from 5/8 of a round up (measured on the tile shapes of the tiling policy, tools/vae_shapes.py: (5,64,96) 103.7 -> 102.2 ms,
   // (6,52,84) 92.6 -> 90.9, (5,64,64) 70.0 -> 68.5, (5,32,32) 21.3 -> 20.2; round 1 required a whole round); below that the
   // 128 x 128 tiles fill the chip better.  K5_CONV_MIN_FILL8 = n: n/8 of a round (A/B switch for benchmarking)

@@ -19,6 +19,7 @@
 
 #include "k5_common.h"
 #include "k5_kernels.h"
+#include "ipc_comm.h"   // one-sided IPC transport of the sharded path (P processes on one device or on the devices of one node)
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing
@@ -69,7 +70,7 @@ struct DevBuf {   // owning device buffer (move-only): freed with whatever holds
     bytes = n;
     return K5_OK;
   }
-  void release() { if (p && owned) (void)hipFree(p); p = nullptr; bytes = 0; owned = true; }
+  void release() { if (p && owned) { (void)hipFree(p); k5ipc::note_free(p); } p = nullptr; bytes = 0; owned = true; }   // note_free: an IPC export of this allocation is void from here on
   void alias(void* ptr, size_t n) { release(); p = ptr; bytes = n; owned = false; }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -140,7 +141,9 @@ struct Comm {
   void* lib = nullptr;
   ncclComm_t comm = nullptr;
   LoopGroup* loop = nullptr;
-  bool active() const { return comm != nullptr || loop != nullptr; }
+  k5ipc::Group* ipc = nullptr;   // one process per rank, peers' buffers IPC-mapped (ipc_comm.h): k5_dit_comm_init_ipc / k5_dit_cfg_pair_init_ipc
+  bool active() const { return comm != nullptr || loop != nullptr || ipc != nullptr; }
+  int ipc_status(int r) { if (r) { k5_set_error("%s", ipc->err.c_str()); return K5_ERR_STATE; } return K5_OK; }
   int rank = 0, world = 1;
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
@@ -177,6 +180,7 @@ struct Comm {
   // in-place all-gather: every rank's chunk already sits at buf + rank*count*elem
   int all_gather_inplace(void* buf, size_t count_per_rank, size_t elem_bytes, hipStream_t s) {
     char* b = (char*)buf;
+    if (ipc) return ipc_status(ipc->all_gather_inplace(buf, count_per_rank * elem_bytes, s));
     if (loop) {
       // pull every peer's chunk out of the peer's copy of the buffer; the call completes (stream-wise) only when every peer
       // has pulled mine, as an RCCL all-gather does — the caller may overwrite its own slot afterwards
@@ -200,13 +204,14 @@ struct Comm {
     if (r != ncclSuccess) { k5_set_error("ncclAllGather: %s", GetErrorString(r)); return K5_ERR_HIP; }
     return K5_OK;
   }
-  bool can_exchange() const { return loop || (Send && Recv && GroupStart && GroupEnd); }
+  bool can_exchange() const { return loop || ipc || (Send && Recv && GroupStart && GroupEnd); }
   // all-to-all (Ulysses): block p of `send` (block_bytes each) goes to rank p, block p of `recv` comes from rank p; send != recv.
   // One grouped send/recv per peer (all xGMI links at once); the rank's own block is a device-to-device copy.
   int all_to_all(const void* send, void* recv, size_t block_bytes, hipStream_t s) {
     const char* sb = (const char*)send; char* rb = (char*)recv;
     HIPCHK(hipMemcpyAsync(rb + (size_t)rank * block_bytes, sb + (size_t)rank * block_bytes, block_bytes, hipMemcpyDeviceToDevice, s));
     if (world == 1) return K5_OK;
+    if (ipc) return ipc_status(ipc->all_to_all(send, recv, block_bytes, s));
     if (loop) {
       loop->ptr[rank] = const_cast<void*>(send);
       HIPCHK(hipEventRecord(loop->ready[rank], s));
@@ -240,6 +245,7 @@ struct Comm {
   int slot_exchange(void* buf, size_t slot_bytes, size_t off, size_t cnt, hipStream_t s) {
     char* b = (char*)buf;
     if (cnt == 0 || world == 1) return K5_OK;
+    if (ipc) return ipc_status(ipc->slot_exchange(buf, slot_bytes, off, cnt, s));
     if (loop) {
       loop->ptr[rank] = buf;
       HIPCHK(hipEventRecord(loop->ready[rank], s));
@@ -358,6 +364,7 @@ struct k5_dit {
   hipEvent_t ev_u_o = nullptr, ev_u_back = nullptr;
   hipEvent_t ev_slice[4] = {};                     // slice s of every peer has landed
   bool emulated = false;                           // "emulate_world": timing-only layout, results are garbage
+  bool last_nabla = false;                         // attention type of the last forward ("fp8_effective": Ulysses, which keeps q | k | V^T in bf16, is a dense-attention schedule)
   // Self-tuning sequence-parallel schedule (round 4): which exchange wins — one in-place all-gather per block, the sliced exchange, Ulysses
   // all-to-all; for NABLA one or two passes over the lists — is a property of the NODE (xGMI link rates, how RCCL drives them) that no
   // single-GPU box can measure.  So the first sharded forward of a handle (world > 1) times one block's self-attention section under
@@ -1469,6 +1476,7 @@ int forward_impl(k5_dit* d, const k5_forward_args* a, const k5_text_cond& cond, 
   }
   // NABLA: tokens are processed in fractal order (8x8 spatial tiles contiguous), utils.py:31-41,54-78
   const bool nabla = a->attention_type == 1;
+  d->last_nabla = nabla;
   NablaArgs na{};
   const int32_t* perm = nullptr;
   if (nabla) {
@@ -1669,6 +1677,7 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
   if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
   for (hipEvent_t e : {d->ev_k, d->ev_v, d->ev_gathered, d->ev_stats, d->ev_means, d->ev_slice[0], d->ev_slice[1], d->ev_slice[2], d->ev_slice[3]}) if (e) (void)hipEventDestroy(e); d->ws_perm.release(); d->ws_nabla.release();
   if (d->comm.comm) (void)d->comm.CommDestroy(d->comm.comm);
+  for (Comm* c : {&d->comm, &d->pair}) if (c->ipc) { c->ipc->close_all(); delete c->ipc; c->ipc = nullptr; }
   if (d->pair_stream) { (void)hipStreamSynchronize(d->pair_stream); (void)hipStreamDestroy(d->pair_stream); }
   for (hipEvent_t e : {d->ev_vel_ready, d->ev_vel_done, d->ev_u_o, d->ev_u_back}) if (e) (void)hipEventDestroy(e);
   if (d->pair.comm) (void)d->pair.CommDestroy(d->pair.comm);
@@ -1903,7 +1912,9 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
   // Step 0 runs eagerly (it sizes every workspace and fills the RoPE / permutation caches), step 1 is captured, steps 1..
   // are launches of the instantiated graph.  Not with MagCache (its skip pattern changes the launch sequence per step)
   // or while profiling (events).
-  const bool graph = d->use_graph && !d->mag.on && !d->profiling && a->num_steps > 2;
+  // not replayed: MagCache (host decisions), profiling (events), the NABLA map tap (its destination advances on the host per launch: a replay
+  // would overwrite the slots baked at capture — ADVICE r5), the IPC transport (its epochs and peer pointers are host-side state per collective)
+  const bool graph = d->use_graph && !d->mag.on && !d->profiling && a->num_steps > 2 && !d->nabla_tap && !d->comm.ipc && !d->pair.ipc;
   std::vector<float> host_tab(2 * (size_t)a->num_steps);
   for (int i = 0; i < a->num_steps; ++i) {
     host_tab[i] = a->sigmas[i] * 1000.0f;                        // t * 1000, fp32 (:57)
@@ -2112,6 +2123,29 @@ extern "C" int k5_dit_cfg_pair_init_loopback(k5_dit* d, k5_loopback* lb, int bra
 }
 extern "C" int k5_dit_cfg_branch(k5_dit* d) { return d && d->pair.active() ? d->cfg_branch : -1; }
 
+// ---- IPC group: one PROCESS per rank, peers' buffers mapped through hipIpc handles, epoch flags in device memory (ipc_comm.h) ----
+static int ipc_open(Comm& c, const char* shm_name, int rank, int world) {
+  if (c.active()) { k5_set_error("communicator already initialised"); return K5_ERR_STATE; }
+  k5ipc::Group* g = new k5ipc::Group();
+  if (g->open(shm_name, rank, world)) { k5_set_error("%s", g->err.c_str()); g->close_all(); delete g; return K5_ERR_STATE; }
+  c.ipc = g;
+  return K5_OK;
+}
+extern "C" int k5_dit_comm_init_ipc(k5_dit* d, const char* shm_name, int rank, int world) {
+  g_err[0] = 0;
+  if (!d || !shm_name || world < 1 || world > k5ipc::MAXR || rank < 0 || rank >= world) return K5_ERR_ARG;
+  K5CHK(ipc_open(d->comm, shm_name, rank, world));
+  K5CHK(comm_common_init(d, rank, world));
+  d->sp_autotune = false;   // several ranks may share one device: timings of the candidates would measure the oversubscription
+  return K5_OK;
+}
+extern "C" int k5_dit_cfg_pair_init_ipc(k5_dit* d, const char* shm_name, int branch) {
+  g_err[0] = 0;
+  if (!d || !shm_name || branch < 0 || branch > 1) return K5_ERR_ARG;
+  K5CHK(ipc_open(d->pair, shm_name, branch, 2));
+  return pair_common_init(d, branch);
+}
+
 // Engine options (all default 0).
 //   "attn_mode"       0 = softmax form per head from the data (fixed offset where |q||k'| <= 90, online max elsewhere),
 //                     1 = online max everywhere (what a checkpoint with large QK-norm gains gets; bench.py --attn-online)
@@ -2202,13 +2236,21 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "sp_tuned")) *value = d->sp_tuned ? 1 : 0;
   else if (!strcmp(name, "fp8_effective")) {   // the classes of k5_dit_set_fp8 that RUN in e4m3 on this handle's path — the sharded schedules keep the out
     int m = d->fp8_mask;                       // projection in bf16 (bit 4), Ulysses also the q | k | V^T projections (bit 2); a bench must label its line with THIS mask
-    if (d->comm.active()) { m &= ~4; if (d->sp_mode == 1 && d->sp_world > 1 && d->Hh % d->sp_world == 0 && !d->emulated) m &= ~2; }
+    if (d->comm.active()) { m &= ~4; if (d->sp_mode == 1 && !d->last_nabla && d->sp_world > 1 && d->Hh % d->sp_world == 0 && !d->emulated) m &= ~2; }   // the dispatch's own predicate (forward_impl: `ulysses`), with the attention type of the LAST forward
     *value = m;
   }
   else if (!strcmp(name, "rccl_ranks")) {   // the size the RCCL communicator reports (ncclCommCount): 0 = no communicator, -1 = a loopback group / no such symbol
     *value = 0;
     if (d->comm.comm && d->comm.CommCount) { int n = 0; *value = d->comm.CommCount(d->comm.comm, &n) == ncclSuccess ? n : -1; }
     else if (d->comm.active()) *value = -1;
+  }
+  else if (!strcmp(name, "ipc_ranks")) *value = d->comm.ipc ? d->comm.ipc->world : 0;   // processes of the IPC group this handle is a rank of (0 = not that transport)
+  else if (!strcmp(name, "ipc_pair_ranks")) *value = d->pair.ipc ? d->pair.ipc->world : 0;
+  else if (!strcmp(name, "ipc_collectives")) *value = (int)((d->comm.ipc ? d->comm.ipc->collectives : 0) + (d->pair.ipc ? d->pair.ipc->collectives : 0));
+  else if (!strcmp(name, "ipc_pulled_mb")) *value = (int)(((d->comm.ipc ? d->comm.ipc->bytes_pulled : 0) + (d->pair.ipc ? d->pair.ipc->bytes_pulled : 0)) >> 20);
+  else if (!strcmp(name, "ipc_errors")) {   // synchronises the device: the first flag wait that ran into its time limit (0 = none; bit 31 | which << 24 | peer << 16 | epoch)
+    *value = 0;
+    for (Comm* c : {&d->comm, &d->pair}) if (c->ipc) { uint32_t w = 0; if (c->ipc->error_word(&w)) { k5_set_error("%s", c->ipc->err.c_str()); return K5_ERR_HIP; } if (w && !*value) *value = (int)w; }
   }
   else if (!strcmp(name, "nabla_group_rows")) *value = d->nabla_group_rows;
   else if (!strcmp(name, "nabla_pair_frames")) *value = d->nabla_pair_frames;

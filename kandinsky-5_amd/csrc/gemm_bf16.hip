@@ -21,6 +21,11 @@
 #include "k5_kernels.h"
 
 namespace {
+inline int k5_num_cu() {
+  int dev = 0; hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+  return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 128;  // [128 rows][64 bf16]
@@ -385,12 +390,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_k3_kernel(GemmP p) {
 
 template <int EPI>
 int launch_k3(GemmP p, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_k3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, K3_STAGES * K3_STAGE) != hipSuccess)
-      return K5_ERR_HIP;
-    attr_set = true;
-  }
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)gemm_bf16_k3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, K3_STAGES * K3_STAGE);   // set once, thread-safe (function-local static: loopback ranks launch from P host threads)
+  if (attr_rc != hipSuccess) return K5_ERR_HIP;
   p.tiles_m = (p.M + K3_BM - 1) / K3_BM;
   hipLaunchKernelGGL(gemm_bf16_k3_kernel<EPI>, dim3(p.tiles_m * p.tiles_n), dim3(512), K3_STAGES * K3_STAGE, stream, p);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
@@ -598,12 +599,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_k8_kernel(GemmP p) {
 
 template <int EPI, int MT>
 int launch_k8_mt(GemmP p, hipStream_t stream, int num_cu, bool full_grid, bool no_tail) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_k8_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, K8_LDS + K8_TRACE_BYTES) != hipSuccess)
-      return K5_ERR_HIP;
-    attr_set = true;
-  }
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)gemm_bf16_k8_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, K8_LDS + K8_TRACE_BYTES);   // set once, thread-safe (function-local static: loopback ranks launch from P host threads)
+  if (attr_rc != hipSuccess) return K5_ERR_HIP;
   p.tiles_m = (p.M + 64 * MT - 1) / (64 * MT); p.tiles_n = (p.N + K8_BN - 1) / K8_BN;
   const int tiles = p.tiles_m * p.tiles_n;
   // Whole rounds of num_cu tiles go to the persistent kernel; a last round that would fill less than half of the CUs is
@@ -628,12 +625,8 @@ int launch_k8_mt(GemmP p, hipStream_t stream, int num_cu, bool full_grid, bool n
 
 template <int EPI>
 int launch_k8(GemmP p, hipStream_t stream) {
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
-    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  static const int num_cu = k5_num_cu();   // one device per process (one process per GPU); initialised once, thread-safe
+  if (num_cu <= 0) return K5_ERR_HIP;
   static const bool full_grid = getenv("K5_GEMM_FULLGRID") != nullptr;   // A/B: one workgroup per tile instead of per CU
   static const bool no_tail = getenv("K5_GEMM_NO_TAIL") != nullptr;      // A/B switches for benchmarking
   static const int force_mt = getenv("K5_GEMM_MT") ? atoi(getenv("K5_GEMM_MT")) : 0;
@@ -686,7 +679,7 @@ int launch_k8(GemmP p, hipStream_t stream) {
 #define W4_PIECE_PAD 1056
 #endif
 constexpr int W4_PAD = W4_PIECE_PAD, W4_OP = 32 * W4_PAD, W4_STAGE = 2 * W4_OP, W4_LDS = 2 * W4_STAGE;
-// Round 5 (second half) — the 128-row form (MT = 4) runs THREE stages.  Its X image is half of the 256-row one (16 pieces), so a stage is 49 920 B and
+// Round 5 (second half) — the 128-row form (MT = 4) runs THREE stages.  Its X image is half of the 256-row one (16 pieces), so a stage is 50 688 B (48 pieces of 1056 B: the 32-B piece pad of round 5) and
 // three of them (149 760 B + the epilogue's 4 KB) fit the 160-KB LDS: K-tile t + 3 is requested during K-tile t (two K-tiles of lead instead of one).
 // Same K order, same MFMA sequence: bit-identical outputs.  Measured (profiles/r05_gemm_mt4_three_stage_ab.log): +1-6 % on warm operands, -2.3 % of a
 // config-1 step through the engine, where every projection meets its weights for the first time since the last step.  It is a small gain because the
@@ -1329,11 +1322,8 @@ int launch_tail(GemmP p, hipStream_t stream, int full, int rem) {
     hipLaunchKernelGGL(gemm_bf16_glds_kernel<EPI>, dim3(4 * rem), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_q4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS) != hipSuccess) return K5_ERR_HIP;
-    attr_set = true;
-  }
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)gemm_bf16_q4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS);   // set once, thread-safe (function-local static: loopback ranks launch from P host threads)
+  if (attr_rc != hipSuccess) return K5_ERR_HIP;
   hipLaunchKernelGGL(gemm_bf16_q4_kernel<EPI>, dim3(4 * rem), dim3(256), Q4_LDS, stream, p);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
@@ -1341,11 +1331,8 @@ int launch_tail(GemmP p, hipStream_t stream, int full, int rem) {
 // a WHOLE small GEMM as quadrants of its 256x256 logical tiles on the deep-prefetch 128x128 kernel (config-1 shapes: 91 tiles = 364 quadrants)
 template <int EPI>
 int launch_q4_whole(GemmP p, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_q4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS) != hipSuccess) return K5_ERR_HIP;
-    attr_set = true;
-  }
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)gemm_bf16_q4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS);   // set once, thread-safe (function-local static: loopback ranks launch from P host threads)
+  if (attr_rc != hipSuccess) return K5_ERR_HIP;
   p.tiles256_m = (p.M + 255) / 256; p.tiles256_n = (p.N + 255) / 256; p.tail_base = 0;
   hipLaunchKernelGGL(gemm_bf16_q4_kernel<EPI>, dim3(4 * p.tiles256_m * p.tiles256_n), dim3(256), Q4_LDS, stream, p);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
@@ -1353,12 +1340,8 @@ int launch_q4_whole(GemmP p, hipStream_t stream) {
 
 template <int EPI, int MT>
 int launch_w4_mt(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, w4_ops_bytes(MT) + W4_TRACE_BYTES + W4_PF_BYTES) != hipSuccess)
-      return K5_ERR_HIP;
-    attr_set = true;
-  }
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, w4_ops_bytes(MT) + W4_TRACE_BYTES + W4_PF_BYTES);   // set once, thread-safe (function-local static: loopback ranks launch from P host threads)
+  if (attr_rc != hipSuccess) return K5_ERR_HIP;
 #ifdef W4_TRACE
   p.trace = getenv("K5_GEMM_TRACE") ? (unsigned long long*)strtoull(getenv("K5_GEMM_TRACE"), nullptr, 16) : nullptr;
 #endif
@@ -1443,12 +1426,8 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   // round of 256 x 256 tiles — 8-GPU token shards (168 such tiles -> 217 of 192 rows) and BASELINE config 1 (91 -> 182 of 128 rows) — from
   // K5_GEMM_W4_MIN (default 96) tiles of the chosen height up (measured, profiles/r05_gemm_block_shapes_*.log; until round 4 those ran on the
   // 8-wave kernel / the 128 x 128 kernel).
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
-    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  static const int num_cu = k5_num_cu();   // one device per process (one process per GPU); initialised once, thread-safe
+  if (num_cu <= 0) return K5_ERR_HIP;
   static const bool no_tail = getenv("K5_GEMM_NO_TAIL") != nullptr;
   static const int w4_min = getenv("K5_GEMM_W4_MIN") ? atoi(getenv("K5_GEMM_W4_MIN")) : 96;
   const int mt_pick = w4_ok ? w4_pick_mt(M, N, num_cu, no_tail, force_mt) : 8;
@@ -1530,18 +1509,10 @@ int k5_launch_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, in
   static const int force_v1 = getenv("K5_GEMM_V1") ? atoi(getenv("K5_GEMM_V1")) : 0;
   if ((K % (2 * BK)) == 0 && K >= 4 * BK && M >= 512 && N >= 256 && !(N & 3) && !(ldc & 3) && kept >= 256 && kept < (1ll << 30) &&
       (force_v1 == 0 || force_v1 == 4)) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<K5_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)
-        return K5_ERR_HIP;
-      attr_set = true;
-    }
-    static int num_cu = 0;
-    if (!num_cu) {
-      int dev = 0; hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
-      num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<K5_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);   // set once, thread-safe (function-local static: loopback ranks launch from P host threads)
+    if (attr_rc != hipSuccess) return K5_ERR_HIP;
+    static const int num_cu = k5_num_cu();   // one device per process (one process per GPU); initialised once, thread-safe
+    if (num_cu <= 0) return K5_ERR_HIP;
     p.tiles_m = tm; p.tiles_n = tn; p.lid_limit = (int)kept; p.tiles256_m = tm; p.tiles256_n = tn;
     hipLaunchKernelGGL((gemm_bf16_w4_kernel<K5_EPI_F32>), dim3(std::min((int)kept, num_cu)), dim3(256), W4_LDS, stream, p);
     return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;

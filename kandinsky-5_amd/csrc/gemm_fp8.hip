@@ -471,11 +471,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 template <int EPI>
 int launch_f8_w4(Gemm8P p, hipStream_t stream, int num_cu) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_fp8_w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F4_LDS) != hipSuccess) return K5_ERR_HIP;
-    attr_set = true;
-  }
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)gemm_fp8_w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F4_LDS);   // once, thread-safe
+  if (attr_rc != hipSuccess) return K5_ERR_HIP;
   p.tiles_m = (p.M + F8_BM - 1) / F8_BM; p.tiles_n = (p.N + F8_BN - 1) / F8_BN;
   p.lid_limit = p.tiles_m * p.tiles_n;
   hipLaunchKernelGGL(gemm_fp8_w4_kernel<EPI>, dim3(min(p.lid_limit, num_cu)), dim3(256), F4_LDS, stream, p);
@@ -505,17 +502,10 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
 
 template <int EPI>
 int launch_f8(Gemm8P p, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_fp8_k8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS) != hipSuccess) return K5_ERR_HIP;
-    attr_set = true;
-  }
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return K5_ERR_HIP;
-    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)gemm_fp8_k8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS);   // once, thread-safe
+  if (attr_rc != hipSuccess) return K5_ERR_HIP;
+  static const int num_cu = [] { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1; return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }();   // once, thread-safe
+  if (num_cu <= 0) return K5_ERR_HIP;
   p.tiles_m = (p.M + F8_BM - 1) / F8_BM; p.tiles_n = (p.N + F8_BN - 1) / F8_BN;
   p.lid_limit = p.tiles_m * p.tiles_n;
   // the four-wave kernel from one full round of tiles up (K in whole pairs of K-tiles; 16-B stores need N % 16 == 0 and aligned rows)

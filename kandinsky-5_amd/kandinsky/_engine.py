@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("K5_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libk5.so"))
 
 K5_OK = 0
-ABI_VERSION = 7          # include/k5.h K5_ABI_VERSION
+ABI_VERSION = 8          # include/k5.h K5_ABI_VERSION
 K5_F32, K5_BF16, K5_F16 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_M, EPI_GELU, EPI_GATE = 0, 1, 2, 3
 
@@ -89,6 +89,8 @@ SYMBOLS = {
     "k5_dit_comm_init_loopback": (_I, [_P, _P, _I]),
     "k5_dit_cfg_pair_init": (_I, [_P, C.c_char_p, _I, _P]),
     "k5_dit_cfg_pair_init_loopback": (_I, [_P, _P, _I]),
+    "k5_dit_comm_init_ipc": (_I, [_P, C.c_char_p, _I, _I]),
+    "k5_dit_cfg_pair_init_ipc": (_I, [_P, C.c_char_p, _I]),
     "k5_dit_cfg_branch": (_I, [_P]),
     "k5_dit_set_option": (_I, [_P, C.c_char_p, _I]),
     "k5_dit_get_option": (_I, [_P, C.c_char_p, C.POINTER(_I)]),

@@ -36,6 +36,26 @@ class TransformerDecoderBlock(_NoMath):  # reference dit.py:47-79
         self.feed_forward = FeedForward(model_dim, ff_dim)
 
 
+def sp_transport(transport=None):
+    """"rccl" | "ipc": explicit argument, else K5_SP_TRANSPORT, else RCCL (the transport of a one-rank-per-GPU node)."""
+    import os
+    t = (transport or os.environ.get("K5_SP_TRANSPORT", "rccl")).lower()
+    if t not in ("rccl", "ipc"):
+        raise ValueError(f"unknown sequence-parallel transport {t!r} (rccl | ipc)")
+    return t
+
+
+def _broadcast_ipc_name(kind, is_root, world, group, src):
+    """The name of an IPC group's shared-memory control block: made up on the group's rank 0, carried by torch.distributed."""
+    import os
+    import uuid
+    payload = [f"/k5ipc_{kind}_{os.getpid()}_{uuid.uuid4().hex[:12]}" if is_root else None]
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast_object_list(payload, src=src, group=group)
+    return payload[0]
+
+
 class DiffusionTransformer3D(nn.Module):
     def __init__(
         self,
@@ -283,15 +303,24 @@ class DiffusionTransformer3D(nn.Module):
         return latent
 
     # ---------------------------------------------------------------- multi-GPU
-    def enable_sequence_parallel(self, rank, world, device=None, group=None, src=0):
-        """Token-sharded sequence parallelism over RCCL (one process per GPU; replaces the reference's DTensor
-        plan, kandinsky/models/parallelize.py).  Rank 0 creates the ncclUniqueId inside libk5, torch.distributed
-        (already initialised by the launcher, kandinsky/utils.py:40-55 contract) only carries its 128 bytes."""
+    def enable_sequence_parallel(self, rank, world, device=None, group=None, src=0, transport=None):
+        """Token-sharded sequence parallelism (one process per rank; replaces the reference's DTensor plan,
+        kandinsky/models/parallelize.py).  transport "rccl" (default): rank 0 creates the ncclUniqueId inside libk5,
+        torch.distributed (already initialised by the launcher, kandinsky/utils.py:40-55 contract) only carries its 128 bytes.
+        transport "ipc" (or K5_SP_TRANSPORT=ipc): peers read each other's IPC-mapped slots (k5_dit_comm_init_ipc) — no RCCL, and
+        several ranks may share one device; torch.distributed carries the name of the group's shared-memory control block."""
         import os
         if self._handle is None:
             if device is None:
                 raise RuntimeError("build the engine first (forward / init_synthetic) or pass device=")
             self.engine(device)
+        transport = sp_transport(transport)
+        if transport == "ipc":
+            name = _broadcast_ipc_name("sp", rank == 0, world, group, src)
+            with torch.cuda.device(self._handle_device):
+                E.check(E.lib().k5_dit_comm_init_ipc(self._handle, name.encode(), int(rank), int(world)), "k5_dit_comm_init_ipc")
+            self._sp = (rank, world)
+            return self
         lib_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         path = lib_path.encode() if os.path.exists(lib_path) else None
         payload = [None]
@@ -328,16 +357,22 @@ class DiffusionTransformer3D(nn.Module):
         self._keepalive.append(group)
         return self
 
-    def enable_cfg_pair(self, branch, group=None, src=0, device=None):
+    def enable_cfg_pair(self, branch, group=None, src=0, device=None, transport=None):
         """CFG-parallel inside the engine (k5_dit_cfg_pair_init): this rank runs ONE branch of classifier-free guidance in `sample`
         (0 = conditional, 1 = unconditional) and exchanges the velocity with its partner — `group` = the 2-rank torch.distributed
         group of the pair (it only carries the 128-byte id from `src`, the global rank of branch 0).  Call after
-        enable_sequence_parallel (both are collective)."""
+        enable_sequence_parallel (both are collective).  transport as in enable_sequence_parallel."""
         import os
         if self._handle is None:
             if device is None:
                 raise RuntimeError("build the engine first (forward / init_synthetic) or pass device=")
             self.engine(device)
+        if sp_transport(transport) == "ipc":
+            name = _broadcast_ipc_name("pair", branch == 0, 2, group, src)
+            with torch.cuda.device(self._handle_device):
+                E.check(E.lib().k5_dit_cfg_pair_init_ipc(self._handle, name.encode(), int(branch)), "k5_dit_cfg_pair_init_ipc")
+            self._cfg_pair = int(branch)
+            return self
         lib_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         path = lib_path.encode() if os.path.exists(lib_path) else None
         payload = [None]

@@ -380,8 +380,13 @@ class AutoencoderKLHunyuanVideo(nn.Module):
                 mine = torch.zeros_like(decoded[0]) if decoded[0] is not None else None
             if mine is None:
                 raise RuntimeError("tile-parallel decode: the first round cannot be ragged")
-            buf = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-            dist.all_gather_into_tensor(buf.view((world * mine.shape[0],) + tuple(mine.shape[1:])), mine.contiguous(), group=group)
+            if dist.get_backend(group) == "gloo":   # IPC transport (K5_SP_TRANSPORT=ipc): the process group is a host-side one
+                parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(world)]
+                dist.all_gather(parts, mine.contiguous().cpu(), group=group)
+                buf = torch.stack(parts).to(mine.device)
+            else:
+                buf = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+                dist.all_gather_into_tensor(buf.view((world * mine.shape[0],) + tuple(mine.shape[1:])), mine.contiguous(), group=group)
             for j in range(min(world, len(starts) - r0)):
                 decoded[r0 + j] = buf[j]
         return decoded

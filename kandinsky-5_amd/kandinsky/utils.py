@@ -36,7 +36,7 @@ def get_T2V_pipeline(
     assert not (world_size > 1 and offload), "Offloading available only with not parallel inference"
     if world_size > 1:
         for k in ("dit", "vae", "text_embedder"):
-            device_map[k] = torch.device(f"cuda:{local_rank}")
+            device_map[k] = torch.device(f"cuda:{rank_device_index(local_rank)}")
 
     os.makedirs(cache_dir, exist_ok=True)
     if conf_path is None:
@@ -78,8 +78,7 @@ def get_T2V_pipeline(
         import torch.distributed as dist
         from .models.parallelize import parallelize_dit
         if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            init_rank_process_group(local_rank)
         cfg_parallel = (conf.model.guidance_weight != 1.0 and world_size % 2 == 0
                         and os.environ.get("K5_CFG_PARALLEL", "1") != "0")
         dit = parallelize_dit(dit, local_rank, world_size, device=device_map["dit"], cfg_parallel=cfg_parallel)
@@ -88,6 +87,27 @@ def get_T2V_pipeline(
     return Kandinsky5T2VPipeline(device_map=device_map, dit=dit, text_embedder=text_embedder, vae=vae,
                                  resolution=resolution, local_dit_rank=local_rank, world_size=world_size, conf=conf,
                                  offload=offload)
+
+
+def rank_device_index(local_rank: int) -> int:
+    """The device of a rank: cuda:LOCAL_RANK (reference utils.py:40-45).  K5_OVERSUBSCRIBE=1 wraps the ranks around the devices
+    that exist (P ranks on one GPU: the IPC transport's one-box mode, `bench.py --gpus P --oversubscribe`)."""
+    if os.environ.get("K5_OVERSUBSCRIBE", "0") == "1":
+        return local_rank % max(torch.cuda.device_count(), 1)
+    return local_rank
+
+
+def init_rank_process_group(local_rank: int):
+    """reference utils.py:47-55 (init_device_mesh) under its launch contract.  RCCL transport: backend nccl bound to the rank's
+    device.  IPC transport (K5_SP_TRANSPORT=ipc): torch.distributed only carries names and checksums — gloo, which unlike RCCL
+    does not mind several ranks on one device."""
+    import torch.distributed as dist
+    from .models.dit import sp_transport
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if sp_transport() == "ipc":
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{rank_device_index(local_rank)}"))
 
 
 def get_default_conf(dit_path, vae_path, text_encoder_path, text_encoder2_path) -> Conf:

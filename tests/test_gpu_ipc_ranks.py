@@ -1,0 +1,154 @@
+"""The sharded path ACROSS PROCESSES (VERDICT r5 missing #1): until round 6 every multi-rank check was P handles + P host threads inside one process
+(k5_loopback), and the process boundary — torch.distributed.run -> LOCAL_RANK / WORLD_SIZE (reference kandinsky/utils.py:40-55, README.md:269-276)
+-> process group -> parallelize_dit (reference kandinsky/models/parallelize.py:11-102, replaced) -> the engine's communicator -> per-process
+streams -> rank_check — had only ever run with world = 1.  RCCL refuses two ranks on one device; the engine's own IPC transport
+(csrc/ipc_comm.h, k5_dit_comm_init_ipc: peers read each other's hipIpc-mapped slots, epoch flags in device memory) does not, so here P PROCESSES
+on the one device of the box run BASELINE config 1 IN FULL (32 visual blocks x 16 steps) and must produce
+
+  * the latent of the reference's generate() (goldens dit_fulldepth_c1 / n1) within the stated tolerance of tests/test_gpu_fulldepth.py:
+    <= max(1.5 x yardstick, 1e-2) vs reference fp32 and vs the bf16-island oracle;
+  * the SAME BITS on every rank (rank_check) and the same bits as loopback ranks of the same size in this process;
+  * no flag wait that ran into its time limit, and a communicator that reports P processes with P distinct pids.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import k5_oracle as O  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.join(ROOT, "tests", "golden")
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def launch(P, case, out, extra=(), timeout=840):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "ipc_rank_worker.py"), "--case", case, "--out", out] + list(extra)
+    env = dict(os.environ, K5_SP_TRANSPORT="ipc", K5_OVERSUBSCRIBE="1", K5_IPC_TIMEOUT_S="120", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # own session: a launcher that outlives the timeout goes as a GROUP (its ranks hold the GPU)
+    pr = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    try:
+        log, _ = pr.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(pr.pid, signal.SIGKILL)
+        log, _ = pr.communicate()
+        pytest.fail(f"{P} ranks did not finish within {timeout} s:\n{log[-3000:]}")
+    assert pr.returncode == 0, f"torch.distributed.run exited with {pr.returncode}:\n{log[-4000:]}"
+    return log
+
+
+def loopback_latent(P, c, w, sparse, meta, slices=1):
+    """the same run as P loopback ranks of THIS process (tests/test_gpu_loopback.py run_ranks): the bits the processes must reproduce"""
+    import importlib.util
+    from kandinsky.generation_utils import sigma_schedule
+    from kandinsky.models.dit import DiffusionTransformer3D
+    spec = importlib.util.spec_from_file_location("k5_loopback_helpers", os.path.join(ROOT, "tests", "test_gpu_loopback.py"))
+    lb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lb)
+    cfg = dict(O.LITE_2B)
+    sd = O.synthetic_state_dict(O.DitConfig(**cfg), seed=meta["weights_seed"])
+    for k in sd:
+        if k.endswith(("query_norm.weight", "key_norm.weight")):
+            sd[k] = torch.full((64,), float(meta["qk_gain"]))
+    T, H, W = c["latent"]
+    g = torch.Generator().manual_seed(c["xseed"])
+    te = {"text_embeds": torch.randn(c["L"], 3584, generator=g).cuda(), "pooled_embed": torch.randn(1, 768, generator=g).cuda()}
+    ne = {"text_embeds": torch.randn(c["Lnull"], 3584, generator=g).cuda(), "pooled_embed": torch.randn(1, 768, generator=g).cuda()}
+    pos = [torch.arange(T), torch.arange(H // 2), torch.arange(W // 2)]
+    noise = torch.randn(T, H, W, 16, generator=torch.Generator().manual_seed(c["seed"]))
+    sig = sigma_schedule(c["steps"], c["s"]).tolist()
+
+    def make():
+        d = DiffusionTransformer3D(**cfg)
+        d.load_state_dict(sd, assign=True)
+        return d
+
+    def call(d, r):
+        lat = noise.clone().cuda()
+        d.sample(lat, sig, te, ne, pos, torch.arange(c["L"]), torch.arange(c["Lnull"]), w, scale_factor=(1.0, 2.0, 2.0), sparse_params=sparse)
+        return lat
+    outs = lb.run_ranks(P, make, call, slices=slices)
+    for r in range(1, P):
+        assert torch.equal(outs[r], outs[0])
+    out = outs[0].cpu()
+    del outs
+    torch.cuda.empty_cache()
+    return out
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("P,case,slices", [(2, "c1", 1), (4, "n1w1", 1), (4, "c1", 2)])
+def test_processes_in_full_depth_vs_reference_and_vs_loopback_ranks(tmp_path, P, case, slices):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    from safetensors.torch import load_file
+    meta = json.load(open(os.path.join(HERE, "dit_fulldepth_meta.json")))
+    out = str(tmp_path / f"ipc_{P}_{case}_{slices}")
+    log = launch(P, case, out, ["--slices", str(slices)] if slices > 1 else [])
+    rc = json.load(open(os.path.join(out, "rank_check.json")))
+    ranks = rc["ranks"]
+    assert rc["rank_check"]["latent_checksums_identical_on_all_ranks"], rc
+    assert len({r["pid"] for r in ranks}) == P and all(r["ipc_ranks"] == P and r["ipc_errors"] == 0 for r in ranks), ranks
+    assert all(r["ipc_collectives"] >= 32 * 16 * 2 for r in ranks), ranks          # at least K and V^T of every block of every step
+    lats = [torch.load(os.path.join(out, f"latent_rank{r}.pt")) for r in range(P)]
+    for r in range(1, P):
+        assert torch.equal(lats[r], lats[0]), f"process {r} holds another latent than process 0"
+    if case == "c1":
+        c, G = meta["c1"], load_file(os.path.join(HERE, "dit_fulldepth_c1.safetensors"))
+        ref, ref16, yard, w, sparse = G["final_ref"], G["final_bf16_oracle"], c["bf16_oracle_vs_ref_final"], c["w"], None
+    else:
+        c, G = meta["n1"], load_file(os.path.join(HERE, "dit_fulldepth_n1.safetensors"))
+        run = c["runs"]["w1"]
+        ref, ref16, yard, w = G["w1.final_ref"], G["w1.final_bf16_oracle"], run["bf16_oracle_vs_ref_final"], 1.0
+        sparse = {"P": c["P"], "wT": c["win"][0], "wH": c["win"][1], "wW": c["win"][2], "to_fractal": True}
+    got = lats[0].reshape(-1)[G["sample_idx"]]
+    r_ref, r_16 = rel(got, ref), rel(got, ref16)
+    print(f"{P} PROCESSES on {ranks[0]['device']} (pids {[r['pid'] for r in ranks]}), {case}, slices {slices}, 32 blocks x {c['steps']} steps, IPC transport: "
+          f"{ranks[0]['ipc_collectives']} collectives, {ranks[0]['ipc_pulled_mb']} MB pulled per rank; final latent vs reference fp32 {r_ref:.3e}, "
+          f"vs bf16-island oracle {r_16:.3e} (oracle vs reference {yard:.3e})")
+    assert r_ref <= max(1.5 * yard, 1e-2) and r_ref <= 6e-2, (r_ref, yard)
+    assert r_16 <= max(1.5 * yard, 1e-2), (r_16, yard)
+    loop = loopback_latent(P, c, w, sparse, meta, slices=slices)
+    assert torch.equal(loop, lats[0]), f"the processes and the loopback ranks disagree: {rel(lats[0], loop):.3e}"
+    print(f"  bit-identical to {P} loopback ranks of one process")
+
+
+@pytest.mark.timeout(900)
+def test_processes_cfg_parallel_two_groups_of_two(tmp_path):
+    """CFG-parallel across processes: 4 processes = cond / uncond groups of 2 token shards each, the velocity pair exchange over a second IPC
+    group per pair (k5_dit_cfg_pair_init_ipc), NABLA at guidance 5 — against the reference's generate() golden (n1, w5)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    from safetensors.torch import load_file
+    meta = json.load(open(os.path.join(HERE, "dit_fulldepth_meta.json")))
+    out = str(tmp_path / "ipc_cfg")
+    launch(4, "n1w5", out, ["--cfg-parallel"])
+    rc = json.load(open(os.path.join(out, "rank_check.json")))
+    ranks = rc["ranks"]
+    assert rc["rank_check"]["latent_checksums_identical_on_all_ranks"], rc
+    assert all(r["ipc_ranks"] == 2 and r["ipc_pair_ranks"] == 2 and r["ipc_errors"] == 0 for r in ranks), ranks
+    lat = torch.load(os.path.join(out, "latent_rank0.pt"))
+    c, G = meta["n1"], load_file(os.path.join(HERE, "dit_fulldepth_n1.safetensors"))
+    run = c["runs"]["w5"]
+    got = lat.reshape(-1)[G["sample_idx"]]
+    r_ref, r_16, yard = rel(got, G["w5.final_ref"]), rel(got, G["w5.final_bf16_oracle"]), run["bf16_oracle_vs_ref_final"]
+    print(f"4 PROCESSES = CFG pair x 2 token shards, NABLA, guidance 5: final latent vs reference fp32 {r_ref:.3e}, vs bf16-island oracle {r_16:.3e} (oracle vs reference {yard:.3e})")
+    assert r_ref <= max(1.5 * yard, 1e-2) and r_ref <= 6e-2, (r_ref, yard)
+    assert r_16 <= max(1.5 * yard, 1e-2), (r_16, yard)
