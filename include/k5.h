@@ -359,7 +359,7 @@ int k5_dit_cfg_pair_init_loopback(k5_dit* dit, k5_loopback* group, int branch);
  * process boundary of the sharded path is exercised on a one-GPU box (bench.py --gpus P --oversubscribe; tests/test_gpu_ipc_ranks.py) —
  * and on an xGMI node it needs no library at all.  shm_name: name of a POSIX shared-memory control block, unique per group and per run
  * (the host makes one up on the group's rank 0 and broadcasts it over torch.distributed); collective over the `world` processes of the
- * group (<= 16).  Not with k5_dit_set_graph (k5_sample runs the step eagerly).  Options (k5_dit_get_option): "ipc_ranks", "ipc_pair_ranks"
+ * group (<= 16).  Works under k5_dit_set_graph: the collectives' epochs live on the device, so the captured step replays.  Options (k5_dit_get_option): "ipc_ranks", "ipc_pair_ranks"
  * (0 = another transport), "ipc_collectives", "ipc_pulled_mb", "ipc_errors" (synchronises; first flag wait that hit K5_IPC_TIMEOUT_S). */
 int k5_dit_comm_init_ipc(k5_dit* dit, const char* shm_name, int rank, int world);
 int k5_dit_cfg_pair_init_ipc(k5_dit* dit, const char* shm_name, int branch);

@@ -1913,8 +1913,9 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
   // are launches of the instantiated graph.  Not with MagCache (its skip pattern changes the launch sequence per step)
   // or while profiling (events).
   // not replayed: MagCache (host decisions), profiling (events), the NABLA map tap (its destination advances on the host per launch: a replay
-  // would overwrite the slots baked at capture — ADVICE r5), the IPC transport (its epochs and peer pointers are host-side state per collective)
-  const bool graph = d->use_graph && !d->mag.on && !d->profiling && a->num_steps > 2 && !d->nabla_tap && !d->comm.ipc && !d->pair.ipc;
+  // would overwrite the slots baked at capture — ADVICE r5), loopback groups (their collectives are host rendezvous).  The IPC transport IS
+  // replayable: its epochs live on the device and the peers' buffers were mapped by the eager first step (ipc_comm.h)
+  const bool graph = d->use_graph && !d->mag.on && !d->profiling && a->num_steps > 2 && !d->nabla_tap && !d->comm.loop && !d->pair.loop;
   std::vector<float> host_tab(2 * (size_t)a->num_steps);
   for (int i = 0; i < a->num_steps; ++i) {
     host_tab[i] = a->sigmas[i] * 1000.0f;                        // t * 1000, fp32 (:57)

@@ -17,11 +17,12 @@
 //                   written", PULLED[p] = "rank p has read mine".  Written by the peers' signal kernels with system-scope release
 //                   stores, polled by the rank's own wait kernel with system-scope acquire loads (bounded: a wait that outlives
 //                   K5_IPC_TIMEOUT_S — default 60 s of the 100-MHz wall clock — raises the error word instead of hanging the GPU).
-//   a collective    epoch e = ++epoch; host: publish (allocation, offset), ONE barrier, map the peers' allocations (cached by
-//                   serial number; an allocation freed and re-made is re-opened); device, on the caller's stream: signal READY
-//                   -> per peer { wait READY[p] ; copy p's bytes out of p's buffer } -> signal PULLED -> wait PULLED[all].
-//                   The call therefore completes, stream-wise, exactly when an RCCL all-gather would: the caller may overwrite
-//                   its own slot afterwards.  Nothing is captured-graph safe (epochs are host-side): k5_sample refuses graphs.
+//   a collective    host: publish (allocation, offset), ONE barrier, map the peers' allocations (cached by serial number; an
+//                   allocation freed and re-made is re-opened); device, on the caller's stream: signal READY (bumps the epoch, which
+//                   lives in the rank's own flag buffer) -> per peer { wait READY[p] ; copy p's bytes out of p's buffer } -> signal
+//                   PULLED -> wait PULLED[all].  The call therefore completes, stream-wise, exactly when an RCCL all-gather would:
+//                   the caller may overwrite its own slot afterwards.  The kernels carry no host-side state (pointers are those of
+//                   buffers that do not move between steps), so a captured step that contains collectives replays correctly.
 // The same header is compiled into tools/probes/ipc_probe.hip, which checks the mechanism on its own (P forked processes).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -66,16 +67,25 @@ struct Shm {
 struct PeerFlags { uint32_t* f[MAXR]; };
 
 // ---- device side ----
-__global__ void ipc_signal_kernel(PeerFlags pf, int world, int rank, int which, uint32_t epoch) {
+// flag buffer of a rank (uint32): [0, MAXR) READY | [MAXR, 2 MAXR) PULLED | [ERRW] first timed-out wait | [CTR] the epoch of the collective in flight.
+// The epoch lives ON THE DEVICE: the first kernel of a collective bumps it, the others read it — nothing about a collective's kernels depends on a
+// host-side counter, so a captured graph that contains collectives can be replayed (k5_dit_set_graph).  All collectives of a group are issued in one
+// order on streams that are chained by events (engine.hip: the side stream's gathers, then the velocity gather after the join), so every rank's
+// device counts the same collectives in the same order.
+constexpr int ERRW = 2 * MAXR, CTR = 2 * MAXR + 1;
+__global__ void ipc_signal_kernel(PeerFlags pf, uint32_t* mine, int world, int rank, int which, int bump) {
   const int p = threadIdx.x;
+  const uint32_t epoch = mine[CTR] + (bump ? 1u : 0u);
+  __syncthreads();
+  if (bump && p == 0) mine[CTR] = epoch;
   if (p >= world || p == rank) return;
   __hip_atomic_store(pf.f[p] + which * MAXR + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// waits until flags[which][p] has reached `epoch` for p = first .. first + count - 1 (p != rank); limit in 100-MHz ticks
-__global__ void ipc_wait_kernel(uint32_t* flags, int first, int count, int rank, int which, uint32_t epoch, unsigned long long limit,
-                                uint32_t* err) {
+// waits until flags[which][p] has reached the current epoch for p = first .. first + count - 1 (p != rank); limit in 100-MHz ticks
+__global__ void ipc_wait_kernel(uint32_t* flags, int first, int count, int rank, int which, unsigned long long limit) {
   const int p = first + threadIdx.x;
   if ((int)threadIdx.x >= count || p == rank) return;
+  const uint32_t epoch = flags[CTR];
   const uint32_t* f = flags + which * MAXR + p;
   const unsigned long long t0 = wall_clock64();
   // relaxed polls (a system-scope load goes to memory on its own; an acquire per poll would invalidate this XCD's L2 under the kernels
@@ -83,7 +93,7 @@ __global__ void ipc_wait_kernel(uint32_t* flags, int first, int count, int rank,
   while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
     __builtin_amdgcn_s_sleep(16);
     if (wall_clock64() - t0 > limit) {
-      __hip_atomic_store(err, 0x80000000u | ((uint32_t)which << 24) | ((uint32_t)p << 16) | (epoch & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(flags + ERRW, 0x80000000u | ((uint32_t)which << 24) | ((uint32_t)p << 16) | (epoch & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
   }
@@ -114,12 +124,13 @@ struct Group {
   uint32_t* flags = nullptr;        // mine (device)
   uint32_t* errword = nullptr;      // device: first wait that timed out
   PeerFlags peer_flags{};           // the peers' flag buffers mapped here (mine at [rank])
-  uint32_t epoch = 0;
   uint64_t calls = 0, next_serial = 1;
   unsigned long long wait_limit = 6000000000ull;   // 60 s of the 100-MHz wall clock
   double host_timeout_s = 120.0;
   struct Mapped { uint64_t serial = 0; void* base = nullptr; };
   Mapped mapped[MAXR][MAXREG];
+  struct Range { void* base; size_t size; };
+  std::vector<Range> ranges;      // allocations of THIS process already looked up (forget() drops them)
   long long bytes_pulled = 0, collectives = 0;
 
   int fail(const char* fmt, const char* a = "", long long b = 0) {
@@ -167,7 +178,7 @@ struct Group {
     shm = (Shm*)m;   // a fresh segment is zero-filled: every atomic starts at 0
     K5IPC_HIP(hipMalloc((void**)&flags, 4096));
     K5IPC_HIP(hipMemset(flags, 0, 4096));
-    errword = flags + 2 * MAXR;
+    errword = flags + ERRW;
     int dev = 0;
     K5IPC_HIP(hipGetDevice(&dev));
     ShmRank& me = shm->r[rank];
@@ -217,13 +228,18 @@ struct Group {
     if (!shm) return;
     ShmRank& me = shm->r[rank];
     for (auto& rg : me.reg) if (rg.base == (uint64_t)(uintptr_t)base) { rg.base = 0; rg.size = 0; rg.serial = 0; }
+    for (size_t i = 0; i < ranges.size(); ++i) if (ranges[i].base == base) { ranges.erase(ranges.begin() + i); break; }
   }
 
   // host half of a collective: tell the peers which allocation / offset `buf` is, learn theirs.  peer[p] = rank p's `buf` mapped here.
   int resolve(const void* buf, size_t bytes, void** peer) {
     ShmRank& me = shm->r[rank];
     hipDeviceptr_t base = nullptr; size_t size = 0;
-    K5IPC_HIP(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)buf));
+    for (const Range& rg : ranges) if ((const char*)buf >= (const char*)rg.base && (const char*)buf < (const char*)rg.base + rg.size) { base = rg.base; size = rg.size; break; }
+    if (!base) {   // (not inside a stream capture: the first step of a sampling run is never captured)
+      K5IPC_HIP(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)buf));
+      ranges.push_back(Range{base, size});
+    }
     int idx = -1, free_idx = -1;
     for (int i = 0; i < MAXREG; ++i) {
       if (me.reg[i].base == (uint64_t)(uintptr_t)base && me.reg[i].size == size) { idx = i; break; }
@@ -258,12 +274,12 @@ struct Group {
     return 0;
   }
 
-  int signal(int which, hipStream_t s) {
-    hipLaunchKernelGGL(ipc_signal_kernel, dim3(1), dim3(64), 0, s, peer_flags, world, rank, which, epoch);
+  int signal(int which, hipStream_t s) {   // which = 0 (READY) opens a collective: it bumps the device-side epoch
+    hipLaunchKernelGGL(ipc_signal_kernel, dim3(1), dim3(64), 0, s, peer_flags, flags, world, rank, which, which == 0 ? 1 : 0);
     return 0;
   }
   int wait(int first, int count, int which, hipStream_t s) {
-    hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, s, flags, first, count, rank, which, epoch, wait_limit, errword);
+    hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, s, flags, first, count, rank, which, wait_limit);
     return 0;
   }
   int copy(void* dst, const void* src, size_t bytes, hipStream_t s) {
@@ -290,7 +306,7 @@ struct Group {
     if (world == 1 || cnt == 0) return 0;
     void* peer[MAXR];
     if (resolve(buf, slot_bytes, peer)) return -1;
-    ++epoch; ++collectives;
+    ++collectives;
     signal(0, s);
     for (int i = 1; i < world; ++i) {
       const int p = (rank + i) % world;   // every rank starts at a different peer
@@ -307,7 +323,7 @@ struct Group {
     if (world == 1) return 0;
     void* peer[MAXR];
     if (resolve(send, block_bytes, peer)) return -1;
-    ++epoch; ++collectives;
+    ++collectives;
     signal(0, s);
     for (int i = 1; i < world; ++i) {
       const int p = (rank + i) % world;

@@ -25,7 +25,8 @@ HERE = os.path.join(ROOT, "tests", "golden")
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--case", required=True, choices=("c1", "n1w1", "n1w5"))
+    ap.add_argument("--case", required=True, choices=("c1", "n1w1", "n1w5", "c5"))
+    ap.add_argument("--graph", action="store_true", help="k5_dit_set_graph: one captured step replayed (the IPC collectives inside the capture)")
     ap.add_argument("--out", required=True)
     ap.add_argument("--slices", type=int, default=1)
     ap.add_argument("--cfg-parallel", action="store_true")
@@ -47,7 +48,13 @@ def main():
     torch.cuda.set_device(dev)
     init_rank_process_group(local_rank)
     meta = json.load(open(os.path.join(HERE, "dit_fulldepth_meta.json")))
-    if args.case == "c1":
+    if args.case == "c5":
+        # BASELINE config 5's shape as ONE configuration (tests/test_gpu_loopback.py::test_config5_cfg_parallel_2x4_on_one_gpu): 1280x768 10 s latent
+        # (61, 96, 160) = 234 240 tokens = 3660 blocks of 64, NABLA P 0.9 window (11, 3, 3), guidance 5, full width, ONE visual block, 4 Euler steps
+        c = {"latent": [61, 96, 160], "L": 48, "Lnull": 8, "steps": 4, "s": 10.0, "seed": 13, "xseed": 14, "P": 0.9, "win": [11, 3, 3]}
+        w, sparse = 5.0, {"P": 0.9, "wT": 11, "wH": 3, "wW": 3, "to_fractal": True}
+        meta = dict(meta, weights_seed=4, qk_gain=1.0)
+    elif args.case == "c1":
         c, w, sparse = meta["c1"], meta["c1"]["w"], None
     else:
         c = meta["n1"]
@@ -56,6 +63,8 @@ def main():
     cfg = dict(O.LITE_2B)
     if args.tiny:
         cfg.update(num_visual_blocks=2, num_text_blocks=1)
+    if args.case == "c5":
+        cfg.update(num_visual_blocks=1, num_text_blocks=1)
     sd = O.synthetic_state_dict(O.DitConfig(**cfg), seed=meta["weights_seed"])
     for k in sd:
         if k.endswith(("query_norm.weight", "key_norm.weight")):
@@ -67,6 +76,8 @@ def main():
     parallelize_dit(dit, rank, world, device=dev, cfg_parallel=args.cfg_parallel)
     if args.slices > 1:
         dit.set_option("sp_slices", args.slices)
+    if args.graph:
+        dit.set_graph(True)
     assert dit.get_option("ipc_ranks") == (world // 2 if args.cfg_parallel else world), dit.get_option("ipc_ranks")
     assert dit.get_option("rccl_ranks") == -1          # a communicator, and not RCCL's
 

