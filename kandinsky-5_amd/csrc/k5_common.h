@@ -56,7 +56,12 @@ K5_DEV float wave_max(float v) {
 
 // exact-erf GELU (nn.GELU default, approximate='none'), fp32 math
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, below the bf16 rounding every caller applies to the result):
-// branch-free, 14 VALU ops against ~40 for the device library's erff — the GELU epilogue is VALU time the matrix pipe waits for
+// branch-free, 14 VALU ops against ~40 for the device library's erff.
+// Round 6 measured the one-transcendental form 7.1.28, 1 - 1 / (1 + a1 x + ... + a6 x^6)^16 (-DK5_GELU_AS28; as accurate: over all bf16 inputs the
+// rounded GELU differs from the exactly rounded one in 141 of 33 410 values against 117, profiles/r06_gelu_erf_forms.log): FF1 + GELU 1036-1052 us
+// against 1038-1043 at 47 616 rows, alternating on one box (profiles/r06_gelu_ab.log) — the fused GELU's cost is not its transcendentals.  7.1.26
+// stays (the bits of rounds 1-5).
+#ifndef K5_GELU_AS28
 K5_DEV float erf_as(float x) {
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
@@ -67,6 +72,19 @@ K5_DEV float erf_as(float x) {
   const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
   return copysignf(fmaf(-p * t, e, 1.0f), x);
 }
+#else
+K5_DEV float erf_as(float x) {
+  const float ax = fabsf(x);
+  float p = fmaf(0.0000430638f, ax, 0.0002765672f);
+  p = fmaf(p, ax, 0.0001520143f);
+  p = fmaf(p, ax, 0.0092705272f);
+  p = fmaf(p, ax, 0.0422820123f);
+  p = fmaf(p, ax, 0.0705230784f);
+  p = fmaf(p, ax, 1.0f);
+  p = p * p; p = p * p; p = p * p; p = p * p;          // ^16; overflows to +inf beyond |x| ~ 13, where 1 / inf = 0 is the right answer
+  return copysignf(1.0f - __builtin_amdgcn_rcpf(p), x);
+}
+#endif
 K5_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 // two values at once on the packed fp32 pipe (v_pk_mul / v_pk_fma_f32; rcp and exp2 stay scalar): the SAME operations in the same order as
 // gelu_erf, so the bits are the same — 21 VALU instructions per pair instead of 36.  For epilogues with no MFMA beside them (beside MFMAs
@@ -95,6 +113,7 @@ K5_DEV void gelu_erf_x2(float& a, float& b) {
   const k5_f32x2 x0 = {a, b};
   const k5_f32x2 x = x0 * k5_f32x2{0.70710678118654752440f, 0.70710678118654752440f};
   const k5_f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+#ifndef K5_GELU_AS28
   const k5_f32x2 d = __builtin_elementwise_fma(k5_f32x2{0.3275911f, 0.3275911f}, ax, k5_f32x2{1.0f, 1.0f});
   const k5_f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
   k5_f32x2 p = __builtin_elementwise_fma(k5_f32x2{1.061405429f, 1.061405429f}, t, k5_f32x2{-1.453152027f, -1.453152027f});
@@ -104,6 +123,16 @@ K5_DEV void gelu_erf_x2(float& a, float& b) {
   const k5_f32x2 a2 = (k5_f32x2{-1.44269504088896340736f, -1.44269504088896340736f} * ax) * ax;
   const k5_f32x2 e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
   const k5_f32x2 r = __builtin_elementwise_fma(-(p * t), e, k5_f32x2{1.0f, 1.0f});
+#else
+  k5_f32x2 p = __builtin_elementwise_fma(k5_f32x2{0.0000430638f, 0.0000430638f}, ax, k5_f32x2{0.0002765672f, 0.0002765672f});
+  p = __builtin_elementwise_fma(p, ax, k5_f32x2{0.0001520143f, 0.0001520143f});
+  p = __builtin_elementwise_fma(p, ax, k5_f32x2{0.0092705272f, 0.0092705272f});
+  p = __builtin_elementwise_fma(p, ax, k5_f32x2{0.0422820123f, 0.0422820123f});
+  p = __builtin_elementwise_fma(p, ax, k5_f32x2{0.0705230784f, 0.0705230784f});
+  p = __builtin_elementwise_fma(p, ax, k5_f32x2{1.0f, 1.0f});
+  p = p * p; p = p * p; p = p * p; p = p * p;
+  const k5_f32x2 r = k5_f32x2{1.0f, 1.0f} - k5_f32x2{__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+#endif
   const k5_f32x2 er = {copysignf(r[0], x[0]), copysignf(r[1], x[1])};
   const k5_f32x2 o = (k5_f32x2{0.5f, 0.5f} * x0) * (k5_f32x2{1.0f, 1.0f} + er);
   a = o[0]; b = o[1];

@@ -11,6 +11,8 @@
 //   OutLayer un-patchify    nn.py:384-399 (+ fractal_unflatten :44-51)             -> unpatchify_kernel
 //   CFG combine + Euler     generation_utils.py:74-76,128      -> cfg_euler_kernel       (K18)
 //   RoPE1D/RoPE3D tables    nn.py:99-150                        -> rope_table_kernel      (K15)
+#include <stdlib.h>
+
 #include "k5_common.h"
 #include "k5_kernels.h"
 
@@ -19,71 +21,103 @@ namespace {
 constexpr int MAXC = 4;  // 16-B chunks per lane per row: D <= 64*8*4 = 2048
 
 // ---------------------------------------------------------------------------------------------
-// K1: one wave per row
+// K1: one wave per row.  Round 6: the per-column vectors (scale + 1 | shift, or weight | bias) are staged ONCE per workgroup in LDS — until
+// round 5 every row re-read both vectors from L1 (14 KB of fp32 per 3.5-KB row at D = 1792: two thirds of the bytes the texture path moved).
+// 76 -> 64 us per call at 47 616 x 1792 (4.5 -> 5.4 TB/s, profiles/r06_ln_rows_ab.log).  A wave may walk several rows (`4 gridDim` apart;
+// K5_LN_WG caps the grid) but one row per wave measured best: 5.36 TB/s against 4.7-5.2 with 512-4096 workgroups.  Same operations in the same
+// order per row: the bits do not change.  (All four 16-B loads of a row are issued in one burst ahead of the arithmetic: the same kernel with the
+// loads inside the chunk loop ran at 4.1 TB/s, profiles/r06_ln_rows_ab.log second table.)
 template <bool AFFINE>
 __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, const float* __restrict__ a,
                                                  const float* __restrict__ b, bf16_t* __restrict__ out,
                                                  float* __restrict__ out_f32, int rows, int D, int ldx, int ldo,
                                                  uint8_t* __restrict__ out8 = nullptr) {   // e4m3(bf16(.)), static scale 1, row stride D (fp8 modes of the engine)
+  // [a | b][half 0 | half 1][chunk][4]: a lane's two 16-B halves of a chunk sit in two planes, so that consecutive lanes read consecutive
+  // 16 B (conflict-free ds_read_b128)
+  __shared__ __attribute__((aligned(16))) float vec[2][2][64 * MAXC][4];
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
   const int nch = D >> 3;
-  float v[MAXC][8];
-  float sum = 0.f;
+  for (int c = threadIdx.x; c < 2 * nch; c += 256) {       // c = 2 chunk + half
+    const f32x4 av = *reinterpret_cast<const f32x4*>(a + 4 * c), bv = *reinterpret_cast<const f32x4*>(b + 4 * c);
+    *reinterpret_cast<f32x4*>(vec[0][c & 1][c >> 1]) = AFFINE ? av : f32x4{av[0] + 1.0f, av[1] + 1.0f, av[2] + 1.0f, av[3] + 1.0f};   // K1: scale + 1
+    *reinterpret_cast<f32x4*>(vec[1][c & 1][c >> 1]) = bv;
+  }
+  __syncthreads();
+  const int stride = 4 * gridDim.x;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  u32x4 raw[MAXC];
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)row * ldx + 8 * ch);
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < nch) raw[i] = *reinterpret_cast<const u32x4*>(x + (size_t)row * ldx + 8 * (lane + 64 * i));
+  for (; row < rows; row += stride) {
+    float v[MAXC][8];
+    float sum = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[i][2 * j] = __uint_as_float(raw[j] << 16);
-        v[i][2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u);
-        sum += v[i][2 * j] + v[i][2 * j + 1];
+    for (int i = 0; i < MAXC; ++i) {
+      if (lane + 64 * i < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[i][2 * j] = __uint_as_float(raw[i][j] << 16);
+          v[i][2 * j + 1] = __uint_as_float(raw[i][j] & 0xffff0000u);
+          sum += v[i][2 * j] + v[i][2 * j + 1];
+        }
+      }
+    }
+    const int nrow = row + stride;
+    if (nrow < rows) {   // (a capped grid) the next row of this wave: in flight under this row's arithmetic and stores
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i)
+        if (lane + 64 * i < nch) raw[i] = *reinterpret_cast<const u32x4*>(x + (size_t)nrow * ldx + 8 * (lane + 64 * i));
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      if (lane + 64 * i < nch) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[8];
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(vec[0][0][ch]), a1 = *reinterpret_cast<const f32x4*>(vec[0][1][ch]);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(vec[1][0][ch]), b1 = *reinterpret_cast<const f32x4*>(vec[1][1][ch]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float n = (v[i][j] - mean) * rstd;
+          const float aj = j < 4 ? a0[j] : a1[j - 4], bj = j < 4 ? b0[j] : b1[j - 4];
+          // K1: n * (scale + 1) + shift ; K13: n * weight + bias
+          o[j] = __fadd_rn(__fmul_rn(n, aj), bj);
+        }
+        if (out) {
+          u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+          *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + 8 * ch) = pk;
+        }
+        if (out_f32) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) out_f32[(size_t)row * D + 8 * ch + j] = bf_round(o[j]);
+        }
+        if (out8) {   // what k5_launch_quant_rows_fp8 (static scale) makes of the bf16 row: the bf16 rounding first, then the saturating e4m3 one
+          uint2 q8;
+          q8.x = pack_fp8x4(bf_round(o[0]), bf_round(o[1]), bf_round(o[2]), bf_round(o[3]));
+          q8.y = pack_fp8x4(bf_round(o[4]), bf_round(o[5]), bf_round(o[6]), bf_round(o[7]));
+          *reinterpret_cast<uint2*>(out8 + (size_t)row * D + 8 * ch) = q8;
+        }
       }
     }
   }
-  const float mean = wave_sum(sum) / (float)D;
-  float sq = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    if (lane + 64 * i < nch) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)D + 1e-5f);
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
-      float o[8];
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(a + 8 * ch), a1 = *reinterpret_cast<const f32x4*>(a + 8 * ch + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + 8 * ch), b1 = *reinterpret_cast<const f32x4*>(b + 8 * ch + 4);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float n = (v[i][j] - mean) * rstd;
-        const float aj = j < 4 ? a0[j] : a1[j - 4], bj = j < 4 ? b0[j] : b1[j - 4];
-        // K1: n * (scale + 1) + shift ; K13: n * weight + bias
-        o[j] = AFFINE ? __fadd_rn(__fmul_rn(n, aj), bj) : __fadd_rn(__fmul_rn(n, aj + 1.0f), bj);
-      }
-      if (out) {
-        u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-        *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + 8 * ch) = pk;
-      }
-      if (out_f32) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) out_f32[(size_t)row * D + 8 * ch + j] = bf_round(o[j]);
-      }
-      if (out8) {   // what k5_launch_quant_rows_fp8 (static scale) makes of the bf16 row: the bf16 rounding first, then the saturating e4m3 one
-        uint2 q8;
-        q8.x = pack_fp8x4(bf_round(o[0]), bf_round(o[1]), bf_round(o[2]), bf_round(o[3]));
-        q8.y = pack_fp8x4(bf_round(o[4]), bf_round(o[5]), bf_round(o[6]), bf_round(o[7]));
-        *reinterpret_cast<uint2*>(out8 + (size_t)row * D + 8 * ch) = q8;
-      }
-    }
-  }
+}
+
+// workgroups of a launch: one wave per row unless K5_LN_WG caps the grid (A/B: a wave then walks several rows)
+inline int ln_grid(int rows) {
+  static const int cap = getenv("K5_LN_WG") ? atoi(getenv("K5_LN_WG")) : 0x7fffffff;
+  const int wg = (rows + 3) / 4;
+  return wg < cap ? wg : cap;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -132,6 +166,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
   // MEANS: the NEXT row's 16 bytes are requested before this row is worked on and stored (the compiler cannot move a load of x above a store
   // to x by itself): two loads in flight per thread — with whole 64-row blocks per thread the launch is a little over one round of resident
   // workgroups, and one load per thread did not keep HBM busy through its second round
+  // (Round 6: the same prefetch in the dense form — rows `stride` apart, ~20 per thread at 47 616 tokens — measured SLOWER: 154 us against 142-144,
+  // profiles/r06_elem_ab.log; seven waves per SIMD with one load each already cover the latency, the second load only adds to the queue.)
   u32x4 raw_pf = {0u, 0u, 0u, 0u};
   if (MEANS && slot0 < nblk) raw_pf = *reinterpret_cast<const u32x4*>(x + (size_t)(64 * slot0) * ld + head * 64 + 8 * c);
   for (int64_t g = g0, it = 0; MEANS ? (slot0 + (int)(it >> 6) * nslot < nblk) : (g < total); g += stride, ++it) {
@@ -481,7 +517,7 @@ int k5_launch_ln_modulate(const void* x, const float* scale, const float* shift,
   if (rows <= 0 || D <= 0 || (!out && !out_e4m3)) return K5_ERR_ARG;
   if ((D & 7) || (ldx & 7) || (ldo & 7)) return K5_ERR_ALIGN;
   if (D > 64 * 8 * MAXC) return K5_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ln_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, scale, shift,
+  hipLaunchKernelGGL(ln_kernel<false>, dim3(ln_grid(rows)), dim3(256), 0, s, (const bf16_t*)x, scale, shift,
                      (bf16_t*)out, (float*)nullptr, rows, D, ldx, ldo, (uint8_t*)out_e4m3);
   return done();
 }
@@ -491,7 +527,7 @@ int k5_launch_ln_affine(const void* x, const float* w, const float* b, void* out
   if (rows <= 0 || D <= 0) return K5_ERR_ARG;
   if (D & 7) return K5_ERR_ALIGN;
   if (D > 64 * 8 * MAXC) return K5_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ln_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, w, b,
+  hipLaunchKernelGGL(ln_kernel<true>, dim3(ln_grid(rows)), dim3(256), 0, s, (const bf16_t*)x, w, b,
                      (bf16_t*)out_bf16, out_f32, rows, D, D, D);
   return done();
 }
