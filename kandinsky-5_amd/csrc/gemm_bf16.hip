@@ -829,7 +829,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // fragment registers: k-step 0 of the current K-tile, and k-step 1 in one of two buffers (the other one receives the NEXT
   // K-tile's k-step 1 while this one is in use; k-step 0 of the next K-tile goes to wf0/xf0, dead after the first 64 MFMAs)
   bf16x8 wf0[8], xf0[MT], wf1[2][8], xf1[2][MT];
-  f32x4 acc[8][MT];   // [n-tile][m-tile]; written (not accumulated) by the first k-step of every output tile
+  // Round 6: the accumulators are PHYSICAL AGPRs, invisible to the compiler — quad q = 8 (m-tile) + (n-tile) lives in a[4 q : 4 q + 3], named in
+  // the instruction text of the MFMA statements and read back by v_accvgpr_read in the epilogue (acc_read).  Rounds 2-5 kept them as 64 C++
+  // values bound to the AGPR file ("+a"): correct and fast, but ANY second consumer of all 64 quads (a stream-K helper's partial store, a second
+  // epilogue) made the register allocator park 150-500 registers in scratch (HISTORY §R5).  Now a second consumer is just more asm.  The AGPR
+  // budget is reserved by an empty statement that clobbers a0 .. a[32 MT - 1] (the allocation is sized by it, and the VGPR spiller never picks an
+  // AGPR that some statement clobbers); tests/test_abi_and_host.py checks that the ISA holds no AGPR move outside these statements.
+  if constexpr (MT == 8) asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+  else if constexpr (MT == 6) asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
+  else asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+  // quad q -> four VGPRs (the epilogue's one way to an accumulator); Q is a constant after unrolling
+#define W4_ACC(DST, Q) asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]" \
+                                    : "=v"(DST[0]), "=v"(DST[1]), "=v"(DST[2]), "=v"(DST[3]) : "n"(4 * (Q)), "n"(4 * (Q) + 1), "n"(4 * (Q) + 2), "n"(4 * (Q) + 3))
 
   // ds_read_b128 as asm: the compiler would otherwise guard every fragment read with s_waitcnt vmcnt(..) against the LDS-DMA
   // writes in flight (it cannot tell the stages apart) and serialise the prefetch.  All waits are explicit below.
@@ -838,10 +849,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // allocator mixes the two files and shuffles ~500 registers per two K-tiles.  volatile asm statements keep their order, and
   // loads cannot cross them, so the source order below IS the instruction schedule: fragment reads and DMAs are placed
   // between the MFMAs by hand.  (An accumulator is revisited 64 MFMAs later: no dependent-issue hazard inside the stream.)
-#define W4_MF(WF, XF, Q) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(Q) & 7][(Q) >> 3]) : "v"(WF[(Q) & 7]), "v"(XF[(Q) >> 3]))
+#define W4_MF(WF, XF, Q) asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, a[%2:%3]" :: "v"(WF[(Q) & 7]), "v"(XF[(Q) >> 3]), "n"(4 * (Q)), "n"(4 * (Q) + 3))
   // first k-step of an output tile: C = 0 as an inline constant, the accumulator is only written — so the epilogue never has
   // to create 256 zeroed registers while the old sums are still live (which made the allocator park them in scratch)
-#define W4_MF0(WF, XF, Q) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[(Q) & 7][(Q) >> 3]) : "v"(WF[(Q) & 7]), "v"(XF[(Q) >> 3]))
+#define W4_MF0(WF, XF, Q) asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, 0" :: "v"(WF[(Q) & 7]), "v"(XF[(Q) >> 3]), "n"(4 * (Q)), "n"(4 * (Q) + 3))
 #ifndef W4_DBG
 #define W4_DBG 0
 #endif
@@ -1051,9 +1062,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int n = nb + 16 * i;
+            float a4[4];
+            W4_ACC(a4, 8 * j + i);
             if (m < p.M && n < p.N)
-              *reinterpret_cast<f32x4*>(cf + (size_t)m * p.ldc + n) =
-                  f32x4{acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
+              *reinterpret_cast<f32x4*>(cf + (size_t)m * p.ldc + n) = f32x4{a4[0] * p.alpha, a4[1] * p.alpha, a4[2] * p.alpha, a4[3] * p.alpha};
           }
         }
         return;
@@ -1108,7 +1120,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int i = 2 * iq + h;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            float v[4];
+            W4_ACC(v, 8 * j + i);
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, gv = bv;
             if constexpr (EPI == K5_EPI_GATE) { bv = bq[iq & 1][h]; gv = gq[iq & 1][h]; }
             else if (EPI != K5_EPI_BIAS_M && has_bias) bv = bvec[i];
@@ -1203,6 +1216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W4_KT
 #undef W4_MF
 #undef W4_MF0
+#undef W4_ACC
 #undef W4_RD
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wrapped DMAs still write this workgroup's LDS
 }
