@@ -2164,6 +2164,9 @@ extern "C" int k5_dit_cfg_pair_init_ipc(k5_dit* d, const char* shm_name, int bra
 //                     depending on how the compiler schedules the tile loop of the extra instantiation), hence opt-in.
 //   "nabla_group_rows" 0 (default) / 2 / 4: 64-query rows per NABLA key-tile list = per attention workgroup on one GPU; 0 picks 2 (128-query
 //                     workgroups) when the previous forward's first map kept less than half of its blocks, else 4; same bits either way
+//   "gemm_split_tail" 0 (default) / 1 / 2 (PROCESS-wide, like K5_GEMM_SK): 1 = the ragged last round of a four-wave GEMM launch is cut along K into two
+//                     aligned slices per tile on two workgroups of one XCD (csrc/gemm_bf16.hip) where at most half of the CUs would be busy, 2 = wherever
+//                     a tile can be cut; 0 = whole tiles everywhere (one K order in every kernel).  Measured neutral through the engine, hence opt-in
 //   "cross_kv_batched" 1 (default) / 0: the cross-attention key / V^T projections of all visual blocks as two GEMMs against stacked weights before
 //                     the visual stack (they depend on the text stream only), their key norms as one launch; same bits as the per-block launches
 //   "nabla_fuse_means" 1 (default: where the launch has >= 150 k threads) / 2 (always) / 0: the 64-token block means NABLA's map is built from are taken by the norm + RoPE pass itself (one read of q | k
@@ -2203,6 +2206,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   if (!strcmp(name, "attn_anchor")) { d->anchor = value != 0; return K5_OK; }
   if (!strcmp(name, "attn_pref_reset")) return reset_attn_pref(d, nullptr, true);   // an action, not a state: the per-step path (k5_dit_forward) calls it per run
   if (!strcmp(name, "cross_kv_batched")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->cross_kv_batched = value; return K5_OK; }
+  if (!strcmp(name, "gemm_split_tail")) { if (value < -1 || value > 2) return K5_ERR_ARG; k5_gemm_set_stream_k_default(value); return K5_OK; }   // process-wide: the GEMM launcher has no handle
   if (!strcmp(name, "nabla_fuse_means")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->nabla_fuse_means = value; return K5_OK; }
   if (!strcmp(name, "fp8_fuse_ln")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->fp8_fuse_ln = value; return K5_OK; }
   if (!strcmp(name, "nabla_pair_frames")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->nabla_pair_frames = value; return K5_OK; }
@@ -2258,6 +2262,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "fp8_fuse_ln")) *value = d->fp8_fuse_ln;
   else if (!strcmp(name, "nabla_fuse_means")) *value = d->nabla_fuse_means;
   else if (!strcmp(name, "cross_kv_batched")) *value = d->cross_kv_batched;
+  else if (!strcmp(name, "gemm_split_tail")) *value = k5_gemm_stream_k_policy();
   else if (!strcmp(name, "emulate_world")) *value = d->emulated ? d->sp_world : 0;
   else if (!strcmp(name, "emulated")) *value = d->emulated ? 1 : 0;
   else { k5_set_error("unknown option %s", name); return K5_ERR_ARG; }

@@ -15,10 +15,22 @@
 // the global loads of tile k+1 are issued before the MFMAs of tile k and written to LDS after.
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "k5_common.h"
 #include "k5_kernels.h"
+
+#ifndef K5_GEMM_SK_DEFAULT
+#define K5_GEMM_SK_DEFAULT 0   // split-K tail policy when neither K5_GEMM_SK nor a setter says otherwise (k5_gemm_set_stream_k_default): OFF.  Measured
+                               // honestly — launches back to back for a second, both orders — the split tail is worth 0 +- 0.6 % on every projection of
+                               // the model and nothing through the engine (profiles/r06_split_tail_sustained.log, r06_split_tail_engine_ab.log): a tail
+                               // round costs a launch's latency chain + an epilogue (~40 us) whether its K loop is 28 K-tiles on 128 x 128 quadrants or 14
+                               // on half tiles + a 256-KB hand-over.  It is correct, tested (kernel id 24) and stays as an option; off keeps one K order
+                               // in every kernel (the bits of rounds 1-5)
+#endif
 
 namespace {
 inline int k5_num_cu() {
@@ -45,6 +57,10 @@ struct GemmP {
   // quadrant b & 3 of the 256x256 logical tile tail_base + b / 4 (tiles256_m/n = that grid's extent).
   int lid_limit, tail_base, tiles256_m, tiles256_n;
   unsigned long long* trace;  // -DK8_TRACE builds only
+  // four-wave kernel, stream-K schedule (round 6): fp32 partial tiles [workgroup][wave][accumulator quad][lane] f32x4 + one flag per (workgroup, wave)
+  // behind them; null = whole tiles per workgroup
+  float* sk_ws;
+  int sk_smax;            // most K slices a tail tile is cut into
 };
 
 // four consecutive output columns n .. n+3 of token row m (v = fp32 accumulators)
@@ -748,9 +764,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     m0 = (first_m + (lid % per_group) % gsz) * TM;
     n0 = ((lid % per_group) / gsz) * K8_BN;
   };
-  if (slot >= x_cnt) return;
-
   const int nk = p.K / BK;                     // even, >= 4 (launcher)
+  // ---- the workgroup's walk as SEGMENTS (tile, first K-tile pair, end pair).  Without stream-K: whole tiles x_first + slot + r per_xcd.
+  // Split-K TAIL (p.sk_ws; round 6): the whole rounds of an XCD run as before, in lockstep; the rem_x < per_xcd tiles that are left — the ragged
+  // round, which costs a whole round's latency chain whoever computes it (43 of 255 us on an N = K = 1792 projection, 150 of 906 on FF2) — are cut
+  // along K into S = min(per_xcd / rem_x, sk_smax) ALIGNED slices, slice s of tile t on workgroup t + s rem_x of the XCD.  The LAST slice owns the
+  // tile: the helpers store their raw fp32 accumulators and raise a flag, the owner adds them to its own (slice order: deterministic) and runs the
+  // epilogue.  (The owner is the workgroup with the HIGHEST index of the tile's team: a workgroup only ever waits for workgroups that were dispatched
+  // before it and that wait for nobody, so the wait cannot deadlock however few CUs the launch gets — two such GEMMs of two streams side by side.)  All S rem_x workgroups start their slices together and the workgroups of one slice index walk K in lockstep, so a panel's K-tile is
+  // still fetched once per XCD — the first form of this, the data-parallel + two-tile stream-K hybrid of Osama et al. (equal runs of 1 + rem_x /
+  // per_xcd tiles per workgroup), put every workgroup on its own K phase and ran its region at HALF the K-tile rate (profiles/r06_streamk_*.log:
+  // never faster than whole tiles, 30-45 % slower at most remainders; the operand stream of this kernel lives on the lockstep).  Helper and owner
+  // sit on the SAME XCD (workgroup b runs on XCD b & 7, tools/probes/xcc_map.hip; the flag carries the hardware XCC id and a mismatch traps), so
+  // the sums travel through that XCD's L2.  Possible since the accumulators are physical AGPRs the register allocator does not see (above).  The
+  // sum over K of a split tile is ((s_last + s0) + s1) + ...: the last fp32 bit of some sums differs from the whole-tile schedule.
+  const int np = nk >> 1;
+  const bool sk_on = EPI != K5_EPI_F32 && p.sk_ws != nullptr;
+  const int r_dp = x_cnt / per_xcd, rem_x = x_cnt - r_dp * per_xcd;
+  int S = 1;
+  if (sk_on && rem_x > 0) { S = min(min(per_xcd / rem_x, p.sk_smax), np); if (S < 2) S = 1; }
+  const bool sk = S >= 2;
+  const int sk_t = sk ? slot % rem_x : 0, sk_sl = sk ? slot / rem_x : 0;   // this workgroup's tail tile and K slice (if slot < S rem_x)
+  const int nseg = sk ? r_dp + (slot < S * rem_x ? 1 : 0) : (slot < x_cnt ? (x_cnt - slot + per_xcd - 1) / per_xcd : 0);
+  if (nseg == 0) return;
+  auto seg = [&](int si, int& lid, int& kb, int& ke) {   // segment si of this workgroup: logical tile, K-tile pairs [kb, ke)
+    if (sk && si >= r_dp) {
+      lid = x_first + r_dp * per_xcd + sk_t;
+      kb = sk_sl * np / S; ke = (sk_sl + 1) * np / S;
+    } else {
+      lid = x_first + si * per_xcd + slot; kb = 0; ke = np;
+    }
+  };
   const uint32_t ldw2 = (uint32_t)p.ldw * 2u, lda2 = (uint32_t)p.lda * 2u;
   const uint32_t vw0 = (uint32_t)(16 * (lane >> 3)) * ldw2 + (uint32_t)(lane & 7) * 16u;
   const uint32_t vx0 = (uint32_t)(16 * (lane >> 3)) * lda2 + (uint32_t)(lane & 7) * 16u;
@@ -759,23 +803,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int drow_x = MT == 4 ? 4 * wave : drow, dslot_x = MT == 4 ? 4 * wave : dslot;   // MT = 4: the 16 pieces of the first 128 rows, 4 per wave
   uint32_t vw = vw0, vx = vx0;                           // lane offsets incl. the K advance of the DMA cursor
   __amdgpu_buffer_rsrc_t rW, rX;
-  int d_ti = slot, d_kt = 0, d_cnt = 0;                  // DMA cursor: tile (index into this workgroup's walk), K-tile, K-tiles done
-#ifndef W4_STAGGER
-#define W4_STAGGER 0   // measured: 1, 2, 4 K-tiles per tile index all LOSE 1-6 % (lockstep workgroups share L2 fills)
-#endif
-  auto set_dma_tile = [&](int ti) {
-    int m0, n0;
-    tile_origin(x_first + ti, m0, n0);
+  int d_si = 0, d_cnt = 0, d_len = 0;                    // DMA cursor: segment, K-tiles issued of it, K-tiles in it
+  // (a staggered K start per tile — every tile walking K from its own offset, wrapping — was measured in round 2: 1, 2, 4 K-tiles per tile index
+  // all LOSE 1-6 %: lockstep workgroups share L2 fills)
+  auto set_dma_seg = [&](int si) {
+    int lid, kb, ke, m0, n0;
+    seg(si, lid, kb, ke);
+    tile_origin(lid, m0, n0);
     const int rows_w = min(p.N - n0, K8_BN), rows_x = min(p.M - m0, MT == 4 ? 128 : K8_BM);
     rW = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.W) + (size_t)n0 * ldw2), 0,
                                            (int)(((uint32_t)(rows_w - 1) * (uint32_t)p.ldw + (uint32_t)p.K) * 2u), 0x00020000);
     rX = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.A) + (size_t)m0 * lda2), 0,
                                            (int)(((uint32_t)(rows_x - 1) * (uint32_t)p.lda + (uint32_t)p.K) * 2u), 0x00020000);
-    // staggered start: each tile walks K from its own offset and wraps (the sum is order-independent up to fp32 rounding), so
-    // the workgroups that run in lockstep do not all pull the same K columns - i.e. the same few L2 channels - at once
-    d_kt = W4_STAGGER ? (int)((unsigned)(W4_STAGGER * (m0 / TM + n0 / K8_BN)) % (unsigned)nk) : 0;
-    d_cnt = 0;
-    vw = vw0 + (uint32_t)d_kt * (2 * BK); vx = vx0 + (uint32_t)d_kt * (2 * BK);
+    d_cnt = 0; d_len = 2 * (ke - kb);
+    vw = vw0 + (uint32_t)kb * (4 * BK); vx = vx0 + (uint32_t)kb * (4 * BK);     // a K-tile is 2 BK bytes of a row, a pair 4 BK
   };
 #ifndef W4_AUX
 #define W4_AUX 0   // cache policy of the operand DMAs (A/B macro: sc0 = 1, nt = 2, sc1 = 16 — none of them moved the stream)
@@ -798,14 +839,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (w4_lds_t*)(dsm + so + W4_OP + (dslot_x + jj) * W4_PAD), 16, vx,
                                                (uint32_t)(drow_x + jj) * lda2, 0, W4_AUX_X);
   };
-  // after a K-tile's 16 DMAs: move the cursor; past the last tile it wraps onto the same tile (harmless loads that keep
+  // after a K-tile's 16 DMAs: move the cursor; past the last segment it wraps onto the same segment (harmless loads that keep
   // the vmcnt arithmetic uniform; nothing reads them)
   auto dma_advance = [&]() {
     vw += 2 * BK; vx += 2 * BK;
-    if (++d_kt == nk) { d_kt = 0; vw = vw0; vx = vx0; }
-    if (++d_cnt == nk) {
-      if (d_ti + per_xcd < x_cnt) d_ti += per_xcd;
-      set_dma_tile(d_ti);
+    if (++d_cnt == d_len) {
+      if (d_si + 1 < nseg) ++d_si;
+      set_dma_seg(d_si);
     }
   };
 
@@ -865,7 +905,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                   (uint32_t)(drow_x + d - 8) * lda2, 0, W4_AUX_X);
   };
 
-  set_dma_tile(slot);
+  set_dma_seg(0);
 #pragma unroll
   for (int st = 0; st < NST; ++st) { dma_w(st * STG); dma_x(st * STG); dma_advance(); }
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND * (NST - 1)) : "memory");   // K-tile 0 has landed
@@ -1030,22 +1070,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
 #define W4_STAMP() do {} while (0)
 #endif
-  for (int ti = slot; ti < x_cnt; ti += per_xcd) {
+  for (int si = 0; si < nseg; ++si) {
+    int s_lid, s_kb, s_ke;
+    seg(si, s_lid, s_kb, s_ke);
     W4_STAMP();
     W4_KT(std::integral_constant<int, 0>{}, std::true_type{});
     W4_KT(std::integral_constant<int, 1>{}, std::false_type{});
-    for (int t = 2; t < nk; t += 2) {
+    for (int t = 1; t < s_ke - s_kb; ++t) {
       W4_KT(std::integral_constant<int, 0>{}, std::false_type{});
       W4_KT(std::integral_constant<int, 1>{}, std::false_type{});
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs are invisible to the hazard recogniser: let the last ones retire
     W4_STAMP();
     int m0, n0;
-    tile_origin(x_first + ti, m0, n0);
+    tile_origin(s_lid, m0, n0);
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));
     const int e_l15 = tid2 & 15, e_lc = (tid2 >> 4) & 3, e_wave = tid2 >> 6;
     const int e_wn = e_wave & 1, e_wm = e_wave >> 1;
+    // ---- split-K tail (see the walk above).  Helper (slice > 0): the 8 MT accumulator quads go to the workspace straight from the AGPR file, 1 KB
+    // per wave and instruction, then this wave raises its flag (the owner's wave w needs only the helpers' wave w: same lane <-> output map) — no
+    // epilogue.  Owner (the last slice): for every helper in slice order, wait for this wave's flag and add the helper's sums into the AGPRs quad by quad;
+    // then the ordinary epilogue.  Once per workgroup and launch at most.
+    // The partial sums move with PLAIN accesses: the helper's stores are write-through in its L1 and acknowledged by the XCD's L2 (vmcnt(0) before
+    // the flag), the owner's CU has not touched these lines since its L1 was invalidated at the dispatch, so its loads miss the L1 and find them in
+    // that L2 (-DK5_SK_SC1: agent-scope accesses instead; same time).  The flags are agent-scope atomics.
+#ifdef K5_SK_SC1
+#define W4_SK_SC " sc1"
+#else
+#define W4_SK_SC ""
+#endif
+    if constexpr (EPI != K5_EPI_F32) {
+      if (sk && si >= r_dp) {
+        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(e_wave);
+        uint32_t sk_xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(sk_xcc));
+        sk_xcc = (sk_xcc & 15u) + 1u;
+        uint32_t* flags = reinterpret_cast<uint32_t*>(p.sk_ws + (size_t)gridDim.x * (4 * 64 * 256));     // behind the partial tiles (zeroed once by the launcher, and by every owner after use)
+        if (sk_sl < S - 1) {   // helper
+          const float* part = p.sk_ws + ((size_t)blockIdx.x * 4 + wv) * (64 * 256) + (tid2 & 63) * 4;
+#pragma unroll
+          for (int q = 0; q < 8 * MT; ++q)
+            asm volatile("global_store_dwordx4 %0, a[%1:%2], off" W4_SK_SC :: "v"(part + (size_t)q * 256), "n"(4 * q), "n"(4 * q + 3) : "memory");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this wave acknowledged by the L2, then the flag
+          if ((tid2 & 63) == 0) __hip_atomic_store(flags + (size_t)blockIdx.x * 4 + wv, sk_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+          W4_STAMP();
+          continue;
+        }
+        for (int hs = 0; hs < S - 1; ++hs) {   // owner: the helpers in slice order
+          const uint32_t hb = (uint32_t)(xcd + 8 * (sk_t + hs * rem_x));
+          const float* part = p.sk_ws + ((size_t)hb * 4 + wv) * (64 * 256) + (tid2 & 63) * 4;
+          uint32_t* fp = flags + (size_t)hb * 4 + wv;
+          uint32_t f;
+          for (;;) {
+            f = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+            if (f != 0u) break;
+            __builtin_amdgcn_s_sleep(4);
+          }
+          if (f != sk_xcc) __builtin_trap();   // the helper ran on another XCD: its sums are not in this L2
+          if ((tid2 & 63) == 0) __hip_atomic_store(fp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: zero again for the next launch
+#pragma unroll
+          for (int q0 = 0; q0 < 8 * MT; q0 += 8) {   // eight quads (8 KB per wave) in flight at a time
+            f32x4 pq[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("global_load_dwordx4 %0, %1, off" W4_SK_SC : "=v"(pq[i]) : "v"(part + (size_t)(q0 + i) * 256) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              asm volatile("" : "+v"(pq[i]));       // nothing of pq[i] is touched before the wait above
+              float a4[4];
+              W4_ACC(a4, q0 + i);
+              a4[0] += pq[i][0]; a4[1] += pq[i][1]; a4[2] += pq[i][2]; a4[3] += pq[i][3];
+              asm volatile("v_accvgpr_write_b32 a[%4], %0\n\tv_accvgpr_write_b32 a[%5], %1\n\tv_accvgpr_write_b32 a[%6], %2\n\tv_accvgpr_write_b32 a[%7], %3"
+                           :: "v"(a4[0]), "v"(a4[1]), "v"(a4[2]), "v"(a4[3]), "n"(4 * (q0 + i)), "n"(4 * (q0 + i) + 1), "n"(4 * (q0 + i) + 2), "n"(4 * (q0 + i) + 3));
+            }
+          }
+        }
+        asm volatile("s_nop 4" ::: "memory");
+      }
+    }
     // straight-line quads (the launcher guarantees N % 4 == 0 and 4-element aligned ldc / ldr): the only predicate is
     // "inside the matrix", so there is no control flow for the allocator to park accumulators around
     // Loads first, stores after: a load that follows stores can only be awaited with vmcnt(0), i.e. after every earlier
@@ -1217,6 +1322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W4_MF
 #undef W4_MF0
 #undef W4_ACC
+#undef W4_SK_SC
 #undef W4_RD
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wrapped DMAs still write this workgroup's LDS
 }
@@ -1352,8 +1458,39 @@ int launch_q4_whole(GemmP p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
+// ---- stream-K workspace: one per (device, stream) — launches on a stream are serialised, so its partial tiles and flags are never shared by two
+// kernels in flight.  num_cu x 4 waves x 64 quads x 1 KB of fp32 partial sums (64 MB at 256 CUs) + the flags; allocated on first use (never inside
+// a stream capture: the engine's step 0 runs eagerly on the capture stream first), kept for the life of the process.
+constexpr size_t SK_WS_PER_CU = 4 * 64 * 1024, SK_FLAGS_PER_CU = 16;
+std::mutex g_sk_mu;
+std::map<std::pair<int, hipStream_t>, float*> g_sk_ws;
+int g_sk_default = -1;                    // k5_gemm_set_stream_k: -1 = K5_GEMM_SK from the environment
+thread_local int t_sk_override = -1;      // the engine's per-handle option, set around a forward on the calling thread
+
+int sk_policy() {
+  static const int env = getenv("K5_GEMM_SK") ? atoi(getenv("K5_GEMM_SK")) : K5_GEMM_SK_DEFAULT;
+  if (t_sk_override >= 0) return t_sk_override;
+  return g_sk_default >= 0 ? g_sk_default : env;
+}
+
+float* sk_workspace(hipStream_t stream, int num_cu) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  auto it = g_sk_ws.find({dev, stream});
+  if (it != g_sk_ws.end()) return it->second;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  void* ptr = nullptr;
+  const size_t bytes = (size_t)num_cu * (SK_WS_PER_CU + SK_FLAGS_PER_CU);
+  if (hipMalloc(&ptr, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemset((char*)ptr + (size_t)num_cu * SK_WS_PER_CU, 0, (size_t)num_cu * SK_FLAGS_PER_CU) != hipSuccess) { (void)hipFree(ptr); return nullptr; }
+  g_sk_ws[{dev, stream}] = (float*)ptr;
+  return (float*)ptr;
+}
+
 template <int EPI, int MT>
-int launch_w4_mt(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
+int launch_w4_mt(GemmP p, hipStream_t stream, int num_cu, bool no_tail, int sk_mode) {
   static const hipError_t attr_rc = hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, w4_ops_bytes(MT) + W4_TRACE_BYTES + W4_PF_BYTES);   // set once, thread-safe (function-local static: loopback ranks launch from P host threads)
   if (attr_rc != hipSuccess) return K5_ERR_HIP;
 #ifdef W4_TRACE
@@ -1362,6 +1499,20 @@ int launch_w4_mt(GemmP p, hipStream_t stream, int num_cu, bool no_tail) {
   p.tiles_m = (p.M + 32 * MT - 1) / (32 * MT); p.tiles_n = (p.N + K8_BN - 1) / K8_BN;
   const int tiles = p.tiles_m * p.tiles_n;
   const int full = tiles / num_cu * num_cu, rem = tiles - full;
+  // stream-K (sk_mode 1: where the ragged round leaves at least K5_GEMM_SK_IDLE percent of the CUs idle; 2: wherever it applies): the tiles do not
+  // divide over the CUs and there is at least one per CU (a run is then at least a tile long: a tile is cut in at most two); the kernel's flag
+  // layout is sized by the GRID, which is all CUs; the XCD ownership it relies on (workgroup b on XCD b & 7) needs whole groups of 8
+  static const int sk_idle = getenv("K5_GEMM_SK_IDLE") ? atoi(getenv("K5_GEMM_SK_IDLE")) : 50;
+  static const int sk_smax = getenv("K5_GEMM_SK_S") ? atoi(getenv("K5_GEMM_SK_S")) : 2;   // 2 / 4 / 8 slices: within 1 % of each other (the owner adds S - 1 partial tiles one after the other)
+  p.sk_ws = nullptr; p.sk_smax = sk_smax < 2 ? 2 : (sk_smax > 16 ? 16 : sk_smax);
+  if (sk_mode > 0 && EPI != K5_EPI_F32 && (rem != 0 || sk_mode == 3) && tiles >= num_cu && (num_cu & 7) == 0 && (sk_mode >= 2 || 100 * (num_cu - rem) >= sk_idle * num_cu))
+    p.sk_ws = sk_workspace(stream, num_cu);
+  if (p.sk_ws) {
+    p.lid_limit = tiles;
+    p.tiles256_m = p.tiles_m; p.tiles256_n = p.tiles_n;
+    hipLaunchKernelGGL((gemm_bf16_w4_kernel<EPI, MT>), dim3(num_cu), dim3(256), w4_ops_bytes(MT) + W4_TRACE_BYTES + W4_PF_BYTES, stream, p);
+    return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
+  }
   const bool split_tail = MT == 8 && !no_tail && full > 0 && rem > 0 && 2 * rem < num_cu;   // see launch_k8_mt
   p.lid_limit = split_tail ? full : tiles;
   p.tiles256_m = p.tiles_m; p.tiles256_n = p.tiles_n;
@@ -1394,15 +1545,21 @@ inline int w4_pick_mt(int M, int N, int num_cu, bool no_tail, int force_mt = 0, 
 }
 
 template <int EPI>
-int launch_w4(GemmP p, hipStream_t stream, int num_cu, bool no_tail, int mt) {
+int launch_w4(GemmP p, hipStream_t stream, int num_cu, bool no_tail, int mt, int sk_mode) {
   switch (mt) {
-    case 4: return launch_w4_mt<EPI, 4>(p, stream, num_cu, no_tail);
-    case 6: return launch_w4_mt<EPI, 6>(p, stream, num_cu, no_tail);
-    default: return launch_w4_mt<EPI, 8>(p, stream, num_cu, no_tail);
+    case 4: return launch_w4_mt<EPI, 4>(p, stream, num_cu, no_tail, sk_mode);
+    case 6: return launch_w4_mt<EPI, 6>(p, stream, num_cu, no_tail, sk_mode);
+    default: return launch_w4_mt<EPI, 8>(p, stream, num_cu, no_tail, sk_mode);
   }
 }
 
 }  // namespace
+
+// stream-K policy of the four-wave kernel: 0 = whole tiles (the schedule of rounds 2-5, one K order everywhere: bit-identical across kernels and
+// tile heights), 1 = stream-K where the ragged round idles enough CUs, 2 = wherever it applies; -1 = back to K5_GEMM_SK / the built-in default
+void k5_gemm_set_stream_k_default(int mode) { g_sk_default = mode < 0 ? -1 : (mode > 2 ? 2 : mode); }
+void k5_gemm_set_stream_k_thread(int mode) { t_sk_override = mode < 0 ? -1 : (mode > 2 ? 2 : mode); }
+int k5_gemm_stream_k_policy() { return sk_policy(); }
 
 // Host launcher (C++ linkage, used by the C-ABI layer in k5_api.hip and by the engine).
 int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K,
@@ -1417,7 +1574,10 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   p.resid = (const bf16_t*)resid; p.gate = gate;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
-  p.alpha = 1.f; p.causal_hw = 0; p.trace = nullptr; p.lid_limit = 0; p.tail_base = -1; p.tiles256_m = p.tiles256_n = 0;
+  p.alpha = 1.f; p.causal_hw = 0; p.trace = nullptr; p.lid_limit = 0; p.tail_base = -1; p.tiles256_m = p.tiles256_n = 0; p.sk_ws = nullptr; p.sk_smax = 2;
+  // force_kernel 14 / 24: the four-wave kernel WITH stream-K (where the ragged round idles enough CUs / wherever it applies); 4: without; 0: the policy
+  const int sk_mode = force_kernel == 14 ? 1 : (force_kernel == 24 ? 2 : (force_kernel == 34 ? 3 : (force_kernel != 0 ? 0 : sk_policy())));   // 34: even when the tiles divide (A/B of the walk itself)
+  if (force_kernel == 14 || force_kernel == 24 || force_kernel == 34) force_kernel = 4;
   static const int dbg = getenv("K5_GEMM_DBG") ? atoi(getenv("K5_GEMM_DBG")) : 0;
   p.dbg = dbg;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
@@ -1448,10 +1608,10 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
   const long long tiles_pick = (long long)((M + 32 * mt_pick - 1) / (32 * mt_pick)) * ((N + 255) / 256);
   if (w4_ok && (force_v1 == 4 || (force_v1 == 0 && tiles_pick >= w4_min))) {
     switch (epi) {
-      case K5_EPI_BIAS: return launch_w4<K5_EPI_BIAS>(p, stream, num_cu, no_tail, mt_pick);
-      case K5_EPI_BIAS_M: return launch_w4<K5_EPI_BIAS_M>(p, stream, num_cu, no_tail, mt_pick);
-      case K5_EPI_GELU: return launch_w4<K5_EPI_GELU>(p, stream, num_cu, no_tail, mt_pick);
-      case K5_EPI_GATE: return launch_w4<K5_EPI_GATE>(p, stream, num_cu, no_tail, mt_pick);
+      case K5_EPI_BIAS: return launch_w4<K5_EPI_BIAS>(p, stream, num_cu, no_tail, mt_pick, sk_mode);
+      case K5_EPI_BIAS_M: return launch_w4<K5_EPI_BIAS_M>(p, stream, num_cu, no_tail, mt_pick, sk_mode);
+      case K5_EPI_GELU: return launch_w4<K5_EPI_GELU>(p, stream, num_cu, no_tail, mt_pick, sk_mode);
+      case K5_EPI_GATE: return launch_w4<K5_EPI_GATE>(p, stream, num_cu, no_tail, mt_pick, sk_mode);
       default: return K5_ERR_ARG;
     }
   }
@@ -1511,7 +1671,7 @@ int k5_launch_gemm_bf16_f32out(const void* A, const void* W, float* C, int M, in
   if ((K & 7) || (lda & 7) || (ldw & 7)) return K5_ERR_ALIGN;
   GemmP p;
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = (bf16_t*)C; p.bias = nullptr; p.resid = nullptr; p.gate = nullptr;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.alpha = alpha; p.dbg = 0; p.trace = nullptr; p.lid_limit = 0; p.tail_base = -1; p.tiles256_m = p.tiles256_n = 0;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.alpha = alpha; p.dbg = 0; p.trace = nullptr; p.lid_limit = 0; p.tail_base = -1; p.tiles256_m = p.tiles256_n = 0; p.sk_ws = nullptr; p.sk_smax = 2;
   p.causal_hw = causal_hw;
   // the 4-wave persistent kernel from one round of kept 256x256 tiles up (same conditions as k5_launch_gemm_bf16)
   const int tm = (M + K8_BM - 1) / K8_BM, tn = (N + K8_BN - 1) / K8_BN;

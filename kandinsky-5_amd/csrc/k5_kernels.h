@@ -11,6 +11,13 @@ int k5_launch_gemm_bf16(const void* A, const void* W, const float* bias, void* C
                         int force_kernel = 0,    // K5_GEMM_V1's numbering: 2 = the 128 x 128 direct-to-LDS kernel whatever the shape (callers that must keep a summation order)
                         int force_mt = 0);       // four-wave kernel: 16-row token tiles per wave, 8 / 6 / 4 = 256- / 192- / 128-row workgroup tiles (0 = by cost)
 
+// split-K tail of the four-wave GEMM (round 6): 0 = whole tiles everywhere (one K order: bit-identical across kernels and tile heights — what force_kernel
+// 2 / 4 / 5 / 8 always give), 1 = the ragged last round of a launch is cut along K where at most half of the CUs would be busy, 2 = wherever a
+// tile can be cut (default 0: measured neutral, csrc/gemm_bf16.hip); -1 = back to K5_GEMM_SK / the built-in default.  Process-wide (the GEMM launcher has no handle).
+void k5_gemm_set_stream_k_default(int mode);
+void k5_gemm_set_stream_k_thread(int mode);
+int k5_gemm_stream_k_policy();
+
 // Attention: O[q][h*64+d] = softmax(Q K^T / 8) V, bf16, head_dim 64, non-causal.
 //   Q  [q_len][ldq]  (head h at columns h*64..), K [kv_len][ldk], Vt [H*64][ldvt] = V transposed, O [q_len][ldo].
 // Dense attention with a caller-proved bound |q.k| <= score_bound (0 = unknown -> online running max).

@@ -273,6 +273,58 @@ def test_hot_kernels_keep_their_register_budget():
         assert v["VGPRs"] <= 128 and v["SGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] <= 32, (k, v)   # spilled dwords sit outside the bisection loop
 
 
+def test_gemm_accumulators_stay_invisible_to_the_compiler():
+    """Round 6: the four-wave GEMM keeps its accumulators in PHYSICAL AGPRs that only its own asm statements name (a[4 q : 4 q + 3] in the MFMA text,
+    v_accvgpr_read in the epilogue, global_store from the AGPR file in the split-K tail's helper path) — the register allocator never sees them, which is
+    what lets a second consumer of the accumulators exist at all (rounds 2-5: 150-500 spilled registers).  That only works while the COMPILER never
+    touches an AGPR of its own accord (a VGPR spilled into the AGPR file would land on an accumulator).  This compiles the kernel to ISA and demands:
+    no AGPR mentioned outside an inline-asm block, every MFMA of a kernel on its own quads with C = 0 or C = D, all 8 MT quads read back by the epilogue."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    src = os.path.join(PKG, "csrc", "gemm_bf16.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                          "-I", os.path.join(PKG, "csrc"), "-fno-slp-vectorize", "-Wno-unused-result", "--cuda-device-only", "-S", src, "-o", "-"],
+                         check=True, capture_output=True, text=True).stdout
+    kernels, cur = {}, None
+    for line in out.splitlines():
+        m = re.match(r"^(_Z\w*gemm_bf16_w4_kernel\w*):", line)
+        if m:
+            cur = m.group(1); kernels[cur] = []
+        elif cur and line.startswith(".Lfunc_end"):
+            cur = None
+        elif cur:
+            kernels[cur].append(line.strip())
+    assert len(kernels) == 13, sorted(kernels)            # 4 epilogues x 3 tile heights + the fp32-score form
+    for k, body in kernels.items():
+        mt = int(re.search(r"ILi\d+ELi(\d+)E", k).group(1))
+        inasm, stray, mfma, reads = False, [], [], set()
+        for t in body:
+            if "ASMSTART" in t:
+                inasm = True
+            elif "ASMEND" in t:
+                inasm = False
+            elif t.startswith(";") or not t:
+                continue
+            elif not inasm and re.search(r"\ba\d+\b|\ba\[", t):
+                stray.append(t)
+            elif inasm:
+                m = re.match(r"v_mfma_f32_16x16x32_bf16 a\[(\w+):(\w+)\], v\[\d+:\d+\], v\[\d+:\d+\], (\S+)", t)
+                if m:
+                    mfma.append((int(m.group(1), 0), int(m.group(2), 0), m.group(3)))
+                m = re.match(r"v_accvgpr_read_b32 v\d+, a\[(\w+)\]", t)
+                if m:
+                    reads.add(int(m.group(1), 0))
+        assert not stray, (k, stray[:3])
+        assert len(mfma) == 4 * 16 * mt, (k, len(mfma))                     # four K-tile bodies (two stages x first / steady) of 16 MT MFMAs
+        assert {lo for lo, _, _ in mfma} == {4 * q for q in range(8 * mt)} and all(hi == lo + 3 for lo, hi, _ in mfma), k
+        assert all(c == "0" or re.fullmatch(r"a\[(\w+):(\w+)\]", c) and int(re.fullmatch(r"a\[(\w+):(\w+)\]", c).group(1), 0) == lo for lo, _, c in mfma), k
+        assert reads == set(range(32 * mt)), (k, len(reads))
+
+
 def test_attention_tile_prefetch_survives_the_compiler():
     """The attention kernels issue the DMA of key tile e+1 at the top of tile e and drain it (`s_waitcnt vmcnt(0)`) just before the
     barrier that ends the tile.  Nothing in the source pins that distance: the compiler places the wait, and it moved it right behind the

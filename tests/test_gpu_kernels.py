@@ -158,6 +158,45 @@ def test_gemm_four_wave_token_tile_heights(E, M, N, K):
         assert torch.count_nonzero(got["bias_m"][:, N:]) == 0
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(47616, 1792, 1792, "gate"), (47616, 1792, 7168, "gate_nobias"), (20000, 3584, 1792, "bias"), (1792, 47616, 1792, "bias_m"),
+                                       (33333, 2048 + 8, 3584, "gelu"), (17000, 4096, 256, "bias")])
+def test_gemm_split_k_tail_vs_whole_tiles_and_fp32(E, M, N, K, epi):
+    """Round 6: the ragged last round of a four-wave launch is cut along K into two aligned slices per tile on two workgroups of one XCD (kernel id 24 =
+    wherever a tile can be cut; the default policy takes it where at most half of the CUs would be busy) — the helper hands its raw fp32 accumulators over
+    through the XCD's L2, the owner adds them and runs the epilogue.  K-ORDER CONTRACT: a split tile's sum is (second half) + (first half) instead of one
+    chain, so the last fp32 bit of some sums moves and a bf16 rounding flips here and there; everything else of the launch is the whole-tile schedule.
+    Demanded: repeatable bit for bit (the flags are left clean), at most 1e-4 of the outputs differ from the whole-tile schedule (kernel id 4), and against
+    an fp32 evaluation with the engine's rounding points the split schedule is no worse than the whole-tile one (max within 25 %, mean within 2 %)."""
+    a, w = bfr(rnd(M, K, seed=91)), bfr(rnd(N, K, seed=92, scale=0.05))
+    ad, wd = a.cuda().to(BF), w.cuda().to(BF)
+    b = bfr(rnd(M if epi == "bias_m" else N, seed=93, scale=0.1)).cuda()
+    resid, gate = bfr(rnd(M, N, seed=94)).cuda().to(BF), rnd(N, seed=95).cuda()
+    code = {"bias": E.EPI_BIAS, "bias_m": E.EPI_BIAS_M, "gelu": E.EPI_GELU, "gate": E.EPI_GATE, "gate_nobias": E.EPI_GATE}[epi]
+
+    def run(kernel):
+        r = resid.clone() if code == E.EPI_GATE else None
+        return E.gemm(ad, wd, None if epi in ("gelu", "gate_nobias") else b, code, resid=r, gate=gate if code == E.EPI_GATE else None, kernel=kernel)
+    whole, split = run(4), run(24)
+    for _ in range(3):
+        assert torch.equal(run(24), split), "the split-K tail is not repeatable"
+    frac = (whole != split).float().mean().item()
+    rows = torch.randperm(M, generator=torch.Generator().manual_seed(1))[:1024].cuda()
+    y = ad[rows].float() @ wd.float().t()
+    if epi in ("bias", "gate"):
+        y = y + b[None, :]
+    if epi == "bias_m":
+        y = y + b[rows][:, None]
+    y = y.to(BF).float()
+    if epi == "gelu":
+        y = torch.nn.functional.gelu(y)
+    if code == E.EPI_GATE:
+        y = resid[rows].float() + gate[None, :] * y
+    e_w, e_s = (whole[rows].float() - y).abs(), (split[rows].float() - y).abs()
+    print(f"{M}x{N}x{K} {epi}: outputs that differ from the whole-tile schedule {frac:.2e}; |error| vs fp32 max {e_w.max():.3e} / {e_s.max():.3e}, mean {e_w.mean():.3e} / {e_s.mean():.3e}")
+    assert frac < 1e-4
+    assert e_s.max().item() <= 1.25 * e_w.max().item() + 1e-6 and e_s.mean().item() <= 1.02 * e_w.mean().item() + 1e-9
+
+
 def test_gemm_is_transpose_correct(E):
     """A = I with an asymmetric W catches any row/col swap in the MFMA C/D mapping (guide rule 16)."""
     n = 256
