@@ -446,6 +446,9 @@ int k5_vae_finalize(k5_vae* vae);
 /* z: device fp32 (latent_channels,T,H,W) (already divided by scaling_factor, generation_utils.py:220) ->
  * out: device bf16 (out_channels, 4(T-1)+1, 8H, 8W) = self.decoder(self.post_quant_conv(z)) */
 int k5_vae_decode_tile(k5_vae* vae, const float* z, int T, int H, int W, void* out, void* stream);
+/* (ABI 8) the same with z read IN PLACE out of a longer latent: z_channel_stride = elements between the latent channels of z (0 = T*H*W), i.e. the
+ * temporal slice z[:, :, t0 : t0 + T] of the tiling loop (vae.py:1144-1204 `_temporal_tiled_decode`) without a copy */
+int k5_vae_decode_tile_strided(k5_vae* vae, const float* z, int64_t z_channel_stride, int T, int H, int W, void* out, void* stream);
 /* Encoder half (SURVEY.md §8 f4 — image / video conditioning): quant_conv(HunyuanVideoEncoder3D.forward(x)) on ONE tile
  * (vae.py:574-586, 808-809); the tiling policy (tiled_encode :938-1010, _temporal_tiled_encode :1096-1142) stays on the
  * host mirror.  Needs the encoder.* / quant_conv.* tensors (k5_vae_has_encoder = 1; a decode-only load leaves them out).
@@ -461,6 +464,16 @@ int k5_vae_path_counts(k5_vae* vae, long long* out8, int reset);
 /* blend_t / blend_v / blend_h (vae.py:908-936) on contiguous bf16 tensors viewed as [outer][len][inner]:
  * b[:, y, :] = a[:, len_a-extent+y, :]*(1-y/extent) + b[:, y, :]*(y/extent), y < extent (eager bf16 rounding) */
 int k5_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, void* stream);
+/* (ABI 8) blend_t + `tile[:, :, :keep]` + the `torch.cat` of `_temporal_tiled_decode` (vae.py:1185-1204) as ONE pass: views [outer][len][inner] with
+ * explicit outer strides in elements (a decoded tile minus its first frame; the output video); dst[:, y] = y < extent ? the cross-fade of k5_blend_bf16
+ * (a[:, len_a - extent + y], b[:, y]) : b[:, y], y < keep.  a = NULL: no cross-fade (the first tile).  inner a multiple of 8, 16-byte aligned pointers.
+ * Neither a nor b is written: the previous tile's tail is read as the decoder left it, which is what the reference blends with while tiles are at
+ * least 2 * extent long (the host mirror falls back to k5_blend_bf16 otherwise). */
+int k5_blend_place_bf16(const void* a, int64_t a_stride, int len_a, const void* b, int64_t b_stride, void* dst, int64_t dst_stride, int64_t outer,
+                        int64_t inner, int extent, int keep, void* stream);
+/* (ABI 8) the pipeline's uint8 frames, ((x.clamp(-1, 1) + 1) * 127.5).to(torch.uint8) (reference generation_utils.py:222-224) in one pass with torch's
+ * bf16 rounding after every elementwise op and the truncating conversion; n a multiple of 8 */
+int k5_frames_to_uint8(const void* x_bf16, void* out_u8, int64_t n, void* stream);
 
 /* fp8 (OCP e4m3) W8A8 GEMM, opt-in (BASELINE config 5 "fp8 MFMA weights"): C = epilogue(w_scale[n] * A8 . W8^T) with fp32
  * accumulation on v_mfma_scale_f32_16x16x128_f8f6f4.  A8 [M][lda] and W8 [N][ldw] are fp8 bytes (K a multiple of 128, >= 256,

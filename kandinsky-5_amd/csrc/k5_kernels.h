@@ -200,6 +200,9 @@ int k5_launch_causal_softmax(const float* scores, void* P, int S, int hw, int ld
 // the mid block's attention in one kernel for C = 512 (vae_attn.hip): q, k [S][ldqk], vt [512][ldvt >= ceil(S/32)*32], o [S][ldo]
 int k5_launch_vae_attention512(const void* q, const void* k, const void* vt, void* o, int S, int hw, int ldqk, int ldvt, int ldo,
                                float scale, hipStream_t stream);
-int k5_launch_nchw_to_mc(const float* z, void* out, int C, int64_t M, int Cpad, hipStream_t s);
+int k5_launch_nchw_to_mc(const float* z, void* out, int C, int64_t M, int Cpad, hipStream_t s, int64_t cstride = 0);   // cstride: elements between the channels of z (0 = M)
+int k5_launch_blend_place_bf16(const void* a, int64_t a_stride, int len_a, const void* b, int64_t b_stride, void* dst, int64_t dst_stride, int64_t outer,
+                               int64_t inner, int extent, int keep, hipStream_t s);
+int k5_launch_frames_to_uint8(const void* x, void* out, int64_t n, hipStream_t s);
 int k5_launch_mc_to_nchw(const void* x, void* out, int C, int64_t M, int ldx, hipStream_t s);
 int k5_launch_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, hipStream_t s);

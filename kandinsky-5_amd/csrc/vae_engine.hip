@@ -395,8 +395,14 @@ extern "C" int k5_vae_finalize(k5_vae* v) {
 }
 
 // z: device fp32 (Cz, T, H, W) ; out: device bf16 (Cout, To, 8H, 8W), To = 4(T-1)+1
+extern "C" int k5_vae_decode_tile_strided(k5_vae* v, const float* z, int64_t z_channel_stride, int T, int H, int W, void* out, void* stream);
 extern "C" int k5_vae_decode_tile(k5_vae* v, const float* z, int T, int H, int W, void* out, void* stream) {
-  if (!v || !z || !out || T <= 0 || H <= 0 || W <= 0) return K5_ERR_ARG;
+  return k5_vae_decode_tile_strided(v, z, 0, T, H, W, out, stream);
+}
+// z_channel_stride: elements between the latent channels of z (0 = T H W: contiguous) — a temporal slice z[:, t0 : t0 + T] of a longer latent is read in
+// place (round 6: the host mirror's tiling loop no longer copies it)
+extern "C" int k5_vae_decode_tile_strided(k5_vae* v, const float* z, int64_t z_channel_stride, int T, int H, int W, void* out, void* stream) {
+  if (!v || !z || !out || T <= 0 || H <= 0 || W <= 0 || (z_channel_stride != 0 && z_channel_stride < (int64_t)T * H * W)) return K5_ERR_ARG;
   if (!v->finalized) { k5_set_error("k5_vae_decode_tile before k5_vae_finalize"); return K5_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   const k5_vae_config& c = v->cfg;
@@ -418,7 +424,7 @@ extern "C" int k5_vae_decode_tile(k5_vae* v, const float* z, int T, int H, int W
   K5CHK(v->zin.ensure((size_t)M0 * Cz * 2)); K5CHK(v->x0.ensure((size_t)M0 * 64 * 2));
   for (Buf* b : {&v->bx, &v->balt, &v->bt1, &v->bt2, &v->bres}) K5CHK(b->ensure(maxel * 2));
   // post_quant_conv (1x1x1) into a 64-channel zero-padded buffer, then conv_in
-  K5CHK(k5_launch_nchw_to_mc(z, v->zin.p, Cz, M0, Cz, s));
+  K5CHK(k5_launch_nchw_to_mc(z, v->zin.p, Cz, M0, Cz, s, z_channel_stride));
   HIPCHK(hipMemsetAsync(v->x0.p, 0, (size_t)M0 * 64 * 2, s));
   K5CHK(k5_launch_gemm_bf16(v->zin.p, v->pq.w.p, v->pq.b.as<float>(), v->x0.p, M0, Cz, v->pq.cin_pad, Cz, v->pq.cin_pad, 64, K5_EPI_BIAS,
                             nullptr, 0, nullptr, s));
@@ -508,4 +514,11 @@ extern "C" int k5_vae_path_counts(k5_vae* v, long long* out8, int reset) {
 
 extern "C" int k5_blend_bf16(const void* a, void* b, int64_t outer, int len_a, int len_b, int64_t inner, int extent, void* stream) {
   return k5_launch_blend_bf16(a, b, outer, len_a, len_b, inner, extent, (hipStream_t)stream);
+}
+extern "C" int k5_blend_place_bf16(const void* a, int64_t a_stride, int len_a, const void* b, int64_t b_stride, void* dst, int64_t dst_stride, int64_t outer,
+                                   int64_t inner, int extent, int keep, void* stream) {
+  return k5_launch_blend_place_bf16(a, a_stride, len_a, b, b_stride, dst, dst_stride, outer, inner, extent, keep, (hipStream_t)stream);
+}
+extern "C" int k5_frames_to_uint8(const void* x_bf16, void* out_u8, int64_t n, void* stream) {
+  return k5_launch_frames_to_uint8(x_bf16, out_u8, n, (hipStream_t)stream);
 }

@@ -233,11 +233,11 @@ __global__ __launch_bounds__(1024) void causal_softmax_reg_kernel(const float* _
 }
 
 // z (C,T,H,W) fp32 -> [M][Cpad] bf16, channels >= C zero
-__global__ __launch_bounds__(256) void nchw_to_mc_kernel(const float* __restrict__ z, bf16_t* __restrict__ out, int C, int64_t M, int Cpad) {
+__global__ __launch_bounds__(256) void nchw_to_mc_kernel(const float* __restrict__ z, bf16_t* __restrict__ out, int C, int64_t M, int Cpad, int64_t cstride) {
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < M * Cpad; g += (int64_t)gridDim.x * 256) {
     const int c = (int)(g % Cpad);
     const int64_t m = g / Cpad;
-    out[g] = f2bf(c < C ? z[(int64_t)c * M + m] : 0.f);
+    out[g] = f2bf(c < C ? z[(int64_t)c * cstride + m] : 0.f);   // cstride >= M: a temporal slice of a longer latent, read in place
   }
 }
 // [M][ldx] bf16 (first C channels) -> (C, M) bf16
@@ -262,6 +262,50 @@ __global__ __launch_bounds__(256) void blend_kernel(const bf16_t* __restrict__ a
     const float av = bf2f(a[(o * la + (la - extent + y)) * inner + in]);
     bf16_t* bp = b + (o * lb + y) * inner + in;
     *bp = f2bf(__fadd_rn(bf_round(__fmul_rn(av, wa)), bf_round(__fmul_rn(bf2f(*bp), wb))));
+  }
+}
+
+// Round 6 — blend_t + the slice + the concatenation of the temporal tiling loop (vae.py:1144-1204) as ONE pass: views [outer][len][inner] with explicit
+// outer strides (a decoded tile minus its first frame, the output video).  dst[o][y] = y < extent ? blend(a[o][la - extent + y], b[o][y]) : b[o][y] for
+// y < keep — the arithmetic and rounding points of blend_kernel.  a == nullptr: no cross-fade (the first tile).  16 bytes per thread where inner allows.
+__global__ __launch_bounds__(256) void blend_place_kernel(const bf16_t* __restrict__ a, int64_t sa, int la, const bf16_t* __restrict__ b, int64_t sb,
+                                                          bf16_t* __restrict__ dst, int64_t sd, int64_t outer, int64_t inner8, int extent, int keep) {
+  const int64_t total = outer * keep * inner8;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const int64_t in = (g % inner8) * 8;
+    const int y = (int)((g / inner8) % keep);
+    const int64_t o = g / (inner8 * keep);
+    const int64_t inner = inner8 * 8;
+    u32x4 bv = *reinterpret_cast<const u32x4*>(b + o * sb + (int64_t)y * inner + in);
+    if (a && y < extent) {
+      const u32x4 av = *reinterpret_cast<const u32x4*>(a + o * sa + (int64_t)(la - extent + y) * inner + in);
+      const float wb = (float)((double)y / (double)extent), wa = (float)(1.0 - (double)y / (double)extent);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a0 = __uint_as_float(av[j] << 16), a1 = __uint_as_float(av[j] & 0xffff0000u);
+        const float b0 = __uint_as_float(bv[j] << 16), b1 = __uint_as_float(bv[j] & 0xffff0000u);
+        bv[j] = pack_bf16x2(__fadd_rn(bf_round(__fmul_rn(a0, wa)), bf_round(__fmul_rn(b0, wb))), __fadd_rn(bf_round(__fmul_rn(a1, wa)), bf_round(__fmul_rn(b1, wb))));
+      }
+    }
+    *reinterpret_cast<u32x4*>(dst + o * sd + (int64_t)y * inner + in) = bv;
+  }
+}
+
+// uint8 frames of the pipeline (generation_utils.py:150-151 of the mirror; reference generation_utils.py:222-224): ((x.clamp(-1, 1) + 1) * 127.5).to(uint8) with
+// torch's bf16 rounding after every elementwise op and truncation in the conversion — one pass instead of four
+__global__ __launch_bounds__(256) void frames_to_uint8_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ out, int64_t n8) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n8; g += (int64_t)gridDim.x * 256) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + 8 * g);
+    uint32_t o[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (j & 1) ? __uint_as_float(v[j >> 1] & 0xffff0000u) : __uint_as_float(v[j >> 1] << 16);
+      f = fminf(fmaxf(f, -1.0f), 1.0f);
+      f = bf_round(f + 1.0f);
+      f = bf_round(f * 127.5f);
+      o[j >> 2] |= (uint32_t)(uint8_t)(int)f << (8 * (j & 3));
+    }
+    *reinterpret_cast<uint2*>(out + 8 * g) = uint2{o[0], o[1]};
   }
 }
 
@@ -339,9 +383,25 @@ int k5_launch_causal_softmax(const float* scores, void* P, int S, int hw, int ld
   return done();
 }
 
-int k5_launch_nchw_to_mc(const float* z, void* out, int C, int64_t M, int Cpad, hipStream_t s) {
-  if (C <= 0 || M <= 0 || Cpad < C) return K5_ERR_ARG;
-  hipLaunchKernelGGL(nchw_to_mc_kernel, dim3(grid_for(M * Cpad)), dim3(256), 0, s, z, (bf16_t*)out, C, M, Cpad);
+int k5_launch_nchw_to_mc(const float* z, void* out, int C, int64_t M, int Cpad, hipStream_t s, int64_t cstride) {
+  if (C <= 0 || M <= 0 || Cpad < C || (cstride != 0 && cstride < M)) return K5_ERR_ARG;
+  hipLaunchKernelGGL(nchw_to_mc_kernel, dim3(grid_for(M * Cpad)), dim3(256), 0, s, z, (bf16_t*)out, C, M, Cpad, cstride ? cstride : M);
+  return done();
+}
+
+int k5_launch_blend_place_bf16(const void* a, int64_t a_stride, int len_a, const void* b, int64_t b_stride, void* dst, int64_t dst_stride, int64_t outer,
+                               int64_t inner, int extent, int keep, hipStream_t s) {
+  if (!b || !dst || outer <= 0 || inner <= 0 || keep <= 0 || extent < 0 || (inner & 7)) return K5_ERR_ARG;
+  if (a && (extent > len_a || extent > keep)) return K5_ERR_ARG;
+  if (((uintptr_t)b | (uintptr_t)dst | (uintptr_t)a) & 15 || ((b_stride | dst_stride | a_stride) & 7)) return K5_ERR_ALIGN;
+  hipLaunchKernelGGL(blend_place_kernel, dim3(grid_for(outer * keep * (inner / 8))), dim3(256), 0, s, (const bf16_t*)a, a_stride, len_a, (const bf16_t*)b, b_stride,
+                     (bf16_t*)dst, dst_stride, outer, inner / 8, a ? extent : 0, keep);
+  return done();
+}
+
+int k5_launch_frames_to_uint8(const void* x, void* out, int64_t n, hipStream_t s) {
+  if (!x || !out || n <= 0 || (n & 7)) return K5_ERR_ARG;
+  hipLaunchKernelGGL(frames_to_uint8_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (uint8_t*)out, n / 8);
   return done();
 }
 

@@ -148,6 +148,9 @@ SYMBOLS = {
     "k5_vae_encode_tile": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "k5_vae_has_encoder": (_I, [_P]),
     "k5_blend_bf16": (_I, [_P, _P, _I64, _I, _I, _I64, _I, _P]),
+    "k5_blend_place_bf16": (_I, [_P, _I64, _I, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _P]),
+    "k5_frames_to_uint8": (_I, [_P, _P, _I64, _P]),
+    "k5_vae_decode_tile_strided": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P]),
     "k5_dit_set_graph": (_I, [_P, _I]),
     "k5_dit_set_fp8": (_I, [_P, _I]),
     "k5_dit_set_magcache": (_I, [_P, C.POINTER(C.c_double), _I, _I, C.c_double, _I, C.c_double]),

@@ -246,14 +246,18 @@ class AutoencoderKLHunyuanVideo(nn.Module):
 
     # ------------------------------------------------------------------ engine calls
     def _decode_tile(self, z):
-        """z (1,C,t,h,w) -> (1,3,4(t-1)+1,8h,8w) bf16 = decoder(post_quant_conv(z))."""
+        """z (1,C,t,h,w) -> (1,3,4(t-1)+1,8h,8w) bf16 = decoder(post_quant_conv(z)).  A temporal slice of a longer fp32 latent (the tiling loop's
+        z[:, :, i : i + t]) is read in place through its channel stride (k5_vae_decode_tile_strided): no copy, no torch kernel."""
         h = self._engine(z.device)
-        zz = z[0].float().contiguous()
+        zz = z[0]
         _, t, hh, ww = zz.shape
+        in_place = zz.dtype == torch.float32 and zz.stride()[1:] == (hh * ww, ww, 1) and zz.stride(0) >= t * hh * ww
+        if not in_place:
+            zz = zz.float().contiguous()
         out = torch.empty(1, self.config.out_channels, 4 * (t - 1) + 1, 8 * hh, 8 * ww, dtype=torch.bfloat16, device=z.device)
         with torch.cuda.device(z.device):
-            E.check(E.lib().k5_vae_decode_tile(h, zz.data_ptr(), t, hh, ww, out.data_ptr(), E.stream_ptr(z.device)),
-                    "k5_vae_decode_tile")
+            E.check(E.lib().k5_vae_decode_tile_strided(h, zz.data_ptr(), int(zz.stride(0)), t, hh, ww, out.data_ptr(), E.stream_ptr(z.device)),
+                    "k5_vae_decode_tile_strided")
         return out
 
     def _encode_tile(self, x):
@@ -346,7 +350,35 @@ class AutoencoderKLHunyuanVideo(nn.Module):
             return self._decode_tile(tile)
 
         tp = getattr(self, "_tile_parallel", None)
-        if tp is not None and tp[1] > 1 and len(starts) > 1:
+        # Round 6 — one GPU, contiguous tiles at least two cross-fades long: tile k is decoded, cross-faded with the tail of tile k - 1 and written
+        # into its frames of the output in ONE pass (k5_blend_place_bf16); the slices, .contiguous() copies and torch.cat of the loop below are gone
+        # (the same numbers: blend_t only ever reads the previous tile's LAST bf frames, which its own cross-fade — the first bf — did not touch).
+        sn, mn = self.tile_sample_stride_num_frames, self.tile_sample_min_num_frames
+        if (tp is None or tp[1] <= 1) and len(starts) > 1 and mn >= 2 * bf and os.environ.get("K5_VAE_LEGACY_GLUE", "0") != "1":
+            total = (nf - 1) * 4 + 1
+            first = decode_one(starts[0])
+            _, C3, F0, Ho, Wo = first.shape
+            if first.is_cuda and first.dtype == torch.bfloat16 and first.is_contiguous() and F0 == mn + 1 and (Ho * Wo) % 8 == 0:
+                dec = torch.empty(1, C3, sn + 1 + sn * (len(starts) - 2) + mn, Ho, Wo, dtype=first.dtype, device=first.device)
+                inner, stream = Ho * Wo, E.stream_ptr(first.device)
+
+                def place(prev, cur, drop, f0, keep):   # frames [drop, drop + keep) of cur -> dec[:, :, f0 : f0 + keep], the first bf cross-faded with prev's tail
+                    a_ptr = 0 if prev is None else prev[0].data_ptr() + prev[1] * inner * 2
+                    E.check(E.lib().k5_blend_place_bf16(a_ptr, 0 if prev is None else prev[0].stride(1), 0 if prev is None else prev[0].shape[2] - prev[1],
+                                                        cur.data_ptr() + drop * inner * 2, cur.stride(1), dec.data_ptr() + f0 * inner * 2, dec.stride(1),
+                                                        C3, inner, 0 if prev is None else bf, keep, stream), "k5_blend_place_bf16")
+                with torch.cuda.device(first.device):
+                    place(None, first, 0, 0, sn + 1)
+                    prev, f0 = (first, 0), sn + 1
+                    for k in range(1, len(starts)):
+                        cur = decode_one(starts[k])
+                        keep = mn if k == len(starts) - 1 else sn
+                        place(prev, cur, 1, f0, keep)
+                        prev, f0 = (cur, 1), f0 + keep
+                dec = dec[:, :, :total]
+                return DecoderOutput(dec) if return_dict else (dec,)
+            decoded = [first] + [decode_one(i) for i in starts[1:]]
+        elif tp is not None and tp[1] > 1 and len(starts) > 1:
             decoded = self._decode_tiles_distributed(starts, decode_one, *tp)
         else:
             decoded = [decode_one(i) for i in starts]

@@ -257,6 +257,31 @@ def test_blend_kernel_bit_exact(vae):
         assert torch.equal(got.float().cpu(), ref), dim
 
 
+def test_temporal_tiling_in_one_pass_equals_the_slice_blend_cat_loop(vae, monkeypatch):
+    """Round 6: `_temporal_tiled_decode` decodes a tile straight out of the long latent (k5_vae_decode_tile_strided) and cross-fades + places it in the
+    output in one pass (k5_blend_place_bf16) instead of the reference loop's slices, .contiguous() copies, blend_t and torch.cat (vae.py:1144-1204).
+    Same numbers, bit for bit, as that loop (K5_VAE_LEGACY_GLUE=1 keeps it callable)."""
+    m, _ = vae
+    for shape, tile, stride in (((1, 16, 13, 4, 4), (1, 9, 32, 32), (4, 32, 32)), ((1, 16, 9, 4, 6), (1, 17, 32, 48), (8, 32, 48))):
+        z = torch.randn(*shape, generator=torch.Generator().manual_seed(8)).cuda()
+        m.apply_tiling(tile, stride)
+        monkeypatch.setenv("K5_VAE_LEGACY_GLUE", "1")
+        old = m._decode(z).sample
+        monkeypatch.setenv("K5_VAE_LEGACY_GLUE", "0")
+        new = m._decode(z).sample
+        assert new.shape == old.shape and torch.equal(new, old), (shape, rel(new, old))
+
+
+def test_frames_to_uint8_kernel_equals_the_torch_expression():
+    from kandinsky.generation_utils import frames_to_uint8
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(1, 3, 5, 16, 24, generator=g) * 0.8).bfloat16().cuda()
+    x.view(-1)[:8] = torch.tensor([-1.0, 1.0, -3.0, 3.0, 0.0, -0.0, 0.99609375, -0.99609375], dtype=torch.bfloat16)
+    ref = ((x.clamp(-1.0, 1.0) + 1.0) * 127.5).to(torch.uint8)              # generation_utils.py:222-224 of the reference
+    assert torch.equal(frames_to_uint8(x), ref)
+    assert torch.equal(frames_to_uint8(x.float().cpu()), ((x.float().cpu().clamp(-1.0, 1.0) + 1.0) * 127.5).to(torch.uint8))   # not bf16-on-GPU: torch
+
+
 def test_decode_picks_reference_tiling(vae):
     m, _ = vae
     meta = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vae_meta.json")))
