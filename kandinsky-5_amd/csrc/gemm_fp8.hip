@@ -265,7 +265,14 @@ __global__ __launch_bounds__(512) void gemm_fp8_k8_kernel(Gemm8P p) {
 //                      first eight MFMAs (m-tile 0), which is why the top-of-K-tile barrier sits at q = 7 and not at q = 0
 // Measured / parity: tests/test_gpu_kernels.py::test_gemm_fp8_* (the 256-tile shapes take this kernel), DESIGN.md §4.2.
 // ---------------------------------------------------------------------------------------------
-constexpr int F4_PAD = 1040, F4_OP = 32 * F4_PAD, F4_STAGE = 2 * F4_OP, F4_LDS = 2 * F4_STAGE;
+// Round 6 — fragment reads without bank conflicts.  A lane's 32 operand bytes are two ds_read_b128; the hardware serves a b128 read in the lane groups
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32) (profiles/r05_lds_conflicts.md), and with the 1040-B piece stride of round 4 two lanes of every group
+// met on the same four banks (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE, HISTORY §R5: "left").  Searched exhaustively over (stride, swizzle):
+// a 1088-B piece stride (68 slots of 16 B = 4 mod 16) and the two 16-B halves of a lane's chunk pair SWAPPED in the pieces 8..15 of every 16 — the DMA of the
+// odd waves fetches chunk c ^ 1 into position c, and a lane with l15 >= 8 reads its low half from + 16 and its high half from + 0 (two base registers per
+// operand): all sixteen lanes of every group on sixteen different slots, for both halves.
+constexpr int F4_PAD = 1088, F4_OP = 32 * F4_PAD, F4_STAGE = 2 * F4_OP, F4_LDS = 2 * F4_STAGE;
+static_assert(F4_LDS <= 160 * 1024, "LDS budget of the four-wave fp8 kernel");
 typedef __attribute__((address_space(3))) void f4_lds_t;
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -292,8 +299,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const int nk = p.K / F8_BK;                  // even, >= 4 (launcher)
   const uint32_t ldw1 = (uint32_t)p.ldw, lda1 = (uint32_t)p.lda;   // bytes per row
-  const uint32_t vw0 = (uint32_t)(16 * (lane >> 3)) * ldw1 + (uint32_t)(lane & 7) * 16u;
-  const uint32_t vx0 = (uint32_t)(16 * (lane >> 3)) * lda1 + (uint32_t)(lane & 7) * 16u;
+  const uint32_t dch = (uint32_t)((lane & 7) ^ (wave & 1)) * 16u;   // this wave's pieces are 8 (wave & 1) + d of every 16: the odd waves swap the chunk pairs
+  const uint32_t vw0 = (uint32_t)(16 * (lane >> 3)) * ldw1 + dch;
+  const uint32_t vx0 = (uint32_t)(16 * (lane >> 3)) * lda1 + dch;
   const int drow = 128 * (wave >> 1) + 8 * (wave & 1);
   const int dslot = 8 * wave;
   uint32_t vw = vw0, vx = vx0;
@@ -320,12 +328,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(f4_lds_t*)dsm;
-  uint32_t wbs[2], xbs[2];
+  uint32_t wbs[2], xbs[2], wbh[2], xbh[2];   // low / high half of the lane's 32 bytes: + 128 i each
+  const uint32_t hsw = (uint32_t)(l15 >> 3) * 16u;
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    wbs[st] = lds0 + st * F4_STAGE + (16 * wn + l15) * F4_PAD + lc * 32;           // + 128 i (+ 16: upper half of the lane's 32 bytes)
-    xbs[st] = lds0 + st * F4_STAGE + F4_OP + (16 * wm + l15) * F4_PAD + lc * 32;
-    asm volatile("" : "+v"(wbs[st]), "+v"(xbs[st]));
+    const uint32_t wb = lds0 + st * F4_STAGE + (16 * wn + l15) * F4_PAD + lc * 32, xb = lds0 + st * F4_STAGE + F4_OP + (16 * wm + l15) * F4_PAD + lc * 32;
+    wbs[st] = wb + hsw; wbh[st] = wb + 16u - hsw;
+    xbs[st] = xb + hsw; xbh[st] = xb + 16u - hsw;
+    asm volatile("" : "+v"(wbs[st]), "+v"(xbs[st]), "+v"(wbh[st]), "+v"(xbh[st]));
   }
   v4i wl[2][8], wh[2][8], xl[8], xh[8];
   f32x4 acc[8][8];   // [n-tile][m-tile]
@@ -346,14 +356,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { F4_RD(wl[0][i], wbs[0], i * 128); F4_RD(wh[0][i], wbs[0], i * 128 + 16); }
+  for (int i = 0; i < 8; ++i) { F4_RD(wl[0][i], wbs[0], i * 128); F4_RD(wh[0][i], wbh[0], i * 128); }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { F4_RD(xl[j], xbs[0], j * 128); F4_RD(xh[j], xbs[0], j * 128 + 16); }
+  for (int j = 0; j < 8; ++j) { F4_RD(xl[j], xbs[0], j * 128); F4_RD(xh[j], xbh[0], j * 128); }
 
   auto ktile = [&](auto STC, auto FIRSTC) {
     constexpr int st = decltype(STC)::value;        // K-tile parity: its stage, and the W buffer its fragments sit in
     constexpr bool first = decltype(FIRSTC)::value;
-    const uint32_t wb_n = wbs[st ^ 1], xb_n = xbs[st ^ 1];   // the stage K-tile t + 1 lands in
+    const uint32_t wb_n = wbs[st ^ 1], xb_n = xbs[st ^ 1], wh_n = wbh[st ^ 1], xh_n = xbh[st ^ 1];   // the stage K-tile t + 1 lands in
     // (one flat loop: a nested generic lambda per 16 MFMAs, as in the bf16 kernel, trips a clang capture bug on the asm operands here)
 #pragma unroll
     for (int q = 0; q < 64; ++q) {
@@ -363,14 +373,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (q == 31) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
       if (q >= 32 && q < 48) {
         const int r = q - 32;
-        if (r & 1) F4_RD(wh[st ^ 1][r >> 1], wb_n, (r >> 1) * 128 + 16); else F4_RD(wl[st ^ 1][r >> 1], wb_n, (r >> 1) * 128);
+        if (r & 1) F4_RD(wh[st ^ 1][r >> 1], wh_n, (r >> 1) * 128); else F4_RD(wl[st ^ 1][r >> 1], wb_n, (r >> 1) * 128);
       }
       if (q >= 48 && q < 62) {                     // X(t+1)[0..3] at q = 48..55, [4] [5] [6] at 56..61
         const int r = q - 48;
-        if (r & 1) F4_RD(xh[r >> 1], xb_n, (r >> 1) * 128 + 16); else F4_RD(xl[r >> 1], xb_n, (r >> 1) * 128);
+        if (r & 1) F4_RD(xh[r >> 1], xh_n, (r >> 1) * 128); else F4_RD(xl[r >> 1], xb_n, (r >> 1) * 128);
       }
     }
-    F4_RD(xl[7], xb_n, 7 * 128); F4_RD(xh[7], xb_n, 7 * 128 + 16);
+    F4_RD(xl[7], xb_n, 7 * 128); F4_RD(xh[7], xh_n, 7 * 128);
     dma_advance();
   };
 

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--slices", type=int, default=1)
     ap.add_argument("--cfg-parallel", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="a 2-block model instead of the 2B one (quick plumbing check)")
+    ap.add_argument("--die-before-sample", type=int, default=-1, metavar="RANK", help="failure drill: this rank leaves after the communicator is up")
     args = ap.parse_args()
     os.environ.setdefault("K5_SP_TRANSPORT", "ipc")
     os.environ.setdefault("K5_OVERSUBSCRIBE", "1")
@@ -90,6 +91,8 @@ def main():
     sig = sigma_schedule(c["steps"], c["s"]).tolist()
     lat = noise.clone().to(dev)
     dist.barrier()
+    if args.die_before_sample == rank:
+        os._exit(0)          # no teardown: the peers must find out by themselves
     dit.sample(lat, sig, te, ne, pos, torch.arange(c["L"]), torch.arange(c["Lnull"]), w, scale_factor=(1.0, 2.0, 2.0), sparse_params=sparse)
     torch.cuda.synchronize(dev)
     errs = dit.get_option("ipc_errors")

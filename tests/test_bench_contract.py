@@ -47,6 +47,18 @@ def test_bench_launches_itself_for_more_than_one_gpu():
     assert '"WORLD_SIZE" not in os.environ and args.gpus > 1' in src      # one GPU never takes the launcher path
 
 
+def test_bench_oversubscribe_flags_select_the_ipc_transport():
+    """`bench.py --gpus P --oversubscribe` = P ranks on the devices that exist over the engine's IPC transport (RCCL refuses ranks that share a device):
+    the flag sets K5_OVERSUBSCRIBE / K5_SP_TRANSPORT for the ranks it launches, is forwarded to them, refuses RCCL, and its line says INVALID_AS_BENCH."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'os.environ["K5_OVERSUBSCRIBE"] = "1"' in src and 'os.environ["K5_SP_TRANSPORT"] = args.transport' in src
+    assert src.index('os.environ["K5_OVERSUBSCRIBE"] = "1"') < src.index("cmd = self_launch_command(sys.argv[1:], args.gpus)")   # before the ranks are spawned
+    assert "--oversubscribe needs the IPC transport" in src and '"ipc_ranks_seen"' in src and "ranks time-slice" in src
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--transport", "rccl"], capture_output=True,
+                         text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "--oversubscribe needs the IPC transport" in out.stderr
+
+
 def test_bench_self_launch_reports_missing_devices_after_spawning():
     """On a box with fewer devices than --gpus the ranks are really spawned and each says what is missing (no usage message, rc != 0)."""
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:

@@ -32,13 +32,13 @@ def rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-def launch(P, case, out, extra=(), timeout=840):
+def launch(P, case, out, extra=(), timeout=840, expect_failure=False, ipc_timeout="120"):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "ipc_rank_worker.py"), "--case", case, "--out", out] + list(extra)
-    env = dict(os.environ, K5_SP_TRANSPORT="ipc", K5_OVERSUBSCRIBE="1", K5_IPC_TIMEOUT_S="120", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = dict(os.environ, K5_SP_TRANSPORT="ipc", K5_OVERSUBSCRIBE="1", K5_IPC_TIMEOUT_S=ipc_timeout, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     # own session: a launcher that outlives the timeout goes as a GROUP (its ranks hold the GPU)
@@ -50,6 +50,9 @@ def launch(P, case, out, extra=(), timeout=840):
         os.killpg(pr.pid, signal.SIGKILL)
         log, _ = pr.communicate()
         pytest.fail(f"{P} ranks did not finish within {timeout} s:\n{log[-3000:]}")
+    if expect_failure:
+        assert pr.returncode != 0, f"the launcher was expected to fail:\n{log[-2000:]}"
+        return log
     assert pr.returncode == 0, f"torch.distributed.run exited with {pr.returncode}:\n{log[-4000:]}"
     return log
 
@@ -178,3 +181,17 @@ def test_processes_graph_captured_step_at_config5_scale_cfg_2x4(tmp_path):
     print(f"config 5 shape, 8 processes (CFG pair x 4 token shards, NABLA), 4 steps: |latent - noise| / |noise| = {moved:.3e}; graph replay == eager: {torch.equal(lat['graph'], lat['eager'])}")
     assert moved > 0.05
     assert torch.equal(lat["graph"], lat["eager"]), rel(lat["graph"], lat["eager"])
+
+
+@pytest.mark.timeout(600)
+def test_a_rank_that_disappears_is_reported_not_waited_for_forever(tmp_path):
+    """Failure drill of the IPC transport: rank 1 of 2 leaves after the communicator is up.  Rank 0's first collective then finds nobody at the
+    shared-memory barrier: after 2 x K5_IPC_TIMEOUT_S it fails with a message that says so (k5_last_error through the host mirror's RuntimeError) —
+    before a single kernel of the collective was enqueued, so the GPU is left idle, not spinning."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    import time
+    t0 = time.time()
+    log = launch(2, "c1", str(tmp_path / "die"), ["--tiny", "--die-before-sample", "1"], timeout=400, expect_failure=True, ipc_timeout="3")
+    assert "a peer did not reach the barrier within 6 s" in log, log[-3000:]
+    assert time.time() - t0 < 300

@@ -32,5 +32,6 @@ if __name__ == "__main__":
     z = torch.randn(1, 16, 31, 64, 96, device=dev)
     t0 = time.perf_counter(); out = vae.decode(z).sample; torch.cuda.synchronize(); t1 = time.perf_counter()
     print(f"clip (31,64,96) -> {tuple(out.shape)}: {(t1 - t0):.2f} s (14 temporal tiles + blends)", flush=True)
-    u8 = ((out.clamp(-1.0, 1.0) + 1.0) * 127.5).to(torch.uint8); torch.cuda.synchronize()
+    from kandinsky.generation_utils import frames_to_uint8
+    u8 = frames_to_uint8(out); torch.cuda.synchronize()          # one pass of k5_frames_to_uint8 (the pipeline's own conversion)
     print("uint8 video", tuple(u8.shape), "mem GB", torch.cuda.max_memory_allocated() / 2**30)
