@@ -6,7 +6,7 @@ for rep in 1 2; do
   echo "--- round 6 layout"; python tools/gemm_fp8_time.py 2>/dev/null | grep TFLOP
 done
 for v in r5 r6; do
-  L=""; [ $v = r5 ] && L=$PWD/kandinsky-5_amd/lib/variants/libk5_fp8_r5.so
+  L=$PWD/kandinsky-5_amd/lib/libk5.so; [ $v = r5 ] && L=$PWD/kandinsky-5_amd/lib/variants/libk5_fp8_r5.so
   (cd /tmp; K5_LIB=$L rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --kernel-trace --output-format csv -d /root/repo/gpurun_out/pmc_fp8_$v -o p -- python /root/repo/tools/gemm_fp8_time.py > /dev/null 2>&1)
   python - <<PY
 import csv, glob, collections
