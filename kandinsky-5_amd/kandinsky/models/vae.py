@@ -379,7 +379,10 @@ class AutoencoderKLHunyuanVideo(nn.Module):
                 return DecoderOutput(dec) if return_dict else (dec,)
             decoded = [first] + [decode_one(i) for i in starts[1:]]
         elif tp is not None and tp[1] > 1 and len(starts) > 1:
-            decoded = self._decode_tiles_distributed(starts, decode_one, *tp)
+            # a rank without a tile in a round takes part in that round's gather with zeros of a tile's shape (round 6: also in the FIRST round — a
+            # 1 s clip has 2 temporal tiles, a node has 4 or 8 ranks; the launch-contract test found ranks 2 and 3 refusing to decode)
+            tile_shape = (z.shape[0], self.config.out_channels, 4 * mf + 1, 8 * z.shape[-2], 8 * z.shape[-1])
+            decoded = self._decode_tiles_distributed(starts, decode_one, *tp, tile_shape=tile_shape, device=z.device)
         else:
             decoded = [decode_one(i) for i in starts]
         row = [d[:, :, 1:] if k > 0 else d for k, d in enumerate(decoded)]
@@ -402,16 +405,19 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         return self
 
     @staticmethod
-    def _decode_tiles_distributed(starts, decode_one, rank, world, group):
+    def _decode_tiles_distributed(starts, decode_one, rank, world, group, tile_shape=None, device=None):
         import torch.distributed as dist
         decoded = [None] * len(starts)
         for r0 in range(0, len(starts), world):
             k = r0 + rank
             mine = decode_one(starts[k]) if k < len(starts) else None
-            if mine is None:   # ragged last round: take part in the collective with a dummy of the right shape
-                mine = torch.zeros_like(decoded[0]) if decoded[0] is not None else None
+            if mine is None:   # ragged round: take part in the collective with a dummy of the right shape
+                if decoded[0] is not None:
+                    mine = torch.zeros_like(decoded[0])
+                elif tile_shape is not None:
+                    mine = torch.zeros(tile_shape, dtype=torch.bfloat16, device=device)
             if mine is None:
-                raise RuntimeError("tile-parallel decode: the first round cannot be ragged")
+                raise RuntimeError("tile-parallel decode: a rank without a tile needs the tile shape")
             if dist.get_backend(group) == "gloo":   # IPC transport (K5_SP_TRANSPORT=ipc): the process group is a host-side one
                 parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(world)]
                 dist.all_gather(parts, mine.contiguous().cpu(), group=group)

@@ -39,7 +39,12 @@ class Kandinsky5T2VPipeline:
             box = [mine]
             torch.distributed.broadcast_object_list(box, 0)
             return box[0]
-        t = (torch.tensor([mine], dtype=torch.int64) if mine is not None else torch.empty(1, dtype=torch.int64)).to(self.local_dit_rank)
+        # the reference moves the scalar to cuda:LOCAL_RANK (t2v_pipeline.py:112); here the rank's device is whatever the factory assigned it
+        # (K5_OVERSUBSCRIBE wraps ranks around the devices that exist) and a host-side process group (gloo: the IPC transport) takes it on the CPU
+        host = torch.distributed.get_backend() == "gloo"
+        t = torch.tensor([mine], dtype=torch.int64) if mine is not None else torch.empty(1, dtype=torch.int64)
+        if not host:
+            t = t.to(torch.device(self.device_map["dit"]))
         torch.distributed.broadcast(t, 0)
         return int(t.item())
 
