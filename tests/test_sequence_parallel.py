@@ -265,7 +265,7 @@ def test_cfg_parallel_two_ranks_gloo():
         assert err == 0.0, (rank, err, scale)
 
 
-def _vae_worker(rank, world, port, q):
+def _vae_worker(rank, world, port, q, nf=31):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "kandinsky-5_amd"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -289,7 +289,7 @@ def _vae_worker(rank, world, port, q):
         vae._blend = staticmethod(fake_blend).__get__(None, AutoencoderKLHunyuanVideo)
         if parallel:
             vae.enable_tile_parallel(rank, world)
-        z = torch.randn(1, 16, 31, 8, 12, generator=torch.Generator().manual_seed(11))   # 121 frames -> 14 temporal tiles
+        z = torch.randn(1, 16, nf, 8, 12, generator=torch.Generator().manual_seed(11))   # 31: 121 frames -> 14 temporal tiles; 7: 25 frames -> 2 tiles
         outs.append(vae.decode(z).sample)
     q.put((rank, float((outs[0].float() - outs[1].float()).abs().max()), tuple(outs[1].shape)))
     dist.destroy_process_group()
@@ -298,6 +298,17 @@ def _vae_worker(rank, world, port, q):
 def test_vae_temporal_tiles_distributed_two_ranks_gloo():
     for rank, err, shape in _spawn(_vae_worker):
         assert err == 0.0 and shape == (1, 3, 121, 64, 96), (rank, err, shape)
+
+
+def _vae_worker_short(rank, world, port, q):
+    _vae_worker(rank, world, port, q, nf=7)
+
+
+def test_vae_fewer_temporal_tiles_than_ranks_gloo():
+    """Round 6 (found by the multi-process launch-contract test): a 1 s clip has 2 temporal tiles; on 3 (4, 8) ranks the FIRST round of the tile
+    distribution is already ragged — the ranks without a tile take part in the gather with zeros of a tile's shape instead of refusing."""
+    for rank, err, shape in _spawn(_vae_worker_short, world=3):
+        assert err == 0.0 and shape == (1, 3, 25, 64, 96), (rank, err, shape)
 
 
 def _ipc_host_worker(rank, world, port, q):
