@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--slices", type=int, default=1)
     ap.add_argument("--cfg-parallel", action="store_true")
+    ap.add_argument("--ulysses", action="store_true", help="engine option sp_mode = 1: the all-to-all schedule (heads % ranks == 0)")
     ap.add_argument("--tiny", action="store_true", help="a 2-block model instead of the 2B one (quick plumbing check)")
     ap.add_argument("--die-before-sample", type=int, default=-1, metavar="RANK", help="failure drill: this rank leaves after the communicator is up")
     args = ap.parse_args()
@@ -77,6 +78,8 @@ def main():
     parallelize_dit(dit, rank, world, device=dev, cfg_parallel=args.cfg_parallel)
     if args.slices > 1:
         dit.set_option("sp_slices", args.slices)
+    if args.ulysses:
+        dit.set_option("sp_mode", 1)
     if args.graph:
         dit.set_graph(True)
     assert dit.get_option("ipc_ranks") == (world // 2 if args.cfg_parallel else world), dit.get_option("ipc_ranks")

@@ -57,7 +57,7 @@ def launch(P, case, out, extra=(), timeout=840, expect_failure=False, ipc_timeou
     return log
 
 
-def loopback_latent(P, c, w, sparse, meta, slices=1):
+def loopback_latent(P, c, w, sparse, meta, slices=1, options=None):
     """the same run as P loopback ranks of THIS process (tests/test_gpu_loopback.py run_ranks): the bits the processes must reproduce"""
     import importlib.util
     from kandinsky.generation_utils import sigma_schedule
@@ -87,7 +87,7 @@ def loopback_latent(P, c, w, sparse, meta, slices=1):
         lat = noise.clone().cuda()
         d.sample(lat, sig, te, ne, pos, torch.arange(c["L"]), torch.arange(c["Lnull"]), w, scale_factor=(1.0, 2.0, 2.0), sparse_params=sparse)
         return lat
-    outs = lb.run_ranks(P, make, call, slices=slices)
+    outs = lb.run_ranks(P, make, call, slices=slices, options=options)
     for r in range(1, P):
         assert torch.equal(outs[r], outs[0])
     out = outs[0].cpu()
@@ -195,3 +195,28 @@ def test_a_rank_that_disappears_is_reported_not_waited_for_forever(tmp_path):
     log = launch(2, "c1", str(tmp_path / "die"), ["--tiny", "--die-before-sample", "1"], timeout=400, expect_failure=True, ipc_timeout="3")
     assert "a peer did not reach the barrier within 6 s" in log, log[-3000:]
     assert time.time() - t0 < 300
+
+
+@pytest.mark.timeout(1500)
+def test_processes_ulysses_all_to_all_vs_reference_and_vs_loopback_ranks(tmp_path):
+    """The Ulysses schedule (engine option sp_mode = 1: q | k and V^T change hands by all-to-all, each rank attends H / P heads over all tokens, the
+    outputs travel back) across 4 PROCESSES — the transport's third primitive inside the engine — on config 1 in full against the reference golden,
+    and bit for bit against 4 loopback ranks on the same schedule."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    from safetensors.torch import load_file
+    meta = json.load(open(os.path.join(HERE, "dit_fulldepth_meta.json")))
+    out = str(tmp_path / "ipc_ulysses")
+    launch(4, "c1", out, ["--ulysses"])
+    rc = json.load(open(os.path.join(out, "rank_check.json")))
+    assert rc["rank_check"]["latent_checksums_identical_on_all_ranks"], rc
+    assert all(r["ipc_ranks"] == 4 and r["ipc_errors"] == 0 for r in rc["ranks"]), rc["ranks"]
+    lat = torch.load(os.path.join(out, "latent_rank0.pt"))
+    c, G = meta["c1"], load_file(os.path.join(HERE, "dit_fulldepth_c1.safetensors"))
+    got = lat.reshape(-1)[G["sample_idx"]]
+    r_ref, r_16, yard = rel(got, G["final_ref"]), rel(got, G["final_bf16_oracle"]), c["bf16_oracle_vs_ref_final"]
+    print(f"4 PROCESSES, Ulysses all-to-all, 32 blocks x {c['steps']} steps: final latent vs reference fp32 {r_ref:.3e}, vs bf16-island oracle {r_16:.3e} (oracle vs reference {yard:.3e}); "
+          f"{rc['ranks'][0]['ipc_collectives']} collectives")
+    assert r_ref <= max(1.5 * yard, 1e-2) and r_16 <= max(1.5 * yard, 1e-2), (r_ref, r_16, yard)
+    loop = loopback_latent(4, c, c["w"], None, meta, options={"sp_mode": 1})
+    assert torch.equal(loop, lat), f"the processes and the loopback ranks disagree: {rel(lat, loop):.3e}"
