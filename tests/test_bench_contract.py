@@ -98,6 +98,29 @@ def test_bench_json_line_contract():
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu_over_the_ipc_transport():
+    """`python bench.py --gpus 2 --oversubscribe`: the bench launches itself under torch.distributed.run, both ranks sit on the one device, the
+    engine's IPC group carries K / V^T — and the line says so: n_gpus 2, ipc_ranks_seen 2, no timed-out flag wait, identical latents on both ranks
+    (rank_check), rccl_ranks_seen -1 (a communicator that is not RCCL's), and INVALID_AS_BENCH (two ranks time-slice one GPU)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X (torch.cuda.is_available() is False)")
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one device: --oversubscribe would spread the ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "K5_SP_TRANSPORT", "K5_OVERSUBSCRIBE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "1", "--warmup", "1", "--blocks", "2",
+                          "--no-vae", "--no-breakdown"], capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ipc_ranks_seen"] == 2 and d["rccl_ranks_seen"] == -1
+    assert d["ipc_transport"]["flag_wait_timeouts"] == 0 and d["ipc_transport"]["ranks_per_device"] == 2 and d["ipc_transport"]["collectives"] > 0
+    assert d["rank_check"]["latent_checksums_identical_on_all_ranks"] is True
+    assert any("time-slice" in x for x in d["INVALID_AS_BENCH"]) and "sequence-parallel x2" in d["config"]["parallelism"]
+
+
+@pytest.mark.gpu
 def test_bench_measures_its_own_hbm_traffic():
     """`roofline.traffic` of the default line is measured by the run itself (two rocprofv3 --pmc child passes, FETCH_SIZE x2 + WRITE_SIZE, one counter
     per pass): the figure must be a plausible per-launch byte count for the 47 616-token dense attention — at least the algorithmic K / V^T / Q / O
