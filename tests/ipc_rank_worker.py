@@ -25,7 +25,7 @@ HERE = os.path.join(ROOT, "tests", "golden")
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--case", required=True, choices=("c1", "n1w1", "n1w5", "c5"))
+    ap.add_argument("--case", required=True, choices=("c1", "n1w1", "n1w5", "c5", "fwd_c4d", "fwd_c5"))
     ap.add_argument("--graph", action="store_true", help="k5_dit_set_graph: one captured step replayed (the IPC collectives inside the capture)")
     ap.add_argument("--out", required=True)
     ap.add_argument("--slices", type=int, default=1)
@@ -49,6 +49,39 @@ def main():
     dev = torch.device("cuda", rank_device_index(local_rank))
     torch.cuda.set_device(dev)
     init_rank_process_group(local_rank)
+    if args.case.startswith("fwd_"):
+        # ONE forward at the length of BASELINE config 4 / 5 (93 696 / 234 240 tokens, NABLA) against the reference golden of tests/test_gpu_nabla_long.py:
+        # config 4 is "sequence-parallel over 4 x MI355X" by name — here its 4 ranks are 4 processes
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("k5_nabla_long", os.path.join(ROOT, "tests", "test_gpu_nabla_long.py"))
+        nl = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(nl)
+        tag = args.case[4:]
+        m, G, c, sd, (x, text, pooled, pos, sp) = nl._case(tag)
+        dit = DiffusionTransformer3D(**c)
+        dit.load_state_dict(sd, assign=True)
+        dit.engine(dev)
+        del sd
+        parallelize_dit(dit, rank, world, device=dev, cfg_parallel=False)
+        assert dit.get_option("ipc_ranks") == world
+        dist.barrier()
+        out = dit(x.to(dev), text.to(dev), pooled.to(dev), torch.tensor([m["time"]]), pos, torch.arange(m["text_len"]), scale_factor=(1.0, 2.0, 2.0), sparse_params=sp)
+        torch.cuda.synchronize(dev)
+        errs = dit.get_option("ipc_errors")
+        os.makedirs(args.out, exist_ok=True)
+        torch.save(nl._patches(out, m, G["sampled_blocks"]), os.path.join(args.out, f"patches_rank{rank}.pt"))
+        cs = torch.stack([out.double().sum(), out.double().abs().sum(), out.view(torch.int16).to(torch.int64).sum().double()]).cpu()
+        allcs = [torch.empty_like(cs) for _ in range(world)]
+        dist.all_gather(allcs, cs)
+        if rank == 0:
+            json.dump({"identical": all(torch.equal(allcs[0], v) for v in allcs), "ipc_errors": errs, "collectives": dit.get_option("ipc_collectives"),
+                       "finite": bool(torch.isfinite(out.float()).all())}, open(os.path.join(args.out, "fwd_check.json"), "w"))
+        dist.barrier()
+        dit._destroy_engine(force=True)
+        dist.destroy_process_group()
+        if errs:
+            raise SystemExit(f"rank {rank}: an IPC flag wait timed out")
+        return
     meta = json.load(open(os.path.join(HERE, "dit_fulldepth_meta.json")))
     if args.case == "c5":
         # BASELINE config 5's shape as ONE configuration (tests/test_gpu_loopback.py::test_config5_cfg_parallel_2x4_on_one_gpu): 1280x768 10 s latent
