@@ -27,6 +27,21 @@ for (M, N, K, epi) in ((47616, 1792, 1792, "gate"), (47616, 3584, 1792, "bias"),
     nd = sum(0 if torch.equal(run(), first) else 1 for _ in range(reps))
     print(f"gemm {M}x{N}x{K} {epi}: {nd} of {reps} repeats differ", flush=True)
     bad += nd
+# round 6: the split-K tail (kernel id 24: helper -> owner hand-over through the XCD's L2 under flags) must be as repeatable as the whole-tile schedule
+for (M, N, K, epi) in ((47616, 1792, 1792, "gate"), (47616, 1792, 7168, "gate"), (47616, 3584, 1792, "bias"), (23808, 7168, 1792, "gelu")):
+    a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
+    bias = torch.randn(N, device="cuda")
+    resid0 = torch.randn(M, N, device="cuda").to(BF) if epi == "gate" else None
+    gate = torch.randn(N, device="cuda") if epi == "gate" else None
+    code = {"bias": E.EPI_BIAS, "gelu": E.EPI_GELU, "gate": E.EPI_GATE}[epi]
+    def run24():
+        out = resid0.clone() if epi == "gate" else torch.empty(M, N, dtype=BF, device="cuda")
+        E.gemm(a, w, bias, code, resid=out if epi == "gate" else None, gate=gate, out=out, kernel=24)
+        return out
+    first = run24()
+    nd = sum(0 if torch.equal(run24(), first) else 1 for _ in range(reps))
+    print(f"gemm {M}x{N}x{K} {epi}, split-K tail: {nd} of {reps} repeats differ", flush=True)
+    bad += nd
 from kandinsky.models.dit import DiffusionTransformer3D
 LITE = dict(in_visual_dim=16, in_text_dim=3584, in_text_dim2=768, time_dim=512, out_visual_dim=16, patch_size=(1, 2, 2), model_dim=1792,
             ff_dim=7168, num_text_blocks=2, num_visual_blocks=4, axes_dims=(16, 24, 24), visual_cond=True)
