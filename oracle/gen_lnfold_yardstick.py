@@ -1,6 +1,6 @@
 """What would folding the LayerNorm + modulation of the visual blocks into the consumer GEMMs cost in parity?  (VERDICT r5 "Next round" #5: "pinned first".)
 
-    python oracle/gen_lnfold_yardstick.py        # ~ 8 min of host cores; writes profiles/r06_lnfold_yardstick.json
+    python oracle/gen_lnfold_yardstick.py        # ~ 10-30 min of host cores; writes profiles/r06_lnfold_yardstick.json
 
 BASELINE config 1 IN FULL (32 visual blocks x 16 steps, the weights / noise / prompt streams of oracle/gen_golden_fulldepth.py c1) through the bf16-island
 oracle with oracle.k5_oracle.LN_FOLD = True: every `apply_scale_shift_norm` of the visual stream (reference nn.py:25-28, dit.py:61-79, nn.py:374-400)
@@ -22,7 +22,7 @@ from oracle import k5_oracle as O  # noqa: E402
 
 
 def main():
-    torch.set_num_threads(32)
+    torch.set_num_threads(os.cpu_count() or 8)
     meta = json.load(open(os.path.join(ROOT, "tests", "golden", "dit_fulldepth_meta.json")))
     c = meta["c1"]
     G = load_file(os.path.join(ROOT, "tests", "golden", "dit_fulldepth_c1.safetensors"))
