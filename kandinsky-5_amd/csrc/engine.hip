@@ -2164,6 +2164,7 @@ extern "C" int k5_dit_cfg_pair_init_ipc(k5_dit* d, const char* shm_name, int bra
 //                     depending on how the compiler schedules the tile loop of the extra instantiation), hence opt-in.
 //   "nabla_group_rows" 0 (default) / 2 / 4: 64-query rows per NABLA key-tile list = per attention workgroup on one GPU; 0 picks 2 (128-query
 //                     workgroups) when the previous forward's first map kept less than half of its blocks, else 4; same bits either way
+//   "ipc_flags_finegrained" (read-only): 1 when the IPC group's flag page is fine-grained device memory (csrc/ipc_comm.h Group::open; K5_IPC_COARSE_FLAGS=1 forces plain memory)
 //   "gemm_split_tail" 0 (default) / 1 / 2 (PROCESS-wide, like K5_GEMM_SK): 1 = the ragged last round of a four-wave GEMM launch is cut along K into two
 //                     aligned slices per tile on two workgroups of one XCD (csrc/gemm_bf16.hip) where at most half of the CUs would be busy, 2 = wherever
 //                     a tile can be cut; 0 = whole tiles everywhere (one K order in every kernel).  Measured neutral through the engine, hence opt-in
@@ -2253,6 +2254,7 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "ipc_pair_ranks")) *value = d->pair.ipc ? d->pair.ipc->world : 0;
   else if (!strcmp(name, "ipc_collectives")) *value = (int)((d->comm.ipc ? d->comm.ipc->collectives : 0) + (d->pair.ipc ? d->pair.ipc->collectives : 0));
   else if (!strcmp(name, "ipc_pulled_mb")) *value = (int)(((d->comm.ipc ? d->comm.ipc->bytes_pulled : 0) + (d->pair.ipc ? d->pair.ipc->bytes_pulled : 0)) >> 20);
+  else if (!strcmp(name, "ipc_flags_finegrained")) *value = (d->comm.ipc && d->comm.ipc->flags_fine) ? 1 : 0;   // the IPC group's flag page is fine-grained device memory
   else if (!strcmp(name, "ipc_errors")) {   // synchronises the device: the first flag wait that ran into its time limit (0 = none; bit 31 | which << 24 | peer << 16 | epoch)
     *value = 0;
     for (Comm* c : {&d->comm, &d->pair}) if (c->ipc) { uint32_t w = 0; if (c->ipc->error_word(&w)) { k5_set_error("%s", c->ipc->err.c_str()); return K5_ERR_HIP; } if (w && !*value) *value = (int)w; }

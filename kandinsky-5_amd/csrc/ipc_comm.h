@@ -122,6 +122,7 @@ struct Group {
   int rank = 0, world = 1;
   Shm* shm = nullptr;
   uint32_t* flags = nullptr;        // mine (device)
+  bool flags_fine = false;          // the flag page is fine-grained memory (open)
   uint32_t* errword = nullptr;      // device: first wait that timed out
   PeerFlags peer_flags{};           // the peers' flag buffers mapped here (mine at [rank])
   uint64_t calls = 0, next_serial = 1;
@@ -176,14 +177,28 @@ struct Group {
     close(fd);
     if (m == MAP_FAILED) return fail("mmap(%s) failed: errno %lld", name.c_str(), errno);
     shm = (Shm*)m;   // a fresh segment is zero-filled: every atomic starts at 0
-    K5IPC_HIP(hipMalloc((void**)&flags, 4096));
-    K5IPC_HIP(hipMemset(flags, 0, 4096));
-    errword = flags + ERRW;
+    // The flag page is FINE-GRAINED device memory where the runtime offers it: peers on OTHER devices store into it and this rank's wait kernels poll it
+    // while kernels run, which coarse-grained memory only promises to make visible at kernel boundaries (between processes of ONE device the same L2 /
+    // memory side serves both and either kind works: what the one-GPU runs of this transport exercised).  Falls back to plain hipMalloc if the
+    // allocation or its export is refused.
     int dev = 0;
     K5IPC_HIP(hipGetDevice(&dev));
     ShmRank& me = shm->r[rank];
     me.pid = (int)getpid(); me.device = dev;
-    if (world > 1) K5IPC_HIP(hipIpcGetMemHandle(&me.flags_h, flags));
+    static const bool coarse = getenv("K5_IPC_COARSE_FLAGS") != nullptr;   // A/B switch
+    flags_fine = false;
+    if (!coarse && hipExtMallocWithFlags((void**)&flags, 4096, hipDeviceMallocFinegrained) == hipSuccess && flags) {
+      flags_fine = true;
+      if (hipMemset(flags, 0, 4096) != hipSuccess || (world > 1 && hipIpcGetMemHandle(&me.flags_h, flags) != hipSuccess)) {
+        (void)hipGetLastError(); (void)hipFree(flags); flags = nullptr; flags_fine = false;
+      }
+    } else { (void)hipGetLastError(); flags = nullptr; }
+    if (!flags) {
+      K5IPC_HIP(hipMalloc((void**)&flags, 4096));
+      K5IPC_HIP(hipMemset(flags, 0, 4096));
+      if (world > 1) K5IPC_HIP(hipIpcGetMemHandle(&me.flags_h, flags));
+    }
+    errword = flags + ERRW;
     K5IPC_HIP(hipDeviceSynchronize());
     shm->arrived.fetch_add(1, std::memory_order_acq_rel);
     const double t0 = now();

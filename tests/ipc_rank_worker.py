@@ -134,7 +134,7 @@ def main():
     errs = dit.get_option("ipc_errors")
     info = {"rank": rank, "world": world, "pid": os.getpid(), "device": str(dev), "ipc_ranks": dit.get_option("ipc_ranks"),
             "ipc_pair_ranks": dit.get_option("ipc_pair_ranks"), "ipc_collectives": dit.get_option("ipc_collectives"),
-            "ipc_pulled_mb": dit.get_option("ipc_pulled_mb"), "ipc_errors": errs, "cfg_branch": dit.cfg_branch() if hasattr(dit, "cfg_branch") else None}
+            "ipc_pulled_mb": dit.get_option("ipc_pulled_mb"), "ipc_flags_finegrained": dit.get_option("ipc_flags_finegrained"), "ipc_errors": errs, "cfg_branch": dit.cfg_branch() if hasattr(dit, "cfg_branch") else None}
     os.makedirs(args.out, exist_ok=True)
     torch.save(lat.cpu(), os.path.join(args.out, f"latent_rank{rank}.pt"))
     # the bench's rank_check (bench.py): every rank applies the same Euler update to the same gathered velocity -> bit-identical latents

@@ -49,8 +49,8 @@ static int run_rank(const char* name, int rank, int world, size_t mb, int rounds
   }
   unsigned long long hb = 0;
   CK(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
-  printf("rank %d: all-gather x %d of %zu MB per rank: %llu bad words, best %.3f ms = %.1f GB/s pulled\n", rank, rounds, mb, hb, best_ms,
-         (double)chunk * (world - 1) / best_ms * 1e-6);
+  printf("rank %d: all-gather x %d of %zu MB per rank: %llu bad words, best %.3f ms = %.1f GB/s pulled (flag page: %s memory)\n", rank, rounds, mb, hb, best_ms,
+         (double)chunk * (world - 1) / best_ms * 1e-6, g.flags_fine ? "fine-grained" : "coarse-grained");
   int rc = hb ? 4 : 0;
 
   // sliced exchange: four quarters of the slot, each its own collective
