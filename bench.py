@@ -432,6 +432,7 @@ def main():
     run(args.warmup, args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    fuse_used = dit.get_option("attn_fuse_qnorm_used")   # the timed call's choice of where the visual queries are normalised (1: inside the attention kernel from its second step on)
     # ---- the latent the TIMED steps left (before the breakdown pass below moves it on): pinned against a committed value of the same
     # (workload, warm-up + steps) — 512 samples of (latent - noise) + its sum of squares, produced by this engine on an MI355X and tied to
     # the reference through parity_check (same model, same noise, first two steps) and tests/test_gpu_fulldepth.py
@@ -611,6 +612,7 @@ def main():
             invalid.append("the latent after the timed steps differs from the committed pin of this (workload, steps) beyond the stated tolerance (latent_pin)")
         if parity is not None and parity.get("status") == "FAILED":
             invalid.append("the first two steps of this configuration differ from the reference golden beyond the stated tolerance (parity_check)")
+        out["attn_fuse_qnorm_used"] = fuse_used   # engine option "attn_fuse_qnorm_auto" (default on): k5_sample's per-call decision after its first step; same bits either way (latent_pin)
         out["ipc_ranks_seen"] = dit.get_option("ipc_ranks")     # processes of the engine's IPC group (k5_dit_comm_init_ipc): N under --transport ipc, else 0
         if out["ipc_ranks_seen"]:
             out["ipc_transport"] = {"collectives": dit.get_option("ipc_collectives"), "pulled_mb_this_rank": dit.get_option("ipc_pulled_mb"),

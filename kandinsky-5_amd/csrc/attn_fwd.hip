@@ -268,24 +268,29 @@ __global__ __launch_bounds__(QT == 4 ? 256 : 512, PIPE ? (QT == 4 ? 1 : 2) : (QT
     }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      float v[16], ss = 0.f;
+      // The sum of squares in rmsnorm_rope_kernel's ORDER (round 6): there a thread sums its 8-dimension chunk pair by pair, then the eight chunks of a head
+      // combine as a tree (xor 1, 2, 4).  This lane holds chunks g (ks = 0) and 4 + g (ks = 1): each summed on its own with the same expression, chunks
+      // g <-> g ^ 1 and g ^ 2 combined across the lanes 16 and 32 apart per ks, the two halves added last — the same fp32 value, so the normalised
+      // queries, and with them the whole attention, are BIT-IDENTICAL to the standalone pass (before: one running sum over both chunks; the last bit of
+      // 1 / rms differed now and then, and a bf16 rounding of q with it).
+      float v[16], sq2[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const u32x4 w4 = __builtin_bit_cast(u32x4, qf[qt][ks]);
+        float sq = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           v[8 * ks + 2 * j] = __uint_as_float(w4[j] << 16);
           v[8 * ks + 2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u);
-          ss += v[8 * ks + 2 * j] * v[8 * ks + 2 * j] + v[8 * ks + 2 * j + 1] * v[8 * ks + 2 * j + 1];
+          sq = __fadd_rn(sq, fmaf(v[8 * ks + 2 * j + 1], v[8 * ks + 2 * j + 1], __fmul_rn(v[8 * ks + 2 * j], v[8 * ks + 2 * j])));   // operation for operation as rmsnorm_rope_kernel
         }
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+        sq = __fadd_rn(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+        sq2[ks] = __fadd_rn(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
       }
-      {
-        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
-        ss = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
-        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
-        ss = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
-      }
-      const float rs = rsqrtf(ss * (1.0f / 64.0f) + 1.1920928955078125e-07f);
+      const float ss = __fadd_rn(sq2[0], sq2[1]);
+      const float rs = rsqrtf(fmaf(ss, 1.0f / 64.0f, 1.1920928955078125e-07f));
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         float y[8];
@@ -293,9 +298,9 @@ __global__ __launch_bounds__(QT == 4 ? 256 : 512, PIPE ? (QT == 4 ? 1 : 2) : (QT
         for (int j = 0; j < 8; ++j) y[j] = bf_round(__fmul_rn(__fmul_rn(v[8 * ks + j], rs), j < 4 ? wa[ks][j] : wb[ks][j - 4]));   // .type_as(q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float x0 = y[2 * j], x1 = y[2 * j + 1];
-          y[2 * j] = __fadd_rn(__fmul_rn(cs[qt][ks][j], x0), __fmul_rn(-sn[qt][ks][j], x1));
-          y[2 * j + 1] = __fadd_rn(__fmul_rn(sn[qt][ks][j], x0), __fmul_rn(cs[qt][ks][j], x1));
+          const float x0 = y[2 * j], x1 = y[2 * j + 1];   // the rotation operation for operation as rmsnorm_rope_kernel spells it (which product is fused matters)
+          y[2 * j] = fmaf(cs[qt][ks][j], x0, -__fmul_rn(sn[qt][ks][j], x1));
+          y[2 * j + 1] = fmaf(sn[qt][ks][j], x0, __fmul_rn(cs[qt][ks][j], x1));
         }
         const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
         qf[qt][ks] = __builtin_bit_cast(bf16x8, pk);
@@ -1163,7 +1168,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* state0, co
 // out; the head-level bound is then the smaller of |q|max kmax and |q|max R (the centred offsets' survival depends on the latter).
 __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstride, int H, float limit, int force_online,
                                   int* flags, unsigned long long* counters, float* kmax_out, const int* prefer_online, float* rstat, float* krad_out,
-                                  int nq, int qstride, int anchored) {
+                                  int nq, int qstride, int anchored, unsigned int* leave_sig) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
   float q2 = 0.f;   // nq partial maxima at stride qstride (Ulysses: one per rank that holds rows of this head's queries; otherwise 1)
@@ -1184,6 +1189,7 @@ __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstrid
   const bool anchor = anchored && kmax_out && !force_online && !pref && b > limit && b < 3.0e38f;
   const int fast = ((!force_online && b <= limit && !pref) || anchor) ? 1 : 0;   // NaN / inf compare false -> online
   flags[h] = fast;
+  if (leave_sig && (!fast || anchor)) *leave_sig = 1u;   // the engine's per-call choice of where the queries are normalised (k5_sample) reads it
   if (kmax_out) kmax_out[h] = (anchor ? -1.f : 1.f) * sqrtf(k2) * 1.002f;   // negative = anchored head (the magnitude stays usable)   // per-row offsets of the fixed-offset form: |q_row| * this - 90 (AttnP::kmax)
   if (counters) atomicAdd(counters + (fast ? 0 : 1), 1ull);
   for (int i = 0; i < nq; ++i) qstat[(size_t)i * qstride + h] = 0.f;
@@ -1197,12 +1203,12 @@ __global__ void attn_flags_kernel(float* qstat, float* kstat, int nk, int kstrid
 // time the layer runs (the next sampler step: the statistics of a layer change slowly along the trajectory).  Never reset within a
 // handle's life: a head that lost the fixed form does not get it back (no evidence would ever arrive).
 // One wave per head (one thread per head walking its 186 flags serially measured 24 us per block: 0.8 ms per step for nothing).
-__global__ __launch_bounds__(64) void attn_pref_update_kernel(const int* job_flags, int nqb, int H, int* prefer_online) {
+__global__ __launch_bounds__(64) void attn_pref_update_kernel(const int* job_flags, int nqb, int H, int* prefer_online, unsigned int* leave_sig) {
   const int h = blockIdx.x;
   int cnt = 0;
   for (int j = threadIdx.x; j < nqb; j += 64) cnt += job_flags[h * nqb + j] != 0;
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-  if (threadIdx.x == 0 && 4 * cnt > nqb) prefer_online[h] = 1;
+  if (threadIdx.x == 0 && 4 * cnt > nqb) { prefer_online[h] = 1; if (leave_sig) *leave_sig = 1u; }
 }
 
 // Anchored offsets (K5_ATTN_ANCHOR_ADD): for every query row of a head marked by a negative kmax entry, the maximum score over a sample
@@ -1316,22 +1322,22 @@ int attn_slots() {
 }
 }  // namespace
 
-int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_rows, int* prefer_online, hipStream_t stream) {
+int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_rows, int* prefer_online, hipStream_t stream, unsigned int* leave_sig) {
   if (!balance_ws || !prefer_online || H <= 0 || q_len <= 0) return K5_ERR_ARG;
   const int nqb = (q_len + 64 * group_rows - 1) / (64 * group_rows);
-  hipLaunchKernelGGL(attn_pref_update_kernel, dim3(H), dim3(64), 0, stream, attn_job_flags(balance_ws, H, q_len), nqb, H, prefer_online);
+  hipLaunchKernelGGL(attn_pref_update_kernel, dim3(H), dim3(64), 0, stream, attn_job_flags(balance_ws, H, q_len), nqb, H, prefer_online, leave_sig);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 
 int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H, int force_online, int* flags,
                          unsigned long long* counters, hipStream_t stream, float* kmax_out, const int* prefer_online, float* rstat, float* krad_out,
-                         int nq, int qstride, bool anchored) {
+                         int nq, int qstride, bool anchored, unsigned int* leave_sig) {
   if ((rstat == nullptr) != (krad_out == nullptr) || (rstat && !kmax_out) || nq < 1) return K5_ERR_ARG;
   if (!qstat || !kstat || !flags || H <= 0 || nk <= 0) return K5_ERR_ARG;
   // with kmax_out the attention runs per-row offsets: heads up to K5_ATTN_ROWOFF_LIMIT keep the fixed-offset form
   hipLaunchKernelGGL(attn_flags_kernel, dim3((H + 63) / 64), dim3(64), 0, stream, qstat, kstat, nk, kstride, H,
                      kmax_out ? K5_ATTN_ROWOFF_LIMIT : K5_ATTN_EXP_LIMIT, force_online, flags, counters, kmax_out, kmax_out ? prefer_online : nullptr,
-                     rstat, krad_out, nq, qstride, anchored ? 1 : 0);
+                     rstat, krad_out, nq, qstride, anchored ? 1 : 0, leave_sig);
   return hipGetLastError() == hipSuccess ? K5_OK : K5_ERR_HIP;
 }
 

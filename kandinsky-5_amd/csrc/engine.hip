@@ -355,6 +355,16 @@ struct k5_dit {
   bool nabla_hint_pending = false;
   int sp_nabla_passes = 1;                         // "sp_nabla_passes" = 2: NABLA under sequence parallelism attends the rank's own key blocks during the gather
   int fuse_qnorm = 0;                              // "attn_fuse_qnorm": norm_qk + RoPE of the visual queries inside the attention kernel
+  // "attn_fuse_qnorm_auto" (default 1): k5_sample decides per CALL.  Step 0 runs with the standalone norm pass and collects whether any head left
+  // the plain fixed-offset form (online, anchored, or marked as falling back: leave_sig); if none did, steps 1.. normalise the queries inside the
+  // attention kernel (fuse_now) — the same bits (both kernels spell the norm + rotation out operation for operation), half of the norm pass less per
+  // block and a faster attention instantiation.  Heads that
+  // leave the window keep today's routing (anchored offsets need the normalised queries in memory), so such calls stay as they were.
+  int fuse_qnorm_auto = 1;
+  bool fuse_now = false, leave_collect = false;
+  int fuse_last = -1;                              // "attn_fuse_qnorm_used": what the last k5_sample decided (1 fused from step 1 on, 0 not, -1 not evaluated)
+  DevBuf ws_leave_sig;
+  unsigned int* h_leave_sig = nullptr;             // pinned
   bool row_offsets = true;                         // "attn_row_offsets": per-row offsets of the fixed-offset softmax (bound up to 190)
   bool anchor = true;                              // "attn_anchor": heads beyond that window run the fixed form on anchored offsets (one-GPU path)
   DevBuf ws_attn_anchor;                           // [H][rows] anchored offsets (k5_launch_attn_row_anchor)
@@ -647,7 +657,8 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
   K5KeyCentre kcen{nullptr, nullptr};
   const K5KeyCentre* kcp = nullptr;
   // dense visual blocks: norm_qk + RoPE of the queries happen in the attention kernel's Q load ("attn_fuse_qnorm")
-  const bool fuse_q = pre && !nabla && d->fuse_qnorm && ((by_data && d->row_offsets) || d->attn_mode == K5_ATTN_ONLINE);
+  const bool fuse_q = pre && !nabla && (d->fuse_qnorm || d->fuse_now) && ((by_data && d->row_offsets) || d->attn_mode == K5_ATTN_ONLINE);
+  unsigned int* leave_sig = (d->leave_collect && d->ws_leave_sig.p) ? d->ws_leave_sig.as<unsigned int>() : nullptr;
   if (by_data) K5CHK(ensure_attn_flags(d, s));   // before the counters' address is taken
   const K5QueryNorm qn{a.norm.as<float>(), cosT, sinT, by_data ? d->ws_attn_cnt.as<unsigned long long>() : nullptr};
   {
@@ -681,7 +692,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
       // heads beyond the Cauchy-Schwarz window: anchored offsets (needs the normalised queries in memory: not with the fused query norm)
       const bool anchored = centre && d->anchor && !fuse_q && !nabla;   // dense attention only (k5_launch_attn_row_anchor)
       K5CHK(k5_launch_attn_flags(stats, stats + H, 1, H, H, 0, d->ws_attn_flags.as<int>(), d->ws_attn_cnt.as<unsigned long long>(), s, kmax_w,
-                                 kmax_w ? (a.pref.as<int>() + (size_t)pref_slot * H) : nullptr, centre ? stats + 2 * H : nullptr, centre ? kmax_w + H : nullptr, 1, 0, anchored));
+                                 kmax_w ? (a.pref.as<int>() + (size_t)pref_slot * H) : nullptr, centre ? stats + 2 * H : nullptr, centre ? kmax_w + H : nullptr, 1, 0, anchored, leave_sig));
       if (centre) { kcen.centre = centre; kcen.radius = kmax_w + H; kcp = &kcen; }
       if (anchored) {
         K5CHK(d->ws_attn_anchor.ensure((size_t)H * rows * 4));
@@ -733,7 +744,7 @@ int run_self_attention(k5_dit* d, hipStream_t s, const AttnW& a, const void* h, 
                                          0x7fffffff, 0, nullptr, 0, s, d->ws_attn_bal.as<float>(), pre, hflags, variant, nullptr, kmax, 0,
                                          fuse_q ? &qn : nullptr, kcp));
   }
-  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, nabla ? (pre ? d->nabla_grp_now : 4) : 4, (a.pref.as<int>() + (size_t)pref_slot * H), s));
+  if (kmax) K5CHK(k5_launch_attn_pref_update(d->ws_attn_bal.as<float>(), H, rows, nabla ? (pre ? d->nabla_grp_now : 4) : 4, (a.pref.as<int>() + (size_t)pref_slot * H), s, leave_sig));
   if (f8_out) {
     K5CHK(d->ws_h8.ensure((size_t)rows * D));
     {
@@ -1668,7 +1679,8 @@ extern "C" void k5_dit_destroy(k5_dit* d) {
   for (DevBuf* b : all) b->release();
   for (auto& e : d->text_rope) { e.cosT.release(); e.sinT.release(); e.pos.release(); }
   d->ws_q.release(); d->ws_kfull.release(); d->ws_vtfull.release(); d->ws_attn_state.release(); d->ws_attn_bal.release(); d->ws_kc.release(); d->ws_kmeans.release(); d->ws_nabla_kept.release(); if (d->h_nabla_kept) { (void)hipHostFree(d->h_nabla_kept); d->h_nabla_kept = nullptr; } d->ws_sched.release(); d->ws_h8.release(); d->ws_ff8.release();
-  d->ws_attn_stats.release(); d->ws_attn_flags.release(); d->ws_attn_cnt.release(); d->ws_attn_part.release();
+  d->ws_attn_stats.release(); d->ws_attn_flags.release(); d->ws_attn_cnt.release(); d->ws_attn_part.release(); d->ws_leave_sig.release();
+  if (d->h_leave_sig) { (void)hipHostFree(d->h_leave_sig); d->h_leave_sig = nullptr; }
   for (auto& t : d->text_cache) { t.text.release(); t.pool.release(); }
   for (auto& kv : d->staged) kv.second.dev.release();   // a handle destroyed before finalize still holds its staged matrices
   d->mag.residual[0].release(); d->mag.residual[1].release(); d->mag.pm_one.release();
@@ -1940,6 +1952,27 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
   }
   d->text_cache[0].valid = d->text_cache[1].valid = false;   // the prompt tensors are constant for THIS call only
   K5CHK(reset_attn_pref(d, s));                              // ... and so is what the softmax-form memory of the layers is worth
+  // where the visual queries are normalised (see k5_dit::fuse_qnorm_auto): a plain one-handle dense run decides after its first step
+  struct FuseGuard { k5_dit* d; ~FuseGuard() { d->fuse_now = false; d->leave_collect = false; } } fuse_guard{d};
+  d->fuse_now = false; d->leave_collect = false; d->fuse_last = -1;
+  const bool auto_fuse = d->fuse_qnorm_auto && !d->fuse_qnorm && !d->comm.active() && d->attn_mode == K5_ATTN_AUTO && d->row_offsets &&   // (a CFG pair's handles decide each for itself)
+                         a->fwd.attention_type == 0 && a->num_steps >= 2;
+  if (auto_fuse) {
+    K5CHK(d->ws_leave_sig.ensure(4));
+    if (!d->h_leave_sig) HIPCHK(hipHostMalloc((void**)&d->h_leave_sig, 4, hipHostMallocDefault));
+    HIPCHK(hipMemsetAsync(d->ws_leave_sig.p, 0, 4, s));
+    d->leave_collect = true;
+  }
+  auto decide_fuse = [&]() -> int {   // after step 0
+    if (!auto_fuse) return K5_OK;
+    d->leave_collect = false;
+    *d->h_leave_sig = 1u;
+    HIPCHK(hipMemcpyAsync(d->h_leave_sig, d->ws_leave_sig.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));   // once per call: the host runs a step ahead otherwise
+    d->fuse_now = *d->h_leave_sig == 0u;
+    d->fuse_last = d->fuse_now ? 1 : 0;
+    return K5_OK;
+  };
   auto one_step = [&](int i) -> int {
     const float t1000 = host_tab[i], dt = host_tab[a->num_steps + i];
     if (pair) {
@@ -1965,10 +1998,14 @@ extern "C" int k5_sample(k5_dit* d, const k5_sample_args* a, void* stream) {
     return K5_OK;
   };
   if (!graph) {
-    for (int i = 0; i < a->num_steps; ++i) K5CHK(one_step(i));
+    for (int i = 0; i < a->num_steps; ++i) {
+      K5CHK(one_step(i));
+      if (i == 0) K5CHK(decide_fuse());
+    }
     return K5_OK;
   }
   K5CHK(one_step(0));
+  K5CHK(decide_fuse());
   hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
   HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   const int rc = one_step(1);
@@ -2162,6 +2199,11 @@ extern "C" int k5_dit_cfg_pair_init_ipc(k5_dit* d, const char* shm_name, int bra
 //                     applies it inside the attention kernel's Q-fragment load (K5QueryNorm; needs attn_row_offsets or attn_mode 1);
 //                     2 = under sequence parallelism too.  Measured neutral (elementwise -2.0 ms, attention +0.6 .. +3.4 ms per step
 //                     depending on how the compiler schedules the tile loop of the extra instantiation), hence opt-in.
+//   "attn_fuse_qnorm_auto" 1 (default) / 0: with attn_fuse_qnorm = 0, k5_sample on a handle without a sequence-parallel communicator decides per call:
+//                     step 0 as above (standalone pass) while it records whether any head left the plain fixed-offset form; if none did, steps 1.. run as
+//                     attn_fuse_qnorm = 1.  BIT-IDENTICAL either way since round 6 (the two kernels' norm + rotation arithmetic is spelled out operation
+//                     for operation: tools/probes/qn_arith_probe.hip); final build, alternating on one box: 522.8-523.1 -> 516.5 ms per step
+//                     (elementwise -1.4, attention -4).  "attn_fuse_qnorm_used" (read-only): the last call's decision (1 / 0; -1 = not evaluated)
 //   "nabla_group_rows" 0 (default) / 2 / 4: 64-query rows per NABLA key-tile list = per attention workgroup on one GPU; 0 picks 2 (128-query
 //                     workgroups) when the previous forward's first map kept less than half of its blocks, else 4; same bits either way
 //   "ipc_flags_finegrained" (read-only): 1 when the IPC group's flag page is fine-grained device memory (csrc/ipc_comm.h Group::open; K5_IPC_COARSE_FLAGS=1 forces plain memory)
@@ -2214,6 +2256,7 @@ extern "C" int k5_dit_set_option(k5_dit* d, const char* name, int value) {
   if (!strcmp(name, "nabla_group_rows")) { if (value != 0 && value != 1 && value != 2 && value != 4) return K5_ERR_ARG; d->nabla_group_rows = value; return K5_OK; }
   if (!strcmp(name, "sp_nabla_passes")) { if (value < 1 || value > 2) return K5_ERR_ARG; d->sp_nabla_passes = value; d->sp_user_set |= 4; return K5_OK; }
   if (!strcmp(name, "attn_fuse_qnorm")) { if (value < 0 || value > 2) return K5_ERR_ARG; d->fuse_qnorm = value; return K5_OK; }
+  if (!strcmp(name, "attn_fuse_qnorm_auto")) { if (value != 0 && value != 1) return K5_ERR_ARG; d->fuse_qnorm_auto = value; return K5_OK; }
   if (!strcmp(name, "sp_slices")) {
     if (value < 1 || value > 4) return K5_ERR_ARG;
     if (value > 1 && d->comm.comm && !d->comm.can_exchange()) { k5_set_error("sp_slices > 1 needs ncclSend / ncclRecv / ncclGroup* in the RCCL library"); return K5_ERR_STATE; }
@@ -2237,6 +2280,8 @@ extern "C" int k5_dit_get_option(k5_dit* d, const char* name, int* value) {
   else if (!strcmp(name, "attn_row_offsets")) *value = d->row_offsets ? 1 : 0;
   else if (!strcmp(name, "attn_anchor")) *value = d->anchor ? 1 : 0;
   else if (!strcmp(name, "attn_fuse_qnorm")) *value = d->fuse_qnorm;
+  else if (!strcmp(name, "attn_fuse_qnorm_auto")) *value = d->fuse_qnorm_auto;
+  else if (!strcmp(name, "attn_fuse_qnorm_used")) *value = d->fuse_last;
   else if (!strcmp(name, "sp_nabla_passes")) *value = d->sp_nabla_passes;
   else if (!strcmp(name, "sp_autotune")) *value = d->sp_autotune ? 1 : 0;
   else if (!strcmp(name, "sp_tuned")) *value = d->sp_tuned ? 1 : 0;

@@ -75,10 +75,12 @@ int k5_launch_attn_flags(float* qstat, float* kstat, int nk, int kstride, int H,
                          unsigned long long* counters, hipStream_t stream, float* kmax_out = nullptr, const int* prefer_online = nullptr,
                          float* rstat = nullptr, float* krad_out = nullptr,   // squared radii in (consumed) / radii with margin out: K5KeyCentre::radius
                          int nq = 1, int qstride = 0,                          // qstat as nq partial maxima at stride qstride (Ulysses)
-                         bool anchored = false);   // heads beyond the window: fixed form on anchored offsets (kmax_out entry < 0) instead of the online form
+                         bool anchored = false,    // heads beyond the window: fixed form on anchored offsets (kmax_out entry < 0) instead of the online form
+                         unsigned int* leave_sig = nullptr);   // nullable: set to 1 when any head leaves the plain fixed-offset form (online or anchored)
 int k5_launch_attn_row_anchor(const void* Q, const void* Kc, int H, int q_len, int kv_len, int ldq, int ldk, int key0, int kv_total,
                               const float* kmax, float* out, hipStream_t stream);
-int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_rows, int* prefer_online, hipStream_t stream);
+int k5_launch_attn_pref_update(float* balance_ws, int H, int q_len, int group_rows, int* prefer_online, hipStream_t stream,
+                               unsigned int* leave_sig = nullptr);   // nullable: set to 1 when a head is marked
 
 // ---- fp8 (e4m3) feed-forward path, opt-in (gemm_fp8.hip) ----
 int k5_launch_gemm_fp8(const void* A8, const void* W8, const float* w_scale, void* C, int M, int N, int K, int lda, int ldw, int ldc,

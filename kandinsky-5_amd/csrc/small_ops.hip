@@ -184,16 +184,20 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
     }
     float v[8];
     float sq = 0.f;
+    // The sum of squares with its operations SPELLED OUT (round 6) — what the compiler made of `sq += lo * lo + hi * hi` in both instantiations of this
+    // kernel (a pair is fma(hi, hi, lo * lo); the pairs added in order; the eight chunks of a head as a tree; fma(sq, 1/64, eps)) — because the
+    // attention kernel's fused query norm (attn_fwd.hip, K5QueryNorm) restates it and contraction had picked fma(lo, lo, hi * hi) there: 1 (row, head) in
+    // 10^4 then got another last bit of 1 / rms and, now and then, another bf16 rounding of a query element.  Same bits as before here.
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       v[2 * j] = __uint_as_float(raw[j] << 16);
       v[2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u);
-      sq += v[2 * j] * v[2 * j] + v[2 * j + 1] * v[2 * j + 1];
+      sq = __fadd_rn(sq, fmaf(v[2 * j + 1], v[2 * j + 1], __fmul_rn(v[2 * j], v[2 * j])));
     }
-    sq += __shfl_xor(sq, 1, 64);
-    sq += __shfl_xor(sq, 2, 64);
-    sq += __shfl_xor(sq, 4, 64);
-    const float rs = rsqrtf(sq * (1.0f / 64.0f) + 1.1920928955078125e-07f);  // eps = finfo(fp32).eps
+    sq = __fadd_rn(sq, __shfl_xor(sq, 1, 64));
+    sq = __fadd_rn(sq, __shfl_xor(sq, 2, 64));
+    sq = __fadd_rn(sq, __shfl_xor(sq, 4, 64));
+    const float rs = rsqrtf(fmaf(sq, 1.0f / 64.0f, 1.1920928955078125e-07f));  // eps = finfo(fp32).eps
     float y[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = bf_round(__fmul_rn(__fmul_rn(v[j], rs), wv[j]));  // .type_as(q)
@@ -202,9 +206,13 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
       const f32x4 sn = *reinterpret_cast<const f32x4*>(sinT + (size_t)row * 32 + 4 * c);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        // __fmul_rn / __fadd_rn are plain * and + to this compiler (no OCML_BASIC_ROUNDED_OPERATIONS): under -ffp-contract=fast ONE of the two products
+        // of a rotation is fused into the add, and which one is the compiler's choice per kernel.  Spelled out (round 6) as what both instantiations of
+        // this kernel had: the product with the ODD element rounded, the one with the even element fused — the form the attention kernel's fused query
+        // norm restates (it had the other one: 7 (row, head) pairs in 10^4 got another bf16 rounding of one query element).  Same bits as before here.
         const float x0 = y[2 * j], x1 = y[2 * j + 1];
-        y[2 * j] = __fadd_rn(__fmul_rn(cs[j], x0), __fmul_rn(-sn[j], x1));
-        y[2 * j + 1] = __fadd_rn(__fmul_rn(sn[j], x0), __fmul_rn(cs[j], x1));
+        y[2 * j] = fmaf(cs[j], x0, -__fmul_rn(sn[j], x1));
+        y[2 * j + 1] = fmaf(sn[j], x0, __fmul_rn(cs[j], x1));
       }
     }
     if (MEANS) {

@@ -202,6 +202,46 @@ def _qk_gain_sd(cfg, case):
     return sd
 
 
+@pytest.mark.parametrize("case,w,graph,expect_used", [("x2", 1.0, 0, 1), ("n05", 5.0, 0, 1), ("x2", 5.0, 1, 1), ("x6", 1.0, 0, 0), ("x5", 5.0, 1, 0)])
+def test_sample_decides_where_the_queries_are_normalised_same_bits(case, w, graph, expect_used):
+    """k5_sample's per-call choice ("attn_fuse_qnorm_auto", default on): step 0 runs the standalone norm + RoPE pass and records whether any head left
+    the plain fixed-offset form; if none did, steps 1.. normalise the queries inside the attention kernel.  Demanded here: the decision is the
+    one the data call for (gains 2 / N(1, 0.5): fused; gains 5 / 6, beyond the window — anchored offsets need the stored queries: not fused), and
+    the latent is BIT-IDENTICAL to the run with the choice switched off either way, eagerly and with the hipGraph-captured step, with and without CFG."""
+    from kandinsky.generation_utils import sigma_schedule
+    from kandinsky.models.dit import DiffusionTransformer3D
+    c = dict(O.LITE_2B, num_visual_blocks=2, num_text_blocks=1)
+    sd = _qk_gain_sd(O.DitConfig(**c), case)
+    dit = DiffusionTransformer3D(**c)
+    dit.load_state_dict(sd, assign=True)
+    dit = dit.to("cuda:0")
+    dit.engine("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    noise = torch.randn(5, 16, 16, 16, generator=g)
+    te = {"text_embeds": torch.randn(37, 3584, generator=g).cuda(), "pooled_embed": torch.randn(1, 768, generator=g).cuda()}
+    ne = {"text_embeds": torch.randn(9, 3584, generator=g).cuda(), "pooled_embed": torch.randn(1, 768, generator=g).cuda()}
+    pos = [torch.arange(5), torch.arange(8), torch.arange(8)]
+    sig = sigma_schedule(4, 5.0).tolist()
+    outs, used = {}, {}
+    for auto in (0, 1):
+        dit.set_option("attn_fuse_qnorm_auto", auto)
+        dit.set_graph(bool(graph))
+        lat = noise.clone().cuda()
+        dit.sample(lat, sig, te, ne, pos, torch.arange(37), torch.arange(9), w, scale_factor=(1.0, 2.0, 2.0))
+        torch.cuda.synchronize()
+        outs[auto], used[auto] = lat.clone(), dit.get_option("attn_fuse_qnorm_used")
+    assert used[0] == -1 and used[1] == expect_used, used
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[1]), f"max |diff| {(outs[0] - outs[1]).abs().max().item():.3e}"
+    # a forward outside k5_sample is never affected by the last call's decision
+    dit.set_graph(False)
+    x = noise.cuda()
+    a = dit(x, te["text_embeds"], te["pooled_embed"], torch.tensor([500.0]), pos, torch.arange(37), scale_factor=(1.0, 2.0, 2.0))
+    dit.set_option("attn_fuse_qnorm_auto", 0)
+    b = dit(x, te["text_embeds"], te["pooled_embed"], torch.tensor([500.0]), pos, torch.arange(37), scale_factor=(1.0, 2.0, 2.0))
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("case,expect,row_offsets,qfuse,anchor", [("n05", "fixed", 1, 0, 1), ("x2", "fixed", 1, 0, 1), ("ch8", "fixed", 1, 0, 1),
                                                                   ("x3", "fixed", 1, 0, 1), ("x3", "online", 0, 0, 1), ("x5", "fixed", 1, 0, 1),
                                                                   ("x5", "any", 1, 0, 0), ("x6", "fixed", 1, 0, 1), ("x6", "online", 1, 0, 0),
